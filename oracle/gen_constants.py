@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""Derive every Curve25519 / Ed25519 constant the oracle and the HIP engine need from the
+curve's mathematical definition (big-int arithmetic), and write them as C headers.
+
+Nothing here is transcribed from the reference: each value is *computed* (d = -121665/121666,
+sqrt(-1) = 2^((p-1)/4), B = the point with y = 4/5 and even x, l = 2^252 + 277423177773723535358519
+37790883648493, Montgomery constants for R = 2^260, ...).  tests/test_oracle_constants.py then
+checks the results limb-for-limb against the values the reference embeds
+(curve25519-dalek/src/backend/serial/u64/constants.rs:26-160, src/constants.rs:45-123) via the
+golden fixture tests/golden/constants.json.
+
+Outputs:
+  oracle/constants.h                               5 x u64 radix-2^51 limbs (oracle, CPU)
+  curve25519-dalek_amd/csrc/constants_gen.h        10 x u32 radix-2^25.5 limbs (HIP device code)
+"""
+import os
+
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+def inv(x):
+    return pow(x, P - 2, P)
+
+
+def sqrt_m1():
+    return pow(2, (P - 1) // 4, P)
+
+
+def is_neg(x):
+    return x & 1
+
+
+def fsqrt(a):
+    """A square root of a mod p (p = 5 mod 8), or None."""
+    r = pow(a, (P + 3) // 8, P)
+    if (r * r - a) % P == 0:
+        return r
+    r = r * sqrt_m1() % P
+    if (r * r - a) % P == 0:
+        return r
+    return None
+
+
+D = (-121665 * inv(121666)) % P
+D2 = 2 * D % P
+SQRT_M1 = sqrt_m1()
+if is_neg(SQRT_M1):  # the reference uses the non-negative (even) root ...
+    SQRT_M1 = P - SQRT_M1
+# ... check: reference's SQRT_M1 limb0 = 1718705420411056 is even. Asserted in the test.
+
+BY = 4 * inv(5) % P
+BX = fsqrt((BY * BY - 1) * inv(D * BY * BY + 1) % P)
+if is_neg(BX):
+    BX = P - BX
+
+# ristretto constants
+INVSQRT_A_MINUS_D = inv(fsqrt((-1 - D) % P))
+# sign convention: the reference value is whichever root its authors wrote down; both are valid
+# for the algebra only if used consistently, so pick by the documented property
+# "1/sqrt(a-d)" taken with the non-negative sqrt:
+_s = fsqrt((-1 - D) % P)
+if is_neg(_s):
+    _s = P - _s
+INVSQRT_A_MINUS_D = inv(_s)
+SQRT_AD_MINUS_ONE = fsqrt((-D - 1) % P)
+if not is_neg(SQRT_AD_MINUS_ONE):  # the reference's value is the odd root (only elligator uses it)
+    SQRT_AD_MINUS_ONE = P - SQRT_AD_MINUS_ONE
+ONE_MINUS_D_SQ = (1 - D * D) % P
+D_MINUS_ONE_SQ = (D - 1) ** 2 % P
+
+APLUS2_OVER_FOUR = 121666
+
+# scalar Montgomery constants (R = 2^260, 52-bit limbs)
+LFACTOR = (-pow(L, -1, 2**52)) % 2**52
+R = 2**260 % L
+RR = 2**520 % L
+
+
+
+# ---- hash constants, derived from their definitions (FIPS 180-4 / FIPS 202) -------------------
+def _primes(n):
+    ps, c = [], 2
+    while len(ps) < n:
+        if all(c % q for q in ps if q * q <= c):
+            ps.append(c)
+        c += 1
+    return ps
+
+
+def _iroot(x, k):
+    lo, hi = 0, 1
+    while hi ** k <= x:
+        hi *= 2
+    while lo < hi - 1:
+        mid = (lo + hi) // 2
+        if mid ** k <= x:
+            lo = mid
+        else:
+            hi = mid
+    return lo
+
+
+def sha512_constants():
+    ps = _primes(80)
+    K = [_iroot(p << (3 * 64), 3) & (2**64 - 1) for p in ps]     # frac(cbrt(p)) * 2^64
+    H = [_iroot(p << (2 * 64), 2) & (2**64 - 1) for p in ps[:8]]  # frac(sqrt(p)) * 2^64
+    return K, H
+
+
+def keccak_constants():
+    def rc_bit(t):
+        if t % 255 == 0:
+            return 1
+        r = 1
+        for _ in range(t % 255):
+            r <<= 1
+            if r & 0x100:
+                r ^= 0x171
+        return r & 1
+    RC = []
+    for ir in range(24):
+        v = 0
+        for j in range(7):
+            if rc_bit(j + 7 * ir):
+                v |= 1 << (2**j - 1)
+        RC.append(v)
+    rot = [[0] * 5 for _ in range(5)]  # rot[x][y]
+    x, y = 1, 0
+    for t in range(24):
+        rot[x][y] = ((t + 1) * (t + 2) // 2) % 64
+        x, y = y, (2 * x + 3 * y) % 5
+    return RC, rot
+
+
+def limbs51(x):
+    return [(x >> (51 * i)) & (2**51 - 1) for i in range(5)]
+
+
+def limbs52(x):
+    return [(x >> (52 * i)) & (2**52 - 1) for i in range(5)]
+
+
+POS26 = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+BITS26 = [26, 25, 26, 25, 26, 25, 26, 25, 26, 25]
+
+
+def limbs26(x):
+    return [(x >> POS26[i]) & (2 ** BITS26[i] - 1) for i in range(10)]
+
+
+def c_u64(name, ls, comment):
+    return "/* %s */\nstatic const uint64_t %s[5] = { %s };\n" % (
+        comment, name, ", ".join("0x%xULL" % v for v in ls))
+
+
+def c_u32(name, ls, comment):
+    return "/* %s */\n#define %s { %s }\n" % (
+        comment, name, ", ".join("0x%xu" % v for v in ls))
+
+
+def edwards_add(p, q):
+    x1, y1 = p
+    x2, y2 = q
+    dxy = D * x1 * x2 * y1 * y2 % P
+    x3 = (x1 * y2 + x2 * y1) * inv(1 + dxy) % P
+    y3 = (y1 * y2 + x1 * x2) * inv(1 - dxy) % P
+    return (x3, y3)
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    fe = [
+        ("EDWARDS_D", D, "d = -121665/121666"),
+        ("EDWARDS_D2", D2, "2d"),
+        ("SQRT_M1", SQRT_M1, "sqrt(-1), even root"),
+        ("INVSQRT_A_MINUS_D", INVSQRT_A_MINUS_D, "1/sqrt(a-d), a=-1"),
+        ("SQRT_AD_MINUS_ONE", SQRT_AD_MINUS_ONE, "sqrt(ad-1)"),
+        ("ONE_MINUS_EDWARDS_D_SQUARED", ONE_MINUS_D_SQ, "1-d^2"),
+        ("EDWARDS_D_MINUS_ONE_SQUARED", D_MINUS_ONE_SQ, "(d-1)^2"),
+        ("BASEPOINT_X", BX, "Ed25519 basepoint x (even)"),
+        ("BASEPOINT_Y", BY, "Ed25519 basepoint y = 4/5"),
+        ("BASEPOINT_T", BX * BY % P, "x*y of the basepoint"),
+    ]
+    out = ["/* GENERATED by oracle/gen_constants.py -- do not edit. Test infrastructure. */",
+           "#ifndef ORC_CONSTANTS_H", "#define ORC_CONSTANTS_H", "#include <stdint.h>", ""]
+    for name, val, com in fe:
+        out.append(c_u64("ORC_" + name, limbs51(val), com))
+    out.append(c_u64("ORC_SC_L", limbs52(L), "group order l, 52-bit limbs"))
+    out.append(c_u64("ORC_SC_R", limbs52(R), "2^260 mod l"))
+    out.append(c_u64("ORC_SC_RR", limbs52(RR), "2^520 mod l"))
+    out.append("static const uint64_t ORC_SC_LFACTOR = 0x%xULL; /* -1/l mod 2^52 */\n" % LFACTOR)
+    K, H = sha512_constants()
+    out.append("static const uint64_t ORC_SHA512_K[80] = { %s };\n" % ", ".join("0x%016xULL" % v for v in K))
+    out.append("static const uint64_t ORC_SHA512_IV[8] = { %s };\n" % ", ".join("0x%016xULL" % v for v in H))
+    RC, rot = keccak_constants()
+    out.append("static const uint64_t ORC_KECCAK_RC[24] = { %s };\n" % ", ".join("0x%016xULL" % v for v in RC))
+    out.append("/* rotation offsets, index x + 5*y */\nstatic const unsigned ORC_KECCAK_ROT[25] = { %s };\n" % ", ".join(str(rot[i % 5][i // 5]) for i in range(25)))
+    out.append("#endif")
+    with open(os.path.join(here, "constants.h"), "w") as f:
+        f.write("\n".join(out) + "\n")
+
+    dev = ["/* GENERATED by oracle/gen_constants.py -- do not edit.",
+           "   Curve constants as 10 x u32 radix-2^25.5 limbs for the gfx950 device code. */",
+           "#pragma once", ""]
+    for name, val, com in fe:
+        dev.append(c_u32("C25519_" + name + "_26", limbs26(val), com))
+    # l as 8 x u32 little-endian words, and Barrett/Montgomery helpers for the device scalar code
+    dev.append("#define C25519_L_W32 { %s }" % ", ".join("0x%08xu" % ((L >> (32 * i)) & 0xffffffff) for i in range(8)))
+    dev.append("#define C25519_SHA512_K { %s }" % ", ".join("0x%016xULL" % v for v in K))
+    dev.append("#define C25519_SHA512_IV { %s }" % ", ".join("0x%016xULL" % v for v in H))
+    dev.append("")
+    devpath = os.path.join(here, "..", "curve25519-dalek_amd", "csrc", "constants_gen.h")
+    with open(devpath, "w") as f:
+        f.write("\n".join(dev) + "\n")
+
+    # sanity: basepoint has order l, 2B / known facts
+    assert (-BX * BX + BY * BY - 1 - D * BX * BX * BY * BY) % P == 0
+    print("constants written")
+
+
+if __name__ == "__main__":
+    main()
