@@ -1,0 +1,301 @@
+// Host side of libc25519hip.so: context, workspaces, table generation and the extern "C" entry
+// points declared in include/c25519_hip.h.  All arithmetic on the data path runs in the gfx950
+// kernels (kernels.hip, msm.hip); the only curve arithmetic executed on the host is one-time table
+// generation and the O(windows) tail of an MSM, both through the very same fe26/ge26 headers.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/c25519_hip.h"
+#include "ge26.h"
+#include "kernels.h"
+#include "ctx.h"
+
+using namespace c25519;
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------------------------------------
+int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", where, hipGetErrorString(e));
+    ctx->err = buf;
+    return -(int32_t)e;
+}
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes) {
+    if (b.cap >= bytes) return 0;
+    if (b.p) { hipError_t e = hipFree(b.p); b.p = nullptr; b.cap = 0; if (e != hipSuccess) return c25519_fail(ctx, e, "hipFree"); }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return c25519_fail(ctx, e, "hipMalloc(workspace)");
+    b.cap = want;
+    return 0;
+}
+
+// ---- fixed-base table, built by the `create` logic of edwards.rs:1131-1141 -----------------------
+// entry j (1..HALF) of window i = j * 2^(W i) * B, as canonical (y+x, y-x, 2dxy); entry 0 = identity.
+static void build_basepoint_table(int W, std::vector<uint32_t> &out) {
+    const int NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1;
+    std::vector<ge_p3> pts((size_t)NWIN * HALF);
+    ge_p3 base = ge_basepoint();
+    for (int i = 0; i < NWIN; i++) {
+        ge_p3 acc = base;
+        for (int j = 0; j < HALF; j++) {
+            pts[(size_t)i * HALF + j] = acc;
+            acc = ge_add(acc, base);
+        }
+        base = ge_mul_by_pow_2(base, W);
+    }
+    // batch-normalise (Montgomery's trick, field.rs:225-273)
+    size_t m = pts.size();
+    std::vector<feT> pre(m);
+    feT acc = fe_one();
+    for (size_t k = 0; k < m; k++) { pre[k] = acc; acc = fe_mul(acc, pts[k].Z); }
+    feT inv = fe_invert(acc);
+    out.assign((size_t)NWIN * ENT * 24, 0u);
+    std::vector<feT> zinv(m);
+    for (size_t k = m; k-- > 0;) { zinv[k] = fe_mul(inv, pre[k]); inv = fe_mul(inv, pts[k].Z); }
+    for (int i = 0; i < NWIN; i++) {
+        uint32_t *e0 = &out[((size_t)i * ENT) * 24];
+        e0[0] = 1; e0[8] = 1;   // identity: y+x = 1, y-x = 1, 2dxy = 0
+        for (int j = 0; j < HALF; j++) {
+            size_t k = (size_t)i * HALF + j;
+            feT x = fe_mul(pts[k].X, zinv[k]), y = fe_mul(pts[k].Y, zinv[k]);
+            uint32_t *e = &out[((size_t)i * ENT + j + 1) * 24];
+            fe_to_words(fe_add(y, x), e);
+            fe_to_words(fe_sub(y, x), e + 8);
+            fe_to_words(fe_mul(fe_mul(x, y), fe_d2()), e + 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+        fprintf(stderr, "c25519_ctx_create: no usable HIP device %d (count %d) -- this engine has no CPU fallback\n", device, ndev);
+        return nullptr;
+    }
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    c25519_ctx *ctx = new c25519_ctx();
+    ctx->device = device;
+    ctx->flags = flags;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->num_cus = prop.multiProcessorCount;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        fprintf(stderr, "c25519_ctx_create: warning: device arch %s, kernels are built for gfx950 only\n", prop.gcnArchName);
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    ctx->own_stream = true;
+    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
+    int w = (int)(flags & 0xf);
+    ctx->w = (w >= 4 && w <= 6) ? w : 6;
+    std::vector<uint32_t> tab;
+    build_basepoint_table(ctx->w, tab);
+    if (hipMalloc(&ctx->d_table, tab.size() * 4) != hipSuccess ||
+        hipMemcpy(ctx->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMalloc(&ctx->d_flag, 256) != hipSuccess) {
+        fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
+        delete ctx;
+        return nullptr;
+    }
+    return ctx;
+}
+
+EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
+    for (devbuf *b : bufs) if (b->p) hipFree(b->p);
+    if (ctx->d_table) hipFree(ctx->d_table);
+    if (ctx->d_flag) hipFree(ctx->d_flag);
+    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventDestroy(ctx->ring[i][j]);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+EXPORT int32_t c25519_ctx_set_stream(c25519_ctx *ctx, void *hip_stream) {
+    hipSetDevice(ctx->device);
+    if (ctx->own_stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    ctx->stream = (hipStream_t)hip_stream;
+    return C25519_OK;
+}
+EXPORT int32_t c25519_ctx_synchronize(c25519_ctx *ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+EXPORT const char *c25519_last_error(const c25519_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+EXPORT float c25519_last_kernel_ms(c25519_ctx *ctx) {
+    float ms = -1.f;
+    hipSetDevice(ctx->device);
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
+// phase p (0: dominant kernel, 1: the rest) of the call made `back` calls ago (0 = latest)
+EXPORT float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase) {
+    if (back >= ctx->ncalls || back >= (uint32_t)c25519_ctx::RING || phase < 0 || phase > 1) return -1.f;
+    hipSetDevice(ctx->device);
+    hipEvent_t *ev = ctx->ring[(ctx->ncalls - 1 - back) % c25519_ctx::RING];
+    float ms = -1.f;
+    if (hipEventSynchronize(ev[2]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, ev[phase], ev[phase + 1]) != hipSuccess) return -1.f;
+    return ms;
+}
+
+// ---- fixed base --------------------------------------------------------------------------------
+EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_base: out_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    if (out_fmt == C25519_FMT_EDWARDS_Y) {
+        int32_t r;
+        if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    }
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    if (out_fmt == C25519_FMT_RAW160) {
+        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, nullptr, d_out, ctx->num_cus, ctx->stream));
+        HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    } else {
+        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
+        HIPCHK(hipEventRecord(ring[1], ctx->stream));
+        HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ring[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+
+// host-pointer wrapper helper
+struct staged {
+    c25519_ctx *ctx; devbuf &buf; uint8_t *p;
+    staged(c25519_ctx *c, devbuf &b) : ctx(c), buf(b), p(nullptr) {}
+    int32_t up(const void *host, size_t bytes) {
+        int32_t r = ctx_reserve(ctx, buf, bytes ? bytes : 16); if (r) return r;
+        p = (uint8_t *)buf.p;
+        if (bytes) { hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "H2D"); }
+        return 0;
+    }
+    int32_t alloc(size_t bytes) { int32_t r = ctx_reserve(ctx, buf, bytes ? bytes : 16); p = (uint8_t *)buf.p; return r; }
+    int32_t down(void *host, size_t bytes) {
+        if (!bytes) return 0;
+        hipError_t e = hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "D2H");
+        e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "sync");
+        return 0;
+    }
+};
+
+EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    staged in(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
+    int32_t r;
+    if ((r = in.up(scalars, n * 32)) || (r = o.alloc(n * osz))) return r;
+    if ((r = c25519_mul_base_batch_dev(ctx, in.p, n, out_fmt, o.p))) return r;
+    return o.down(out, n * osz);
+}
+
+// ---- X25519 --------------------------------------------------------------------------------------
+EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    HIPCHK(launch_x25519(d_k, d_u, n, d_out, ctx->stream));
+    HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    HIPCHK(hipEventRecord(ring[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    staged a(ctx, ctx->tmp_a), b(ctx, ctx->tmp_b), o(ctx, ctx->tmp_c);
+    int32_t r;
+    if ((r = a.up(k, n * 32)) || (r = b.up(u, n * 32)) || (r = o.alloc(n * 32))) return r;
+    if ((r = c25519_x25519_batch_dev(ctx, a.p, b.p, n, o.p))) return r;
+    return o.down(out, n * 32);
+}
+
+// ---- (de)compression -------------------------------------------------------------------------------
+EXPORT int32_t c25519_decompress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int in_fmt, uint8_t *d_out, uint8_t *d_ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (in_fmt != C25519_FMT_EDWARDS_Y && in_fmt != C25519_FMT_RISTRETTO) { ctx->err = "decompress: in_fmt must be 0 or 1"; return -(int32_t)hipErrorInvalidValue; }
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 4, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_decompress_edwards(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
+    else HIPCHK(launch_decompress_ristretto(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    uint32_t bad = 0;
+    HIPCHK(hipMemcpyAsync(&bad, ctx->d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return bad ? C25519_NONE : C25519_OK;
+}
+EXPORT int32_t c25519_decompress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int in_fmt, uint8_t *out, uint8_t *ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b), k(ctx, ctx->tmp_c);
+    int32_t r;
+    if ((r = a.up(in, n * 32)) || (r = o.alloc(n * 160)) || (r = k.alloc(n))) return r;
+    int32_t st = c25519_decompress_batch_dev(ctx, a.p, n, in_fmt, o.p, k.p);
+    if (st < 0) return st;
+    if ((r = o.down(out, n * 160)) || (r = k.down(ok, n))) return r;
+    return st;
+}
+EXPORT int32_t c25519_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int out_fmt, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RISTRETTO) { ctx->err = "compress: out_fmt must be 0 or 1"; return -(int32_t)hipErrorInvalidValue; }
+    if (out_fmt == C25519_FMT_RISTRETTO) {
+        HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+        HIPCHK(launch_compress_ristretto(d_in, n, d_out, ctx->stream));
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        return C25519_OK;
+    }
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (n < 4096) {
+        HIPCHK(launch_compress_raw(d_in, n, d_out, ctx->stream));
+    } else {
+        HIPCHK(launch_raw_to_p32(d_in, n, (uint32_t *)ctx->scratch.p, ctx->stream));
+        HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int out_fmt, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
+    int32_t r;
+    if ((r = a.up(in, n * 160)) || (r = o.alloc(n * 32))) return r;
+    if ((r = c25519_compress_batch_dev(ctx, a.p, n, out_fmt, o.p))) return r;
+    return o.down(out, n * 32);
+}
+
+// ---- diagnostics -------------------------------------------------------------------------------------
+EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return -1.0;
+    if (ctx_reserve(ctx, ctx->tmp_a, 4096)) return -1.0;
+    hipMemsetAsync(ctx->tmp_a.p, 0x5a, 4096, ctx->stream);
+    unsigned grid = (unsigned)ctx->num_cus * 8;   // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, 16, grid, ctx->stream) != hipSuccess) return -1.0;  // warm-up
+    hipEventRecord(ctx->ev0, ctx->stream);
+    if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, iters, grid, ctx->stream) != hipSuccess) return -1.0;
+    hipEventRecord(ctx->ev1, ctx->stream);
+    float ms = c25519_last_kernel_ms(ctx);
+    if (ms <= 0) return -1.0;
+    double per_lane = (which == 0 || which == 4 || which == 5) ? 8.0 * iters : 2.0 * iters;
+    double total = per_lane * 256.0 * grid;
+    return total / (ms * 1e-3) / 1e9;
+}

@@ -1,0 +1,19 @@
+// Launchers for the gfx950 kernels in kernels.hip / msm.hip (internal to libc25519hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace c25519 {
+
+hipError_t launch_mul_base(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *scratch,
+                           uint8_t *out_raw, int num_cus, hipStream_t st);
+hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_decompress_edwards(const uint8_t *in, uint64_t n, uint8_t *out_raw, uint8_t *ok, uint32_t *any_bad, hipStream_t st);
+hipError_t launch_decompress_ristretto(const uint8_t *in, uint64_t n, uint8_t *out_raw, uint8_t *ok, uint32_t *any_bad, hipStream_t st);
+hipError_t launch_compress_ristretto(const uint8_t *in_raw, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_compress_raw(const uint8_t *in_raw, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_raw_to_p32(const uint8_t *in_raw, uint64_t n, uint32_t *scratch, hipStream_t st);
+hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipStream_t st);
+
+}  // namespace c25519

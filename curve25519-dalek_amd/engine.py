@@ -1,0 +1,266 @@
+"""ctypes binding of libc25519hip.so (include/c25519_hip.h).
+
+PyTorch is plumbing here: device buffers are torch uint8 CUDA tensors, the engine enqueues on
+torch's current stream, and torch.distributed carries the multi-GPU exchange.  The arithmetic is
+all in the HIP library; if it is missing this module raises -- it never falls back to a CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH = 0, 1, 2, 3, 4
+FMT_EDWARDS_Y, FMT_RISTRETTO, FMT_RAW160 = 0, 1, 2
+Z_TRANSCRIPT, Z_DEVICE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libc25519hip.so")
+
+
+def load_library():
+    """Load the HIP library (after torch, so both share one HIP runtime).  Raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EngineError("HIP extension %s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % path)
+    try:
+        import torch  # noqa: F401  (loads libamdhip64 first; our library binds to the same runtime)
+    except Exception:  # pragma: no cover
+        pass
+    lib = C.CDLL(path)
+    vp, u64, i32 = C.c_void_p, C.c_uint64, C.c_int32
+    sigs = {
+        "c25519_ctx_create": (vp, [C.c_int, C.c_uint32]),
+        "c25519_ctx_destroy": (None, [vp]),
+        "c25519_ctx_set_stream": (i32, [vp, vp]),
+        "c25519_ctx_synchronize": (i32, [vp]),
+        "c25519_last_error": (C.c_char_p, [vp]),
+        "c25519_last_kernel_ms": (C.c_float, [vp]),
+        "c25519_phase_ms": (C.c_float, [vp, C.c_uint32, C.c_int]),
+        "c25519_mul_base_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_mul_base_batch": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_x25519_batch_dev": (i32, [vp, vp, vp, u64, vp]),
+        "c25519_x25519_batch": (i32, [vp, vp, vp, u64, vp]),
+        "c25519_decompress_batch_dev": (i32, [vp, vp, u64, C.c_int, vp, vp]),
+        "c25519_decompress_batch": (i32, [vp, vp, u64, C.c_int, vp, vp]),
+        "c25519_compress_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_compress_batch": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_msm_vartime_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
+        "c25519_msm_vartime": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
+        "c25519_msm_partial_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
+        "c25519_fold_partials": (i32, [vp, vp, u64, C.c_int, vp]),
+        "ed25519_verify_batch_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_uint32]),
+        "ed25519_verify_batch": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32]),
+        "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
+        fn.restype, fn.argtypes = res, args
+    _LIB = lib
+    return lib
+
+
+ABI_SYMBOLS = [
+    "c25519_ctx_create", "c25519_ctx_destroy", "c25519_ctx_set_stream", "c25519_ctx_synchronize", "c25519_last_error",
+    "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_mul_base_batch_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
+    "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
+    "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
+    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "c25519_microbench",
+]
+
+_PT = {FMT_EDWARDS_Y: 32, FMT_RISTRETTO: 32, FMT_RAW160: 160}
+
+
+def _np8(x, width):
+    a = np.ascontiguousarray(np.frombuffer(x, dtype=np.uint8) if isinstance(x, (bytes, bytearray)) else x, dtype=np.uint8)
+    return a.reshape(-1, width)
+
+
+class Engine:
+    """One engine = one GPU + one stream (`c25519_ctx`).  Tensor methods (`*_t`) take/return torch
+    uint8 CUDA tensors already resident in HBM; the plain methods take/return numpy arrays / bytes
+    and go through the host-pointer entry points (PCIe copies included)."""
+
+    def __init__(self, device=0, window=6):
+        import torch
+        self.torch = torch
+        self.lib = load_library()
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible to PyTorch-ROCm: the engine has no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.ctx = self.lib.c25519_ctx_create(device, window & 0xf)
+        if not self.ctx:
+            raise EngineError("c25519_ctx_create(%d) failed" % device)
+        self._bind_stream()
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.c25519_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- plumbing ----------------------------------------------------------------------------
+    def _bind_stream(self):
+        st = self.torch.cuda.current_stream(self.device).cuda_stream
+        self.lib.c25519_ctx_set_stream(self.ctx, C.c_void_p(st))
+
+    def _chk(self, st, allowed=(OK,)):
+        if st < 0:
+            raise EngineError("HIP error %d: %s" % (-st, self.lib.c25519_last_error(self.ctx).decode()))
+        if st not in allowed:
+            raise EngineError("unexpected status %d" % st)
+        return st
+
+    def _t(self, t, width):
+        torch = self.torch
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous(), "need a contiguous uint8 CUDA tensor"
+        assert t.numel() % width == 0
+        assert t.data_ptr() % 16 == 0, "device buffers must be 16-byte aligned"
+        return t.numel() // width
+
+    def synchronize(self):
+        self._chk(self.lib.c25519_ctx_synchronize(self.ctx))
+
+    def last_kernel_ms(self):
+        return float(self.lib.c25519_last_kernel_ms(self.ctx))
+
+    def phase_ms(self, back=0, phase=0):
+        return float(self.lib.c25519_phase_ms(self.ctx, back, phase))
+
+    def microbench(self, which, iters=2000):
+        self._bind_stream()
+        return float(self.lib.c25519_microbench(self.ctx, which, iters))
+
+    # -- device-tensor API -------------------------------------------------------------------
+    def mul_base_batch_t(self, scalars, out_fmt=FMT_EDWARDS_Y, out=None):
+        n = self._t(scalars, 32)
+        if out is None:
+            out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_base_batch_dev(self.ctx, scalars.data_ptr(), n, out_fmt, out.data_ptr()))
+        return out
+
+    def x25519_batch_t(self, k, u, out=None):
+        n = self._t(k, 32)
+        assert self._t(u, 32) == n
+        if out is None:
+            out = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_x25519_batch_dev(self.ctx, k.data_ptr(), u.data_ptr(), n, out.data_ptr()))
+        return out
+
+    def decompress_batch_t(self, enc, in_fmt=FMT_EDWARDS_Y):
+        n = self._t(enc, 32)
+        pts = self.torch.empty((n, 160), dtype=self.torch.uint8, device=self.device)
+        ok = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_decompress_batch_dev(self.ctx, enc.data_ptr(), n, in_fmt, pts.data_ptr(), ok.data_ptr()), (OK, NONE))
+        return st, pts, ok
+
+    def compress_batch_t(self, pts, out_fmt=FMT_EDWARDS_Y):
+        n = self._t(pts, 160)
+        out = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_compress_batch_dev(self.ctx, pts.data_ptr(), n, out_fmt, out.data_ptr()))
+        return out
+
+    def msm_vartime_t(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        """-> (status, bytes).  status NONE mirrors Option::None of the reference."""
+        n = self._t(scalars, 32)
+        assert self._t(points, _PT[in_fmt]) == n
+        out = C.create_string_buffer(_PT[out_fmt])
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_msm_vartime_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out_fmt, out), (OK, NONE))
+        return st, out.raw
+
+    def msm_partial_t(self, scalars, points, in_fmt=FMT_RAW160):
+        n = self._t(scalars, 32)
+        assert self._t(points, _PT[in_fmt]) == n
+        out = C.create_string_buffer(160)
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_msm_partial_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out), (OK, NONE))
+        return st, out.raw
+
+    def fold_partials(self, partials, out_fmt=FMT_EDWARDS_Y):
+        blob = b"".join(partials)
+        out = C.create_string_buffer(_PT[out_fmt])
+        self._chk(self.lib.c25519_fold_partials(self.ctx, blob, len(partials), out_fmt, out))
+        return out.raw
+
+    def verify_batch_t(self, msgs, msg_off, sigs, pks, z_mode=Z_DEVICE):
+        """msgs: uint8 CUDA tensor of the concatenated messages; msg_off: int64/uint64 CUDA tensor (n+1)."""
+        n = self._t(sigs, 64)
+        assert self._t(pks, 32) == n and msg_off.numel() == n + 1
+        self._bind_stream()
+        return self._chk(self.lib.ed25519_verify_batch_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(),
+                                                           sigs.data_ptr(), pks.data_ptr(), n, z_mode),
+                         (OK, NONE, SCALAR_FORMAT, VERIFY))
+
+    # -- host-buffer API (numpy in / numpy out) ---------------------------------------------------
+    def mul_base_batch(self, scalars, out_fmt=FMT_EDWARDS_Y):
+        s = _np8(scalars, 32); n = s.shape[0]
+        out = np.empty((n, _PT[out_fmt]), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_base_batch(self.ctx, s.ctypes.data, n, out_fmt, out.ctypes.data))
+        return out
+
+    def x25519_batch(self, k, u):
+        k = _np8(k, 32); u = _np8(u, 32); n = k.shape[0]
+        assert u.shape[0] == n
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_x25519_batch(self.ctx, k.ctypes.data, u.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def decompress_batch(self, enc, in_fmt=FMT_EDWARDS_Y):
+        e = _np8(enc, 32); n = e.shape[0]
+        pts = np.empty((n, 160), dtype=np.uint8); ok = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_decompress_batch(self.ctx, e.ctypes.data, n, in_fmt, pts.ctypes.data, ok.ctypes.data), (OK, NONE))
+        return st, pts, ok
+
+    def compress_batch(self, pts, out_fmt=FMT_EDWARDS_Y):
+        p = _np8(pts, 160); n = p.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_compress_batch(self.ctx, p.ctypes.data, n, out_fmt, out.ctypes.data))
+        return out
+
+    def msm_vartime(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        s = _np8(scalars, 32); p = _np8(points, _PT[in_fmt]); n = s.shape[0]
+        assert p.shape[0] == n
+        out = C.create_string_buffer(_PT[out_fmt])
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_msm_vartime(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out), (OK, NONE))
+        return st, out.raw
+
+    def verify_batch(self, msgs, sigs, pks, z_mode=Z_TRANSCRIPT):
+        """msgs: list of bytes; sigs: list of 64-byte; pks: list of 32-byte.  Status code out."""
+        if not (len(msgs) == len(sigs) == len(pks)):
+            return ARRAY_LENGTH  # batch.rs:152-165
+        n = len(msgs)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        for i, m in enumerate(msgs):
+            off[i + 1] = off[i] + len(m)
+        blob = np.frombuffer(b"".join(msgs) + b"\0" * 16, dtype=np.uint8)
+        s = _np8(b"".join(sigs) if n else b"", 64) if n else np.zeros((0, 64), np.uint8)
+        p = _np8(b"".join(pks) if n else b"", 32) if n else np.zeros((0, 32), np.uint8)
+        self._bind_stream()
+        return self._chk(self.lib.ed25519_verify_batch(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, z_mode),
+                         (OK, NONE, SCALAR_FORMAT, VERIFY))

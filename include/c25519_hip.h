@@ -1,0 +1,133 @@
+/* c25519_hip.h -- C ABI of libc25519hip.so, the MI355X (gfx950) batched Curve25519 engine.
+ *
+ * Drop-in boundary for the hot path of dalek-cryptography/curve25519-dalek.  The
+ * reference has no FFI; the seam these entry points serve is its internal backend switch
+ * (curve25519-dalek/src/backend.rs:45-277) plus the three callers that bypass it
+ * (edwards.rs:1192 mul_base, montgomery.rs:183 mul_bits_be, ed25519-dalek/src/batch.rs:146
+ * verify_batch).  INTEGRATION.md shows the Rust `extern "C"` block and the BackendKind::Hip arm a
+ * maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes; all buffers caller-owned, contiguous, little-endian; nothing is
+ *     retained after return.
+ *   - `_dev` entry points take DEVICE pointers (HBM) and enqueue on the context's HIP stream;
+ *     those that return a verdict/point to the host synchronise that stream.  The un-suffixed
+ *     twins take HOST pointers and do the H2D/D2H copies themselves.
+ *   - return value: int32 status.  0 OK; 1 NONE (a point failed to decompress: the Rust side maps
+ *     it to Option::None); 2 SCALAR_FORMAT; 3 VERIFY; 4 ARRAY_LENGTH (mirrors
+ *     ed25519-dalek/src/errors.rs:21-42 InternalError); negative = -(hipError_t) runtime failure.
+ *   - point formats (`fmt`): 0 = 32-byte CompressedEdwardsY (edwards.rs:175),
+ *     1 = 32-byte CompressedRistretto (ristretto.rs:223),
+ *     2 = 160-byte raw EdwardsPoint {X,Y,Z,T} x 5 x u64 radix-2^51 limbs, every limb < 2^52
+ *         (edwards.rs:390-395 is not repr(C); the Rust shim copies limb-by-limb into this layout).
+ *   - scalars: 32 bytes little-endian, < 2^255 (Scalar invariant #1, scalar.rs:197-205); they need
+ *     NOT be reduced mod l for point multiplication (clamped integers are legal).
+ *   - a context is bound to one GPU and one stream; calls on one context must not overlap.
+ *     Results never depend on which GPU ran them.
+ */
+#ifndef C25519_HIP_H
+#define C25519_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C25519_OK 0
+#define C25519_NONE 1
+#define C25519_SCALAR_FORMAT 2
+#define C25519_VERIFY 3
+#define C25519_ARRAY_LENGTH 4
+
+#define C25519_FMT_EDWARDS_Y 0
+#define C25519_FMT_RISTRETTO 1
+#define C25519_FMT_RAW160 2
+
+/* ed25519_verify_batch z_mode: how the 128-bit batch coefficients z_i are derived */
+#define C25519_Z_TRANSCRIPT 0 /* byte-for-byte the reference's Merlin/STROBE transcript (batch.rs:168-222), host-sequential */
+#define C25519_Z_DEVICE 1     /* per-signature SHA-512 counter mode keyed by a digest of the whole batch, on device */
+
+typedef struct c25519_ctx c25519_ctx;
+
+/* Create a context on HIP device `device` (>= 0).  Builds the fixed-base table (the `create` logic
+ * of edwards.rs:1131-1141, window width chosen for the 160 KiB LDS) and uploads it.  Returns NULL
+ * if there is no usable GPU: there is NO CPU fallback. */
+c25519_ctx *c25519_ctx_create(int device, uint32_t flags);
+void c25519_ctx_destroy(c25519_ctx *ctx);
+/* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the context's own. */
+int32_t c25519_ctx_set_stream(c25519_ctx *ctx, void *hip_stream);
+/* Block until everything enqueued on the context's stream has finished. */
+int32_t c25519_ctx_synchronize(c25519_ctx *ctx);
+const char *c25519_last_error(const c25519_ctx *ctx);
+/* milliseconds the device spent in the most recent entry point's kernels (hipEvent pair on the
+ * context's stream); valid after the call returned / the stream was synchronised. */
+float c25519_last_kernel_ms(c25519_ctx *ctx);
+/* Per-call phase timing from a ring of hipEvents recorded on the context's stream (the last 64
+ * calls): phase 0 = the dominant kernel of the call made `back` calls ago (0 = most recent),
+ * phase 1 = the kernels after it (e.g. batched compression).  Synchronises that call's last event.
+ * Recorded by c25519_mul_base_batch_dev, c25519_x25519_batch_dev, c25519_msm_*_dev and
+ * ed25519_verify_batch_dev.  Returns -1 if unavailable. */
+float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase);
+
+/* ---- fixed base: out[i] = scalars[i] * B ------------------------------------------------------
+ * replaces EdwardsBasepointTable::mul_base / EdwardsPoint::mul_base (edwards.rs:918, :1192-1209),
+ * followed by compress (edwards.rs:615 / :634 batch) when out_fmt is 0 or 1.
+ * scalars: n x 32;  out: n x 32 (fmt 0/1) or n x 160 (fmt 2). */
+int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out);
+int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out);
+
+/* ---- X25519: out[i] = x25519(k[i], u[i]) -------------------------------------------------------
+ * replaces x25519-dalek/src/x25519.rs:390 = MontgomeryPoint(u).mul_clamped(k) (montgomery.rs:150,
+ * :183-211): k is clamped inside, bit 255 of u ignored, u >= p reduced, low-order u -> all-zero. */
+int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out);
+int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out);
+
+/* ---- (de)compression ------------------------------------------------------------------------------
+ * decompress: CompressedEdwardsY::decompress (edwards.rs:211-258, ZIP-215 rules) for in_fmt 0,
+ * CompressedRistretto::decompress (ristretto.rs:266-345) for in_fmt 1.
+ * in: n x 32; out: n x 160 raw points (unspecified where ok[i] == 0); ok: n bytes (1 = Some).
+ * Returns C25519_NONE if any ok[i] == 0, else C25519_OK (ok[] tells which). */
+int32_t c25519_decompress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int in_fmt, uint8_t *d_out, uint8_t *d_ok);
+int32_t c25519_decompress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int in_fmt, uint8_t *out, uint8_t *ok);
+/* compress: EdwardsPoint::compress_batch (edwards.rs:621-647) for out_fmt 0,
+ * RistrettoPoint::compress (ristretto.rs:500-533) for out_fmt 1.  in: n x 160 raw; out: n x 32. */
+int32_t c25519_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int out_fmt, uint8_t *d_out);
+int32_t c25519_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int out_fmt, uint8_t *out);
+
+/* ---- variable-time multiscalar multiplication: out = sum scalars[i] * points[i] -----------------
+ * replaces backend::pippenger_optional_multiscalar_mul / straus_optional_multiscalar_mul
+ * (backend.rs:79, :224; edwards.rs:1002-1031; ristretto.rs:984).  points: n x 32 (fmt 0/1) or
+ * n x 160 (fmt 2).  `out` is a HOST pointer (32 or 160 bytes) in both variants; the call
+ * synchronises.  Returns C25519_NONE iff some point fails to decompress (Option::None of the
+ * reference); n == 0 gives the identity. */
+int32_t c25519_msm_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
+int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
+/* Multi-GPU building block: this rank's partial sum as a raw 160-byte point (no final compress),
+ * and the fold of `count` partial points gathered from all ranks.  Both are
+ * deterministic functions of their inputs. */
+int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160);
+int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64_t count, int out_fmt, uint8_t *out);
+
+/* ---- ed25519_dalek::verify_batch (ed25519-dalek/src/batch.rs:146-251) ---------------------------
+ * msgs: concatenated messages; msg_off: n+1 offsets into msgs (u64); sigs: n x 64; pks: n x 32.
+ * Error precedence as in the reference: a public key that does not decompress -> C25519_NONE (the
+ * reference fails earlier, at VerifyingKey::from_bytes, verifying.rs:167); any non-canonical s ->
+ * SCALAR_FORMAT; any R that does not decompress, or a non-identity result -> VERIFY.
+ * (ARRAY_LENGTH is raised by the host-language wrapper, which owns the three lengths.) */
+int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                 const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode);
+int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
+                             const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint32_t z_mode);
+
+/* ---- diagnostics ----------------------------------------------------------------------------------
+ * Integer-multiplier roofline probes: runs a dependent-free chain microbenchmark and
+ * returns giga-operations per second.  which: 0 v_mad_u64_u32, 1 fe_mul (radix 2^25.5, this
+ * engine), 2 fe_sq, 3 fe_mul written on 5 x u64 limbs with unsigned __int128 products (the
+ * reference's literal layout, for the A/B in DESIGN.md), 4 v_add_u32, 5 v_mul_lo_u32. */
+double c25519_microbench(c25519_ctx *ctx, int which, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

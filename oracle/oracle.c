@@ -4,7 +4,7 @@
  * Exported C API (ctypes) over the CPU restatement of the reference's serial u64 path.
  * PARITY PINNING: the reference is Rust and cannot be built here (no rustc/cargo), so there is no
  * oracle/_ref.  The restatement is pinned against the reference's own golden vectors
- * (tests/golden/*, extracted by tests/golden/extract_vectors.py from /root/reference) -- see
+ * (tests/golden/, extracted by tests/golden/extract_vectors.py from /root/reference) -- see
  * tests/test_oracle_*.py.  The only unpinned piece is the z_i derivation of verify_batch
  * (STROBE transcript): the reference holds no byte-level vector for it ("parity unpinned" for z).
  */

@@ -1,0 +1,65 @@
+// Host build of the DEVICE headers (fe26.h / ge26.h are __host__ __device__) with bound checking
+// enabled, so the exact arithmetic the HIP kernels run can be fuzzed on a machine with no GPU.
+// Test-only: built by tests/test_fe26_host.py into tests/host/libfe26host.so.
+#define C25519_CHECK_BOUNDS 1
+#include "../../curve25519-dalek_amd/csrc/ge26.h"
+#include <string.h>
+using namespace c25519;
+
+static feT load(const uint8_t b[32]) { u32 w[8]; memcpy(w, b, 32); return fe_from_words(w); }
+static void store(uint8_t b[32], const feW &a) { u32 w[8]; fe_to_words(a, w); memcpy(b, w, 32); }
+
+extern "C" {
+void h_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *o) { store(o, fe_mul(load(a), load(b))); }
+void h_fe_sq(const uint8_t *a, uint8_t *o) { store(o, fe_sq(load(a))); }
+void h_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *o) { store(o, fe_add(load(a), load(b))); }
+void h_fe_sub(const uint8_t *a, const uint8_t *b, uint8_t *o) { store(o, fe_sub(load(a), load(b))); }
+void h_fe_invert(const uint8_t *a, uint8_t *o) { store(o, fe_invert(load(a))); }
+void h_fe_pow_p58(const uint8_t *a, uint8_t *o) { store(o, fe_pow_p58(load(a))); }
+void h_fe_canon(const uint8_t *a, uint8_t *o) { store(o, load(a)); }
+void h_fe_mul_small(const uint8_t *a, uint32_t c, uint8_t *o) { store(o, fe_mul_small(load(a), c)); }
+// raw-limb entry points: f wide-bounded, g loose-bounded
+void h_fe_mul_limbs(const uint32_t *f, const uint32_t *g, uint8_t *o) {
+    feW F; feL G; for (int i = 0; i < 10; i++) { F.v[i] = f[i]; G.v[i] = g[i]; }
+    store(o, fe_mul(F, G));
+}
+void h_fe_sq_limbs(const uint32_t *f, uint8_t *o) { feL F; for (int i = 0; i < 10; i++) F.v[i] = f[i]; store(o, fe_sq(F)); }
+void h_fe_carry_limbs(const uint32_t *f, uint8_t *o) { feW F; for (int i = 0; i < 10; i++) F.v[i] = f[i]; store(o, fe_carry(F)); }
+void h_fe_tobytes_limbs(const uint32_t *f, uint8_t *o) { feW F; for (int i = 0; i < 10; i++) F.v[i] = f[i]; store(o, F); }
+int h_fe_sqrt_ratio_i(const uint8_t *u, const uint8_t *v, uint8_t *o) { feT r; bool ok = fe_sqrt_ratio_i(r, load(u), load(v)); store(o, r); return ok; }
+
+// points: 4 x 32 canonical bytes (X,Y,Z,T)
+static ge_p3 pload(const uint8_t *p) { ge_p3 r; r.X = load(p); r.Y = load(p + 32); r.Z = load(p + 64); r.T = load(p + 96); return r; }
+static void pstore(uint8_t *p, const ge_p3 &r) { store(p, r.X); store(p + 32, r.Y); store(p + 64, r.Z); store(p + 96, r.T); }
+void h_ge_basepoint(uint8_t *o) { pstore(o, ge_basepoint()); }
+void h_ge_identity(uint8_t *o) { pstore(o, ge_identity()); }
+void h_ge_add(const uint8_t *a, const uint8_t *b, uint8_t *o) { pstore(o, ge_add(pload(a), pload(b))); }
+void h_ge_dbl(const uint8_t *a, uint8_t *o) { pstore(o, ge_dbl_p3(pload(a))); }
+void h_ge_neg(const uint8_t *a, uint8_t *o) { pstore(o, ge_neg(pload(a))); }
+void h_ge_mul_by_pow_2(const uint8_t *a, int k, uint8_t *o) { pstore(o, ge_mul_by_pow_2(pload(a), k)); }
+int h_ge_eq(const uint8_t *a, const uint8_t *b) { return ge_eq(pload(a), pload(b)); }
+int h_ge_is_identity(const uint8_t *a) { return ge_is_identity(pload(a)); }
+int h_ge_decompress(const uint8_t *in, uint8_t *o) { u32 w[8]; memcpy(w, in, 32); ge_p3 p; bool ok = ge_decompress(p, w); pstore(o, p); return ok; }
+void h_ge_compress(const uint8_t *a, uint8_t *o) {
+    ge_p3 p = pload(a); feT zi = fe_invert(p.Z);
+    u32 w[8]; ge_affine_compress(fe_mul(p.X, zi), fe_mul(p.Y, zi), w); memcpy(o, w, 32);
+}
+// p +/- q where q is given as an extended point with Z = 1 (converted to affine Niels here)
+void h_ge_madd(const uint8_t *a, const uint8_t *q, int neg, uint8_t *o) {
+    ge_p3 Q = pload(q); ge_aniels n;
+    n.ypx = fe_carry(fe_add(Q.Y, Q.X)); n.ymx = fe_carry(fe_sub(Q.Y, Q.X)); n.xy2d = fe_mul(Q.T, fe_d2());
+    pstore(o, ge_p1p1_to_p3(ge_madd(pload(a), n, neg != 0)));
+}
+// X25519 ladder exactly as the kernel runs it (montgomery.rs:183-211), s = already-clamped scalar
+void h_x25519_ladder(const uint8_t *s, const uint8_t *u, uint8_t *o) {
+    feT au = load(u); mont_pp x0, x1; x0.U = fe_one(); x0.W = fe_zero(); x1.U = au; x1.W = fe_one();
+    u32 prev = 0;
+    for (int i = 254; i >= 0; i--) {
+        u32 cur = (s[i >> 3] >> (i & 7)) & 1;
+        u32 sw = prev ^ cur; fe_cswap(x0.U, x1.U, sw); fe_cswap(x0.W, x1.W, sw);
+        mont_diff_add_and_double(x0, x1, au); prev = cur;
+    }
+    fe_cswap(x0.U, x1.U, prev); fe_cswap(x0.W, x1.W, prev);
+    store(o, fe_mul(x0.U, fe_invert(x0.W)));
+}
+}

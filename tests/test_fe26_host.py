@@ -1,0 +1,174 @@
+"""CPU fuzz of the DEVICE arithmetic headers (curve25519-dalek_amd/csrc/fe26.h, ge26.h).
+
+The headers are __host__ __device__; tests/host/fe26_host.cpp builds them for the host with
+C25519_CHECK_BOUNDS, so every limb-bound assumption documented in fe26.h aborts the process if it
+is violated.  Each operation is compared with the oracle (same inputs) and with Python big-ints, at
+random points AND at the extreme limb values each bound class allows.  No GPU needed.
+"""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import pytest
+
+import pyref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2**255 - 19
+L = 2**252 + 27742317777372353535851937790883648493
+POS = [0, 26, 51, 77, 102, 128, 153, 179, 204, 230]
+T_EVEN, T_ODD = (1 << 26) + (1 << 19), (1 << 25) + (1 << 19)
+L_EVEN, L_ODD = 204010946, 102005473
+W_EVEN, W_ODD = 1 << 29, 1 << 28
+
+
+def i2b(x):
+    return int(x).to_bytes(32, "little")
+
+
+def b2i(b):
+    return int.from_bytes(b, "little")
+
+
+@pytest.fixture(scope="module")
+def host():
+    src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
+    so = os.path.join(ROOT, "tests", "host", "libfe26host.so")
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "constants_gen.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+    return C.CDLL(so)
+
+
+def call(host, name, *args, out=32):
+    o = C.create_string_buffer(out)
+    getattr(host, name)(*args, o)
+    return o.raw
+
+
+def limbs_val(l):
+    return sum(v << POS[i] for i, v in enumerate(l))
+
+
+def rand_limbs(rng, emax, omax, extreme):
+    out = []
+    for i in range(10):
+        m = omax if i & 1 else emax
+        out.append(m if (extreme and rng.random() < 0.7) else rng.randrange(m + 1))
+    return out
+
+
+def test_field_ops_vs_bigint_and_oracle(host, orc):
+    rng = random.Random(100)
+    edge = [0, 1, 2, 19, P - 1, P, P + 1, 2**255 - 1, 2**255 - 19 + 18, 2**256 - 1, (1 << 255) - 20]
+    vals = edge + [rng.getrandbits(256) for _ in range(300)]
+    for a in vals:
+        ab = i2b(a); am = (a & (2**255 - 1)) % P
+        assert b2i(call(host, "h_fe_canon", ab)) == am
+        assert b2i(call(host, "h_fe_sq", ab)) == am * am % P
+        for b in (rng.choice(vals), rng.getrandbits(256)):
+            bb = i2b(b); bm = (b & (2**255 - 1)) % P
+            assert b2i(call(host, "h_fe_mul", ab, bb)) == am * bm % P
+            assert call(host, "h_fe_mul", ab, bb) == orc.fe_mul(ab, bb)
+            assert b2i(call(host, "h_fe_add", ab, bb)) == (am + bm) % P
+            assert b2i(call(host, "h_fe_sub", ab, bb)) == (am - bm) % P
+        assert b2i(call(host, "h_fe_mul_small", ab, C.c_uint32(121666))) == am * 121666 % P
+    for a in edge + [rng.getrandbits(255) for _ in range(20)]:
+        am = (a & (2**255 - 1)) % P
+        assert b2i(call(host, "h_fe_invert", i2b(a))) == pow(am, P - 2, P)
+        assert call(host, "h_fe_pow_p58", i2b(a)) == orc.fe_pow_p58(i2b(a))
+
+
+def test_mul_sq_at_bound_extremes(host):
+    """fe_mul(f wide, g loose), fe_sq(loose), fe_carry / to_bytes of anything < 2^32."""
+    rng = random.Random(101)
+    A10 = C.c_uint32 * 10
+    for it in range(400):
+        extreme = it % 2 == 0
+        f = rand_limbs(rng, W_EVEN, W_ODD, extreme); g = rand_limbs(rng, L_EVEN, L_ODD, extreme)
+        assert b2i(call(host, "h_fe_mul_limbs", A10(*f), A10(*g))) == limbs_val(f) * limbs_val(g) % P
+        s = rand_limbs(rng, L_EVEN, L_ODD, extreme)
+        assert b2i(call(host, "h_fe_sq_limbs", A10(*s))) == limbs_val(s) ** 2 % P
+        x = rand_limbs(rng, 2**32 - 1, 2**32 - 1, extreme)
+        assert b2i(call(host, "h_fe_carry_limbs", A10(*x))) == limbs_val(x) % P
+        assert b2i(call(host, "h_fe_tobytes_limbs", A10(*x))) == limbs_val(x) % P
+    allmax_f = [W_ODD if i & 1 else W_EVEN for i in range(10)]
+    allmax_g = [L_ODD if i & 1 else L_EVEN for i in range(10)]
+    assert b2i(call(host, "h_fe_mul_limbs", A10(*allmax_f), A10(*allmax_g))) == limbs_val(allmax_f) * limbs_val(allmax_g) % P
+    assert b2i(call(host, "h_fe_sq_limbs", A10(*allmax_g))) == limbs_val(allmax_g) ** 2 % P
+    # values just around p and 2p in limb form
+    for v in (P - 1, P, P + 1, 2 * P - 1, 2 * P, 2 * P + 1, 2**255 - 1, 2**255, 2**256 - 38):
+        l = [(v >> POS[i]) & ((1 << (25 if i & 1 else 26)) - 1) for i in range(9)] + [v >> 230]
+        assert b2i(call(host, "h_fe_tobytes_limbs", A10(*l))) == v % P
+
+
+def test_sqrt_ratio_and_decompress_vs_oracle(host, orc):
+    rng = random.Random(102)
+    cases = [(0, 0), (1, 0), (2, 1), (4, 1), (1, 4), (0, 5)] + [(rng.getrandbits(255), rng.getrandbits(255)) for _ in range(40)]
+    for u, v in cases:
+        o = C.create_string_buffer(32)
+        ok = host.h_fe_sqrt_ratio_i(i2b(u), i2b(v), o)
+        ook, oval = orc.fe_sqrt_ratio_i(i2b(u), i2b(v))
+        assert bool(ok) == ook and o.raw == oval
+    encs = [i2b(1), i2b(0), i2b(P + 1), i2b(2**255 + 1), i2b(2**256 - 1), i2b(2)] + [i2b(rng.getrandbits(256)) for _ in range(120)]
+    for e in encs:
+        o = C.create_string_buffer(128)
+        ok = host.h_ge_decompress(e, o)
+        want = orc.ed_decompress(e)
+        assert bool(ok) == (want is not None)
+        if ok:
+            assert call(host, "h_ge_compress", o.raw) == orc.ed_compress(want)
+
+
+def test_point_formulas_vs_oracle(host, orc):
+    rng = random.Random(103)
+
+    def to_host(p160):  # oracle 160-byte limb blob -> 4 x 32 canonical bytes
+        X, Y, Z, T = (p160[40 * i:40 * i + 40] for i in range(4))
+        def canon(l40):
+            limbs = [int.from_bytes(l40[8 * i:8 * i + 8], "little") for i in range(5)]
+            return i2b(sum(v << (51 * i) for i, v in enumerate(limbs)) % P)
+        return canon(X) + canon(Y) + canon(Z) + canon(T)
+
+    B = call(host, "h_ge_basepoint", out=128)
+    assert call(host, "h_ge_compress", B) == orc.ed_compress(orc.ed_basepoint())
+    assert host.h_ge_is_identity(call(host, "h_ge_identity", out=128))
+    pts = []
+    for _ in range(12):
+        k = rng.randrange(L)
+        po = orc.ed_mul_base(i2b(k))
+        pts.append((po, to_host(po)))
+    for (ao, ah) in pts[:6]:
+        for (bo, bh) in pts[6:]:
+            assert call(host, "h_ge_compress", call(host, "h_ge_add", ah, bh, out=128)) == orc.ed_compress(orc.ed_add(ao, bo))
+        assert call(host, "h_ge_compress", call(host, "h_ge_dbl", ah, out=128)) == orc.ed_compress(orc.ed_double(ao))
+        assert call(host, "h_ge_compress", call(host, "h_ge_neg", ah, out=128)) == orc.ed_compress(orc.ed_neg(ao))
+        assert call(host, "h_ge_compress", call(host, "h_ge_mul_by_pow_2", ah, C.c_int(6), out=128)) == orc.ed_compress(orc.ed_mul_by_pow_2(ao, 6))
+        # exceptional-looking operands go through the same complete formulas
+        assert host.h_ge_is_identity(call(host, "h_ge_add", ah, call(host, "h_ge_neg", ah, out=128), out=128))
+        assert call(host, "h_ge_compress", call(host, "h_ge_add", ah, ah, out=128)) == orc.ed_compress(orc.ed_double(ao))
+        assert host.h_ge_eq(call(host, "h_ge_add", ah, call(host, "h_ge_identity", out=128), out=128), ah)
+    # mixed add/sub with an affine (Z=1) operand
+    for (ao, ah) in pts[:5]:
+        q = orc.ed_decompress(orc.ed_compress(pts[7][0]))  # affine copy, Z = 1
+        qh = to_host(q)
+        assert call(host, "h_ge_compress", call(host, "h_ge_madd", ah, qh, C.c_int(0), out=128)) == orc.ed_compress(orc.ed_add(ao, q))
+        assert call(host, "h_ge_compress", call(host, "h_ge_madd", ah, qh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, q))
+    # a long chain (the reference's overflow hunt, edwards.rs:2254-2261): 300 chained doublings+adds
+    acc_h, acc_o = pts[0][1], pts[0][0]
+    for i in range(300):
+        acc_h = call(host, "h_ge_dbl", acc_h, out=128); acc_o = orc.ed_double(acc_o)
+        acc_h = call(host, "h_ge_add", acc_h, pts[i % 12][1], out=128); acc_o = orc.ed_add(acc_o, pts[i % 12][0])
+    assert call(host, "h_ge_compress", acc_h) == orc.ed_compress(acc_o)
+
+
+def test_ladder_vs_oracle(host, orc, golden):
+    rng = random.Random(104)
+    cases = [(golden.bytes("x25519_tests.rs", "input_scalar", fn="rfc7748_ladder_test1_vectorset1"),
+              golden.bytes("x25519_tests.rs", "input_point", fn="rfc7748_ladder_test1_vectorset1"))]
+    cases += [(i2b(rng.getrandbits(256)), i2b(rng.getrandbits(256))) for _ in range(25)]
+    cases += [(i2b(rng.getrandbits(256)), golden.bytes("src/constants.rs", "X25519_LOW_ORDER_POINTS", i)) for i in range(7)]
+    for k, u in cases:
+        s = orc.sc_clamp(k)
+        assert call(host, "h_x25519_ladder", s, u) == orc.x25519(k, u) == pyref.x25519(k, u)

@@ -1,0 +1,143 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against the CPU oracle on the same seeded inputs -- bit-exact on canonical encodings / flags.
+Nothing here reads /root/reference."""
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import curve25519_dalek_amd as pkg
+    return pkg.Engine(0)
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_microbench_reports(eng):
+    names = ["v_mad_u64_u32", "fe_mul(2^25.5)", "fe_sq", "fe_mul(5x51,u128)", "v_add_u32", "v_mul_lo_u32"]
+    for i, nm in enumerate(names):
+        r = eng.microbench(i, 4000)
+        print("MICROBENCH %-20s %10.1f Gop/s" % (nm, r))
+        assert r > 1.0
+
+
+@pytest.mark.parametrize("window", [4, 5, 6])
+def test_mul_base_vs_oracle(orc, window):
+    import curve25519_dalek_amd as pkg
+    e = pkg.Engine(0, window=window)
+    s = np.concatenate([util.edge_scalars(), util.rand_scalars(11, 3000), util.rand_bytes(12, 500) & np.uint8(0xFF)])
+    s[-500:, 31] &= 0x7F   # unreduced but < 2^255
+    got = e.mul_base_batch(s)
+    want = orc.mul_base_compress_batch(s, threads=8)
+    assert np.array_equal(got, want)
+    # raw 160-byte output: compare through the reference's compress
+    raw = e.mul_base_batch(s[:300], out_fmt=2)
+    assert [orc.ed_compress(raw[i].tobytes()) for i in range(300)] == [want[i].tobytes() for i in range(300)]
+    # empty batch
+    assert e.mul_base_batch(np.zeros((0, 32), np.uint8)).shape == (0, 32)
+    e.close()
+
+
+def test_mul_base_full_size_2p20(eng, orc, torch):
+    """BASELINE configs[1] at full size: 2^20 scalars; sampled bit-exact check + two independent
+    table configurations agree everywhere (window 6 vs window 5)."""
+    import curve25519_dalek_amd as pkg
+    n = 1 << 20
+    s = util.rand_scalars(21, n)
+    ds = dev(torch, s)
+    out6 = eng.mul_base_batch_t(ds).cpu().numpy()
+    e5 = pkg.Engine(0, window=5)
+    out5 = e5.mul_base_batch_t(ds).cpu().numpy()
+    e5.close()
+    assert np.array_equal(out6, out5)
+    idx = np.random.default_rng(5).choice(n, 4096, replace=False)
+    want = orc.mul_base_compress_batch(s[idx], threads=8)
+    assert np.array_equal(out6[idx], want)
+
+
+def test_x25519_vs_oracle(eng, orc, golden):
+    f = "x25519_tests.rs"
+    ks = [golden.bytes(f, "input_scalar", fn="rfc7748_ladder_test1_vectorset1"), golden.bytes(f, "input_scalar", fn="rfc7748_ladder_test1_vectorset2"),
+          golden.bytes(f, "ALICE_PRIVATE_KEY"), golden.bytes(f, "BOB_PRIVATE_KEY")]
+    us = [golden.bytes(f, "input_point", fn="rfc7748_ladder_test1_vectorset1"), golden.bytes(f, "input_point", fn="rfc7748_ladder_test1_vectorset2"),
+          golden.bytes(f, "BOB_PUBLIC_KEY"), golden.bytes(f, "ALICE_PUBLIC_KEY")]
+    exp = [golden.bytes(f, "expected", fn="rfc7748_ladder_test1_vectorset1"), golden.bytes(f, "expected", fn="rfc7748_ladder_test1_vectorset2"),
+           golden.bytes(f, "SHARED_SECRET"), golden.bytes(f, "SHARED_SECRET")]
+    got = eng.x25519_batch(np.frombuffer(b"".join(ks), np.uint8).reshape(-1, 32), np.frombuffer(b"".join(us), np.uint8).reshape(-1, 32))
+    assert [got[i].tobytes() for i in range(4)] == exp
+    # the 7 low-order points -> all-zero output (constants.rs:208-222)
+    lo = np.frombuffer(b"".join(golden.bytes("src/constants.rs", "X25519_LOW_ORDER_POINTS", i) for i in range(7)), np.uint8).reshape(7, 32)
+    k7 = util.rand_bytes(31, 7)
+    assert not eng.x25519_batch(k7, lo).any()
+    # random k, u (about half of the u on the twist), u >= p and bit 255 set included
+    n = 3000
+    k = util.rand_bytes(32, n); u = util.rand_bytes(33, n)
+    u[:8] = 0xFF
+    got = eng.x25519_batch(k, u)
+    want = orc.x25519_batch(k, u, threads=8)
+    assert np.array_equal(got, want)
+    assert eng.x25519_batch(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8)).shape == (0, 32)
+
+
+def test_decompress_compress_vs_oracle(eng, orc):
+    n = 4000
+    enc = util.rand_bytes(41, n)
+    enc[0] = 0; enc[0, 0] = 1                      # identity
+    enc[1] = np.frombuffer((2**255 - 19 + 1).to_bytes(32, "little"), np.uint8)   # non-canonical y = p+1
+    enc[2] = enc[0]; enc[2, 31] |= 0x80            # "negative zero" x
+    st, pts, ok = eng.decompress_batch(enc)
+    want_ok = orc.ed_decompress_ok_batch(enc, threads=8)
+    assert np.array_equal(ok, want_ok)
+    assert st == (1 if (want_ok == 0).any() else 0)
+    good = np.nonzero(ok)[0]
+    assert 1000 < len(good) < 3000
+    # decompressed points re-compress to what the oracle's decompress->compress gives
+    comp = eng.compress_batch(pts[good])
+    for j in list(range(50)) + [len(good) - 1]:
+        i = good[j]
+        assert comp[j].tobytes() == orc.ed_compress(orc.ed_decompress(enc[i].tobytes()))
+    # batched (n >= 4096) and per-lane (n < 4096) compress kernels agree
+    big = np.concatenate([pts[good]] * 4)[:6000]
+    assert np.array_equal(eng.compress_batch(big)[:len(good)], comp[:min(len(good), 6000)])
+    # all-valid batch -> status OK
+    valid = orc.mul_base_compress_batch(util.rand_scalars(42, 300))
+    st, pts2, ok2 = eng.decompress_batch(valid)
+    assert st == 0 and ok2.all()
+    assert np.array_equal(eng.compress_batch(pts2), valid)
+
+
+def test_ristretto_vs_oracle(eng, orc, golden):
+    f = "src/ristretto.rs"
+    encs = np.frombuffer(b"".join(golden.bytes(f, "compressed", i) for i in range(16)), np.uint8).reshape(16, 32)
+    st, pts, ok = eng.decompress_batch(encs, in_fmt=1)
+    assert st == 0 and ok.all()
+    assert np.array_equal(eng.compress_batch(pts, out_fmt=1), encs)
+    # i*B computed by the engine, compressed as Ristretto, equals the sage table (ristretto.rs:1387)
+    sc = np.zeros((16, 32), np.uint8); sc[:, 0] = np.arange(16)
+    raw = eng.mul_base_batch(sc, out_fmt=2)
+    assert np.array_equal(eng.compress_batch(raw, out_fmt=1), encs)
+    # invalid encodings: negative s, non-canonical s, random junk -> flags match the oracle
+    bad = util.rand_bytes(51, 500)
+    bad[0] = np.frombuffer((2**255 - 20).to_bytes(32, "little"), np.uint8)
+    bad[1] = np.frombuffer((2**255 - 19).to_bytes(32, "little"), np.uint8)
+    st, _, ok = eng.decompress_batch(bad, in_fmt=1)
+    want = np.array([orc.ris_decompress(bad[i].tobytes()) is not None for i in range(500)], dtype=np.uint8)
+    assert np.array_equal(ok, want) and st == 1
+    # random points: engine ristretto compress == oracle ristretto compress
+    s = util.rand_scalars(52, 200)
+    raw = eng.mul_base_batch(s, out_fmt=2)
+    got = eng.compress_batch(raw, out_fmt=1)
+    for i in range(200):
+        assert got[i].tobytes() == orc.ris_compress(orc.ed_mul_base(s[i].tobytes()))

@@ -169,7 +169,8 @@ def edwards_add(p, q):
 
 
 def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    here = os.path.join(root, "oracle")
     fe = [
         ("EDWARDS_D", D, "d = -121665/121666"),
         ("EDWARDS_D2", D2, "2d"),
@@ -182,7 +183,7 @@ def main():
         ("BASEPOINT_Y", BY, "Ed25519 basepoint y = 4/5"),
         ("BASEPOINT_T", BX * BY % P, "x*y of the basepoint"),
     ]
-    out = ["/* GENERATED by oracle/gen_constants.py -- do not edit. Test infrastructure. */",
+    out = ["/* GENERATED by tools/gen_constants.py -- do not edit. Test infrastructure. */",
            "#ifndef ORC_CONSTANTS_H", "#define ORC_CONSTANTS_H", "#include <stdint.h>", ""]
     for name, val, com in fe:
         out.append(c_u64("ORC_" + name, limbs51(val), com))
@@ -200,7 +201,7 @@ def main():
     with open(os.path.join(here, "constants.h"), "w") as f:
         f.write("\n".join(out) + "\n")
 
-    dev = ["/* GENERATED by oracle/gen_constants.py -- do not edit.",
+    dev = ["/* GENERATED by tools/gen_constants.py -- do not edit.",
            "   Curve constants as 10 x u32 radix-2^25.5 limbs for the gfx950 device code. */",
            "#pragma once", ""]
     for name, val, com in fe:
@@ -210,7 +211,7 @@ def main():
     dev.append("#define C25519_SHA512_K { %s }" % ", ".join("0x%016xULL" % v for v in K))
     dev.append("#define C25519_SHA512_IV { %s }" % ", ".join("0x%016xULL" % v for v in H))
     dev.append("")
-    devpath = os.path.join(here, "..", "curve25519-dalek_amd", "csrc", "constants_gen.h")
+    devpath = os.path.join(root, "curve25519-dalek_amd", "csrc", "constants_gen.h")
     with open(devpath, "w") as f:
         f.write("\n".join(dev) + "\n")
 
