@@ -288,7 +288,7 @@ EXPORT int orc_ed25519_verify_batch(const uint8_t *msgs, const uint64_t *msg_off
 
 /* ---------------- batch drivers (cpu_baseline leg of bench.py, and bulk parity tests) ----------
    Each splits [0,n) into `threads` contiguous slices, one pthread per slice. */
-typedef struct { int kind; const uint8_t *a, *b; uint8_t *out; size_t lo, hi; } job;
+typedef struct { int kind; const uint8_t *a, *b; uint8_t *out; size_t lo, hi; uint8_t *out2; size_t mlen; } job;
 static void *job_run(void *arg) {
     job *j = arg;
     for (size_t i = j->lo; i < j->hi; i++) {
@@ -296,16 +296,18 @@ static void *job_run(void *arg) {
         case 0: { ge_p3 p = ge_mul_base_table(g_btab, j->a + 32 * i); ge_compress(j->out + 32 * i, p); break; }  /* mul_base + compress */
         case 1: orc_x25519(j->a + 32 * i, j->b + 32 * i, j->out + 32 * i); break;
         case 2: { ge_p3 p; j->out[i] = (uint8_t)ge_decompress(&p, j->a + 32 * i); break; }
+        case 3: orc_ed25519_pubkey(j->a + 32 * i, j->out + 32 * i); orc_ed25519_sign(j->a + 32 * i, j->b + j->mlen * i, j->mlen, j->out2 + 64 * i); break;
         }
     }
     return NULL;
 }
+static uint8_t *g_out2; static size_t g_mlen;   /* extra operands of job kind 3 (set by its only caller) */
 static void run_jobs(int kind, const uint8_t *a, const uint8_t *b, uint8_t *out, size_t n, int threads) {
     ensure_tables();
     if (threads < 1) threads = 1;
     pthread_t *th = malloc(threads * sizeof *th); job *js = malloc(threads * sizeof *js);
     for (int t = 0; t < threads; t++) {
-        js[t] = (job){kind, a, b, out, n * t / threads, n * (t + 1) / threads};
+        js[t] = (job){kind, a, b, out, n * t / threads, n * (t + 1) / threads, g_out2, g_mlen};
         pthread_create(&th[t], NULL, job_run, &js[t]);
     }
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
@@ -314,3 +316,7 @@ static void run_jobs(int kind, const uint8_t *a, const uint8_t *b, uint8_t *out,
 EXPORT void orc_mul_base_compress_batch(const uint8_t *scalars, size_t n, uint8_t *out, int threads) { run_jobs(0, scalars, NULL, out, n, threads); }
 EXPORT void orc_x25519_batch(const uint8_t *k, const uint8_t *u, size_t n, uint8_t *out, int threads) { run_jobs(1, k, u, out, n, threads); }
 EXPORT void orc_ed_decompress_ok_batch(const uint8_t *in, size_t n, uint8_t *ok, int threads) { run_jobs(2, in, NULL, ok, n, threads); }
+/* keypairs + signatures over fixed-length messages (test-input generator for verify_batch) */
+EXPORT void orc_ed25519_keygen_sign_batch(const uint8_t *seeds, const uint8_t *msgs, size_t mlen, size_t n, uint8_t *pks, uint8_t *sigs, int threads) {
+    g_out2 = sigs; g_mlen = mlen; run_jobs(3, seeds, msgs, pks, n, threads);
+}

@@ -258,3 +258,13 @@ def ed_decompress_ok_batch(enc, threads=1):
     out = np.empty(n, dtype=np.uint8)
     lib().orc_ed_decompress_ok_batch(e.ctypes.data_as(C.c_void_p), C.c_size_t(n), out.ctypes.data_as(C.c_void_p), C.c_int(threads))
     return out
+
+
+def ed25519_keygen_sign_batch(seeds, msgs, threads=1):
+    """seeds (n,32) uint8, msgs (n,mlen) uint8 -> (pks (n,32), sigs (n,64))"""
+    sd = np.ascontiguousarray(seeds, dtype=np.uint8); m = np.ascontiguousarray(msgs, dtype=np.uint8)
+    n, mlen = sd.shape[0], (m.shape[1] if m.ndim == 2 else 0)
+    pks = np.empty((n, 32), dtype=np.uint8); sigs = np.empty((n, 64), dtype=np.uint8)
+    lib().orc_ed25519_keygen_sign_batch(sd.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), C.c_size_t(mlen), C.c_size_t(n),
+                                        pks.ctypes.data_as(C.c_void_p), sigs.ctypes.data_as(C.c_void_p), C.c_int(threads))
+    return pks, sigs

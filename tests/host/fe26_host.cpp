@@ -63,3 +63,23 @@ void h_x25519_ladder(const uint8_t *s, const uint8_t *u, uint8_t *o) {
     store(o, fe_mul(x0.U, fe_invert(x0.W)));
 }
 }
+
+// ---- scalar arithmetic, SHA-512 and the host transcript of the verify_batch pipeline ----------------
+#include "../../curve25519-dalek_amd/csrc/sc_sha.h"
+#include "../../curve25519-dalek_amd/csrc/transcript_host.h"
+extern "C" {
+void h_sc_mul(const uint8_t *a, const uint8_t *b, uint8_t *o) { u32 x[8], y[8], r[8]; memcpy(x, a, 32); memcpy(y, b, 32); sc_to_words(sc_mul(sc_from_words(x), sc_from_words(y)), r); memcpy(o, r, 32); }
+void h_sc_add(const uint8_t *a, const uint8_t *b, uint8_t *o) { u32 x[8], y[8], r[8]; memcpy(x, a, 32); memcpy(y, b, 32); sc_to_words(sc_add(sc_from_words(x), sc_from_words(y)), r); memcpy(o, r, 32); }
+void h_sc_neg(const uint8_t *a, uint8_t *o) { u32 x[8], r[8]; memcpy(x, a, 32); sc_to_words(sc_neg(sc_from_words(x)), r); memcpy(o, r, 32); }
+void h_sc_from_wide(const uint8_t *a, uint8_t *o) { u32 x[16], r[8]; memcpy(x, a, 64); sc_to_words(sc_from_wide(x), r); memcpy(o, r, 32); }
+int h_sc_is_canonical(const uint8_t *a) { u32 x[8]; memcpy(x, a, 32); return sc_is_canonical(x); }
+void h_sha512(const uint8_t *m, size_t n, uint8_t *o) {
+    sha512_stream st; st.init();
+    size_t i = 0;
+    for (; i + 8 <= n && i < 64; i += 8) { u64 v; memcpy(&v, m + i, 8); st.put_be64(bswap64(v)); }   // word path, like the kernels' prefix
+    for (; i < n; i++) st.put_byte(m[i]);
+    st.finish();
+    u32 w[16]; sha512_digest_words(st.h, w); memcpy(o, w, 64);
+}
+void h_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint64_t n, uint8_t *zs) { c25519_transcript_zs(hrams, sigs, n, zs); }
+}

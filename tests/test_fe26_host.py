@@ -35,7 +35,7 @@ def b2i(b):
 def host():
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libfe26host.so")
-    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "constants_gen.h")]
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "sc_sha.h", "transcript_host.h", "constants_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
     return C.CDLL(so)
@@ -172,3 +172,29 @@ def test_ladder_vs_oracle(host, orc, golden):
     for k, u in cases:
         s = orc.sc_clamp(k)
         assert call(host, "h_x25519_ladder", s, u) == orc.x25519(k, u) == pyref.x25519(k, u)
+
+
+def test_scalar_sha_transcript_host_vs_oracle(host, orc):
+    """the verify_batch pipeline's scalar arithmetic (sc_sha.h), SHA-512 and host transcript"""
+    import hashlib
+    rng = random.Random(105)
+    for _ in range(200):
+        a, b = rng.randrange(L), rng.randrange(L)
+        assert b2i(call(host, "h_sc_mul", i2b(a), i2b(b))) == a * b % L
+        assert b2i(call(host, "h_sc_add", i2b(a), i2b(b))) == (a + b) % L
+        assert b2i(call(host, "h_sc_neg", i2b(a))) == (-a) % L
+        w = rng.getrandbits(512)
+        assert b2i(call(host, "h_sc_from_wide", w.to_bytes(64, "little"))) == w % L
+        z = rng.getrandbits(128)
+        assert b2i(call(host, "h_sc_mul", i2b(z), i2b(b))) == z * b % L
+    for v, want in [(0, 1), (L - 1, 1), (L, 0), (L + 1, 0), (2**255, 0), (2**252, 1), (2**256 - 1, 0)]:
+        assert host.h_sc_is_canonical(i2b(v)) == want
+    for n in [0, 1, 7, 8, 63, 64, 65, 95, 96, 111, 112, 113, 119, 120, 127, 128, 129, 200, 255, 256, 300]:
+        m = bytes(rng.getrandbits(8) for _ in range(n))
+        assert call(host, "h_sha512", m, C.c_size_t(n), out=64) == hashlib.sha512(m).digest(), n
+    for n in [1, 2, 7, 40]:
+        hr = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
+        sg = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
+        got = call(host, "h_transcript_zs", b"".join(hr), b"".join(sg), C.c_uint64(n), out=16 * n)
+        want = b"".join(orc.batch_transcript_zs(hr, [s[32:] for s in sg]))
+        assert got == want

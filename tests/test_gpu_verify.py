@@ -1,0 +1,123 @@
+"""GPU parity tests for ed25519_dalek::verify_batch (batch.rs:146-251) through the C ABI: status codes
+equal the oracle's (and the reference's documented precedence) on the reference's fixtures and on
+seeded synthetic batches, in both z-modes."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+L = util.L
+OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH = 0, 1, 2, 3, 4
+
+
+@pytest.fixture(scope="module")
+def eng():
+    import curve25519_dalek_amd as pkg
+    return pkg.Engine(0)
+
+
+def i2b(x):
+    return int(x).to_bytes(32, "little")
+
+
+def testvectors():
+    out = []
+    with open(os.path.join(ROOT, "tests", "golden", "ed25519_testvectors.txt")) as fh:
+        for line in fh:
+            p = line.strip().split(":")
+            if len(p) >= 4:
+                out.append((bytes.fromhex(p[1]), bytes.fromhex(p[2]), bytes.fromhex(p[3])[:64]))
+    return out
+
+
+@pytest.mark.parametrize("z_mode", [0, 1])
+def test_verify_batch_testvectors(eng, orc, z_mode):
+    """all 128 TESTVECTORS triples (message lengths 0..1023 bytes) as one batch"""
+    tv = testvectors()
+    pks, msgs, sigs = [t[0] for t in tv], [t[1] for t in tv], [t[2] for t in tv]
+    assert eng.verify_batch(msgs, sigs, pks, z_mode) == OK == orc.ed25519_verify_batch(msgs, sigs, pks)
+    for m in (1, 2, 7, 64):
+        assert eng.verify_batch(msgs[:m], sigs[:m], pks[:m], z_mode) == OK
+    assert eng.verify_batch([], [], [], z_mode) == OK
+    assert eng.verify_batch(msgs[:-1], sigs, pks, z_mode) == ARRAY_LENGTH
+    # a flipped bit anywhere breaks the batch
+    for which in (0, 63, 127):
+        bad = list(sigs); b = bytearray(bad[which]); b[3] ^= 0x10; bad[which] = bytes(b)
+        assert eng.verify_batch(msgs, bad, pks, z_mode) == orc.ed25519_verify_batch(msgs, bad, pks) == VERIFY
+    m2 = list(msgs); m2[5] = msgs[5] + b"x"
+    assert eng.verify_batch(m2, sigs, pks, z_mode) == VERIFY
+    swapped = list(pks); swapped[1], swapped[2] = swapped[2], swapped[1]
+    assert eng.verify_batch(msgs, sigs, swapped, z_mode) == VERIFY
+
+
+@pytest.mark.parametrize("z_mode", [0, 1])
+def test_verify_batch_error_precedence(eng, orc, z_mode):
+    """batch.rs:152-165 / :208-211 / :244-250 and VerifyingKey::from_bytes (verifying.rs:167)"""
+    tv = testvectors()[:20]
+    pks, msgs, sigs = [t[0] for t in tv], [t[1] for t in tv], [t[2] for t in tv]
+    s_big = list(sigs); s_big[4] = sigs[4][:32] + i2b(int.from_bytes(sigs[4][32:], "little") + L)
+    assert eng.verify_batch(msgs, s_big, pks, z_mode) == orc.ed25519_verify_batch(msgs, s_big, pks) == SCALAR_FORMAT
+    r_bad = list(sigs); r_bad[9] = i2b(2) + sigs[9][32:]
+    assert eng.verify_batch(msgs, r_bad, pks, z_mode) == orc.ed25519_verify_batch(msgs, r_bad, pks) == VERIFY
+    both = list(s_big); both[9] = r_bad[9]
+    assert eng.verify_batch(msgs, both, pks, z_mode) == orc.ed25519_verify_batch(msgs, both, pks) == SCALAR_FORMAT
+    a_bad = list(pks); a_bad[0] = i2b(2)
+    assert eng.verify_batch(msgs, both, a_bad, z_mode) == orc.ed25519_verify_batch(msgs, both, a_bad) == NONE
+    import curve25519_dalek_amd as pkg
+    with pytest.raises(pkg.dalek.SignatureError) as e:
+        pkg.dalek.verify_batch(msgs, s_big, pks, engine=eng, z_mode=z_mode)
+    assert e.value.kind == "ScalarFormat"
+    with pytest.raises(pkg.dalek.SignatureError) as e:
+        pkg.dalek.verify_batch(msgs[:3], sigs, pks, engine=eng, z_mode=z_mode)
+    assert e.value.kind == "ArrayLength"
+    assert pkg.dalek.verify_batch(msgs, sigs, pks, engine=eng, z_mode=z_mode) is None
+
+
+def test_verify_batch_validation_vectors_consistency(eng, orc):
+    """the 914 C2SP vectors, each as a batch of one: verify_batch is the cofactor-less equation with
+    no small-order checks (ed25519-dalek/README.md:159-165) -- statuses must equal the oracle's
+    restatement of batch.rs for every vector (keys that do not decode included)."""
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "ed25519_validation.json")) as fh:
+        vv = json.load(fh)
+    mism = 0
+    for v in vv[::3]:
+        pk, sig, msg = bytes.fromhex(v["key"]), bytes.fromhex(v["sig"]), v["msg"].encode()
+        want = orc.ed25519_verify_batch([msg], [sig], [pk])
+        got = eng.verify_batch([msg], [sig], [pk], 0)
+        mism += want != got
+    assert mism == 0
+
+
+@pytest.mark.parametrize("log2n,z_mode", [(12, 0), (16, 1)])
+def test_verify_batch_synthetic(eng, orc, log2n, z_mode):
+    """seeded keypairs, 59-byte messages (the reference's bench shape, ed25519_benchmarks.rs:64)"""
+    n = 1 << log2n
+    seeds = util.rand_bytes(300 + log2n, n); msgs = util.rand_bytes(301 + log2n, n, 59)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    M = [msgs[i].tobytes() for i in range(n)]; S = [sigs[i].tobytes() for i in range(n)]; P = [pks[i].tobytes() for i in range(n)]
+    assert eng.verify_batch(M, S, P, z_mode) == OK
+    bad = list(S); j = n // 3; b = bytearray(bad[j]); b[40] ^= 1; bad[j] = bytes(b)
+    assert eng.verify_batch(M, bad, P, z_mode) in (VERIFY, SCALAR_FORMAT)
+    bad = list(S); b = bytearray(bad[n - 1]); b[0] ^= 1; bad[n - 1] = bytes(b)
+    assert eng.verify_batch(M, bad, P, z_mode) == VERIFY
+
+
+def test_verify_batch_full_size_2p20(eng, orc):
+    """BASELINE configs[2]: 2^20 signatures, device-resident inputs, device z-mode."""
+    import torch
+    n = 1 << 20
+    seeds = util.rand_bytes(400, n); msgs = util.rand_bytes(401, n, 32)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    dm = torch.from_numpy(msgs.reshape(-1)).cuda(); doff = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+    ds = torch.from_numpy(sigs).cuda(); dp = torch.from_numpy(pks).cuda()
+    assert eng.verify_batch_t(dm, doff, ds, dp, 1) == OK
+    print("verify_batch 2^20: %.3f ms total, accumulate %.3f ms" % (eng.last_kernel_ms(), eng.phase_ms(0, 0)))
+    ds2 = ds.clone(); ds2[777777, 5] ^= 1
+    assert eng.verify_batch_t(dm, doff, ds2, dp, 1) == VERIFY
+    ds3 = ds.clone(); ds3[12345, 63] |= 0x20       # s >= 2^253 > l
+    assert eng.verify_batch_t(dm, doff, ds3, dp, 1) == SCALAR_FORMAT

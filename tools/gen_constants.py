@@ -210,6 +210,8 @@ def main():
     dev.append("#define C25519_L_W32 { %s }" % ", ".join("0x%08xu" % ((L >> (32 * i)) & 0xffffffff) for i in range(8)))
     dev.append("#define C25519_SHA512_K { %s }" % ", ".join("0x%016xULL" % v for v in K))
     dev.append("#define C25519_SHA512_IV { %s }" % ", ".join("0x%016xULL" % v for v in H))
+    dev.append("#define C25519_KECCAK_RC { %s }" % ", ".join("0x%016xULL" % v for v in RC))
+    dev.append("#define C25519_KECCAK_ROT { %s }" % ", ".join(str(rot[i % 5][i // 5]) for i in range(25)))
     dev.append("")
     devpath = os.path.join(root, "curve25519-dalek_amd", "csrc", "constants_gen.h")
     with open(devpath, "w") as f:
