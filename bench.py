@@ -31,6 +31,21 @@ ALGO = {
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def host_cores():
+    """CPUs this process may actually use (affinity mask and cgroup quota), not the box's core count."""
+    try:
+        c = len(os.sched_getaffinity(0))
+    except AttributeError:
+        c = os.cpu_count() or 1
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            c = max(1, min(c, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        pass
+    return c
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,8 +93,36 @@ def main():
 
         def run():
             eng.x25519_batch_t(ks, us, out)
-    else:
-        raise SystemExit("workload %s: not wired into bench.py yet" % wl)
+    elif wl == "msm":
+        # config 4 shape: P_i = y_i * B generated on the device (the host never materialises the points)
+        xs, ys = rnd(n), rnd(n)
+        xs[:, 31] &= 0x0F; ys[:, 31] &= 0x0F
+        pts = eng.mul_base_batch_t(ys, pkg.engine.FMT_RAW160)
+        result = {}
+
+        def run():
+            st, part = eng.msm_partial_t(xs, pts, pkg.engine.FMT_RAW160)
+            assert st == 0
+            if world > 1:                      # the one exchange step: 160 bytes per rank over RCCL
+                mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
+                allp = torch.empty((world, 160), dtype=torch.uint8, device=dev)
+                dist.all_gather_into_tensor(allp, mine)
+                parts = [bytes(r) for r in allp.cpu().numpy()]
+            else:
+                parts = [part]
+            result["out"] = eng.fold_partials(parts, pkg.engine.FMT_EDWARDS_Y)
+    elif wl == "verify":
+        from oracle import orc as _orc       # input GENERATOR only (signing is not on the measured path)
+        seeds = np.random.default_rng(1000 + rank).integers(0, 256, size=(n, 32), dtype=np.uint8)
+        mh = np.random.default_rng(2000 + rank).integers(0, 256, size=(n, 32), dtype=np.uint8)
+        pk_h, sig_h = _orc.ed25519_keygen_sign_batch(seeds, mh, threads=host_cores())
+        d_msgs = torch.from_numpy(mh.reshape(-1)).to(dev)
+        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+        d_sigs, d_pks = torch.from_numpy(sig_h).to(dev), torch.from_numpy(pk_h).to(dev)
+        result = {}
+
+        def run():
+            result["st"] = eng.verify_batch_t(d_msgs, d_off, d_sigs, d_pks, pkg.engine.Z_DEVICE)
 
     def barrier():
         if world > 1:
@@ -92,13 +135,27 @@ def main():
     torch.cuda.synchronize(dev)
     if rank == 0:
         from oracle import orc
-        idx = torch.randperm(n, device=dev, generator=gen)[:1024].cpu().numpy()
-        if wl == "fixed_base":
-            want = orc.mul_base_compress_batch(scalars[idx].cpu().numpy(), threads=os.cpu_count() or 1)
-        else:
-            want = orc.x25519_batch(ks[idx].cpu().numpy(), us[idx].cpu().numpy(), threads=os.cpu_count() or 1)
-        if not np.array_equal(out[idx].cpu().numpy(), want):
-            raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
+        cores = host_cores()
+        if wl in ("fixed_base", "x25519"):
+            idx = torch.randperm(n, device=dev, generator=gen)[:1024].cpu().numpy()
+            if wl == "fixed_base":
+                want = orc.mul_base_compress_batch(scalars[idx].cpu().numpy(), threads=cores)
+            else:
+                want = orc.x25519_batch(ks[idx].cpu().numpy(), us[idx].cpu().numpy(), threads=cores)
+            if not np.array_equal(out[idx].cpu().numpy(), want):
+                raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
+        elif wl == "msm" and world == 1:
+            L = 2**252 + 27742317777372353535851937790883648493
+            xb, yb = xs.cpu().numpy(), ys.cpu().numpy()
+            acc = 0
+            for i in range(n):
+                acc += int.from_bytes(xb[i].tobytes(), "little") * int.from_bytes(yb[i].tobytes(), "little")
+            want = orc.ed_compress(orc.ed_mul_base((acc % L).to_bytes(32, "little")))
+            if result["out"] != want:
+                raise SystemExit("PARITY FAILURE: MSM result differs from (sum x_i y_i) B")
+        elif wl == "verify":
+            if result["st"] != 0:
+                raise SystemExit("PARITY FAILURE: valid batch rejected (status %d)" % result["st"])
 
     for _ in range(args.warmup):
         run()
@@ -121,19 +178,34 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import orc
-        cores = os.cpu_count() or 1
-        probe = 2048 * cores
-        if wl == "fixed_base":
-            a = scalars[:probe].cpu().numpy()
-            f = lambda m: orc.mul_base_compress_batch(a[:m] if m <= probe else np.resize(a, (m, 32)), threads=cores)
+        cores = host_cores()
+        if wl in ("fixed_base", "x25519"):
+            # embarrassingly parallel in the reference too: one slice per host core
+            probe = min(n, 1024 * cores)
+            if wl == "fixed_base":
+                a = scalars[:probe].cpu().numpy()
+                f = lambda m: orc.mul_base_compress_batch(np.resize(a, (m, 32)), threads=cores)
+            else:
+                a, b = ks[:probe].cpu().numpy(), us[:probe].cpu().numpy()
+                f = lambda m: orc.x25519_batch(np.resize(a, (m, 32)), np.resize(b, (m, 32)), threads=cores)
+            used = cores
+        elif wl == "msm":
+            # the reference's MSM is one single-threaded call (Pippenger, w = 8): time it as such
+            probe = 4096
+            xa = xs[:1 << 17].cpu().numpy(); pa = pts[:1 << 17].cpu().numpy()
+            f = lambda m: orc.ed_msm([xa[i].tobytes() for i in range(m)], [pa[i].tobytes() for i in range(m)])
+            used = 1
         else:
-            a, b = ks[:probe].cpu().numpy(), us[:probe].cpu().numpy()
-            f = lambda m: orc.x25519_batch(np.resize(a, (m, 32)), np.resize(b, (m, 32)), threads=cores)
+            probe = 2048
+            f = lambda m: orc.ed25519_verify_batch([mh[i].tobytes() for i in range(m)], [sig_h[i].tobytes() for i in range(m)], [pk_h[i].tobytes() for i in range(m)])
+            used = 1
+        f(min(probe, 256))                                              # warm caches / tables
         c0 = time.perf_counter(); f(probe); c1 = time.perf_counter() - c0
-        m = int(max(probe, min(n, probe * 12.0 / max(c1, 1e-3))))     # ~12 s of wall-clock work
+        cap = n if wl in ("fixed_base", "x25519", "verify") else (1 << 17)
+        m = int(max(probe, min(cap, probe * 10.0 / max(c1, 1e-4))))     # ~10 s of work
         c0 = time.perf_counter(); f(m); c1 = time.perf_counter() - c0
-        cpu_baseline = {"value": m / c1, "unit": ALGO[wl]["unit"], "cores": cores, "kind": "port",
-                        "sample": "%d units of the same workload, C restatement of the reference serial_u64 path (oracle/), %d threads, %.1f s" % (m, cores, c1)}
+        cpu_baseline = {"value": m / c1, "unit": ALGO[wl]["unit"], "cores": used, "kind": "port",
+                        "sample": "%d units of the same workload through the C restatement of the reference serial_u64 path (oracle/), %d thread(s), %.1f s; host exposes %d usable cores" % (m, used, c1, cores)}
 
     if rank == 0:
         units = float(n) * world * args.steps
@@ -145,7 +217,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
             "config": {"workload": "%s: 2^%d units per GPU, inputs resident in HBM, canonical 32-byte outputs" % (wl, log2n),
-                       "units_per_gpu": n, "parallelism": "replicas x%d" % world},
+                       "units_per_gpu": n, "parallelism": ("sharded terms, all_gather of 160-B partials x%d" if wl == "msm" else "replicas x%d") % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
                          "dominant_kernel_ms": dom_ms, "other_kernels_ms": rest_ms,

@@ -235,12 +235,18 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
 // ================================================================================================
 // bucket accumulation: one lane per (window, bucket)   [pippenger.rs:122-136, as gather lists]
 // ================================================================================================
+// Buckets longer than LONG_CAP are left to the wave-cooperative path below, so that no lane ever walks a
+// long list alone (skewed inputs: e.g. the +1 carry digit of every 128-bit z_i in verify_batch lands
+// ~n/2 terms in ONE bucket; identical scalars do the same in every window).
+constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
+constexpr u32 LONG_SEG = 4096;     // entries per wave in the long path (64 per lane)
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
                                                     u64 n, msm_geom g, u32 *__restrict__ buckets) {
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (u64)g.nwin * g.half) return;
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
     u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
+    if (hi - lo > LONG_CAP) return;
     const u32 *list = sorted + (u64)k * n;
     ge_p3 acc = ge_identity();
 #pragma unroll 1
@@ -250,6 +256,78 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
         acc = ge_p1p1_to_p3(ge_madd(acc, A, (e >> 31) != 0));
     }
     p40_store(buckets, gid, acc);
+}
+
+
+// ---- long buckets -------------------------------------------------------------------------------------
+// work list: one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
+struct long_item { u32 gid, lo, hi, first; };
+__global__ void __launch_bounds__(256) k_find_long(const u32 *__restrict__ base, msm_geom g, u32 max_items, long_item *__restrict__ items,
+                                                   u32 *__restrict__ counters /* [0]=#items [1]=#long buckets */, u32 *__restrict__ long_gids,
+                                                   u32 *__restrict__ long_first) {
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (u64)g.nwin * g.half) return;
+    int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
+    u32 cnt = hi - lo;
+    if (cnt <= LONG_CAP) return;
+    u32 nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
+    u32 first = atomicAdd(&counters[0], nseg);
+    u32 lb = atomicAdd(&counters[1], 1u);
+    long_gids[lb] = (u32)gid;
+    long_first[lb] = first;
+    // number of segments of this bucket is recomputed by the combiner from base[]
+    for (u32 s = 0; s < nseg && first + s < max_items; s++) {
+        long_item it; it.gid = (u32)gid; it.lo = lo + s * LONG_SEG; it.hi = (it.lo + LONG_SEG < hi) ? it.lo + LONG_SEG : hi; it.first = first;
+        items[first + s] = it;
+    }
+}
+// sum across the 64 lanes of a wave (complete additions; lane 0 ends with the total)
+__device__ __forceinline__ ge_p3 wave_sum(ge_p3 acc) {
+#pragma unroll 1
+    for (int off = 32; off > 0; off >>= 1) {
+        ge_p3 o;
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_down(acc.X.v[i], off, 64); o.Y.v[i] = __shfl_down(acc.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_down(acc.Z.v[i], off, 64); o.T.v[i] = __shfl_down(acc.T.v[i], off, 64);
+        }
+        acc = ge_add(acc, o);
+    }
+    return acc;
+}
+// one wave per work item: every lane adds its strided share of the segment, then a shuffle tree
+__global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, u64 n, msm_geom g,
+                                                      const long_item *__restrict__ items, const u32 *__restrict__ counters, u32 max_items,
+                                                      u32 *__restrict__ seg_sums) {
+    u32 item = blockIdx.x, nitems = counters[0] < max_items ? counters[0] : max_items;
+    if (item >= nitems) return;
+    long_item it = items[item];
+    int k = (int)(it.gid / g.half);
+    const u32 *list = sorted + (u64)k * n;
+    ge_p3 acc = ge_identity();
+#pragma unroll 1
+    for (u32 i = it.lo + threadIdx.x; i < it.hi; i += 64) {
+        u32 e = list[i];
+        acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu), (e >> 31) != 0));
+    }
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) p40_store(seg_sums, item, acc);
+}
+// one wave per long bucket: sum its segment sums -> buckets[gid]
+__global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ base, msm_geom g, const u32 *__restrict__ counters, u32 max_items,
+                                                     const u32 *__restrict__ long_gids, const u32 *__restrict__ long_first,
+                                                     const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets) {
+    u32 lb = blockIdx.x;
+    if (lb >= counters[1]) return;
+    u32 gid = long_gids[lb], first = long_first[lb];
+    int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    u32 cnt = base[(u64)k * (g.half + 1) + b + 1] - base[(u64)k * (g.half + 1) + b];
+    u32 nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
+    ge_p3 acc = ge_identity();
+#pragma unroll 1
+    for (u32 s = threadIdx.x; s < nseg && first + s < max_items; s += 64) acc = ge_add(acc, p40_load(seg_sums, first + s));
+    acc = wave_sum(acc);
+    if (threadIdx.x == 0) p40_store(buckets, gid, acc);
 }
 
 // ================================================================================================
@@ -462,6 +540,12 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160);
     size_t lvl_pts = plan.empty() ? (size_t)g.nwin : (size_t)g.nwin * (plan[0].m_in / plan[0].L);
     size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256);
+    // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
+    const uint64_t entries = (uint64_t)g.nwin * n;
+    const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / LONG_CAP + 1);
+    const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
+    size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
+    size_t oLS = carve((size_t)max_items * 160);
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
     if (r) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
@@ -481,6 +565,13 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     hipLaunchKernelGGL(k_scatter, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, sorted);
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
     hipLaunchKernelGGL(k_accumulate, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, n, g, buckets);
+    {
+        long_item *items = (long_item *)(ws + oLI);
+        uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
+        hipLaunchKernelGGL(k_find_long, dim3(div_up64(nb, 256)), dim3(256), 0, st, base, g, max_items, items, counters, lgids, lfirst);
+        hipLaunchKernelGGL(k_long_segments, dim3(max_items), dim3(64), 0, st, d_pts, sorted, n, g, items, counters, max_items, segs);
+        hipLaunchKernelGGL(k_long_combine, dim3(max_long), dim3(64), 0, st, base, g, counters, max_items, lgids, lfirst, segs, buckets);
+    }
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     // reduction levels
     const uint32_t *S_in = buckets, *P_in = nullptr;
