@@ -201,7 +201,7 @@ def main():
             used = 1
         f(min(probe, 256))                                              # warm caches / tables
         c0 = time.perf_counter(); f(probe); c1 = time.perf_counter() - c0
-        cap = n if wl in ("fixed_base", "x25519", "verify") else (1 << 17)
+        cap = (16 * n) if wl in ("fixed_base", "x25519") else (n if wl == "verify" else (1 << 17))
         m = int(max(probe, min(cap, probe * 10.0 / max(c1, 1e-4))))     # ~10 s of work
         c0 = time.perf_counter(); f(m); c1 = time.perf_counter() - c0
         cpu_baseline = {"value": m / c1, "unit": ALGO[wl]["unit"], "cores": used, "kind": "port",

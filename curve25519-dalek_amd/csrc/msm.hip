@@ -185,19 +185,29 @@ __global__ void __launch_bounds__(1024) k_hist(const uint16_t *__restrict__ D, u
     u32 *out = counts + ((u64)k * nchunk + j) * g.half;
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) out[b] = hist[b];
 }
-// per window: base[k][b] = start of bucket b in the sorted list; counts[k][j][b] -> start of chunk j's
-// share of that bucket.  One block per window.
-__global__ void __launch_bounds__(1024) k_scan(u32 *__restrict__ counts, int nchunk, msm_geom g, u32 *__restrict__ base) {
+// counting-sort offsets in two steps.
+// (1) one lane per (window, bucket): exclusive prefix over the chunks (in place) and the bucket total
+__global__ void __launch_bounds__(256) k_scan_chunks(u32 *__restrict__ counts, int nchunk, msm_geom g, u32 *__restrict__ totals) {
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (u64)g.nwin * g.half) return;
+    int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    u32 run = 0;
+    for (int j = 0; j < nchunk; j++) {
+        u64 at = ((u64)k * nchunk + j) * g.half + b;
+        u32 c = counts[at]; counts[at] = run; run += c;
+    }
+    totals[gid] = run;
+}
+// (2) one block per window: base[k][b] = exclusive scan of the bucket totals; base[k][half] = #entries
+__global__ void __launch_bounds__(1024) k_scan_buckets(const u32 *__restrict__ totals, msm_geom g, u32 *__restrict__ base) {
     __shared__ u32 part[1024];
     const int k = blockIdx.x, tid = threadIdx.x;
     const int per = (g.half + 1023) / 1024;
     const int b0 = tid * per, b1 = b0 + per < g.half ? b0 + per : g.half;
     u32 sum = 0;
-    for (int b = b0; b < b1; b++)
-        for (int j = 0; j < nchunk; j++) sum += counts[((u64)k * nchunk + j) * g.half + b];
+    for (int b = b0; b < b1; b++) sum += totals[(u64)k * g.half + b];
     part[tid] = sum;
     __syncthreads();
-    // exclusive scan of part[] (Hillis-Steele, 1024 entries)
     for (int off = 1; off < 1024; off <<= 1) {
         u32 v = tid >= off ? part[tid - off] : 0;
         __syncthreads();
@@ -205,22 +215,17 @@ __global__ void __launch_bounds__(1024) k_scan(u32 *__restrict__ counts, int nch
         __syncthreads();
     }
     u32 run = part[tid] - sum;
-    for (int b = b0; b < b1; b++) {
-        base[(u64)k * (g.half + 1) + b] = run;
-        for (int j = 0; j < nchunk; j++) {
-            u64 at = ((u64)k * nchunk + j) * g.half + b;
-            u32 c = counts[at]; counts[at] = run; run += c;
-        }
-    }
+    for (int b = b0; b < b1; b++) { base[(u64)k * (g.half + 1) + b] = run; run += totals[(u64)k * g.half + b]; }
     if (tid == 1023) base[(u64)k * (g.half + 1) + g.half] = part[1023];
 }
 // scatter term indices (sign in bit 31) into bucket order
 __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, const u32 *__restrict__ starts,
-                                                  u32 *__restrict__ sorted) {
+                                                  const u32 *__restrict__ base, u32 *__restrict__ sorted) {
     extern __shared__ u32 cursor[];
     const int k = blockIdx.y, j = blockIdx.x, nchunk = gridDim.x;
     const u32 *st = starts + ((u64)k * nchunk + j) * g.half;
-    for (int b = threadIdx.x; b < g.half; b += blockDim.x) cursor[b] = st[b];
+    const u32 *bs = base + (u64)k * (g.half + 1);
+    for (int b = threadIdx.x; b < g.half; b += blockDim.x) cursor[b] = st[b] + bs[b];
     __syncthreads();
     u64 lo = (u64)j * chunk, hi = lo + chunk < n ? lo + chunk : n;
     for (u64 t = lo + threadIdx.x; t < hi; t += blockDim.x) {
@@ -299,35 +304,42 @@ __device__ __forceinline__ ge_p3 wave_sum(ge_p3 acc) {
 __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, u64 n, msm_geom g,
                                                       const long_item *__restrict__ items, const u32 *__restrict__ counters, u32 max_items,
                                                       u32 *__restrict__ seg_sums) {
-    u32 item = blockIdx.x, nitems = counters[0] < max_items ? counters[0] : max_items;
-    if (item >= nitems) return;
-    long_item it = items[item];
-    int k = (int)(it.gid / g.half);
-    const u32 *list = sorted + (u64)k * n;
-    ge_p3 acc = ge_identity();
+    const u32 nitems = counters[0] < max_items ? counters[0] : max_items;
 #pragma unroll 1
-    for (u32 i = it.lo + threadIdx.x; i < it.hi; i += 64) {
-        u32 e = list[i];
-        acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu), (e >> 31) != 0));
+    for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
+        long_item it = items[item];
+        int k = (int)(it.gid / g.half);
+        const u32 *list = sorted + (u64)k * n;
+        ge_p3 acc = ge_identity();
+#pragma unroll 1
+        for (u32 i = it.lo + threadIdx.x; i < it.hi; i += 64) {
+            u32 e = list[i];
+            acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu), (e >> 31) != 0));
+        }
+        acc = wave_sum(acc);
+        if (threadIdx.x == 0) p40_store(seg_sums, item, acc);
     }
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) p40_store(seg_sums, item, acc);
 }
 // one wave per long bucket: sum its segment sums -> buckets[gid]
 __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ base, msm_geom g, const u32 *__restrict__ counters, u32 max_items,
                                                      const u32 *__restrict__ long_gids, const u32 *__restrict__ long_first,
                                                      const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets) {
-    u32 lb = blockIdx.x;
-    if (lb >= counters[1]) return;
-    u32 gid = long_gids[lb], first = long_first[lb];
-    int k = (int)(gid / g.half), b = (int)(gid % g.half);
-    u32 cnt = base[(u64)k * (g.half + 1) + b + 1] - base[(u64)k * (g.half + 1) + b];
-    u32 nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
-    ge_p3 acc = ge_identity();
 #pragma unroll 1
-    for (u32 s = threadIdx.x; s < nseg && first + s < max_items; s += 64) acc = ge_add(acc, p40_load(seg_sums, first + s));
-    acc = wave_sum(acc);
-    if (threadIdx.x == 0) p40_store(buckets, gid, acc);
+    for (u32 lb = blockIdx.x; lb < counters[1]; lb += gridDim.x) {
+        u32 gid = long_gids[lb], first = long_first[lb];
+        int k = (int)(gid / g.half), b = (int)(gid % g.half);
+        u32 cnt = base[(u64)k * (g.half + 1) + b + 1] - base[(u64)k * (g.half + 1) + b];
+        u32 nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
+        ge_p3 acc = ge_identity();
+        if (nseg == 1) {
+            acc = p40_load(seg_sums, first);
+        } else {
+#pragma unroll 1
+            for (u32 s = threadIdx.x; s < nseg && first + s < max_items; s += 64) acc = ge_add(acc, p40_load(seg_sums, first + s));
+            acc = wave_sum(acc);
+        }
+        if (threadIdx.x == 0) p40_store(buckets, gid, acc);
+    }
 }
 
 // ================================================================================================
@@ -378,8 +390,9 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     if (!sc_is_canonical(s)) atomicAdd(bad_s, 1u);     // signature.rs:89-94 check_scalar
     sha512_stream st;
     st.init();
-    for (int j = 0; j < 4; j++) st.put_be64(bswap64((u64)r[2 * j] | ((u64)r[2 * j + 1] << 32)));
-    for (int j = 0; j < 4; j++) st.put_be64(bswap64((u64)a[2 * j] | ((u64)a[2 * j + 1] << 32)));
+    for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)r[2 * j] | ((u64)r[2 * j + 1] << 32));       // R || A fills the
+    for (int j = 0; j < 4; j++) st.w[4 + j] = bswap64((u64)a[2 * j] | ((u64)a[2 * j + 1] << 32));   // first 64 bytes
+    st.fill = 64; st.total = 64;
     const uint8_t *m = msgs + msg_off[i];
     u64 len = msg_off[i + 1] - msg_off[i];
     for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
@@ -396,43 +409,53 @@ __global__ void __launch_bounds__(256) k_zleaf(const uint8_t *__restrict__ hram,
     const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * i;
     u32 s[8];
     load8w(sigs, 2 * i + 1, s);
-    sha512_stream st;
-    st.init();
-    for (int j = 0; j < 8; j++) st.put_be64(bswap64(h[j]));
-    for (int j = 0; j < 4; j++) st.put_be64(bswap64((u64)s[2 * j] | ((u64)s[2 * j + 1] << 32)));
-    st.put_be64(bswap64(i));
-    st.finish();
+    u64 hs[8], w[16];   // 104-byte message: one block
+    sha512_init(hs);
+    for (int j = 0; j < 8; j++) w[j] = bswap64(h[j]);
+    for (int j = 0; j < 4; j++) w[8 + j] = bswap64((u64)s[2 * j] | ((u64)s[2 * j + 1] << 32));
+    w[12] = bswap64(i); w[13] = 0x8000000000000000ull; w[14] = 0; w[15] = 104 * 8;
+    sha512_compress(hs, w);
     u64 *o = reinterpret_cast<u64 *>(leaf) + 8 * i;
-    for (int j = 0; j < 8; j++) o[j] = bswap64(st.h[j]);
+    for (int j = 0; j < 8; j++) o[j] = bswap64(hs[j]);
 }
 // step 2: 16-ary Merkle level: out[j] = SHA-512(in[16j] || ... || in[16j+15]) (missing children skipped)
 __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (m_in + 15) / 16;
     if (j >= m_out) return;
-    sha512_stream st;
-    st.init();
-    for (u64 c = 16 * j; c < 16 * j + 16 && c < m_in; c++) {
-        const u64 *h = reinterpret_cast<const u64 *>(in) + 8 * c;
-        for (int q = 0; q < 8; q++) st.put_be64(bswap64(h[q]));
+    // message = 16 children x 64 bytes (absent children = zero bytes) || LE64(m_in): 8 full blocks + 1
+    u64 hs[8], w[16];
+    sha512_init(hs);
+#pragma unroll 1
+    for (int blk = 0; blk < 8; blk++) {
+        for (int half = 0; half < 2; half++) {
+            u64 c = 16 * j + 2 * blk + half;
+            const u64 *h = reinterpret_cast<const u64 *>(in) + 8 * c;
+            for (int q = 0; q < 8; q++) w[8 * half + q] = c < m_in ? bswap64(h[q]) : 0ull;
+        }
+        sha512_compress(hs, w);
     }
-    st.put_be64(bswap64(m_in));
-    st.finish();
+    w[0] = bswap64(m_in); w[1] = 0x8000000000000000ull;
+    for (int q = 2; q < 15; q++) w[q] = 0;
+    w[15] = (u64)(1024 + 8) * 8;
+    sha512_compress(hs, w);
     u64 *o = reinterpret_cast<u64 *>(out) + 8 * j;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(st.h[q]);
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
 }
 // step 3: z_i = first 16 bytes of SHA-512(root || LE64(i))
 __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n, uint8_t *__restrict__ z16) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
-    sha512_stream st;
-    st.init();
-    for (int q = 0; q < 8; q++) st.put_be64(bswap64(h[q]));
-    st.put_be64(bswap64(i));
-    st.finish();
+    u64 hs[8], w[16];   // 72-byte message: one block
+    sha512_init(hs);
+    for (int q = 0; q < 8; q++) w[q] = bswap64(h[q]);
+    w[8] = bswap64(i); w[9] = 0x8000000000000000ull;
+    for (int q = 10; q < 15; q++) w[q] = 0;
+    w[15] = 72 * 8;
+    sha512_compress(hs, w);
     u64 *o = reinterpret_cast<u64 *>(z16) + 2 * i;
-    o[0] = bswap64(st.h[0]); o[1] = bswap64(st.h[1]);
+    o[0] = bswap64(hs[0]); o[1] = bswap64(hs[1]);
 }
 // scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = z_i, [1+n+i] = z_i*h_i;
 // per-block partial sums of z_i*s_i (mod l) to `partial`
@@ -537,7 +560,7 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oD = carve((size_t)g.nwin * n * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
-    size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160);
+    size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oT = carve(nb * 4);
     size_t lvl_pts = plan.empty() ? (size_t)g.nwin : (size_t)g.nwin * (plan[0].m_in / plan[0].L);
     size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
@@ -551,7 +574,7 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
-    uint32_t *flags = (uint32_t *)(ws + oF);
+    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT);
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(flags, 0, 256, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
@@ -561,16 +584,17 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     hipLaunchKernelGGL(k_hist, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
-    hipLaunchKernelGGL(k_scan, dim3(g.nwin), dim3(1024), 0, st, counts, nchunk, g, base);
-    hipLaunchKernelGGL(k_scatter, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, sorted);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
+    hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
+    hipLaunchKernelGGL(k_scatter, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
     hipLaunchKernelGGL(k_accumulate, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, n, g, buckets);
     {
         long_item *items = (long_item *)(ws + oLI);
         uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
         hipLaunchKernelGGL(k_find_long, dim3(div_up64(nb, 256)), dim3(256), 0, st, base, g, max_items, items, counters, lgids, lfirst);
-        hipLaunchKernelGGL(k_long_segments, dim3(max_items), dim3(64), 0, st, d_pts, sorted, n, g, items, counters, max_items, segs);
-        hipLaunchKernelGGL(k_long_combine, dim3(max_long), dim3(64), 0, st, base, g, counters, max_items, lgids, lfirst, segs, buckets);
+        hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 8192u)), dim3(64), 0, st, d_pts, sorted, n, g, items, counters, max_items, segs);
+        hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 2048u)), dim3(64), 0, st, base, g, counters, max_items, lgids, lfirst, segs, buckets);
     }
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     // reduction levels
