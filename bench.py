@@ -101,16 +101,10 @@ def main():
         result = {}
 
         def run():
-            st, part = eng.msm_partial_t(xs, pts, pkg.engine.FMT_RAW160)
+            # partial sum on this GPU, then the one exchange step (160 B per rank over RCCL) + fold
+            st, out = pkg.multi.msm_vartime_sharded(eng, xs, pts, pkg.engine.FMT_RAW160, pkg.engine.FMT_EDWARDS_Y)
             assert st == 0
-            if world > 1:                      # the one exchange step: 160 bytes per rank over RCCL
-                mine = torch.frombuffer(bytearray(part), dtype=torch.uint8).to(dev)
-                allp = torch.empty((world, 160), dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(allp, mine)
-                parts = [bytes(r) for r in allp.cpu().numpy()]
-            else:
-                parts = [part]
-            result["out"] = eng.fold_partials(parts, pkg.engine.FMT_EDWARDS_Y)
+            result["out"] = out
     elif wl == "verify":
         from oracle import orc as _orc       # input GENERATOR only (signing is not on the measured path)
         seeds = np.random.default_rng(1000 + rank).integers(0, 256, size=(n, 32), dtype=np.uint8)

@@ -6,5 +6,6 @@ There is no CPU fallback: constructing an Engine without the built library or wi
 """
 from .engine import Engine, EngineError, lib_path, load_library  # noqa: F401
 from . import dalek  # noqa: F401
+from . import multi  # noqa: F401
 
-__all__ = ["Engine", "EngineError", "lib_path", "load_library", "dalek"]
+__all__ = ["Engine", "EngineError", "lib_path", "load_library", "dalek", "multi"]

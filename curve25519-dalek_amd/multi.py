@@ -1,0 +1,65 @@
+"""Multi-GPU decomposition of the hot path: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+
+* MSM is a sum over terms: rank r takes the contiguous term range shard_range(n, r, world), computes
+  its partial sum on its own GPU (c25519_msm_partial_dev), then ONE exchange step: an all_gather of
+  one 160-byte raw point per rank, followed by the same complete-addition fold on every rank.
+  RCCL has no elliptic-curve reduction operator, so the "all-reduce of partial sums" is
+  all_gather + local fold; the payload is 160 B per rank, i.e. latency-bound.
+* fixed-base, X25519, (de)compression and verify_batch are independent units: replicas only, the
+  batch is split with shard_range and no collective is involved.
+"""
+import ctypes as C
+
+from . import engine as _e
+
+
+def shard_range(n, rank, world):
+    """Contiguous, balanced [lo, hi) of rank among world ranks (sizes differ by at most one)."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def fold_partials(partials, out_fmt=_e.FMT_EDWARDS_Y):
+    """Fold 160-byte partial sums into one encoded point.  Host arithmetic in the C library; needs no GPU."""
+    lib = _e.load_library()
+    width = {_e.FMT_EDWARDS_Y: 32, _e.FMT_RISTRETTO: 32, _e.FMT_RAW160: 160}[out_fmt]
+    out = C.create_string_buffer(width)
+    st = lib.c25519_fold_partials(None, b"".join(partials), len(partials), out_fmt, out)
+    if st != 0:
+        raise _e.EngineError("fold_partials failed with status %d" % st)
+    return out.raw
+
+
+def gather_fold(partial160, out_fmt=_e.FMT_EDWARDS_Y, group=None, device=None):
+    """The exchange step: all_gather this rank's 160-byte partial, fold on every rank.
+    Returns the same bytes on every rank."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return fold_partials([partial160], out_fmt)
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    mine = torch.frombuffer(bytearray(partial160), dtype=torch.uint8).to(dev)
+    allp = torch.empty((world * 160,), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allp, mine, group=group)
+    rows = allp.view(world, 160).cpu().numpy()
+    return fold_partials([rows[i].tobytes() for i in range(world)], out_fmt)
+
+
+def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None):
+    """scalars_t / points_t: THIS rank's shard, already on its GPU.  -> (status, bytes).  status NONE if
+    any rank saw a point that does not decompress (agreed on with one tiny all_reduce)."""
+    import torch
+    import torch.distributed as dist
+    st, part = eng.msm_partial_t(scalars_t, points_t, in_fmt)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        flag = torch.tensor([1 if st == _e.NONE else 0], dtype=torch.int32, device=scalars_t.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+        if int(flag.item()):
+            return _e.NONE, None
+    elif st == _e.NONE:
+        return _e.NONE, None
+    return _e.OK, gather_fold(part, out_fmt, group, scalars_t.device)

@@ -105,7 +105,8 @@ int32_t c25519_msm_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const 
 int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
 /* Multi-GPU building block: this rank's partial sum as a raw 160-byte point (no final compress),
  * and the fold of `count` partial points gathered from all ranks.  Both are
- * deterministic functions of their inputs. */
+ * deterministic functions of their inputs.  c25519_fold_partials is host arithmetic over `count`
+ * points (count = number of GPUs) and accepts ctx == NULL. */
 int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160);
 int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64_t count, int out_fmt, uint8_t *out);
 
