@@ -24,7 +24,7 @@ def i2b(x):
     return int(x).to_bytes(32, "little")
 
 
-def testvectors():
+def _testvectors():
     out = []
     with open(os.path.join(ROOT, "tests", "golden", "ed25519_testvectors.txt")) as fh:
         for line in fh:
@@ -37,7 +37,7 @@ def testvectors():
 @pytest.mark.parametrize("z_mode", [0, 1])
 def test_verify_batch_testvectors(eng, orc, z_mode):
     """all 128 TESTVECTORS triples (message lengths 0..1023 bytes) as one batch"""
-    tv = testvectors()
+    tv = _testvectors()
     pks, msgs, sigs = [t[0] for t in tv], [t[1] for t in tv], [t[2] for t in tv]
     assert eng.verify_batch(msgs, sigs, pks, z_mode) == OK == orc.ed25519_verify_batch(msgs, sigs, pks)
     for m in (1, 2, 7, 64):
@@ -57,7 +57,7 @@ def test_verify_batch_testvectors(eng, orc, z_mode):
 @pytest.mark.parametrize("z_mode", [0, 1])
 def test_verify_batch_error_precedence(eng, orc, z_mode):
     """batch.rs:152-165 / :208-211 / :244-250 and VerifyingKey::from_bytes (verifying.rs:167)"""
-    tv = testvectors()[:20]
+    tv = _testvectors()[:20]
     pks, msgs, sigs = [t[0] for t in tv], [t[1] for t in tv], [t[2] for t in tv]
     s_big = list(sigs); s_big[4] = sigs[4][:32] + i2b(int.from_bytes(sigs[4][32:], "little") + L)
     assert eng.verify_batch(msgs, s_big, pks, z_mode) == orc.ed25519_verify_batch(msgs, s_big, pks) == SCALAR_FORMAT
