@@ -102,7 +102,8 @@ __device__ __forceinline__ ge_p3 raw160_load(const uint8_t *in, u64 idx) {
 //     Table layout (global and LDS): [NWIN][HALF+1] entries x 6 uint4; entry j of window i is
 //     j * 2^(W*i) * B as canonical (y+x, y-x, 2dxy) 3 x 32 bytes; entry 0 is the identity.
 // ================================================================================================
-template <int W, int BS, bool RAW_OUT>
+// OUT: 0 = P32 scratch record (X,Y,Z) for the batched compressor, 1 = raw 160-byte point, 2 = P40 (tight limbs)
+template <int W, int BS, int OUT>
 __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ scalars, u64 n,
                                                  const uint4 *__restrict__ gtab, u32 *__restrict__ scratch,
                                                  uint8_t *__restrict__ out_raw) {
@@ -133,8 +134,13 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
             P = ge_p1p1_to_p3(ge_madd(P, A, neg));
             wtab += ENT * 6;
         }
-        if (RAW_OUT) raw160_store(out_raw, idx, P);
-        else p32_store(scratch, idx, P.X, P.Y, P.Z);
+        if (OUT == 1) raw160_store(out_raw, idx, P);
+        else if (OUT == 2) {
+            uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
+            u32 t[40];
+            for (int i = 0; i < 10; i++) { t[i] = P.X.v[i]; t[10 + i] = P.Y.v[i]; t[20 + i] = P.Z.v[i]; t[30 + i] = P.T.v[i]; }
+            for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        } else p32_store(scratch, idx, P.X, P.Y, P.Z);
     }
 }
 
@@ -352,19 +358,24 @@ static inline unsigned div_up(u64 a, u64 b) { return (unsigned)((a + b - 1) / b)
 
 template <int W, int BS>
 static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw,
-                                    int num_cus, hipStream_t st) {
+                                    int num_cus, hipStream_t st, bool p40 = false) {
     constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
     size_t lds_bytes = (size_t)NWIN * ENT * 96;
     unsigned grid = div_up(n, BS);
     unsigned maxgrid = (unsigned)num_cus * (lds_bytes > 80 * 1024 ? 1u : 2u);
     if (grid > maxgrid) grid = maxgrid;
-    if (out_raw) {
-        auto kfn = k_mul_base<W, BS, true>;
+    if (p40) {
+        auto kfn = k_mul_base<W, BS, 2>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
+    } else if (out_raw) {
+        auto kfn = k_mul_base<W, BS, 1>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
     } else {
-        auto kfn = k_mul_base<W, BS, false>;
+        auto kfn = k_mul_base<W, BS, 0>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
@@ -379,6 +390,16 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t 
     case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, scratch, out_raw, num_cus, st);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    switch (w) {
+    case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
+    case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
+    case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, out40, nullptr, num_cus, st, true);
     default: return hipErrorInvalidValue;
     }
 }

@@ -493,6 +493,12 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
     if (threadIdx.x == 0) for (int j = 0; j < 5; j++) partial[(u64)blockIdx.x * 5 + j] = red[0][j];
 }
 
+hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msgs, msg_off, sigs, pks, n, hram, bad_s);
+    return hipGetLastError();
+}
+
 }  // namespace c25519
 
 // ================================================================================================

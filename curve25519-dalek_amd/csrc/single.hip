@@ -1,0 +1,467 @@
+// Per-item (not batched-equation) paths that sit either side of the MSM on the reference's hot path:
+//
+//   c25519_mul_batch            out[i] = s_i * P_i          variable_base::mul (backend/serial/scalar_mul/
+//                                                           variable_base.rs:11-47; edwards.rs:890-911)
+//   ed25519_verify_each         per-signature verify / verify_strict, one status byte per signature:
+//                               R' = [s]B - [k]A, compress(R') == R bytes  (verifying.rs:203-214,
+//                               :359-382, RCompute::finish :549-556 over vartime_double_base.rs:23-72)
+//   ed25519_keygen_batch / ed25519_sign_batch   consumers of the fixed-base kernel
+//                               (verifying.rs:97-101, signing.rs:878-905; RFC 8032 5.1.5 / 5.1.6)
+//
+// GPU schedule of the double-base computation: the reference interleaves NAF(5) of k on a per-call
+// table of A with NAF(8) of s on a static table of B inside one 256-step doubling chain.  One chain per
+// lane with per-lane NAF patterns would diverge on every step, so the two halves are split:
+// [s]B comes from the LDS fixed-base table kernel (43 mixed additions, no doublings, k_mul_base) and
+// [k](-A) from a regular radix-16 fixed-window ladder (63 x 4 doublings + 64 additions, the schedule of
+// variable_base.rs) whose per-lane table of 8 multiples lives in an L2-resident scratch array laid out
+// [entry][quad][lane] so that a wave's reads stay within at most 9 contiguous 1-KiB rows.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <string.h>
+#include <vector>
+#include "../../include/c25519_hip.h"
+#include "ge26.h"
+#include "sc_sha.h"
+#include "kernels.h"
+#include "ctx.h"
+
+using namespace c25519;
+#define EXPORT extern "C" __attribute__((visibility("default")))
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+namespace c25519 {
+
+__device__ __forceinline__ void ld8(const uint8_t *base, u64 idx, u32 w[8]) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 2 * idx;
+    uint4 a = q[0], b = q[1];
+    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+}
+__device__ __forceinline__ void st8(uint8_t *base, u64 idx, const u32 w[8]) {
+    uint4 *q = reinterpret_cast<uint4 *>(base) + 2 * idx;
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+__device__ __forceinline__ feT fe51x5(const u64 *p) {
+    feW t;
+    for (int i = 0; i < 5; i++) { u64 l = p[i]; t.v[2 * i] = (u32)l & M26; t.v[2 * i + 1] = (u32)(l >> 26); }
+    return fe_carry(t);
+}
+__device__ __forceinline__ ge_p3 raw160_ld(const uint8_t *in, u64 idx) {
+    const u64 *p = reinterpret_cast<const u64 *>(in + idx * 160);
+    ge_p3 r;
+    r.X = fe51x5(p); r.Y = fe51x5(p + 5); r.Z = fe51x5(p + 10); r.T = fe51x5(p + 15);
+    return r;
+}
+__device__ __forceinline__ void p40_st(u32 *base, u64 idx, const ge_p3 &p) {
+    uint4 *q = reinterpret_cast<uint4 *>(base) + 10 * idx;
+    u32 t[40];
+    for (int i = 0; i < 10; i++) { t[i] = p.X.v[i]; t[10 + i] = p.Y.v[i]; t[20 + i] = p.Z.v[i]; t[30 + i] = p.T.v[i]; }
+    for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+}
+__device__ __forceinline__ ge_p3 p40_ld(const u32 *base, u64 idx) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 10 * idx;
+    u32 t[40];
+    for (int i = 0; i < 10; i++) { uint4 v = q[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
+    ge_p3 p;
+    for (int i = 0; i < 10; i++) { p.X.v[i] = t[i]; p.Y.v[i] = t[10 + i]; p.Z.v[i] = t[20 + i]; p.T.v[i] = t[30 + i]; }
+    return p;
+}
+
+// per-lane table entry j of lane L: quad q at  tab[((j * 10 + q) * stride + L)]   (uint4 units)
+__device__ __forceinline__ void tab_store(uint4 *tab, u64 stride, u64 lane, int j, const ge_cached &c) {
+    u32 t[40];
+    for (int i = 0; i < 10; i++) { t[i] = c.YpX.v[i]; t[10 + i] = c.YmX.v[i]; t[20 + i] = c.Z.v[i]; t[30 + i] = c.T2d.v[i]; }
+    for (int q = 0; q < 10; q++) tab[((u64)(j * 10 + q)) * stride + lane] = make_uint4(t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]);
+}
+__device__ __forceinline__ ge_cached tab_load(const uint4 *tab, u64 stride, u64 lane, u32 j) {
+    u32 t[40];
+    for (int q = 0; q < 10; q++) { uint4 v = tab[((u64)(j * 10 + q)) * stride + lane]; t[4 * q] = v.x; t[4 * q + 1] = v.y; t[4 * q + 2] = v.z; t[4 * q + 3] = v.w; }
+    ge_cached c;
+    for (int i = 0; i < 10; i++) { c.YpX.v[i] = t[i]; c.YmX.v[i] = t[10 + i]; c.Z.v[i] = t[20 + i]; c.T2d.v[i] = t[30 + i]; }
+    return c;
+}
+// p +/- q for a cached (ProjectiveNiels) operand: curve_models.rs:411-451, sign chosen per lane
+__device__ __forceinline__ ge_p1p1 ge_add_cached_signed(const ge_p3 &p, const ge_cached &q, bool neg) {
+    feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
+    feL a = fe_select(q.YpX, q.YmX, neg), b = fe_select(q.YmX, q.YpX, neg);
+    feT PP = fe_mul(YpX, a), MM = fe_mul(YmX, b);
+    feT TT = fe_mul(p.T, q.T2d), ZZ = fe_mul(p.Z, q.Z);
+    feL ZZ2 = fe_add(ZZ, ZZ);
+    feW Zp = fe_add_w(ZZ2, TT), Zm = fe_sub_w(ZZ2, TT);
+    ge_p1p1 r;
+    r.X = fe_sub(PP, MM); r.Y = fe_add(PP, MM);
+    r.Z = fe_select(Zp, Zm, neg); r.T = fe_select(Zm, Zp, neg);
+    return r;
+}
+
+// ================================================================================================
+// variable-base scalar multiplication, radix 16 (variable_base.rs:11-47), one (scalar, point) per lane
+//   IN_FMT 0: CompressedEdwardsY, 2: raw 160-byte;  NEGATE: multiply -P (verify: [k](-A))
+//   ok[i] = 0 if the point does not decompress (result unspecified)
+// ================================================================================================
+template <int IN_FMT, bool NEGATE>
+__global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points, u64 n,
+                                                  uint4 *__restrict__ tab, u32 *__restrict__ out40, uint8_t *__restrict__ ok) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    ge_p3 P;
+    bool good = true;
+    if (IN_FMT == 0) { u32 w[8]; ld8(points, idx, w); good = ge_decompress(P, w); }
+    else P = raw160_ld(points, idx);
+    if (NEGATE) P = ge_neg(P);
+    if (ok) ok[idx] = good ? 1 : 0;
+    // table: entry 0 = identity, entry j = j*P (j = 1..8), window.rs:97-104
+    {
+        ge_cached id;
+        id.YpX = fe_one(); id.YmX = fe_one(); id.Z = fe_one(); id.T2d = fe_zero();
+        tab_store(tab, stride, idx, 0, id);
+        ge_cached c1 = ge_p3_to_cached(P);
+        tab_store(tab, stride, idx, 1, c1);
+        ge_p3 acc = P;
+#pragma unroll 1
+        for (int j = 2; j <= 8; j++) {
+            acc = ge_p1p1_to_p3(ge_add_cached(acc, c1));
+            tab_store(tab, stride, idx, j, ge_p3_to_cached(acc));
+        }
+    }
+    // digits: nibble_i(s') - 8 with s' = s + 0x0888...8 (top nibble left unsigned), scalar.rs:1019-1051
+    u32 s[8];
+    ld8(scalars, idx, s);
+    {
+        u64 carry = 0;
+        for (int i = 0; i < 8; i++) { u64 v = (u64)s[i] + (i == 7 ? 0x08888888u : 0x88888888u) + carry; s[i] = (u32)v; carry = v >> 32; }
+    }
+    ge_p3 acc = ge_identity();
+#pragma unroll 1
+    for (int i = 63; i >= 0; i--) {
+        u32 nib = s[7] >> 28;
+#pragma unroll
+        for (int k = 7; k > 0; k--) s[k] = (s[k] << 4) | (s[k - 1] >> 28);
+        s[0] <<= 4;
+        int d = (i == 63) ? (int)nib : (int)nib - 8;
+        if (i != 63) acc = ge_mul_by_pow_2(acc, 4);
+        bool neg = d < 0;
+        u32 mag = (u32)(neg ? -d : d);
+        ge_cached c = tab_load(tab, stride, idx, mag);
+        acc = ge_p1p1_to_p3(ge_add_cached_signed(acc, c, neg));
+    }
+    p40_st(out40, idx, acc);
+}
+
+// P40 -> raw160 / P32 (for the batched compressor)
+__global__ void __launch_bounds__(256) k_p40_to_raw(const u32 *__restrict__ in40, u64 n, uint8_t *__restrict__ out_raw) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    ge_p3 p = p40_ld(in40, idx);
+    u64 l[20];
+    const feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
+    for (int c = 0; c < 4; c++) { u32 cl[10]; fe_canonical_limbs(*f[c], cl); for (int i = 0; i < 5; i++) l[5 * c + i] = (u64)cl[2 * i] | ((u64)cl[2 * i + 1] << 26); }
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out_raw) + 10 * idx;
+    for (int i = 0; i < 10; i++) q[i] = make_ulonglong2(l[2 * i], l[2 * i + 1]);
+}
+// sum of two P40 arrays -> P32 scratch (X,Y,Z) for the batched compressor
+__global__ void __launch_bounds__(256) k_p40_add_to_p32(const u32 *__restrict__ a40, const u32 *__restrict__ b40, u64 n, u32 *__restrict__ scratch) {
+    u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    ge_p3 r = b40 ? ge_add(p40_ld(a40, idx), p40_ld(b40, idx)) : p40_ld(a40, idx);
+    uint4 *q = reinterpret_cast<uint4 *>(scratch) + 8 * idx;
+    q[0] = make_uint4(r.X.v[0], r.X.v[1], r.X.v[2], r.X.v[3]); q[1] = make_uint4(r.X.v[4], r.X.v[5], r.X.v[6], r.X.v[7]);
+    q[2] = make_uint4(r.X.v[8], r.X.v[9], r.Y.v[0], r.Y.v[1]); q[3] = make_uint4(r.Y.v[2], r.Y.v[3], r.Y.v[4], r.Y.v[5]);
+    q[4] = make_uint4(r.Y.v[6], r.Y.v[7], r.Y.v[8], r.Y.v[9]); q[5] = make_uint4(r.Z.v[0], r.Z.v[1], r.Z.v[2], r.Z.v[3]);
+    q[6] = make_uint4(r.Z.v[4], r.Z.v[5], r.Z.v[6], r.Z.v[7]); q[7] = make_uint4(r.Z.v[8], r.Z.v[9], 0u, 0u);
+}
+
+// ================================================================================================
+// per-signature verification glue
+// ================================================================================================
+// k_i = SHA-512(R||A||M) mod l from the 64-byte digests (scalar.rs:248); s canonical flag
+__global__ void __launch_bounds__(256) k_hram_reduce(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n,
+                                                     uint8_t *__restrict__ kscal, uint8_t *__restrict__ sscal, uint8_t *__restrict__ s_ok) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 *hw = reinterpret_cast<const u32 *>(hram) + 16 * i;
+    u32 h16[16];
+    for (int j = 0; j < 16; j++) h16[j] = hw[j];
+    u32 kw[8];
+    sc_to_words(sc_from_wide(h16), kw);
+    st8(kscal, i, kw);
+    u32 s[8];
+    ld8(sigs, 2 * i + 1, s);
+    bool canon = sc_is_canonical(s);
+    s_ok[i] = canon ? 1 : 0;
+    if (!canon) { for (int j = 0; j < 8; j++) s[j] = 0; }   // keep the fixed-base kernel's precondition (< 2^255)
+    st8(sscal, i, s);
+}
+// strict mode: small-order checks on R and A (verifying.rs:371-374, edwards.rs:1405)
+__global__ void __launch_bounds__(256) k_strict_checks(const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ strict_bad) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 r[8], a[8];
+    ld8(sigs, 2 * i, r);
+    ld8(pks, i, a);
+    ge_p3 R, A;
+    bool okR = ge_decompress(R, r), okA = ge_decompress(A, a);
+    bool bad = !okR;
+    bad |= ge_is_identity(ge_mul_by_pow_2(R, 3));
+    bad |= okA && ge_is_identity(ge_mul_by_pow_2(A, 3));
+    strict_bad[i] = bad ? 1 : 0;
+}
+// status_i from the flags and compress(R') == R bytes   (verifying.rs:211, :377-381)
+__global__ void __launch_bounds__(256) k_verdict(const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ rcheck, const uint8_t *__restrict__ a_ok,
+                                                 const uint8_t *__restrict__ s_ok, const uint8_t *__restrict__ strict_bad, u64 n, uint8_t *__restrict__ status) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 r[8], c[8];
+    ld8(sigs, 2 * i, r);
+    ld8(rcheck, i, c);
+    u32 d = 0;
+    for (int j = 0; j < 8; j++) d |= r[j] ^ c[j];
+    uint8_t st = C25519_OK;
+    if (!a_ok[i]) st = C25519_NONE;
+    else if (!s_ok[i]) st = C25519_SCALAR_FORMAT;
+    else if ((strict_bad && strict_bad[i]) || d != 0) st = C25519_VERIFY;
+    status[i] = st;
+}
+
+// ================================================================================================
+// batched key generation and signing (RFC 8032 5.1.5 / 5.1.6; signing.rs:878-905, verifying.rs:97-101)
+// ================================================================================================
+// h = SHA-512(seed): a = clamp(h[0..32]) -> scal_a;  prefix = h[32..64]
+__global__ void __launch_bounds__(256) k_expand_seed(const uint8_t *__restrict__ seeds, u64 n, uint8_t *__restrict__ scal_a, uint8_t *__restrict__ prefix) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 sd[8];
+    ld8(seeds, i, sd);
+    u64 hs[8], w[16];
+    sha512_init(hs);
+    for (int j = 0; j < 4; j++) w[j] = bswap64((u64)sd[2 * j] | ((u64)sd[2 * j + 1] << 32));
+    w[4] = 0x8000000000000000ull;
+    for (int j = 5; j < 15; j++) w[j] = 0;
+    w[15] = 32 * 8;
+    sha512_compress(hs, w);
+    u32 d[16];
+    sha512_digest_words(hs, d);
+    d[0] &= 0xfffffff8u; d[7] &= 0x7fffffffu; d[7] |= 0x40000000u;   // clamp_integer, scalar.rs:1407
+    st8(scal_a, i, d);
+    st8(prefix, i, d + 8);
+}
+// r_i = SHA-512(prefix_i || M_i) mod l
+__global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ prefix, const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 n,
+                                                    uint8_t *__restrict__ rscal) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 p[8];
+    ld8(prefix, i, p);
+    sha512_stream st;
+    st.init();
+    for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)p[2 * j] | ((u64)p[2 * j + 1] << 32));
+    st.fill = 32; st.total = 32;
+    const uint8_t *m = msgs + msg_off[i];
+    u64 len = msg_off[i + 1] - msg_off[i];
+    for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
+    st.finish();
+    u32 d[16], r[8];
+    sha512_digest_words(st.h, d);
+    sc_to_words(sc_from_wide(d), r);
+    st8(rscal, i, r);
+}
+// s_i = k_i * a_i + r_i mod l;  sig_i = R_i || s_i      (k_i = H(R||A||M) mod l given as 64-byte digests)
+__global__ void __launch_bounds__(256) k_sign_finish(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ scal_a, const uint8_t *__restrict__ rscal,
+                                                     const uint8_t *__restrict__ Renc, u64 n, uint8_t *__restrict__ sigs) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 *hw = reinterpret_cast<const u32 *>(hram) + 16 * i;
+    u32 h16[16];
+    for (int j = 0; j < 16; j++) h16[j] = hw[j];
+    u32 a[8], r[8], R[8], s[8];
+    ld8(scal_a, i, a); ld8(rscal, i, r); ld8(Renc, i, R);
+    sc52 sv = sc_add(sc_mul(sc_from_wide(h16), sc_reduce256(a)), sc_from_words(r));
+    sc_to_words(sv, s);
+    st8(sigs, 2 * i, R);
+    st8(sigs, 2 * i + 1, s);
+}
+// signatures with R filled in only (so k_hram can hash R || A || M): copy R into sig slots
+__global__ void __launch_bounds__(256) k_place_R(const uint8_t *__restrict__ Renc, u64 n, uint8_t *__restrict__ sigs) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 R[8];
+    ld8(Renc, i, R);
+    st8(sigs, 2 * i, R);
+}
+
+}  // namespace c25519
+
+static inline unsigned dup(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- variable base ------------------------------------------------------------------------------------
+static int32_t var_base_launch(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, bool negate, uint32_t *out40, uint8_t *d_ok) {
+    const unsigned grid = dup(n, 256);
+    const uint64_t stride = (uint64_t)grid * 256;
+    int32_t r = ctx_reserve(ctx, ctx->tmp_d, stride * 9 * 160);
+    if (r) return r;
+    uint4 *tab = (uint4 *)ctx->tmp_d.p;
+    hipStream_t st = ctx->stream;
+    if (in_fmt == C25519_FMT_EDWARDS_Y) {
+        if (negate) hipLaunchKernelGGL((k_var_base<0, true>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+        else hipLaunchKernelGGL((k_var_base<0, false>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+    } else if (in_fmt == C25519_FMT_RAW160) {
+        if (negate) hipLaunchKernelGGL((k_var_base<2, true>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+        else hipLaunchKernelGGL((k_var_base<2, false>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+    } else { ctx->err = "mul_batch: in_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+
+EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_batch: out_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + n + 256))) return r;
+    uint32_t *p40 = (uint32_t *)ctx->tmp_e.p;
+    uint8_t *okbuf = d_ok ? d_ok : (uint8_t *)ctx->tmp_e.p + n * 160;
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    if ((r = var_base_launch(ctx, d_scalars, d_points, n, in_fmt, false, p40, okbuf))) return r;
+    HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    if (out_fmt == C25519_FMT_RAW160) {
+        hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, n, d_out);
+    } else {
+        if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+        hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, (uint32_t *)ctx->scratch.p);
+        HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ring[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * osz + n + 16))) return r;
+    if (n == 0) return C25519_OK;
+    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
+    if ((r = c25519_mul_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, out_fmt, dout, dok))) return r;
+    HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
+    if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+
+// ---- per-signature verify ---------------------------------------------------------------------------------
+EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                       const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status) {
+    (void)msgs_len;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    hipStream_t st = ctx->stream;
+    int32_t r;
+    // tmp_f: hram 64n | k 32n | s 32n | s_ok n | a_ok n | strict n | rcheck 32n | P40 [k](-A) 160n | Q40 [s]B 160n
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oH = carve(n * 64), oK = carve(n * 32), oS = carve(n * 32), oSo = carve(n), oAo = carve(n), oSt = carve(n), oRc = carve(n * 32), oP = carve(n * 160), oQ = carve(n * 160);
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, off)) || (r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
+    uint8_t *hram = ws + oH, *kscal = ws + oK, *sscal = ws + oS, *s_ok = ws + oSo, *a_ok = ws + oAo, *sbad = ws + oSt, *rcheck = ws + oRc;
+    uint32_t *P40 = (uint32_t *)(ws + oP), *Q40 = (uint32_t *)(ws + oQ);
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
+    hipLaunchKernelGGL(k_hram_reduce, dim3(dup(n, 256)), dim3(256), 0, st, hram, d_sigs, n, kscal, sscal, s_ok);
+    HIPCHK(hipEventRecord(ring[0], st));
+    if ((r = var_base_launch(ctx, kscal, d_pks, n, C25519_FMT_EDWARDS_Y, true, P40, a_ok))) return r;    // [k](-A)
+    HIPCHK(hipEventRecord(ring[1], st));
+    HIPCHK(launch_mul_base_p40(ctx->w, sscal, n, ctx->d_table, Q40, ctx->num_cus, st));                      // [s]B
+    hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, st, P40, Q40, n, (uint32_t *)ctx->scratch.p);
+    HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, rcheck, st));
+    if (strict) hipLaunchKernelGGL(k_strict_checks, dim3(dup(n, 256)), dim3(256), 0, st, d_sigs, d_pks, n, sbad);
+    hipLaunchKernelGGL(k_verdict, dim3(dup(n, 256)), dim3(256), 0, st, d_sigs, rcheck, a_ok, s_ok, strict ? sbad : (const uint8_t *)nullptr, n, d_status);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ring[2], st));
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                   uint64_t n, int strict, uint8_t *status) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    uint64_t mlen = msg_off[n];
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64 + n * 32 + n + 64))) return r;
+    uint8_t *dsig = (uint8_t *)ctx->tmp_c.p, *dpk = dsig + n * 64, *dst = dpk + n * 32;
+    if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dsig, sigs, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dpk, pks, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((r = ed25519_verify_each_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, dsig, dpk, n, strict, dst))) return r;
+    HIPCHK(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+
+// ---- key generation / signing -------------------------------------------------------------------------------
+EXPORT int32_t ed25519_keygen_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, uint64_t n, uint8_t *d_pks) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, n * 64 + 256))) return r;
+    uint8_t *a = (uint8_t *)ctx->tmp_f.p, *prefix = a + n * 32;
+    hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, d_seeds, n, a, prefix);
+    HIPCHK(hipGetLastError());
+    if ((r = c25519_mul_base_batch_dev(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks))) return r;
+    HIPCHK(hipMemsetAsync(a, 0, n * 64, ctx->stream));   // wipe the expanded secrets
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                      uint64_t n, uint8_t *d_pks, uint8_t *d_sigs) {
+    (void)msgs_len;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    hipStream_t st = ctx->stream;
+    int32_t r;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oA = carve(n * 32), oPre = carve(n * 32), oR = carve(n * 32), oRe = carve(n * 32), oH = carve(n * 64);
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
+    uint8_t *a = ws + oA, *prefix = ws + oPre, *rscal = ws + oR, *Renc = ws + oRe, *hram = ws + oH;
+    hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, st, d_seeds, n, a, prefix);
+    if ((r = c25519_mul_base_batch_dev(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks))) return r;              // A = a*B
+    hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, n, rscal);
+    if ((r = c25519_mul_base_batch_dev(ctx, rscal, n, C25519_FMT_EDWARDS_Y, Renc))) return r;           // R = r*B
+    hipLaunchKernelGGL(k_place_R, dim3(dup(n, 256)), dim3(256), 0, st, Renc, n, d_sigs);
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
+    hipLaunchKernelGGL(k_sign_finish, dim3(dup(n, 256)), dim3(256), 0, st, hram, a, rscal, Renc, n, d_sigs);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(ws, 0, oRe, st));     // wipe secret scalars / prefixes / nonces (zeroize discipline)
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    uint64_t mlen = msg_off[n];
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 128 + 64))) return r;
+    uint8_t *dseed = (uint8_t *)ctx->tmp_c.p, *dpk = dseed + n * 32, *dsig = dpk + n * 32;
+    if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(dseed, seeds, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((r = ed25519_sign_batch_dev(ctx, dseed, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, n, dpk, dsig))) return r;
+    HIPCHK(hipMemcpyAsync(pks, dpk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(sigs, dsig, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemsetAsync(dseed, 0, n * 32, ctx->stream));
+    return C25519_OK;
+}

@@ -62,6 +62,13 @@ def load_library():
         "c25519_fold_partials": (i32, [vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_batch_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32]),
+        "c25519_mul_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_mul_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "ed25519_verify_each_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_int, vp]),
+        "ed25519_verify_each": (i32, [vp, vp, vp, vp, vp, u64, C.c_int, vp]),
+        "ed25519_keygen_batch_dev": (i32, [vp, vp, u64, vp]),
+        "ed25519_sign_batch_dev": (i32, [vp, vp, vp, vp, u64, u64, vp, vp]),
+        "ed25519_sign_batch": (i32, [vp, vp, vp, vp, u64, vp, vp]),
         "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
     }
     for name, (res, args) in sigs.items():
@@ -77,6 +84,8 @@ ABI_SYMBOLS = [
     "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "c25519_microbench",
+    "c25519_mul_batch_dev", "c25519_mul_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
+    "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
 ]
 
 _PT = {FMT_EDWARDS_Y: 32, FMT_RISTRETTO: 32, FMT_RAW160: 160}
@@ -212,6 +221,40 @@ class Engine:
                                                            sigs.data_ptr(), pks.data_ptr(), n, z_mode),
                          (OK, NONE, SCALAR_FORMAT, VERIFY))
 
+    def mul_batch_t(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        n = self._t(scalars, 32)
+        assert self._t(points, _PT[in_fmt]) == n
+        out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
+        ok = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_batch_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out_fmt, out.data_ptr(), ok.data_ptr()))
+        return out, ok
+
+    def verify_each_t(self, msgs, msg_off, sigs, pks, strict=False):
+        n = self._t(sigs, 64)
+        assert self._t(pks, 32) == n and msg_off.numel() == n + 1
+        status = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_verify_each_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(), sigs.data_ptr(), pks.data_ptr(),
+                                                   n, 1 if strict else 0, status.data_ptr()))
+        return status
+
+    def keygen_batch_t(self, seeds):
+        n = self._t(seeds, 32)
+        pks = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_keygen_batch_dev(self.ctx, seeds.data_ptr(), n, pks.data_ptr()))
+        return pks
+
+    def sign_batch_t(self, seeds, msgs, msg_off):
+        n = self._t(seeds, 32)
+        assert msg_off.numel() == n + 1
+        pks = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        sigs = self.torch.empty((n, 64), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_sign_batch_dev(self.ctx, seeds.data_ptr(), msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(), n, pks.data_ptr(), sigs.data_ptr()))
+        return pks, sigs
+
     # -- host-buffer API (numpy in / numpy out) ---------------------------------------------------
     def mul_base_batch(self, scalars, out_fmt=FMT_EDWARDS_Y):
         s = _np8(scalars, 32); n = s.shape[0]
@@ -264,3 +307,45 @@ class Engine:
         self._bind_stream()
         return self._chk(self.lib.ed25519_verify_batch(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, z_mode),
                          (OK, NONE, SCALAR_FORMAT, VERIFY))
+
+    def mul_batch(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        s = _np8(scalars, 32); p = _np8(points, _PT[in_fmt]); n = s.shape[0]
+        assert p.shape[0] == n
+        out = np.empty((n, _PT[out_fmt]), dtype=np.uint8); ok = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_batch(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out.ctypes.data, ok.ctypes.data))
+        return out, ok
+
+    @staticmethod
+    def _pack(msgs):
+        n = len(msgs)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        for i, m in enumerate(msgs):
+            off[i + 1] = off[i] + len(m)
+        return np.frombuffer(b"".join(msgs) + b"\0" * 16, dtype=np.uint8), off
+
+    def verify_each(self, msgs, sigs, pks, strict=False):
+        """-> numpy uint8 status per signature (0 OK, 1 bad key, 2 ScalarFormat, 3 Verify)."""
+        n = len(msgs)
+        assert len(sigs) == n and len(pks) == n
+        status = np.empty((n,), dtype=np.uint8)
+        if n == 0:
+            return status
+        blob, off = self._pack(list(msgs))
+        s = _np8(b"".join(sigs), 64); p = _np8(b"".join(pks), 32)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_verify_each(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, 1 if strict else 0, status.ctypes.data))
+        return status
+
+    def sign_batch(self, seeds, msgs):
+        """-> (pks (n,32), sigs (n,64)) numpy arrays; seeds: list of 32-byte secret keys."""
+        n = len(seeds)
+        assert len(msgs) == n
+        pks = np.empty((n, 32), dtype=np.uint8); sigs = np.empty((n, 64), dtype=np.uint8)
+        if n == 0:
+            return pks, sigs
+        blob, off = self._pack(list(msgs))
+        sd = _np8(b"".join(seeds), 32)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_sign_batch(self.ctx, sd.ctypes.data, blob.ctypes.data, off.ctypes.data, n, pks.ctypes.data, sigs.ctypes.data))
+        return pks, sigs

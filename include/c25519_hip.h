@@ -121,6 +121,33 @@ int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const u
 int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                              const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint32_t z_mode);
 
+/* ---- variable base: out[i] = scalars[i] * points[i] ------------------------------------------------
+ * replaces backend::variable_base_mul (backend.rs:253 -> scalar_mul/variable_base.rs:11-47;
+ * `&EdwardsPoint * &Scalar`, edwards.rs:890-911), radix-16 fixed windows, one pair per lane.
+ * points: n x 32 (fmt 0) or n x 160 (fmt 2); out: n x 32 (fmt 0) or n x 160 (fmt 2);
+ * ok (may be NULL): n bytes, 0 where a compressed point did not decode (that output is unspecified). */
+int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
+int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
+
+/* ---- per-signature verification: status[i] for every signature ----------------------------------------
+ * replaces VerifyingKey::verify (verifying.rs:565 -> raw_verify :203 -> RCompute::finish :549-556 over
+ * vartime_double_base::mul, scalar_mul/vartime_double_base.rs:23-72) and, with strict != 0,
+ * VerifyingKey::verify_strict (verifying.rs:359-382: R must decode, R and A must not be of small
+ * order).  status[i]: 0 OK, 1 key does not decode (VerifyingKey::from_bytes), 2 SCALAR_FORMAT, 3 VERIFY.
+ * This is what locates the bad signature after a failed batch. */
+int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status);
+int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                            uint64_t n, int strict, uint8_t *status);
+
+/* ---- batched key generation and signing (consumers of the fixed-base kernel) ---------------------------
+ * keygen: pk_i = compress(clamp(SHA-512(seed_i)[0..32]) * B)   (verifying.rs:97-101, RFC 8032 5.1.5)
+ * sign:   RFC 8032 5.1.6 as in signing.rs:878-905; also returns the public keys.  seeds: n x 32. */
+int32_t ed25519_keygen_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, uint64_t n, uint8_t *d_pks);
+int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                               uint64_t n, uint8_t *d_pks, uint8_t *d_sigs);
+int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------
  * Integer-multiplier roofline probes: runs a dependent-free chain microbenchmark and
  * returns giga-operations per second.  which: 0 v_mad_u64_u32, 1 fe_mul (radix 2^25.5, this

@@ -6,6 +6,15 @@ TAG=${1:-r01}
 OUT=$R/gpurun_out/profiles_$TAG
 RAW=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $RAW
+# microbench FIRST: rocprofv3 counter passes can leave the GPU in a lower profiling clock state
+cd $R
+python - <<'PY' > $OUT/${TAG}_microbench.txt 2>&1
+import curve25519_dalek_amd as pkg
+e = pkg.Engine(0)
+for i, nm in enumerate(["v_mad_u64_u32", "fe_mul (radix 2^25.5, 10 x u32)", "fe_sq", "fe_mul (5 x u64, u128 products)", "v_add_u32+v_xor_b32 pairs", "v_mul_lo_u32"]):
+    print("%-36s %10.1f Gop/s" % (nm, max(e.microbench(i, 4000) for _ in range(3))))
+PY
+(rocm-smi --showclocks --showpower 2>/dev/null | head -30) > $OUT/${TAG}_rocm_smi.txt
 cd /tmp && export TMPDIR=/tmp
 for w in fixed_base x25519 msm verify; do
   timeout 300 rocprofv3 --kernel-trace --stats -d $RAW/kt_$w -o $w -- python $R/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline > $RAW/kt_$w.log 2>&1
@@ -21,11 +30,4 @@ for w in fixed_base verify x25519 msm; do
   done
   python $R/tools/pmc_summary.py $RAW/pmc_${w}_* > $OUT/${TAG}_${w}_pmc.txt 2>&1
 done
-cd $R
-python - <<'PY' > $OUT/${TAG}_microbench.txt 2>&1
-import curve25519_dalek_amd as pkg
-e = pkg.Engine(0)
-for i, nm in enumerate(["v_mad_u64_u32", "fe_mul (radix 2^25.5, 10 x u32)", "fe_sq", "fe_mul (5 x u64, u128 products)", "v_add_u32+v_xor_b32 pairs", "v_mul_lo_u32"]):
-    print("%-36s %10.1f Gop/s" % (nm, max(e.microbench(i, 4000) for _ in range(3))))
-PY
 ls -la $OUT
