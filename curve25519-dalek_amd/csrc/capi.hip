@@ -211,11 +211,15 @@ EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, ui
 // ---- X25519 --------------------------------------------------------------------------------------
 EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
-    HIPCHK(launch_x25519(d_k, d_u, n, d_out, ctx->stream));
+    HIPCHK(launch_x25519(d_k, d_u, n, (uint32_t *)ctx->scratch.p, ctx->stream));
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    HIPCHK(launch_ratio_p32(0, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // U / W, 0 -> 0
+    HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // the projective result is secret-derived: wipe
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
@@ -280,6 +284,26 @@ EXPORT int32_t c25519_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_
     int32_t r;
     if ((r = a.up(in, n * 160)) || (r = o.alloc(n * 32))) return r;
     if ((r = c25519_compress_batch_dev(ctx, a.p, n, out_fmt, o.p))) return r;
+    return o.down(out, n * 32);
+}
+
+// ---- EdwardsPoint::to_montgomery_batch (edwards.rs:595-612) -------------------------------------------------
+EXPORT int32_t c25519_to_montgomery_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(launch_raw_to_p32(d_in, n, (uint32_t *)ctx->scratch.p, ctx->stream));
+    HIPCHK(launch_ratio_p32(1, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
+    int32_t r;
+    if ((r = a.up(in, n * 160)) || (r = o.alloc(n * 32))) return r;
+    if ((r = c25519_to_montgomery_batch_dev(ctx, a.p, n, o.p))) return r;
     return o.down(out, n * 32);
 }
 

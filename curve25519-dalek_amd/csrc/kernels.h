@@ -10,7 +10,8 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, uint64_t n, const uint
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st);
 hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st);
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);
-hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, uint64_t n, uint32_t *scratch, hipStream_t st);
+hipError_t launch_ratio_p32(int mode, const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_decompress_edwards(const uint8_t *in, uint64_t n, uint8_t *out_raw, uint8_t *ok, uint32_t *any_bad, hipStream_t st);
 hipError_t launch_decompress_ristretto(const uint8_t *in, uint64_t n, uint8_t *out_raw, uint8_t *ok, uint32_t *any_bad, hipStream_t st);
 hipError_t launch_compress_ristretto(const uint8_t *in_raw, uint64_t n, uint8_t *out, hipStream_t st);

@@ -185,7 +185,7 @@ __global__ void __launch_bounds__(256) k_compress_p32(const u32 *__restrict__ sc
 //     The scalar is kept as a 256-bit shift register so no register is indexed dynamically.
 // ================================================================================================
 __global__ void __launch_bounds__(256) k_x25519(const uint8_t *__restrict__ ks, const uint8_t *__restrict__ us, u64 n,
-                                                uint8_t *__restrict__ out) {
+                                                u32 *__restrict__ scratch) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
     u32 s[8], uw[8];
@@ -212,9 +212,47 @@ __global__ void __launch_bounds__(256) k_x25519(const uint8_t *__restrict__ ks, 
         prev = cur;
     }
     fe_cswap(x0.U, x1.U, prev); fe_cswap(x0.W, x1.W, prev);
-    u32 w[8];
-    fe_to_words(fe_mul(x0.U, fe_invert(x0.W)), w);
-    store8(out, idx, w);
+    p32_store(scratch, idx, x0.U, x0.U, x0.W);     // (U : W); the division is batched in k_ratio_p32
+}
+
+// ================================================================================================
+// batched ratios N_i / D_i -> canonical 32 bytes, with the reference's invert(0) = 0 convention
+// (field.rs:225-273: zeros are skipped by Montgomery's trick and stay zero).
+//   MODE 0: N = X, D = Z of the P32 record          (X25519 as_affine, montgomery.rs:409: U / W)
+//   MODE 1: N = Z + Y, D = Z - Y                    (EdwardsPoint::to_montgomery_batch, edwards.rs:595-612)
+// ================================================================================================
+template <int CH, int MODE>
+__global__ void __launch_bounds__(256) k_ratio_p32(const u32 *__restrict__ scratch, u32 *__restrict__ prefix, u64 n, uint8_t *__restrict__ out) {
+    const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    feT acc = fe_one();
+#pragma unroll 1
+    for (int j = 0; j < CH; j++) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) break;
+        feT X, Y, Z = p32_load_z(scratch, idx);
+        feT D = Z;
+        if (MODE == 1) { p32_load_xy(scratch, idx, X, Y); D = fe_carry(fe_sub(Z, Y)); }
+        fe48_store(prefix, idx, acc);
+        feT next = fe_mul(acc, D);
+        acc = fe_select(next, acc, fe_is_zero(D));
+    }
+    feT inv = fe_invert(acc);
+#pragma unroll 1
+    for (int j = CH - 1; j >= 0; j--) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) continue;
+        feT X, Y, Z = p32_load_z(scratch, idx);
+        p32_load_xy(scratch, idx, X, Y);
+        feT D = Z, N = X;
+        if (MODE == 1) { D = fe_carry(fe_sub(Z, Y)); N = fe_carry(fe_add(Z, Y)); }
+        bool dz = fe_is_zero(D);
+        feT dinv = fe_select(fe_mul(inv, fe48_load(prefix, idx)), fe_zero(), dz);
+        inv = fe_select(fe_mul(inv, D), inv, dz);
+        u32 w[8];
+        fe_to_words(fe_mul(N, dinv), w);
+        store8(out, idx, w);
+    }
 }
 
 // ================================================================================================
@@ -413,9 +451,18 @@ hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, u64 n,
     return hipGetLastError();
 }
 
-hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, u64 n, uint8_t *out, hipStream_t st) {
+hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, u64 n, uint32_t *scratch, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_x25519, dim3(div_up(n, 256)), dim3(256), 0, st, k, u, n, out);
+    hipLaunchKernelGGL(k_x25519, dim3(div_up(n, 256)), dim3(256), 0, st, k, u, n, scratch);
+    return hipGetLastError();
+}
+// mode 0: X/Z, mode 1: (Z+Y)/(Z-Y) of the P32 records
+hipError_t launch_ratio_p32(int mode, const uint32_t *scratch, uint32_t *prefix, u64 n, uint8_t *out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    constexpr int CH = 16;
+    unsigned grid = div_up((n + CH - 1) / CH, 256);
+    if (mode == 0) hipLaunchKernelGGL((k_ratio_p32<CH, 0>), dim3(grid), dim3(256), 0, st, scratch, prefix, n, out);
+    else hipLaunchKernelGGL((k_ratio_p32<CH, 1>), dim3(grid), dim3(256), 0, st, scratch, prefix, n, out);
     return hipGetLastError();
 }
 

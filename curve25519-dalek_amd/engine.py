@@ -56,6 +56,8 @@ def load_library():
         "c25519_decompress_batch": (i32, [vp, vp, u64, C.c_int, vp, vp]),
         "c25519_compress_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_compress_batch": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_to_montgomery_batch_dev": (i32, [vp, vp, u64, vp]),
+        "c25519_to_montgomery_batch": (i32, [vp, vp, u64, vp]),
         "c25519_msm_vartime_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
         "c25519_msm_vartime": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
         "c25519_msm_partial_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
@@ -86,6 +88,7 @@ ABI_SYMBOLS = [
     "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "c25519_microbench",
     "c25519_mul_batch_dev", "c25519_mul_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
+    "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
 ]
 
 _PT = {FMT_EDWARDS_Y: 32, FMT_RISTRETTO: 32, FMT_RAW160: 160}
@@ -349,3 +352,10 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.ed25519_sign_batch(self.ctx, sd.ctypes.data, blob.ctypes.data, off.ctypes.data, n, pks.ctypes.data, sigs.ctypes.data))
         return pks, sigs
+
+    def to_montgomery_batch(self, pts):
+        p = _np8(pts, 160); n = p.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_to_montgomery_batch(self.ctx, p.ctypes.data, n, out.ctypes.data))
+        return out

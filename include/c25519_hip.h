@@ -95,6 +95,12 @@ int32_t c25519_decompress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, 
 int32_t c25519_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int out_fmt, uint8_t *d_out);
 int32_t c25519_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int out_fmt, uint8_t *out);
 
+/* Edwards -> Montgomery u-coordinate, batched: EdwardsPoint::to_montgomery_batch (edwards.rs:595-612),
+ * u = (Z+Y)/(Z-Y) with one shared inversion per lane-chunk; the identity maps to u = 0 (edwards.rs:574-590).
+ * in: n x 160 raw points; out: n x 32 MontgomeryPoint bytes. */
+int32_t c25519_to_montgomery_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out);
+int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
+
 /* ---- variable-time multiscalar multiplication: out = sum scalars[i] * points[i] -----------------
  * replaces backend::pippenger_optional_multiscalar_mul / straus_optional_multiscalar_mul
  * (backend.rs:79, :224; edwards.rs:1002-1031; ristretto.rs:984).  points: n x 32 (fmt 0/1) or

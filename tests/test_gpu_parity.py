@@ -141,3 +141,20 @@ def test_ristretto_vs_oracle(eng, orc, golden):
     got = eng.compress_batch(raw, out_fmt=1)
     for i in range(200):
         assert got[i].tobytes() == orc.ris_compress(orc.ed_mul_base(s[i].tobytes()))
+
+
+def test_to_montgomery_batch_vs_oracle(eng, orc):
+    """edwards.rs:2339-2360 batch_to_montgomery: batched == one-at-a-time; identity -> 0"""
+    s = util.rand_scalars(81, 5000)
+    s[0] = 0                                   # the identity: Z - Y = 0, must give u = 0 without poisoning the batch
+    s[17] = 0
+    raw = eng.mul_base_batch(s, out_fmt=2)
+    got = eng.to_montgomery_batch(raw)
+    assert not got[0].any() and not got[17].any()
+    for i in list(range(0, 5000, 97)) + [1, 16, 18, 4999]:
+        assert got[i].tobytes() == orc.ed_to_montgomery(raw[i].tobytes()), i
+    # and it agrees with the ladder from the basepoint u = 9 (montgomery.rs:628-641)
+    nine = np.zeros((64, 32), np.uint8); nine[:, 0] = 9
+    for i in range(1, 64):
+        assert got[i].tobytes() == orc.mont_mul(nine[i].tobytes(), s[i].tobytes())
+    assert eng.to_montgomery_batch(np.zeros((0, 160), np.uint8)).shape == (0, 32)
