@@ -14,9 +14,11 @@ namespace c25519 {
 
 struct ge_p3 { feT X, Y, Z, T; };          // EdwardsPoint, edwards.rs:390-395
 struct ge_p2 { feT X, Y, Z; };             // ProjectivePoint, curve_models.rs:154
-struct ge_p1p1 { feL X; feL Y; feW Z; feW T; };  // CompletedPoint with our bound classes (see users)
+// CompletedPoint (curve_models.rs:169).  Every producer below yields X, Y, Z loose and only T wide, so
+// the conversions can always put T first in its two products and need no carry pass.
+struct ge_p1p1 { feL X, Y, Z; feW T; };
 struct ge_aniels { feT ypx, ymx, xy2d; };  // AffineNielsPoint, curve_models.rs:184
-struct ge_cached { feL YpX, YmX; feT Z, T2d; };  // ProjectiveNielsPoint, curve_models.rs:206
+struct ge_cached { feL YpX, YmX; feT Z; feL T2d; };  // ProjectiveNielsPoint, curve_models.rs:206
 
 C25519_HD feT fe_const(const u32 (&c)[10]) { feT r; for (int i = 0; i < 10; i++) r.v[i] = c[i]; return r; }
 C25519_HD feT fe_d() { const u32 c[10] = C25519_EDWARDS_D_26; return fe_const(c); }
@@ -33,22 +35,18 @@ C25519_HD ge_p3 ge_basepoint() {
 // CompletedPoint -> EdwardsPoint, curve_models.rs:365-373 (4 M).  The wide operand goes first.
 C25519_HD ge_p3 ge_p1p1_to_p3(const ge_p1p1 &p) {
     ge_p3 r;
-    // p.X, p.Y loose; p.Z, p.T wide with AT MOST ONE of them beyond loose in any given lane is not
-    // guaranteed, so Z*T needs one carried operand.
-    feT Tt = fe_carry(p.T);
-    r.X = fe_mul(p.X, Tt);
+    r.X = fe_mul(p.T, p.X);
     r.Y = fe_mul(p.Z, p.Y);
-    r.Z = fe_mul(p.Z, Tt);
+    r.Z = fe_mul(p.T, p.Z);
     r.T = fe_mul(p.X, p.Y);
     return r;
 }
 // CompletedPoint -> ProjectivePoint, curve_models.rs:353-359 (3 M)
 C25519_HD ge_p2 ge_p1p1_to_p2(const ge_p1p1 &p) {
     ge_p2 r;
-    feT Tt = fe_carry(p.T);
-    r.X = fe_mul(p.X, Tt);
+    r.X = fe_mul(p.T, p.X);
     r.Y = fe_mul(p.Z, p.Y);
-    r.Z = fe_mul(p.Z, Tt);
+    r.Z = fe_mul(p.T, p.Z);
     return r;
 }
 
@@ -74,27 +72,53 @@ C25519_HD ge_p3 ge_mul_by_pow_2(const ge_p3 &p, int k) {
     return ge_p1p1_to_p3(ge_dbl(s.X, s.Y, s.Z));
 }
 
-// Extended + AffineNiels (curve_models.rs:455-472) / Extended - AffineNiels (:476-494), 3 M,
-// sign chosen per lane without branching: q_neg ? p - q : p + q.
-C25519_HD ge_p1p1 ge_madd(const ge_p3 &p, const ge_aniels &q, bool q_neg) {
+// Extended + AffineNiels (curve_models.rs:455-472), 3 M.  Subtraction (:476-494) is addition of the
+// negated operand: -(y+x, y-x, 2dxy) = (y-x, y+x, -2dxy), applied to the PACKED table words by
+// aniels_words_cneg before unpacking (24 VALU ops instead of 80 selects on limbs and outputs).
+C25519_HD ge_p1p1 ge_madd(const ge_p3 &p, const ge_aniels &q) {
     feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
-    feT a = fe_select(q.ypx, q.ymx, q_neg), b = fe_select(q.ymx, q.ypx, q_neg);
-    feT PP = fe_mul(YpX, a), MM = fe_mul(YmX, b);
+    feT PP = fe_mul(YpX, q.ypx), MM = fe_mul(YmX, q.ymx);
     feT TT = fe_mul(p.T, q.xy2d);
     feL Z2 = fe_add(p.Z, p.Z);
-    feW Zp = fe_add_w(Z2, TT), Zm = fe_sub_w(Z2, TT);
     ge_p1p1 r;
     r.X = fe_sub(PP, MM);
     r.Y = fe_add(PP, MM);
-    r.Z = fe_select(Zp, Zm, q_neg);
-    r.T = fe_select(Zm, Zp, q_neg);
+    r.Z = fe_add_lt(Z2, TT);
+    r.T = fe_sub_w(Z2, TT);
     return r;
+}
+// w[0..7] = y+x, w[8..15] = y-x, w[16..23] = 2dxy as canonical 255-bit words.  neg: swap the first
+// two and replace the third by p - v (v = 0 gives p, a non-canonical but valid representative of 0).
+C25519_HD void aniels_words_cneg(u32 w[24], bool neg) {
+    for (int i = 0; i < 8; i++) { u32 a = w[i], b = w[8 + i]; w[i] = neg ? b : a; w[8 + i] = neg ? a : b; }
+    const u32 P0 = 0xffffffedu, PM = 0xffffffffu, P7 = 0x7fffffffu;
+    u64 borrow = 0;
+    for (int i = 0; i < 8; i++) {
+        u64 pi = (i == 0) ? P0 : (i == 7 ? P7 : PM);
+        u64 d = pi - (u64)w[16 + i] - borrow;
+        borrow = (d >> 63) & 1;
+        w[16 + i] = neg ? (u32)d : w[16 + i];
+    }
+}
+C25519_HD ge_aniels aniels_from_words(const u32 w[24]) {
+    ge_aniels A;
+    A.ypx = fe_from_words(w); A.ymx = fe_from_words(w + 8); A.xy2d = fe_from_words(w + 16);
+    return A;
 }
 
 // EdwardsPoint -> ProjectiveNiels (edwards.rs:528-535), 1 M
 C25519_HD ge_cached ge_p3_to_cached(const ge_p3 &p) {
     ge_cached r;
     r.YpX = fe_add(p.Y, p.X); r.YmX = fe_sub(p.Y, p.X); r.Z = p.Z; r.T2d = fe_mul(p.T, fe_d2());
+    return r;
+}
+// -(Y+X, Y-X, Z, 2dT) = (Y-X, Y+X, Z, -2dT), chosen per lane (curve_models.rs:501-512 Neg)
+C25519_HD ge_cached ge_cached_cneg(const ge_cached &c, bool neg) {
+    ge_cached r;
+    r.YpX = fe_select(c.YpX, c.YmX, neg); r.YmX = fe_select(c.YmX, c.YpX, neg); r.Z = c.Z;
+    feL nt; nt.v[0] = 0x7ffffdau - c.T2d.v[0];
+    for (int i = 1; i < 10; i++) nt.v[i] = ((i & 1) ? 0x3fffffeu : 0x7fffffeu) - c.T2d.v[i];   // 2p - T2d (T2d tight or 2p-tight)
+    r.T2d = fe_select(c.T2d, nt, neg);
     return r;
 }
 // Extended + ProjectiveNiels (curve_models.rs:411-429), 4 M
@@ -106,7 +130,7 @@ C25519_HD ge_p1p1 ge_add_cached(const ge_p3 &p, const ge_cached &q) {
     ge_p1p1 r;
     r.X = fe_sub(PP, MM);
     r.Y = fe_add(PP, MM);
-    r.Z = fe_add_w(ZZ2, TT);
+    r.Z = fe_add_lt(ZZ2, TT);
     r.T = fe_sub_w(ZZ2, TT);
     return r;
 }

@@ -129,9 +129,10 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
             carry = neg ? 1u : 0u;
             const uint4 *e = wtab + mag * 6;
             uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
-            ge_aniels A;
-            A.ypx = fe_from_q(q0, q1); A.ymx = fe_from_q(q2, q3); A.xy2d = fe_from_q(q4, q5);
-            P = ge_p1p1_to_p3(ge_madd(P, A, neg));
+            u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                          q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+            aniels_words_cneg(tw, neg);
+            P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
             wtab += ENT * 6;
         }
         if (OUT == 1) raw160_store(out_raw, idx, P);
@@ -345,7 +346,7 @@ __global__ void __launch_bounds__(256) k_probe_mullo(u32 *out, int iters, u32 se
 }
 __global__ void __launch_bounds__(256) k_probe_femul(u32 *out, int iters, u32 seed) {
     feT x, y, z;   // operands come from memory so nothing is known at compile time
-    for (int i = 0; i < 10; i++) { x.v[i] = (out[i] + seed + threadIdx.x) & M25; y.v[i] = (out[10 + i] + threadIdx.x) & M25; z.v[i] = (out[20 + i] ^ seed) & M25; }
+    for (int i = 0; i < 10; i++) { x.v[i] = (out[i] + seed + threadIdx.x) & M25; y.v[i] = (out[10 + i] + threadIdx.x) & M25; z.v[i] = ((out[20 + i] ^ seed) + threadIdx.x) & M25; }
     for (int i = 0; i < iters; i++) { x = fe_mul(x, z); y = fe_mul(y, z); }
     u32 r = 0;
     for (int i = 0; i < 10; i++) r ^= x.v[i] ^ y.v[i];

@@ -58,15 +58,13 @@ __device__ __forceinline__ void pts96_store(u32 *pts, u64 idx, const feT &x, con
     uint4 *q = reinterpret_cast<uint4 *>(pts) + 6 * idx;
     for (int i = 0; i < 6; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
-__device__ __forceinline__ ge_aniels pts96_load(const u32 *pts, u64 idx) {
+// load +P or -P (sign applied to the packed words, ge26.h aniels_words_cneg)
+__device__ __forceinline__ ge_aniels pts96_load(const u32 *pts, u64 idx, bool neg) {
     const uint4 *q = reinterpret_cast<const uint4 *>(pts) + 6 * idx;
     uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
-    u32 w0[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    u32 w1[8] = {c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
-    u32 w2[8] = {e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
-    ge_aniels A;
-    A.ypx = fe_from_words(w0); A.ymx = fe_from_words(w1); A.xy2d = fe_from_words(w2);
-    return A;
+    u32 w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
+    aniels_words_cneg(w, neg);
+    return aniels_from_words(w);
 }
 // extended point as 40 u32 tight limbs (bucket sums, partial results)
 __device__ __forceinline__ void p40_store(u32 *base, u64 idx, const ge_p3 &p) {
@@ -257,8 +255,8 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
 #pragma unroll 1
     for (u32 i = lo; i < hi; i++) {
         u32 e = list[i];
-        ge_aniels A = pts96_load(pts, e & 0x7fffffffu);
-        acc = ge_p1p1_to_p3(ge_madd(acc, A, (e >> 31) != 0));
+        ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
+        acc = ge_p1p1_to_p3(ge_madd(acc, A));
     }
     p40_store(buckets, gid, acc);
 }
@@ -314,7 +312,7 @@ __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pt
 #pragma unroll 1
         for (u32 i = it.lo + threadIdx.x; i < it.hi; i += 64) {
             u32 e = list[i];
-            acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu), (e >> 31) != 0));
+            acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0)));
         }
         acc = wave_sum(acc);
         if (threadIdx.x == 0) p40_store(seg_sums, item, acc);

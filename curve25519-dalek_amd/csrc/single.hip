@@ -84,20 +84,6 @@ __device__ __forceinline__ ge_cached tab_load(const uint4 *tab, u64 stride, u64 
     for (int i = 0; i < 10; i++) { c.YpX.v[i] = t[i]; c.YmX.v[i] = t[10 + i]; c.Z.v[i] = t[20 + i]; c.T2d.v[i] = t[30 + i]; }
     return c;
 }
-// p +/- q for a cached (ProjectiveNiels) operand: curve_models.rs:411-451, sign chosen per lane
-__device__ __forceinline__ ge_p1p1 ge_add_cached_signed(const ge_p3 &p, const ge_cached &q, bool neg) {
-    feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
-    feL a = fe_select(q.YpX, q.YmX, neg), b = fe_select(q.YmX, q.YpX, neg);
-    feT PP = fe_mul(YpX, a), MM = fe_mul(YmX, b);
-    feT TT = fe_mul(p.T, q.T2d), ZZ = fe_mul(p.Z, q.Z);
-    feL ZZ2 = fe_add(ZZ, ZZ);
-    feW Zp = fe_add_w(ZZ2, TT), Zm = fe_sub_w(ZZ2, TT);
-    ge_p1p1 r;
-    r.X = fe_sub(PP, MM); r.Y = fe_add(PP, MM);
-    r.Z = fe_select(Zp, Zm, neg); r.T = fe_select(Zm, Zp, neg);
-    return r;
-}
-
 // ================================================================================================
 // variable-base scalar multiplication, radix 16 (variable_base.rs:11-47), one (scalar, point) per lane
 //   IN_FMT 0: CompressedEdwardsY, 2: raw 160-byte;  NEGATE: multiply -P (verify: [k](-A))
@@ -148,7 +134,7 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
         bool neg = d < 0;
         u32 mag = (u32)(neg ? -d : d);
         ge_cached c = tab_load(tab, stride, idx, mag);
-        acc = ge_p1p1_to_p3(ge_add_cached_signed(acc, c, neg));
+        acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_cached_cneg(c, neg)));
     }
     p40_st(out40, idx, acc);
 }

@@ -46,9 +46,15 @@ void h_ge_compress(const uint8_t *a, uint8_t *o) {
 }
 // p +/- q where q is given as an extended point with Z = 1 (converted to affine Niels here)
 void h_ge_madd(const uint8_t *a, const uint8_t *q, int neg, uint8_t *o) {
-    ge_p3 Q = pload(q); ge_aniels n;
-    n.ypx = fe_carry(fe_add(Q.Y, Q.X)); n.ymx = fe_carry(fe_sub(Q.Y, Q.X)); n.xy2d = fe_mul(Q.T, fe_d2());
-    pstore(o, ge_p1p1_to_p3(ge_madd(pload(a), n, neg != 0)));
+    ge_p3 Q = pload(q);
+    u32 w[24];
+    fe_to_words(fe_add(Q.Y, Q.X), w); fe_to_words(fe_sub(Q.Y, Q.X), w + 8); fe_to_words(fe_mul(Q.T, fe_d2()), w + 16);
+    aniels_words_cneg(w, neg != 0);
+    pstore(o, ge_p1p1_to_p3(ge_madd(pload(a), aniels_from_words(w))));
+}
+// p +/- q through the cached (ProjectiveNiels) path with the per-lane conditional negation
+void h_ge_add_cached_signed(const uint8_t *a, const uint8_t *q, int neg, uint8_t *o) {
+    pstore(o, ge_p1p1_to_p3(ge_add_cached(pload(a), ge_cached_cneg(ge_p3_to_cached(pload(q)), neg != 0))));
 }
 // X25519 ladder exactly as the kernel runs it (montgomery.rs:183-211), s = already-clamped scalar
 void h_x25519_ladder(const uint8_t *s, const uint8_t *u, uint8_t *o) {
