@@ -76,6 +76,44 @@ static void build_basepoint_table(int W, std::vector<uint32_t> &out) {
     }
 }
 
+// ---- signed comb table (k_mul_base_comb): entry idx of block m =
+//      2^(5m) * ( 2^(240) + sum_{tau<8} (2*bit_tau(idx) - 1) * 2^(30 tau) ) * B ;  last entry = B.
+static void build_comb_table(std::vector<uint32_t> &out) {
+    const int T = 9, D = 30, V = 6, E = 5, ENT = 256;
+    std::vector<ge_p3> pts((size_t)V * ENT + 1);
+    ge_p3 G[T];
+    G[0] = ge_basepoint();
+    for (int t = 1; t < T; t++) G[t] = ge_mul_by_pow_2(G[t - 1], D);
+    for (int m = 0; m < V; m++) {
+        ge_p3 G2[T];
+        for (int t = 0; t < T; t++) G2[t] = ge_dbl_p3(G[t]);
+        ge_p3 e0 = G[T - 1];
+        for (int t = 0; t < T - 1; t++) e0 = ge_add(e0, ge_neg(G[t]));          // all lower digits -1
+        pts[(size_t)m * ENT] = e0;
+        for (int idx = 1; idx < ENT; idx++) {
+            int low = __builtin_ctz(idx);
+            pts[(size_t)m * ENT + idx] = ge_add(pts[(size_t)m * ENT + (idx & (idx - 1))], G2[low]);   // flip digit `low` from -1 to +1
+        }
+        for (int t = 0; t < T; t++) G[t] = ge_mul_by_pow_2(G[t], E);
+    }
+    pts[(size_t)V * ENT] = ge_basepoint();
+    size_t mtot = pts.size();
+    std::vector<feT> pre(mtot);
+    feT acc = fe_one();
+    for (size_t k = 0; k < mtot; k++) { pre[k] = acc; acc = fe_mul(acc, pts[k].Z); }
+    feT inv = fe_invert(acc);
+    out.assign(mtot * 24, 0u);
+    for (size_t k = mtot; k-- > 0;) {
+        feT zi = fe_mul(inv, pre[k]);
+        inv = fe_mul(inv, pts[k].Z);
+        feT x = fe_mul(pts[k].X, zi), y = fe_mul(pts[k].Y, zi);
+        uint32_t *e = &out[k * 24];
+        fe_to_words(fe_add(y, x), e);
+        fe_to_words(fe_sub(y, x), e + 8);
+        fe_to_words(fe_mul(fe_mul(x, y), fe_d2()), e + 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     int ndev = 0;
@@ -97,9 +135,9 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
     int w = (int)(flags & 0xf);
-    ctx->w = (w >= 4 && w <= 6) ? w : 6;
+    ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position window tables; default 9: signed comb
     std::vector<uint32_t> tab;
-    build_basepoint_table(ctx->w, tab);
+    if (ctx->w == 9) build_comb_table(tab); else build_basepoint_table(ctx->w, tab);
     if (hipMalloc(&ctx->d_table, tab.size() * 4) != hipSuccess ||
         hipMemcpy(ctx->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->d_flag, 256) != hipSuccess) {

@@ -146,6 +146,83 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
 }
 
 // ================================================================================================
+// K2c fixed-base batch, signed multi-table comb (the default): 31 mixed additions + 4 doublings per
+//     scalar instead of 43 additions.
+//     With s' = s | 1 and c = (s' + 2^270 - 1)/2 = (s >> 1) + 2^269, s' = sum_{i<270} (2 c_i - 1) 2^i
+//     (every digit is +-1).  Bits are arranged in T = 9 teeth x D = 30 columns (bit i = tooth*30 + col);
+//     column j contributes 2^j * sum_tau (+-1) 2^(30 tau) B, a 9-bit sign pattern looked up in a table
+//     of 2^8 entries (top tooth positive; the opposite pattern is the negated entry).  V = 6 tables
+//     hold the patterns pre-multiplied by 2^(5m), so columns j = 5m + r share one Horner step:
+//         acc = 2*acc + sum_m T_m[pattern(5m + r)],  r = 4..0.
+//     Finally subtract B when s was even.  Table: [6][256] entries x 96 B = 147 456 B of LDS, plus the
+//     entry for B.  Same affine-Niels entry format and mixed addition as k_mul_base.
+// ================================================================================================
+constexpr int COMB_T = 9, COMB_V = 6, COMB_E = 5, COMB_ENT = 256;
+constexpr int COMB_TABLE_Q = (COMB_V * COMB_ENT + 1) * 6;   // uint4 count (last entry = B)
+
+template <int BS, int OUT>
+__global__ void __launch_bounds__(BS) k_mul_base_comb(const uint8_t *__restrict__ scalars, u64 n, const uint4 *__restrict__ gtab,
+                                                      u32 *__restrict__ scratch, uint8_t *__restrict__ out_raw) {
+    extern __shared__ uint4 lds[];
+    for (int i = threadIdx.x; i < COMB_TABLE_Q; i += BS) lds[i] = gtab[i];
+    __syncthreads();
+    for (u64 idx = (u64)blockIdx.x * BS + threadIdx.x; idx < n; idx += (u64)gridDim.x * BS) {
+        u32 s[8];
+        load8(scalars, idx, s);
+        const bool even = (s[0] & 1u) == 0;
+        // c = (s >> 1) + 2^269 as nine 30-bit tooth registers R[tau] = bits [30 tau, 30 tau + 30) of c
+        u32 c[9];
+#pragma unroll
+        for (int i = 0; i < 7; i++) c[i] = (s[i] >> 1) | (s[i + 1] << 31);
+        c[7] = s[7] >> 1; c[8] = 1u << 13;                       // bit 269 = word 8, bit 13
+        u32 R[COMB_T];
+#pragma unroll
+        for (int t = 0; t < COMB_T; t++) {
+            const int bit = 30 * t, wi = bit >> 5, sh = bit & 31;
+            u64 two = (u64)c[wi] | ((u64)(wi + 1 < 9 ? c[wi + 1] : 0u) << 32);
+            R[t] = (u32)(two >> sh) & 0x3fffffffu;
+        }
+        ge_p3 P = ge_identity();
+#pragma unroll 1
+        for (int r = COMB_E - 1; r >= 0; r--) {
+            if (r != COMB_E - 1) P = ge_dbl_p3(P);
+#pragma unroll 1
+            for (int m = 0; m < COMB_V; m++) {
+                const int j = COMB_E * m + r;
+                u32 pat = 0;
+#pragma unroll
+                for (int t = 0; t < COMB_T; t++) pat |= ((R[t] >> j) & 1u) << t;
+                const bool neg = (pat >> (COMB_T - 1)) == 0;     // top tooth digit -1: use the opposite pattern, negated
+                const u32 e_idx = (neg ? ~pat : pat) & (COMB_ENT - 1);
+                const uint4 *e = lds + ((u32)m * COMB_ENT + e_idx) * 6;
+                uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
+                u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                              q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+                aniels_words_cneg(tw, neg);
+                P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
+            }
+        }
+        {   // s even: s = s' - 1  ->  subtract B (add the identity otherwise)
+            const uint4 *e = lds + (COMB_V * COMB_ENT) * 6;
+            uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
+            u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                          q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+            aniels_words_cneg(tw, true);
+            ge_aniels A = aniels_from_words(tw);
+            A.ypx = fe_select(fe_one(), A.ypx, even); A.ymx = fe_select(fe_one(), A.ymx, even); A.xy2d = fe_select(fe_zero(), A.xy2d, even);
+            P = ge_p1p1_to_p3(ge_madd(P, A));
+        }
+        if (OUT == 1) raw160_store(out_raw, idx, P);
+        else if (OUT == 2) {
+            uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
+            u32 t[40];
+            for (int i = 0; i < 10; i++) { t[i] = P.X.v[i]; t[10 + i] = P.Y.v[i]; t[20 + i] = P.Z.v[i]; t[30 + i] = P.T.v[i]; }
+            for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        } else p32_store(scratch, idx, P.X, P.Y, P.Z);
+    }
+}
+
+// ================================================================================================
 // K3  batched compression (edwards.rs:634-647 compress_batch_alloc): Montgomery's trick
 //     (field.rs:225-273) with each lane owning CH projective points: 3 M per point + one field
 //     inversion per lane.  Lane t owns points t, t+T, t+2T, ... so a wave's loads stay adjacent.
@@ -422,10 +499,24 @@ static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_
     return hipGetLastError();
 }
 
+template <int OUT>
+static hipError_t launch_comb(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st) {
+    constexpr int BS = 1024;
+    size_t lds_bytes = (size_t)COMB_TABLE_Q * 16;
+    unsigned grid = div_up(n, BS);
+    if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+    auto kfn = k_mul_base_comb<BS, OUT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
+    return hipGetLastError();
+}
+
 hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw,
                            int num_cus, hipStream_t st) {
     if (n == 0) return hipSuccess;
     switch (w) {
+    case 9: return out_raw ? launch_comb<1>(scalars, n, tab, scratch, out_raw, num_cus, st) : launch_comb<0>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, scratch, out_raw, num_cus, st);
@@ -436,6 +527,7 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t 
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st) {
     if (n == 0) return hipSuccess;
     switch (w) {
+    case 9: return launch_comb<2>(scalars, n, tab, out40, nullptr, num_cus, st);
     case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
     case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
     case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, out40, nullptr, num_cus, st, true);

@@ -104,7 +104,7 @@ class Engine:
     uint8 CUDA tensors already resident in HBM; the plain methods take/return numpy arrays / bytes
     and go through the host-pointer entry points (PCIe copies included)."""
 
-    def __init__(self, device=0, window=6):
+    def __init__(self, device=0, window=0):
         import torch
         self.torch = torch
         self.lib = load_library()

@@ -50,8 +50,10 @@ extern "C" {
 
 typedef struct c25519_ctx c25519_ctx;
 
-/* Create a context on HIP device `device` (>= 0).  Builds the fixed-base table (the `create` logic
- * of edwards.rs:1131-1141, window width chosen for the 160 KiB LDS) and uploads it.  Returns NULL
+/* Create a context on HIP device `device` (>= 0).  Builds the fixed-base table and uploads it:
+ * flags & 0xf = 0 (default): signed 9-tooth x 6-table comb (31 additions + 4 doublings per scalar);
+ * 4, 5 or 6: one radix-2^w window table per digit position, the structure of the reference's
+ * EdwardsBasepointTable (edwards.rs:1131-1141, :1246-1282) sized for the 160 KiB LDS.  Returns NULL
  * if there is no usable GPU: there is NO CPU fallback. */
 c25519_ctx *c25519_ctx_create(int device, uint32_t flags);
 void c25519_ctx_destroy(c25519_ctx *ctx);
