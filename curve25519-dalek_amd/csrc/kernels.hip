@@ -2,6 +2,7 @@
 // Launchers at the bottom are the only symbols the host side (capi.hip) uses.
 #include <hip/hip_runtime.h>
 #include "ge26.h"
+#include <stdlib.h>
 #include "kernels.h"
 
 namespace c25519 {
@@ -499,9 +500,23 @@ static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_
     return hipGetLastError();
 }
 
+static int comb_block_size() {   // tuning knob (A/B on hardware): C25519_COMB_BS = 1024 | 768 | 512
+    static int bs = 0;
+    if (!bs) { const char *e = getenv("C25519_COMB_BS"); bs = e ? atoi(e) : 1024; if (bs != 768 && bs != 512) bs = 1024; }
+    return bs;
+}
+template <int BS, int OUT>
+static hipError_t launch_comb_bs(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st);
 template <int OUT>
 static hipError_t launch_comb(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st) {
-    constexpr int BS = 1024;
+    switch (comb_block_size()) {
+    case 768: return launch_comb_bs<768, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
+    case 512: return launch_comb_bs<512, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
+    default: return launch_comb_bs<1024, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
+    }
+}
+template <int BS, int OUT>
+static hipError_t launch_comb_bs(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st) {
     size_t lds_bytes = (size_t)COMB_TABLE_Q * 16;
     unsigned grid = div_up(n, BS);
     if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;

@@ -238,15 +238,55 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
 // ================================================================================================
 // bucket accumulation: one lane per (window, bucket)   [pippenger.rs:122-136, as gather lists]
 // ================================================================================================
+// ---- bucket order: lanes of one wave should own lists of equal length ----------------------------------
+// Counting sort of the (window, bucket) ids by list length (clamped to 255), longest first, so that a
+// wave's 64 lanes finish together (Poisson-distributed lengths otherwise cost ~25 % idle lanes) and the
+// long lists start first.  ord_hist: 256 global bins; perm: bucket ids in processing order.
+__global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ totals, u64 nb, u32 *__restrict__ ord_hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < nb) { u32 c = totals[gid]; atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&ord_hist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) {   // one block: exclusive scan of 256 bins
+    __shared__ u32 p[256];
+    u32 v = ord_hist[threadIdx.x];
+    p[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        u32 a = (int)threadIdx.x >= off ? p[threadIdx.x - off] : 0;
+        __syncthreads();
+        p[threadIdx.x] += a;
+        __syncthreads();
+    }
+    ord_hist[threadIdx.x] = p[threadIdx.x] - v;
+}
+__global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ totals, u64 nb, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
+    __shared__ u32 h[256], basep[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 bin = 0, local = 0;
+    if (gid < nb) { u32 c = totals[gid]; bin = 255u - (c > 255u ? 255u : c); local = atomicAdd(&h[bin], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) basep[threadIdx.x] = atomicAdd(&ord_cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (gid < nb) perm[basep[bin] + local] = (u32)gid;
+}
+
 // Buckets longer than LONG_CAP are left to the wave-cooperative path below, so that no lane ever walks a
 // long list alone (skewed inputs: e.g. the +1 carry digit of every 128-bit z_i in verify_batch lands
 // ~n/2 terms in ONE bucket; identical scalars do the same in every window).
 constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
-                                                    u64 n, msm_geom g, u32 *__restrict__ buckets) {
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (u64)g.nwin * g.half) return;
+                                                    const u32 *__restrict__ perm, u64 n, msm_geom g, u32 *__restrict__ buckets) {
+    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (u64)g.nwin * g.half) return;
+    const u64 gid = perm[tid];
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
     u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
     if (hi - lo > LONG_CAP) return;
@@ -566,7 +606,7 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     size_t oD = carve((size_t)g.nwin * n * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
     size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oT = carve(nb * 4);
     size_t lvl_pts = plan.empty() ? (size_t)g.nwin : (size_t)g.nwin * (plan[0].m_in / plan[0].L);
-    size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256);
+    size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256 + 1024), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * n;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / LONG_CAP + 1);
@@ -578,9 +618,9 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
-    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT);
+    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(flags, 0, 256, st));
+    HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
     size_t lds = (size_t)g.half * 4;
     if (lds > 48 * 1024) {
@@ -591,8 +631,11 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
     hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
     hipLaunchKernelGGL(k_scatter, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
+    hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist, perm);
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    hipLaunchKernelGGL(k_accumulate, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, n, g, buckets);
+    hipLaunchKernelGGL(k_accumulate, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
     {
         long_item *items = (long_item *)(ws + oLI);
         uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
