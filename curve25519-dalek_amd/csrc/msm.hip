@@ -480,10 +480,11 @@ __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u
     u64 *o = reinterpret_cast<u64 *>(out) + 8 * j;
     for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
 }
-// step 3: z_i = first 16 bytes of SHA-512(root || LE64(i))
-__global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n, uint8_t *__restrict__ z16) {
+// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)); n4 = ceil(n/4) lanes,
+// z16 has room for 4*n4 entries
+__global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n4, uint8_t *__restrict__ z16) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n4) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
     u64 hs[8], w[16];   // 72-byte message: one block
     sha512_init(hs);
@@ -492,8 +493,8 @@ __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ roo
     for (int q = 10; q < 15; q++) w[q] = 0;
     w[15] = 72 * 8;
     sha512_compress(hs, w);
-    u64 *o = reinterpret_cast<u64 *>(z16) + 2 * i;
-    o[0] = bswap64(hs[0]); o[1] = bswap64(hs[1]);
+    u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
 }
 // scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = z_i, [1+n+i] = z_i*h_i;
 // per-block partial sums of z_i*s_i (mod l) to `partial`
@@ -768,7 +769,7 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     const unsigned nblk = div_up64(n, 256);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oH = carve(n * 64), oZ = carve(n * 16), oSc = carve(m * 32), oT0 = carve(n * 64), oT1 = carve((n / 16 + 1) * 64), oP = carve((size_t)nblk * 40);
+    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve(n * 64), oT1 = carve((n / 16 + 1) * 64), oP = carve((size_t)nblk * 40);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1;
@@ -778,39 +779,55 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
-    // points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
+    // Two independent chains: (S) decompress A_i and R_i -- VALU-bound, ~30 % of the call; (A) hash,
+    // derive z_i, batch scalars -- partly latency-bound (the Merkle levels).  They run on two streams
+    // and join before the MSM.
+    hipStream_t sa = ctx->aux;
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
+    // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
     hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_pks, (uint64_t)1, n, d_pts, n + 1, d_cnt + 0);
     hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_sigs, (uint64_t)2, n, d_pts, (uint64_t)1, d_cnt + 1);
-    hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, st, d_msgs, d_msg_off, d_sigs, d_pks, n, hram, d_cnt + 2);
+    // (A)
+    hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, d_sigs, d_pks, n, hram, d_cnt + 2);
     HIPCHK(hipGetLastError());
     if (z_mode == C25519_Z_TRANSCRIPT) {
         // the reference's sequential Merlin transcript (batch.rs:168-222), on the host
         std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
-        HIPCHK(hipMemcpyAsync(hh.data(), hram, n * 64, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpyAsync(hh.data(), hram, n * 64, hipMemcpyDeviceToHost, sa));
+        HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, sa));
+        HIPCHK(hipStreamSynchronize(sa));
         c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
-        HIPCHK(hipMemcpyAsync(z16, hz.data(), n * 16, hipMemcpyHostToDevice, st));
-        HIPCHK(hipStreamSynchronize(st));
+        HIPCHK(hipMemcpyAsync(z16, hz.data(), n * 16, hipMemcpyHostToDevice, sa));
+        HIPCHK(hipStreamSynchronize(sa));
     } else {
-        hipLaunchKernelGGL(k_zleaf, dim3(nblk), dim3(256), 0, st, hram, d_sigs, n, t0);
+        hipLaunchKernelGGL(k_zleaf, dim3(nblk), dim3(256), 0, sa, hram, d_sigs, n, t0);
         uint64_t mm = n; uint8_t *a = t0, *b = t1;
         do {
             uint64_t mo = (mm + 15) / 16;
-            hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, st, a, mm, b);
+            hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, b);
             mm = mo; std::swap(a, b);
         } while (mm > 1);
-        hipLaunchKernelGGL(k_zderive, dim3(nblk), dim3(256), 0, st, a, n, z16);
+        hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, a, (n + 3) / 4, z16);
         HIPCHK(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, st, hram, d_sigs, z16, n, msc, partial);
+    hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hram, d_sigs, z16, n, msc, partial);
     HIPCHK(hipGetLastError());
-    std::vector<uint64_t> hp((size_t)nblk * 5);
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    HIPCHK(hipMemcpyAsync(hp.data(), partial, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    // pinned staging: [partial sums nblk x 40 B][counters 16 B]
+    size_t need = (size_t)nblk * 40 + 64;
+    if (ctx->h_pinned_cap < need) {
+        if (ctx->h_pinned) HIPCHK(hipHostFree(ctx->h_pinned));
+        ctx->h_pinned = nullptr; ctx->h_pinned_cap = 0;
+        HIPCHK(hipHostMalloc(&ctx->h_pinned, need + need / 4, hipHostMallocDefault));
+        ctx->h_pinned_cap = need + need / 4;
+    }
+    uint64_t *hp = (uint64_t *)ctx->h_pinned;
+    uint32_t *cnt = (uint32_t *)((uint8_t *)ctx->h_pinned + (size_t)nblk * 40);
+    HIPCHK(hipMemcpyAsync(hp, partial, (size_t)nblk * 40, hipMemcpyDeviceToHost, sa));
+    HIPCHK(hipStreamSynchronize(sa));                  // chain (A) done: scalars are in place
     HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipStreamSynchronize(st));                  // chain (S) done: points are in place, counters final
     int32_t verdict = -1;
     if (cnt[0]) verdict = C25519_NONE;                  // a key that VerifyingKey::from_bytes rejects
     else if (cnt[2]) verdict = C25519_SCALAR_FORMAT;    // batch.rs:208-211
