@@ -201,6 +201,30 @@ def main():
         cpu_baseline = {"value": m / c1, "unit": ALGO[wl]["unit"], "cores": used, "kind": "port",
                         "sample": "%d units of the same workload through the C restatement of the reference serial_u64 path (oracle/), %d thread(s), %.1f s; host exposes %d usable cores" % (m, used, c1, cores)}
 
+    traffic = None
+    traffic_src = None
+    if rank == 0:
+        # HBM bytes per launch of the dominant kernel from the committed PMC profile of this workload
+        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_all.sh; FETCH_SIZE doubled per the
+        # gfx950 correction in MI355X_MICROARCH.md).  null if no profile has been committed yet.
+        dom_kernel = {"fixed_base": "k_mul_base", "x25519": "k_x25519", "msm": "k_accumulate", "verify": "k_prep_compressed"}[wl]
+        import glob
+        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.txt" % wl)), reverse=True):
+            fetch = write = None
+            cur = None
+            for line in open(f):
+                if not line.startswith(" "):
+                    cur = line.strip()
+                elif cur and dom_kernel in cur:
+                    parts = line.split()
+                    if parts[0] == "FETCH_SIZE":
+                        fetch = float(parts[1])
+                    if parts[0] == "WRITE_SIZE":
+                        write = float(parts[1])
+            if fetch is not None and write is not None:
+                traffic = (2.0 * fetch + write) * 1024.0
+                traffic_src = os.path.relpath(f, ROOT)
+                break
     if rank == 0:
         units = float(n) * world * args.steps
         algo_bytes = ALGO[wl]["bytes"] * n
@@ -213,7 +237,8 @@ def main():
             "config": {"workload": "%s: 2^%d units per GPU, inputs resident in HBM, canonical 32-byte outputs" % (wl, log2n),
                        "units_per_gpu": n, "parallelism": ("sharded terms, all_gather of 160-B partials x%d" if wl == "msm" else "replicas x%d") % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": algo_bytes,
                          "dominant_kernel_ms": dom_ms, "other_kernels_ms": rest_ms,
                          "note": "integer (VALU v_mad_u64_u32) bound kernel: HBM fraction is tiny by construction; see DESIGN.md"},
             "cpu_baseline": cpu_baseline,

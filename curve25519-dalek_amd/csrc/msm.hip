@@ -20,6 +20,7 @@
 // Window width c is chosen per call from n (reference: w = 6/7/8, pippenger.rs:81-87).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 #include "../../include/c25519_hip.h"
@@ -169,9 +170,10 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
 __device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) { return (k == g.nwin - 1) ? (int)v : (int)v - g.half; }
 
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
+template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, u32 *__restrict__ counts) {
     extern __shared__ u32 hist[];
-    const int k = blockIdx.y, j = blockIdx.x, nchunk = gridDim.x;
+    const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     u64 lo = (u64)j * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -217,10 +219,11 @@ __global__ void __launch_bounds__(1024) k_scan_buckets(const u32 *__restrict__ t
     if (tid == 1023) base[(u64)k * (g.half + 1) + g.half] = part[1023];
 }
 // scatter term indices (sign in bit 31) into bucket order
+template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, const u32 *__restrict__ starts,
                                                   const u32 *__restrict__ base, u32 *__restrict__ sorted) {
     extern __shared__ u32 cursor[];
-    const int k = blockIdx.y, j = blockIdx.x, nchunk = gridDim.x;
+    const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
     const u32 *st = starts + ((u64)k * nchunk + j) * g.half;
     const u32 *bs = base + (u64)k * (g.half + 1);
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) cursor[b] = st[b] + bs[b];
@@ -282,6 +285,7 @@ __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ t
 // ~n/2 terms in ONE bucket; identical scalars do the same in every window).
 constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
+template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
                                                     const u32 *__restrict__ perm, u64 n, msm_geom g, u32 *__restrict__ buckets) {
     u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,15 +296,38 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
     if (hi - lo > LONG_CAP) return;
     const u32 *list = sorted + (u64)k * n;
     ge_p3 acc = ge_identity();
+    if (PIPE == 0) {
 #pragma unroll 1
-    for (u32 i = lo; i < hi; i++) {
-        u32 e = list[i];
-        ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
-        acc = ge_p1p1_to_p3(ge_madd(acc, A));
+        for (u32 i = lo; i < hi; i++) {
+            u32 e = list[i];
+            ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
+            acc = ge_p1p1_to_p3(ge_madd(acc, A));
+        }
+    } else if (PIPE == 1) {
+        u32 e_next = lo < hi ? list[lo] : 0u;
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            u32 e = e_next;
+            if (i + 1 < hi) e_next = list[i + 1];
+            ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
+            acc = ge_p1p1_to_p3(ge_madd(acc, A));
+        }
+    } else {
+        uint4 q[6];
+        u32 e = 0;
+        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + 6 * (u64)(e & 0x7fffffffu); for (int j = 0; j < 6; j++) q[j] = src[j]; }
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            u32 w[24] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w,
+                         q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w};
+            bool neg = (e >> 31) != 0;
+            if (i + 1 < hi) { e = list[i + 1]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + 6 * (u64)(e & 0x7fffffffu); for (int j = 0; j < 6; j++) q[j] = src[j]; }
+            aniels_words_cneg(w, neg);
+            acc = ge_p1p1_to_p3(ge_madd(acc, aniels_from_words(w)));
+        }
     }
     p40_store(buckets, gid, acc);
 }
-
 
 // ---- long buckets -------------------------------------------------------------------------------------
 // work list: one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
@@ -624,19 +651,31 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
     size_t lds = (size_t)g.half * 4;
+    static int xswap = -1;   // tuning knob: C25519_XCD_SWAP = 0 | 1
+    if (xswap < 0) { const char *e = getenv("C25519_XCD_SWAP"); xswap = e ? atoi(e) : 1; }
     if (lds > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
-    hipLaunchKernelGGL(k_hist, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
+    if (xswap) hipLaunchKernelGGL(k_hist<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts);
+    else hipLaunchKernelGGL(k_hist<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
     hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
     hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
-    hipLaunchKernelGGL(k_scatter, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
     hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist, perm);
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    hipLaunchKernelGGL(k_accumulate, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
+    {
+        static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2
+        if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 2; if (pipe < 0 || pipe > 2) pipe = 2; }
+        if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
+        else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
+        else hipLaunchKernelGGL(k_accumulate<2>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
+    }
     {
         long_item *items = (long_item *)(ws + oLI);
         uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;

@@ -22,6 +22,8 @@
  *         (edwards.rs:390-395 is not repr(C); the Rust shim copies limb-by-limb into this layout).
  *   - scalars: 32 bytes little-endian, < 2^255 (Scalar invariant #1, scalar.rs:197-205); they need
  *     NOT be reduced mod l for point multiplication (clamped integers are legal).
+ *   - device buffers of 32-, 64- and 160-byte items must be 16-byte aligned (hipMalloc / torch
+ *     allocations are); message blobs may have any alignment.
  *   - a context is bound to one GPU and one stream; calls on one context must not overlap.
  *     Results never depend on which GPU ran them.
  */
