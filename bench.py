@@ -63,10 +63,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
+    torch.cuda.set_device(local_rank)
+    if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     eng = pkg.Engine(local_rank)
 
@@ -119,7 +120,7 @@ def main():
             result["st"] = eng.verify_batch_t(d_msgs, d_off, d_sigs, d_pks, pkg.engine.Z_DEVICE)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -159,7 +160,7 @@ def main():
         run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -244,7 +245,7 @@ def main():
             "cpu_baseline": cpu_baseline,
         }
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
