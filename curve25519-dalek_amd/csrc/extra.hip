@@ -1,0 +1,317 @@
+// Callers and batch conversions either side of the MSM:
+//
+//   c25519_precomp_*        VartimePrecomputedStraus (backend.rs:100-192 ->
+//                           scalar_mul/precomputed_straus.rs:29-127; edwards.rs:1037-1076): the static
+//                           points are normalised once and stay resident in HBM as packed affine Niels
+//                           points; every call runs the bucket-method MSM over static + dynamic terms
+//   c25519_msm_consttime    MultiscalarMul::multiscalar_mul (straus.rs:103-144; edwards.rs:966-1000): a
+//                           regular (input-independent) schedule = one radix-16 variable-base ladder per
+//                           term (k_var_base) followed by a tree sum
+//   c25519_double_and_compress_batch   RistrettoPoint::double_and_compress_batch (ristretto.rs:564-648)
+//   c25519_scalar_invert_batch         Scalar::invert_batch_alloc (scalar.rs:802-856)
+#include <hip/hip_runtime.h>
+#include <string.h>
+#include <vector>
+#include "../../include/c25519_hip.h"
+#include "devio.h"
+#include "sc_sha.h"
+#include "kernels.h"
+#include "ctx.h"
+#include "msm_internal.h"
+
+using namespace c25519;
+#define EXPORT extern "C" __attribute__((visibility("default")))
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+static inline unsigned dup64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+
+struct c25519_precomp { uint32_t *d_pts; uint64_t n; };
+
+namespace c25519 {
+
+// ---- tree sum of P40 points: each wave folds 64*K inputs (K strided per lane, then a shuffle tree) ------
+__global__ void __launch_bounds__(64) k_sum_p40(const u32 *__restrict__ in, u64 m, int K, u32 *__restrict__ out) {
+    u64 base = (u64)blockIdx.x * 64 * K;
+    ge_p3 acc = ge_identity();
+#pragma unroll 1
+    for (int j = 0; j < K; j++) {
+        u64 idx = base + (u64)j * 64 + threadIdx.x;
+        if (idx < m) acc = ge_add(acc, p40_load(in, idx));
+    }
+#pragma unroll 1
+    for (int off = 32; off > 0; off >>= 1) {
+        ge_p3 o;
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_down(acc.X.v[i], off, 64); o.Y.v[i] = __shfl_down(acc.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_down(acc.Z.v[i], off, 64); o.T.v[i] = __shfl_down(acc.T.v[i], off, 64);
+        }
+        acc = ge_add(acc, o);
+    }
+    if (threadIdx.x == 0) p40_store(out, blockIdx.x, acc);
+}
+
+// ---- RistrettoPoint::double_and_compress_batch, ristretto.rs:564-648 ---------------------------------------
+// state per point (6 field elements) is recomputed in the second pass instead of stored: e, f, g, h, eg, fh
+struct dc_state { feT e, f, g, h, eg, fh; };
+__device__ __forceinline__ dc_state dc_state_of(const ge_p3 &P) {
+    feT XX = fe_sq(P.X), YY = fe_sq(P.Y), ZZ = fe_sq(P.Z);
+    feT dTT = fe_mul(fe_sq(P.T), fe_d());
+    dc_state s;
+    s.e = fe_mul(P.X, fe_add(P.Y, P.Y));          // 2XY
+    s.f = fe_carry(fe_add(ZZ, dTT));              // Z^2 + dT^2
+    s.g = fe_carry(fe_add(YY, XX));               // Y^2 + X^2   (a = -1)
+    s.h = fe_carry(fe_sub(ZZ, dTT));              // Z^2 - dT^2
+    s.eg = fe_mul(s.e, s.g);
+    s.fh = fe_mul(s.f, s.h);
+    return s;
+}
+template <int CH>
+__global__ void __launch_bounds__(256) k_double_compress(const uint8_t *__restrict__ in_raw, u32 *__restrict__ prefix, u64 n, uint8_t *__restrict__ out) {
+    const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    feT acc = fe_one();
+#pragma unroll 1
+    for (int j = 0; j < CH; j++) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) break;
+        dc_state s = dc_state_of(raw160_load(in_raw, idx));
+        feT efgh = fe_mul(s.eg, s.fh);
+        fe48_store(prefix, idx, acc);
+        acc = fe_select(fe_mul(acc, efgh), acc, fe_is_zero(efgh));      // zeros skipped (field.rs:225-273)
+    }
+    feT inv = fe_invert(acc);
+#pragma unroll 1
+    for (int j = CH - 1; j >= 0; j--) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) continue;
+        dc_state s = dc_state_of(raw160_load(in_raw, idx));
+        feT efgh = fe_mul(s.eg, s.fh);
+        bool z = fe_is_zero(efgh);
+        feT einv = fe_select(fe_mul(inv, fe48_load(prefix, idx)), efgh, z);   // invert_batch leaves a zero input unchanged
+        inv = fe_select(fe_mul(inv, efgh), inv, z);
+        feT Zinv = fe_mul(s.eg, einv), Tinv = fe_mul(s.fh, einv);
+        bool neg1 = fe_is_negative(fe_mul(s.eg, Zinv)) != 0;
+        feT minus_e = fe_carry(fe_neg(s.e));
+        feT f_sqrta = fe_mul(s.f, fe_sqrtm1());
+        feT e = fe_select(s.e, s.g, neg1), g = fe_select(s.g, minus_e, neg1), h = fe_select(s.h, f_sqrta, neg1);
+        feT magic = fe_select(fe_invsqrt_a_minus_d(), fe_sqrtm1(), neg1);
+        bool neg2 = fe_is_negative(fe_mul(fe_mul(h, e), Zinv)) != 0;
+        g = fe_cneg(g, neg2);
+        feT sv = fe_mul(fe_sub(h, g), fe_mul(magic, fe_mul(g, Tinv)));
+        sv = fe_cneg(sv, fe_is_negative(sv) != 0);
+        u32 w[8];
+        fe_to_words(sv, w);
+        store8(out, idx, w);
+    }
+}
+
+// ---- Scalar::invert_batch_alloc, scalar.rs:802-856 (all inputs must be non-zero) -----------------------------
+// x^(l-2) in Montgomery form by square-and-multiply over the bits of l - 2
+__device__ __forceinline__ sc52 sc_montgomery_invert(const sc52 &xm) {
+    // l - 2 = 2^252 + 27742317777372353535851937790883648491, little-endian 64-bit words
+    const u64 e[4] = {0x5812631a5cf5d3ebull, 0x14def9dea2f79cd6ull, 0x0000000000000000ull, 0x1000000000000000ull};
+    sc52 r = sc_R();                      // 1 in Montgomery form
+#pragma unroll 1
+    for (int i = 252; i >= 0; i--) {
+        r = sc_montgomery_mul(r, r);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = sc_montgomery_mul(r, xm);
+    }
+    return r;
+}
+template <int CH>
+__global__ void __launch_bounds__(256) k_scalar_invert(uint8_t *__restrict__ io, u64 n, u64 *__restrict__ prefix, u64 *__restrict__ partial_inv) {
+    const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    sc52 acc = sc_R();
+#pragma unroll 1
+    for (int j = 0; j < CH; j++) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) break;
+        u32 w[8];
+        load8(io, idx, w);
+        sc52 xm = sc_montgomery_mul(sc_from_words(w), sc_RR());      // as_montgomery
+        for (int q = 0; q < 5; q++) prefix[idx * 5 + q] = acc.v[q];
+        acc = sc_montgomery_mul(acc, xm);
+    }
+    acc = sc_montgomery_invert(acc);                                  // still in Montgomery form
+    // product of all inverses of this lane's chunk (the reference returns the product over the whole batch)
+    { u128 z[9]; for (int q = 0; q < 9; q++) z[q] = q < 5 ? (u128)acc.v[q] : (u128)0; sc52 plain = sc_montgomery_reduce(z); for (int q = 0; q < 5; q++) partial_inv[t * 5 + q] = plain.v[q]; }
+#pragma unroll 1
+    for (int j = CH - 1; j >= 0; j--) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) continue;
+        u32 w[8];
+        load8(io, idx, w);
+        sc52 xm = sc_montgomery_mul(sc_from_words(w), sc_RR());
+        sc52 pre;
+        for (int q = 0; q < 5; q++) pre.v[q] = prefix[idx * 5 + q];
+        sc52 invm = sc_montgomery_mul(acc, pre);                      // (1/x) in Montgomery form
+        acc = sc_montgomery_mul(acc, xm);
+        u128 z[9];
+        for (int q = 0; q < 9; q++) z[q] = q < 5 ? (u128)invm.v[q] : (u128)0;
+        sc_to_words(sc_montgomery_reduce(z), w);                      // from_montgomery
+        store8(io, idx, w);
+    }
+}
+
+}  // namespace c25519
+
+// ---- precomputed static MSM ------------------------------------------------------------------------------------
+EXPORT c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *static_points, uint64_t n, int in_fmt) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    c25519_precomp *p = new c25519_precomp{nullptr, n};
+    if (hipMalloc(&p->d_pts, (n ? n : 1) * 96) != hipSuccess) { delete p; return nullptr; }
+    if (n == 0) return p;
+    if (ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) { hipFree(p->d_pts); delete p; return nullptr; }
+    uint32_t *bad = (uint32_t *)ctx->d_flag;
+    uint32_t hb = 0;
+    if (hipMemsetAsync(bad, 0, 16, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(ctx->tmp_b.p, static_points, n * psz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, p->d_pts, 0, bad) != C25519_OK ||
+        hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess || hb != 0) {
+        ctx->err = "precomp_create: a static point does not decode, or a HIP call failed";
+        hipFree(p->d_pts); delete p; return nullptr;
+    }
+    return p;
+}
+EXPORT void c25519_precomp_destroy(c25519_ctx *ctx, c25519_precomp *p) {
+    if (!p) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(p->d_pts);
+    delete p;
+}
+EXPORT uint64_t c25519_precomp_len(const c25519_precomp *p) { return p ? p->n : 0; }
+EXPORT int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp *p, const uint8_t *static_scalars, uint64_t n_static_scalars,
+                                          const uint8_t *dyn_scalars, const uint8_t *dyn_points, uint64_t n_dyn, int in_fmt, int out_fmt, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt < 0 || out_fmt > 2) { ctx->err = "precomp_msm: bad out_fmt"; return -(int32_t)hipErrorInvalidValue; }
+    if (n_static_scalars > p->n) { ctx->err = "precomp_msm: more static scalars than static points (precomputed_straus.rs:86)"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t ns = n_static_scalars, m = ns + n_dyn;
+    ge_p3 R = ge_identity();
+    if (m == 0) { host_encode(R, out_fmt, out); return C25519_OK; }
+    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, m * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n_dyn * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_e, m * 96 + 256))) return r;
+    uint8_t *d_sc = (uint8_t *)ctx->tmp_a.p;
+    uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p, *bad = (uint32_t *)ctx->d_flag;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemsetAsync(bad, 0, 16, st));
+    if (ns) {
+        HIPCHK(hipMemcpyAsync(d_sc, static_scalars, ns * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_pts, p->d_pts, ns * 96, hipMemcpyDeviceToDevice, st));
+    }
+    if (n_dyn) {
+        HIPCHK(hipMemcpyAsync(d_sc + ns * 32, dyn_scalars, n_dyn * 32, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, dyn_points, n_dyn * psz, hipMemcpyHostToDevice, st));
+        if ((r = prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n_dyn, in_fmt, d_pts, ns, bad))) return r;
+    }
+    uint32_t hb = 0;
+    HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (hb) return C25519_NONE;
+    if ((r = msm_core(ctx, d_sc, m, d_pts, R, nullptr))) return r;
+    host_encode(R, out_fmt, out);
+    return C25519_OK;
+}
+
+// ---- regular-schedule multiscalar multiplication -------------------------------------------------------------------
+EXPORT int32_t c25519_msm_consttime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt < 0 || out_fmt > 2) { ctx->err = "msm_consttime: bad out_fmt"; return -(int32_t)hipErrorInvalidValue; }
+    ge_p3 R = ge_identity();
+    if (n == 0) { host_encode(R, out_fmt, out); return C25519_OK; }
+    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 160 + n + 256))) return r;
+    hipStream_t st = ctx->stream;
+    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, st));
+    uint8_t *d_raw = (uint8_t *)ctx->tmp_c.p, *d_ok = d_raw + n * 160;
+    if ((r = c25519_mul_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, C25519_FMT_RAW160, d_raw, d_ok))) return r;
+    // c25519_mul_batch_dev left the products as P40 records in tmp_e: fold them
+    const int K = 4;
+    uint32_t *cur = (uint32_t *)ctx->tmp_e.p;
+    uint64_t m = n;
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, (size_t)(n / (64 * K) + 2) * 160 * 2 + 512))) return r;
+    uint32_t *bufA = (uint32_t *)ctx->tmp_f.p, *bufB = bufA + (size_t)(n / (64 * K) + 2) * 40;
+    while (m > 64) {
+        uint64_t mo = (m + 64 * K - 1) / (64 * K);
+        uint32_t *dst = (cur == bufA) ? bufB : bufA;
+        hipLaunchKernelGGL(k_sum_p40, dim3((unsigned)mo), dim3(64), 0, st, cur, m, K, dst);
+        cur = dst; m = mo;
+    }
+    HIPCHK(hipGetLastError());
+    std::vector<uint32_t> tail(m * 40);
+    std::vector<uint8_t> okh(n);
+    HIPCHK(hipMemcpyAsync(tail.data(), cur, m * 160, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(okh.data(), d_ok, n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n; i++) if (!okh[i]) return C25519_NONE;
+    for (uint64_t i = 0; i < m; i++) {
+        ge_p3 q;
+        for (int j = 0; j < 10; j++) { q.X.v[j] = tail[i * 40 + j]; q.Y.v[j] = tail[i * 40 + 10 + j]; q.Z.v[j] = tail[i * 40 + 20 + j]; q.T.v[j] = tail[i * 40 + 30 + j]; }
+        R = ge_add(R, q);
+    }
+    host_encode(R, out_fmt, out);
+    return C25519_OK;
+}
+
+// ---- Ristretto double-and-compress -------------------------------------------------------------------------------------
+EXPORT int32_t c25519_double_and_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    constexpr int CH = 16;
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_double_compress<CH>, dim3(dup64((n + CH - 1) / CH, 256)), dim3(256), 0, ctx->stream, d_in, (uint32_t *)ctx->prefix.p, n, d_out);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_double_and_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 160)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 32))) return r;
+    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, in, n * 160, hipMemcpyHostToDevice, ctx->stream));
+    if ((r = c25519_double_and_compress_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, n, (uint8_t *)ctx->tmp_b.p))) return r;
+    HIPCHK(hipMemcpyAsync(out, ctx->tmp_b.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+
+// ---- Scalar::invert_batch ------------------------------------------------------------------------------------------------
+// io: n x 32 canonical non-zero scalars, inverted in place; prod_inv (32 bytes, may be NULL): product of all inverses
+EXPORT int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t n, uint8_t *prod_inv) {
+    HIPCHK(hipSetDevice(ctx->device));
+    sc52 prod = sc_zero(); prod.v[0] = 1;
+    if (n) {
+        constexpr int CH = 16;
+        const uint64_t lanes = (n + CH - 1) / CH;
+        const unsigned grid = dup64(lanes, 256);
+        const uint64_t T = (uint64_t)grid * 256;
+        int32_t r;
+        if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40 + 64)) || (r = ctx_reserve(ctx, ctx->tmp_c, T * 40 + 64))) return r;
+        HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, io, n * 32, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->tmp_c.p, 0, T * 40, ctx->stream));
+        hipLaunchKernelGGL(k_scalar_invert<CH>, dim3(grid), dim3(256), 0, ctx->stream, (uint8_t *)ctx->tmp_a.p, n, (uint64_t *)ctx->tmp_b.p, (uint64_t *)ctx->tmp_c.p);
+        HIPCHK(hipGetLastError());
+        std::vector<uint64_t> parts(T * 5);
+        HIPCHK(hipMemcpyAsync(io, ctx->tmp_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(parts.data(), ctx->tmp_c.p, T * 40, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // zeroize (scalar.rs:852)
+        HIPCHK(hipMemsetAsync(ctx->tmp_b.p, 0, n * 40, ctx->stream));
+        const uint64_t active = lanes < T ? lanes : T;
+        for (uint64_t t = 0; t < active; t++) { sc52 q; for (int j = 0; j < 5; j++) q.v[j] = parts[t * 5 + j]; prod = sc_mul(prod, q); }
+    }
+    if (prod_inv) { u32 w[8]; sc_to_words(prod, w); memcpy(prod_inv, w, 32); }
+    return C25519_OK;
+}

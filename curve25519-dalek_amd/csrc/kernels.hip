@@ -1,98 +1,11 @@
 // HIP kernels for gfx950 (MI355X): one curve point / scalar / ladder per lane.
 // Launchers at the bottom are the only symbols the host side (capi.hip) uses.
 #include <hip/hip_runtime.h>
-#include "ge26.h"
 #include <stdlib.h>
+#include "devio.h"
 #include "kernels.h"
 
 namespace c25519 {
-
-// ------------------------------------------------------------------------------------------------
-// 32-byte items: two 16-byte loads/stores per lane; consecutive lanes touch consecutive 32-byte
-// items, so every 128-byte line a wave touches is fully used.
-__device__ __forceinline__ void load8(const uint8_t *base, u64 idx, u32 w[8]) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 2 * idx;
-    uint4 a = q[0], b = q[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-__device__ __forceinline__ void store8(uint8_t *base, u64 idx, const u32 w[8]) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 2 * idx;
-    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-__device__ __forceinline__ feT fe_from_q(const uint4 &a, const uint4 &b) {
-    u32 w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    return fe_from_words(w);
-}
-
-// Scratch point record "P32": 32 u32 per point = X[10] Y[10] Z[10] pad[2] (tight limbs), 128 bytes.
-__device__ __forceinline__ void p32_store(u32 *scratch, u64 idx, const feT &X, const feT &Y, const feT &Z) {
-    uint4 *q = reinterpret_cast<uint4 *>(scratch) + 8 * idx;
-    q[0] = make_uint4(X.v[0], X.v[1], X.v[2], X.v[3]);
-    q[1] = make_uint4(X.v[4], X.v[5], X.v[6], X.v[7]);
-    q[2] = make_uint4(X.v[8], X.v[9], Y.v[0], Y.v[1]);
-    q[3] = make_uint4(Y.v[2], Y.v[3], Y.v[4], Y.v[5]);
-    q[4] = make_uint4(Y.v[6], Y.v[7], Y.v[8], Y.v[9]);
-    q[5] = make_uint4(Z.v[0], Z.v[1], Z.v[2], Z.v[3]);
-    q[6] = make_uint4(Z.v[4], Z.v[5], Z.v[6], Z.v[7]);
-    q[7] = make_uint4(Z.v[8], Z.v[9], 0u, 0u);
-}
-__device__ __forceinline__ void p32_load_xy(const u32 *scratch, u64 idx, feT &X, feT &Y) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(scratch) + 8 * idx;
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4];
-    X.v[0] = a.x; X.v[1] = a.y; X.v[2] = a.z; X.v[3] = a.w; X.v[4] = b.x; X.v[5] = b.y; X.v[6] = b.z; X.v[7] = b.w;
-    X.v[8] = c.x; X.v[9] = c.y; Y.v[0] = c.z; Y.v[1] = c.w;
-    Y.v[2] = d.x; Y.v[3] = d.y; Y.v[4] = d.z; Y.v[5] = d.w; Y.v[6] = e.x; Y.v[7] = e.y; Y.v[8] = e.z; Y.v[9] = e.w;
-}
-__device__ __forceinline__ feT p32_load_z(const u32 *scratch, u64 idx) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(scratch) + 8 * idx;
-    uint4 f = q[5], g = q[6], h = q[7];
-    feT Z;
-    Z.v[0] = f.x; Z.v[1] = f.y; Z.v[2] = f.z; Z.v[3] = f.w; Z.v[4] = g.x; Z.v[5] = g.y; Z.v[6] = g.z; Z.v[7] = g.w;
-    Z.v[8] = h.x; Z.v[9] = h.y;
-    return Z;
-}
-// 10 tight limbs <-> a 48-byte slot (prefix products of the batched inversion)
-__device__ __forceinline__ void fe48_store(u32 *base, u64 idx, const feT &a) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 3 * idx;
-    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
-    q[2] = make_uint4(a.v[8], a.v[9], 0u, 0u);
-}
-__device__ __forceinline__ feT fe48_load(const u32 *base, u64 idx) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 3 * idx;
-    uint4 a = q[0], b = q[1], c = q[2];
-    feT r;
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    r.v[8] = c.x; r.v[9] = c.y;
-    return r;
-}
-
-// raw 160-byte EdwardsPoint (fmt 2): {X,Y,Z,T} x 5 x u64 radix-2^51, limbs < 2^52
-__device__ __forceinline__ feT fe_from_limbs51(const u64 l[5]) {
-    feW t;
-    for (int i = 0; i < 5; i++) { t.v[2 * i] = (u32)l[i] & M26; t.v[2 * i + 1] = (u32)(l[i] >> 26); }
-    return fe_carry(t);
-}
-__device__ __forceinline__ void fe_to_limbs51(const feT &a, u64 l[5]) {
-    u32 c[10];
-    fe_canonical_limbs(a, c);
-    for (int i = 0; i < 5; i++) l[i] = (u64)c[2 * i] | ((u64)c[2 * i + 1] << 26);
-}
-__device__ __forceinline__ void raw160_store(uint8_t *out, u64 idx, const ge_p3 &p) {
-    u64 l[20];
-    fe_to_limbs51(p.X, l); fe_to_limbs51(p.Y, l + 5); fe_to_limbs51(p.Z, l + 10); fe_to_limbs51(p.T, l + 15);
-    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out) + 10 * idx;
-    for (int i = 0; i < 10; i++) q[i] = make_ulonglong2(l[2 * i], l[2 * i + 1]);
-}
-__device__ __forceinline__ ge_p3 raw160_load(const uint8_t *in, u64 idx) {
-    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(in) + 10 * idx;
-    u64 l[20];
-    for (int i = 0; i < 10; i++) { ulonglong2 v = q[i]; l[2 * i] = v.x; l[2 * i + 1] = v.y; }
-    ge_p3 p;
-    p.X = fe_from_limbs51(l); p.Y = fe_from_limbs51(l + 5); p.Z = fe_from_limbs51(l + 10); p.T = fe_from_limbs51(l + 15);
-    return p;
-}
 
 // ================================================================================================
 // K2  fixed-base batch: s*B with a per-window table of affine Niels multiples staged in LDS.

@@ -24,10 +24,11 @@
 #include <string.h>
 #include <vector>
 #include "../../include/c25519_hip.h"
-#include "ge26.h"
+#include "devio.h"
 #include "sc_sha.h"
 #include "kernels.h"
 #include "ctx.h"
+#include "msm_internal.h"
 
 using namespace c25519;
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -39,50 +40,6 @@ using namespace c25519;
 
 namespace c25519 {
 
-__device__ __forceinline__ void load8w(const uint8_t *base, u64 idx, u32 w[8]) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 2 * idx;
-    uint4 a = q[0], b = q[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-__device__ __forceinline__ void store8w(uint8_t *base, u64 idx, const u32 w[8]) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 2 * idx;
-    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-
-// ---- packed affine Niels point: 24 u32 = canonical (y+x, y-x, 2dxy) --------------------------------
-__device__ __forceinline__ void pts96_store(u32 *pts, u64 idx, const feT &x, const feT &y) {
-    u32 w[24];
-    fe_to_words(fe_add(y, x), w);
-    fe_to_words(fe_sub(y, x), w + 8);
-    fe_to_words(fe_mul(fe_mul(x, y), fe_d2()), w + 16);
-    uint4 *q = reinterpret_cast<uint4 *>(pts) + 6 * idx;
-    for (int i = 0; i < 6; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
-}
-// load +P or -P (sign applied to the packed words, ge26.h aniels_words_cneg)
-__device__ __forceinline__ ge_aniels pts96_load(const u32 *pts, u64 idx, bool neg) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(pts) + 6 * idx;
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
-    u32 w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
-    aniels_words_cneg(w, neg);
-    return aniels_from_words(w);
-}
-// extended point as 40 u32 tight limbs (bucket sums, partial results)
-__device__ __forceinline__ void p40_store(u32 *base, u64 idx, const ge_p3 &p) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 10 * idx;
-    u32 t[40];
-    for (int i = 0; i < 10; i++) { t[i] = p.X.v[i]; t[10 + i] = p.Y.v[i]; t[20 + i] = p.Z.v[i]; t[30 + i] = p.T.v[i]; }
-    for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
-}
-__device__ __forceinline__ ge_p3 p40_load(const u32 *base, u64 idx) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 10 * idx;
-    u32 t[40];
-    for (int i = 0; i < 10; i++) { uint4 v = q[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
-    ge_p3 p;
-    for (int i = 0; i < 10; i++) { p.X.v[i] = t[i]; p.Y.v[i] = t[10 + i]; p.Z.v[i] = t[20 + i]; p.T.v[i] = t[30 + i]; }
-    return p;
-}
-
 // ================================================================================================
 // prep kernels
 // ================================================================================================
@@ -93,21 +50,13 @@ __global__ void __launch_bounds__(256) k_prep_compressed(const uint8_t *__restri
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 w[8];
-    load8w(in, i * stride_items, w);     // stride 1 for point arrays, 2 to pick R out of 64-byte signatures
+    load8(in, i * stride_items, w);     // stride 1 for point arrays, 2 to pick R out of 64-byte signatures
     ge_p3 P;
     bool ok = (FMT == 0) ? ge_decompress(P, w) : ris_decompress(P, w);
     pts96_store(pts, dst0 + i, P.X, P.Y);
     if (!ok) atomicAdd(bad_count, 1u);
 }
 // raw 160-byte points: Montgomery-trick normalisation, CH points per lane (cf. k_compress_p32)
-__device__ __forceinline__ feT raw_fe(const uint8_t *in, u64 idx, int which) {
-    // 40-byte field: (idx*160 + which*40) is only 8-byte aligned -> u64 loads
-    const u64 *p = reinterpret_cast<const u64 *>(in + idx * 160 + which * 40);
-    u64 l[5] = {p[0], p[1], p[2], p[3], p[4]};
-    feW t;
-    for (int i = 0; i < 5; i++) { t.v[2 * i] = (u32)l[i] & M26; t.v[2 * i + 1] = (u32)(l[i] >> 26); }
-    return fe_carry(t);
-}
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +69,7 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
         uint4 *q = reinterpret_cast<uint4 *>(prefix) + 3 * idx;
         q[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]); q[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
         q[2] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
-        acc = fe_mul(acc, raw_fe(in, idx, 2));
+        acc = fe_mul(acc, raw160_fe(in, idx, 2));
     }
     feT inv = fe_invert(acc);
 #pragma unroll 1
@@ -132,10 +81,10 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
         feT pre;
         pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
         pre.v[8] = c.x; pre.v[9] = c.y;
-        feT Z = raw_fe(in, idx, 2);
+        feT Z = raw160_fe(in, idx, 2);
         feT zi = fe_mul(inv, pre);
         inv = fe_mul(inv, Z);
-        pts96_store(pts, dst0 + idx, fe_mul(raw_fe(in, idx, 0), zi), fe_mul(raw_fe(in, idx, 1), zi));
+        pts96_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
     }
 }
 __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
@@ -152,7 +101,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     u32 s[9];
-    load8w(scalars, t, s);
+    load8(scalars, t, s);
     if (s[7] >> 31) atomicOr(bad_scalar, 1u);
     u64 carry = 0;
     for (int i = 0; i < 8; i++) { u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = v >> 32; }
@@ -449,9 +398,9 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 r[8], a[8], s[8];
-    load8w(sigs, 2 * i, r);
-    load8w(sigs, 2 * i + 1, s);
-    load8w(pks, i, a);
+    load8(sigs, 2 * i, r);
+    load8(sigs, 2 * i + 1, s);
+    load8(pks, i, a);
     if (!sc_is_canonical(s)) atomicAdd(bad_s, 1u);     // signature.rs:89-94 check_scalar
     sha512_stream st;
     st.init();
@@ -473,7 +422,7 @@ __global__ void __launch_bounds__(256) k_zleaf(const uint8_t *__restrict__ hram,
     if (i >= n) return;
     const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * i;
     u32 s[8];
-    load8w(sigs, 2 * i + 1, s);
+    load8(sigs, 2 * i + 1, s);
     u64 hs[8], w[16];   // 104-byte message: one block
     sha512_init(hs);
     for (int j = 0; j < 8; j++) w[j] = bswap64(h[j]);
@@ -537,13 +486,13 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
         const u32 *zw = reinterpret_cast<const u32 *>(z16) + 4 * i;
         u32 zwords[8] = {zw[0], zw[1], zw[2], zw[3], 0, 0, 0, 0};
         u32 s[8];
-        load8w(sigs, 2 * i + 1, s);
+        load8(sigs, 2 * i + 1, s);
         sc52 z = sc_from_words(zwords), h = sc_from_wide(h16), sv = sc_from_words(s);
         zs = sc_mul(z, sv);
         u32 out[8];
         sc_to_words(sc_mul(h, z), out);
-        store8w(msm_scalars, 1 + n + i, out);
-        store8w(msm_scalars, 1 + i, zwords);
+        store8(msm_scalars, 1 + n + i, out);
+        store8(msm_scalars, 1 + i, zwords);
     }
     for (int j = 0; j < 5; j++) red[threadIdx.x][j] = zs.v[j];
     __syncthreads();
@@ -577,14 +526,14 @@ static ge_p3 host_p40(const uint32_t *t) {
     for (int i = 0; i < 10; i++) { p.X.v[i] = t[i]; p.Y.v[i] = t[10 + i]; p.Z.v[i] = t[20 + i]; p.T.v[i] = t[30 + i]; }
     return p;
 }
-static void host_raw160(const ge_p3 &p, uint8_t *out) {
+void host_raw160(const ge_p3 &p, uint8_t *out) {
     const feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
     for (int c = 0; c < 4; c++) {
         u32 l[10]; fe_canonical_limbs(*f[c], l);
         for (int i = 0; i < 5; i++) { uint64_t v = (uint64_t)l[2 * i] | ((uint64_t)l[2 * i + 1] << 26); memcpy(out + 40 * c + 8 * i, &v, 8); }
     }
 }
-static ge_p3 host_from_raw160(const uint8_t *in) {
+ge_p3 host_from_raw160(const uint8_t *in) {
     ge_p3 p; feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
     for (int c = 0; c < 4; c++) {
         feW t;
@@ -593,7 +542,7 @@ static ge_p3 host_from_raw160(const uint8_t *in) {
     }
     return p;
 }
-static void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
+void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
     if (out_fmt == C25519_FMT_RAW160) { host_raw160(R, out); return; }
     u32 w[8];
     if (out_fmt == C25519_FMT_RISTRETTO) ris_compress(R, w);
@@ -610,7 +559,7 @@ static int pick_window(uint64_t n) {
 }
 
 // Sum over `nterms` (scalars at d_scalars, packed affine Niels points at d_pts) -> R.
-static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring) {
+int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring) {
     msm_geom g;
     g.c = pick_window(n);
     g.nwin = (256 + g.c - 1) / g.c;
@@ -717,7 +666,7 @@ static int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
 }
 
 // points in any format -> packed affine Niels at d_pts[dst0..]; returns C25519_NONE if some point is invalid
-static int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
+int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
     hipStream_t st = ctx->stream;
     if (n == 0) return C25519_OK;
     if (in_fmt == C25519_FMT_EDWARDS_Y) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up64(n, 256)), dim3(256), 0, st, d_points, (uint64_t)1, n, d_pts, dst0, d_badcount);

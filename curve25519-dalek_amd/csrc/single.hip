@@ -20,7 +20,7 @@
 #include <string.h>
 #include <vector>
 #include "../../include/c25519_hip.h"
-#include "ge26.h"
+#include "devio.h"
 #include "sc_sha.h"
 #include "kernels.h"
 #include "ctx.h"
@@ -34,42 +34,6 @@ using namespace c25519;
     } while (0)
 
 namespace c25519 {
-
-__device__ __forceinline__ void ld8(const uint8_t *base, u64 idx, u32 w[8]) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 2 * idx;
-    uint4 a = q[0], b = q[1];
-    w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
-}
-__device__ __forceinline__ void st8(uint8_t *base, u64 idx, const u32 w[8]) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 2 * idx;
-    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
-    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
-}
-__device__ __forceinline__ feT fe51x5(const u64 *p) {
-    feW t;
-    for (int i = 0; i < 5; i++) { u64 l = p[i]; t.v[2 * i] = (u32)l & M26; t.v[2 * i + 1] = (u32)(l >> 26); }
-    return fe_carry(t);
-}
-__device__ __forceinline__ ge_p3 raw160_ld(const uint8_t *in, u64 idx) {
-    const u64 *p = reinterpret_cast<const u64 *>(in + idx * 160);
-    ge_p3 r;
-    r.X = fe51x5(p); r.Y = fe51x5(p + 5); r.Z = fe51x5(p + 10); r.T = fe51x5(p + 15);
-    return r;
-}
-__device__ __forceinline__ void p40_st(u32 *base, u64 idx, const ge_p3 &p) {
-    uint4 *q = reinterpret_cast<uint4 *>(base) + 10 * idx;
-    u32 t[40];
-    for (int i = 0; i < 10; i++) { t[i] = p.X.v[i]; t[10 + i] = p.Y.v[i]; t[20 + i] = p.Z.v[i]; t[30 + i] = p.T.v[i]; }
-    for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
-}
-__device__ __forceinline__ ge_p3 p40_ld(const u32 *base, u64 idx) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(base) + 10 * idx;
-    u32 t[40];
-    for (int i = 0; i < 10; i++) { uint4 v = q[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
-    ge_p3 p;
-    for (int i = 0; i < 10; i++) { p.X.v[i] = t[i]; p.Y.v[i] = t[10 + i]; p.Z.v[i] = t[20 + i]; p.T.v[i] = t[30 + i]; }
-    return p;
-}
 
 // per-lane table entry j of lane L: quad q at  tab[((j * 10 + q) * stride + L)]   (uint4 units)
 __device__ __forceinline__ void tab_store(uint4 *tab, u64 stride, u64 lane, int j, const ge_cached &c) {
@@ -97,8 +61,8 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
     const u64 stride = (u64)gridDim.x * blockDim.x;
     ge_p3 P;
     bool good = true;
-    if (IN_FMT == 0) { u32 w[8]; ld8(points, idx, w); good = ge_decompress(P, w); }
-    else P = raw160_ld(points, idx);
+    if (IN_FMT == 0) { u32 w[8]; load8(points, idx, w); good = ge_decompress(P, w); }
+    else P = raw160_load(points, idx);
     if (NEGATE) P = ge_neg(P);
     if (ok) ok[idx] = good ? 1 : 0;
     // table: entry 0 = identity, entry j = j*P (j = 1..8), window.rs:97-104
@@ -117,7 +81,7 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
     }
     // digits: nibble_i(s') - 8 with s' = s + 0x0888...8 (top nibble left unsigned), scalar.rs:1019-1051
     u32 s[8];
-    ld8(scalars, idx, s);
+    load8(scalars, idx, s);
     {
         u64 carry = 0;
         for (int i = 0; i < 8; i++) { u64 v = (u64)s[i] + (i == 7 ? 0x08888888u : 0x88888888u) + carry; s[i] = (u32)v; carry = v >> 32; }
@@ -136,14 +100,14 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
         ge_cached c = tab_load(tab, stride, idx, mag);
         acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_cached_cneg(c, neg)));
     }
-    p40_st(out40, idx, acc);
+    p40_store(out40, idx, acc);
 }
 
 // P40 -> raw160 / P32 (for the batched compressor)
 __global__ void __launch_bounds__(256) k_p40_to_raw(const u32 *__restrict__ in40, u64 n, uint8_t *__restrict__ out_raw) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    ge_p3 p = p40_ld(in40, idx);
+    ge_p3 p = p40_load(in40, idx);
     u64 l[20];
     const feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
     for (int c = 0; c < 4; c++) { u32 cl[10]; fe_canonical_limbs(*f[c], cl); for (int i = 0; i < 5; i++) l[5 * c + i] = (u64)cl[2 * i] | ((u64)cl[2 * i + 1] << 26); }
@@ -154,7 +118,7 @@ __global__ void __launch_bounds__(256) k_p40_to_raw(const u32 *__restrict__ in40
 __global__ void __launch_bounds__(256) k_p40_add_to_p32(const u32 *__restrict__ a40, const u32 *__restrict__ b40, u64 n, u32 *__restrict__ scratch) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    ge_p3 r = b40 ? ge_add(p40_ld(a40, idx), p40_ld(b40, idx)) : p40_ld(a40, idx);
+    ge_p3 r = b40 ? ge_add(p40_load(a40, idx), p40_load(b40, idx)) : p40_load(a40, idx);
     uint4 *q = reinterpret_cast<uint4 *>(scratch) + 8 * idx;
     q[0] = make_uint4(r.X.v[0], r.X.v[1], r.X.v[2], r.X.v[3]); q[1] = make_uint4(r.X.v[4], r.X.v[5], r.X.v[6], r.X.v[7]);
     q[2] = make_uint4(r.X.v[8], r.X.v[9], r.Y.v[0], r.Y.v[1]); q[3] = make_uint4(r.Y.v[2], r.Y.v[3], r.Y.v[4], r.Y.v[5]);
@@ -175,21 +139,21 @@ __global__ void __launch_bounds__(256) k_hram_reduce(const uint8_t *__restrict__
     for (int j = 0; j < 16; j++) h16[j] = hw[j];
     u32 kw[8];
     sc_to_words(sc_from_wide(h16), kw);
-    st8(kscal, i, kw);
+    store8(kscal, i, kw);
     u32 s[8];
-    ld8(sigs, 2 * i + 1, s);
+    load8(sigs, 2 * i + 1, s);
     bool canon = sc_is_canonical(s);
     s_ok[i] = canon ? 1 : 0;
     if (!canon) { for (int j = 0; j < 8; j++) s[j] = 0; }   // keep the fixed-base kernel's precondition (< 2^255)
-    st8(sscal, i, s);
+    store8(sscal, i, s);
 }
 // strict mode: small-order checks on R and A (verifying.rs:371-374, edwards.rs:1405)
 __global__ void __launch_bounds__(256) k_strict_checks(const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ strict_bad) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 r[8], a[8];
-    ld8(sigs, 2 * i, r);
-    ld8(pks, i, a);
+    load8(sigs, 2 * i, r);
+    load8(pks, i, a);
     ge_p3 R, A;
     bool okR = ge_decompress(R, r), okA = ge_decompress(A, a);
     bool bad = !okR;
@@ -203,8 +167,8 @@ __global__ void __launch_bounds__(256) k_verdict(const uint8_t *__restrict__ sig
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 r[8], c[8];
-    ld8(sigs, 2 * i, r);
-    ld8(rcheck, i, c);
+    load8(sigs, 2 * i, r);
+    load8(rcheck, i, c);
     u32 d = 0;
     for (int j = 0; j < 8; j++) d |= r[j] ^ c[j];
     uint8_t st = C25519_OK;
@@ -222,7 +186,7 @@ __global__ void __launch_bounds__(256) k_expand_seed(const uint8_t *__restrict__
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 sd[8];
-    ld8(seeds, i, sd);
+    load8(seeds, i, sd);
     u64 hs[8], w[16];
     sha512_init(hs);
     for (int j = 0; j < 4; j++) w[j] = bswap64((u64)sd[2 * j] | ((u64)sd[2 * j + 1] << 32));
@@ -233,8 +197,8 @@ __global__ void __launch_bounds__(256) k_expand_seed(const uint8_t *__restrict__
     u32 d[16];
     sha512_digest_words(hs, d);
     d[0] &= 0xfffffff8u; d[7] &= 0x7fffffffu; d[7] |= 0x40000000u;   // clamp_integer, scalar.rs:1407
-    st8(scal_a, i, d);
-    st8(prefix, i, d + 8);
+    store8(scal_a, i, d);
+    store8(prefix, i, d + 8);
 }
 // r_i = SHA-512(prefix_i || M_i) mod l
 __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ prefix, const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 n,
@@ -242,7 +206,7 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 p[8];
-    ld8(prefix, i, p);
+    load8(prefix, i, p);
     sha512_stream st;
     st.init();
     for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)p[2 * j] | ((u64)p[2 * j + 1] << 32));
@@ -254,7 +218,7 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     u32 d[16], r[8];
     sha512_digest_words(st.h, d);
     sc_to_words(sc_from_wide(d), r);
-    st8(rscal, i, r);
+    store8(rscal, i, r);
 }
 // s_i = k_i * a_i + r_i mod l;  sig_i = R_i || s_i      (k_i = H(R||A||M) mod l given as 64-byte digests)
 __global__ void __launch_bounds__(256) k_sign_finish(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ scal_a, const uint8_t *__restrict__ rscal,
@@ -265,19 +229,19 @@ __global__ void __launch_bounds__(256) k_sign_finish(const uint8_t *__restrict__
     u32 h16[16];
     for (int j = 0; j < 16; j++) h16[j] = hw[j];
     u32 a[8], r[8], R[8], s[8];
-    ld8(scal_a, i, a); ld8(rscal, i, r); ld8(Renc, i, R);
+    load8(scal_a, i, a); load8(rscal, i, r); load8(Renc, i, R);
     sc52 sv = sc_add(sc_mul(sc_from_wide(h16), sc_reduce256(a)), sc_from_words(r));
     sc_to_words(sv, s);
-    st8(sigs, 2 * i, R);
-    st8(sigs, 2 * i + 1, s);
+    store8(sigs, 2 * i, R);
+    store8(sigs, 2 * i + 1, s);
 }
 // signatures with R filled in only (so k_hram can hash R || A || M): copy R into sig slots
 __global__ void __launch_bounds__(256) k_place_R(const uint8_t *__restrict__ Renc, u64 n, uint8_t *__restrict__ sigs) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 R[8];
-    ld8(Renc, i, R);
-    st8(sigs, 2 * i, R);
+    load8(Renc, i, R);
+    store8(sigs, 2 * i, R);
 }
 
 }  // namespace c25519

@@ -71,6 +71,14 @@ def load_library():
         "ed25519_keygen_batch_dev": (i32, [vp, vp, u64, vp]),
         "ed25519_sign_batch_dev": (i32, [vp, vp, vp, vp, u64, u64, vp, vp]),
         "ed25519_sign_batch": (i32, [vp, vp, vp, vp, u64, vp, vp]),
+        "c25519_precomp_create": (vp, [vp, vp, u64, C.c_int]),
+        "c25519_precomp_destroy": (None, [vp, vp]),
+        "c25519_precomp_len": (u64, [vp]),
+        "c25519_precomp_msm_vartime": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_int, C.c_int, vp]),
+        "c25519_msm_consttime": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
+        "c25519_double_and_compress_batch_dev": (i32, [vp, vp, u64, vp]),
+        "c25519_double_and_compress_batch": (i32, [vp, vp, u64, vp]),
+        "c25519_scalar_invert_batch": (i32, [vp, vp, u64, vp]),
         "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
     }
     for name, (res, args) in sigs.items():
@@ -89,6 +97,9 @@ ABI_SYMBOLS = [
     "c25519_mul_batch_dev", "c25519_mul_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
+    "c25519_precomp_create", "c25519_precomp_destroy", "c25519_precomp_len", "c25519_precomp_msm_vartime",
+    "c25519_msm_consttime", "c25519_double_and_compress_batch_dev", "c25519_double_and_compress_batch",
+    "c25519_scalar_invert_batch",
 ]
 
 _PT = {FMT_EDWARDS_Y: 32, FMT_RISTRETTO: 32, FMT_RAW160: 160}
@@ -359,3 +370,50 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.c25519_to_montgomery_batch(self.ctx, p.ctypes.data, n, out.ctypes.data))
         return out
+
+    # -- §8f widening ------------------------------------------------------------------------------------
+    def precomp_create(self, static_points, in_fmt=FMT_RAW160):
+        p = _np8(static_points, _PT[in_fmt])
+        self._bind_stream()
+        h = self.lib.c25519_precomp_create(self.ctx, p.ctypes.data, p.shape[0], in_fmt)
+        if not h:
+            raise EngineError("precomp_create failed: %s" % self.lib.c25519_last_error(self.ctx).decode())
+        return h
+
+    def precomp_destroy(self, h):
+        self.lib.c25519_precomp_destroy(self.ctx, h)
+
+    def precomp_len(self, h):
+        return int(self.lib.c25519_precomp_len(h))
+
+    def precomp_msm_vartime(self, h, static_scalars, dyn_scalars, dyn_points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        ss = _np8(static_scalars, 32); ds = _np8(dyn_scalars, 32); dp = _np8(dyn_points, _PT[in_fmt])
+        assert ds.shape[0] == dp.shape[0]
+        out = C.create_string_buffer(_PT[out_fmt])
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_precomp_msm_vartime(self.ctx, h, ss.ctypes.data, ss.shape[0], ds.ctypes.data, dp.ctypes.data, ds.shape[0],
+                                                           in_fmt, out_fmt, out), (OK, NONE))
+        return st, out.raw
+
+    def msm_consttime(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        s = _np8(scalars, 32); p = _np8(points, _PT[in_fmt])
+        assert s.shape[0] == p.shape[0]
+        out = C.create_string_buffer(_PT[out_fmt])
+        self._bind_stream()
+        st = self._chk(self.lib.c25519_msm_consttime(self.ctx, s.ctypes.data, p.ctypes.data, s.shape[0], in_fmt, out_fmt, out), (OK, NONE))
+        return st, out.raw
+
+    def double_and_compress_batch(self, pts):
+        p = _np8(pts, 160); n = p.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_double_and_compress_batch(self.ctx, p.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def scalar_invert_batch(self, scalars):
+        """-> (inverses (n,32), product of all inverses (32 bytes)); inputs must be canonical and non-zero."""
+        s = _np8(scalars, 32).copy(); n = s.shape[0]
+        prod = C.create_string_buffer(32)
+        self._bind_stream()
+        self._chk(self.lib.c25519_scalar_invert_batch(self.ctx, s.ctypes.data, n, prod))
+        return s, prod.raw

@@ -158,6 +158,36 @@ int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const ui
                                uint64_t n, uint8_t *d_pks, uint8_t *d_sigs);
 int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs);
 
+/* ---- precomputed static points: VartimePrecomputedMultiscalarMul (traits.rs:304-419) ---------------------
+ * replaces backend::VartimePrecomputedStraus::{new, len, optional_mixed_multiscalar_mul}
+ * (backend.rs:100-192 -> scalar_mul/precomputed_straus.rs:29-127; edwards.rs:1037-1076).
+ * create: static points (HOST pointer; fmt 0/1/2) are normalised once and stay resident in HBM; returns
+ * NULL if a point does not decode.  msm: sum static_scalars[i]*S_i (the first n_static_scalars static points;
+ * more scalars than points is an error, precomputed_straus.rs:86) + sum dyn_scalars[j]*dyn_points[j].
+ * All pointers of the msm call are HOST pointers; returns C25519_NONE iff a dynamic point does not decode. */
+typedef struct c25519_precomp c25519_precomp;
+c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *static_points, uint64_t n, int in_fmt);
+void c25519_precomp_destroy(c25519_ctx *ctx, c25519_precomp *p);
+uint64_t c25519_precomp_len(const c25519_precomp *p);
+int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp *p, const uint8_t *static_scalars, uint64_t n_static_scalars,
+                                   const uint8_t *dyn_scalars, const uint8_t *dyn_points, uint64_t n_dyn, int in_fmt, int out_fmt, uint8_t *out);
+
+/* ---- regular-schedule multiscalar multiplication: MultiscalarMul::multiscalar_mul ------------------------
+ * replaces backend::straus_multiscalar_mul (backend.rs:196 -> scalar_mul/straus.rs:103-144;
+ * edwards.rs:966-1000).  One radix-16 fixed-window ladder per term (the schedule of variable_base.rs,
+ * identical instruction stream for every input) and a tree sum; HOST pointers; fmt as c25519_mul_batch. */
+int32_t c25519_msm_consttime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
+
+/* ---- RistrettoPoint::double_and_compress_batch (ristretto.rs:564-648): out[i] = compress(2 * P_i) with one
+ * shared inversion per lane-chunk.  in: n x 160 raw points; out: n x 32 CompressedRistretto. */
+int32_t c25519_double_and_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, uint8_t *d_out);
+int32_t c25519_double_and_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out);
+
+/* ---- Scalar::invert_batch_alloc (scalar.rs:802-856): io[i] <- 1/io[i] mod l in place (HOST pointer; all inputs
+ * must be canonical and non-zero, as in the reference); prod_inv (32 bytes, may be NULL) receives the product of
+ * all inverses, the reference's return value. */
+int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t n, uint8_t *prod_inv);
+
 /* ---- diagnostics ----------------------------------------------------------------------------------
  * Integer-multiplier roofline probes: runs a dependent-free chain microbenchmark and
  * returns giga-operations per second.  which: 0 v_mad_u64_u32, 1 fe_mul (radix 2^25.5, this
