@@ -309,7 +309,7 @@ EXPORT int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t
         HIPCHK(hipStreamSynchronize(ctx->stream));
         HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // zeroize (scalar.rs:852)
         HIPCHK(hipMemsetAsync(ctx->tmp_b.p, 0, n * 40, ctx->stream));
-        const uint64_t active = lanes < T ? lanes : T;
+        const uint64_t active = n < T ? n : T;     // lane t owns elements t, t+T, ...: every lane below n is active
         for (uint64_t t = 0; t < active; t++) { sc52 q; for (int j = 0; j < 5; j++) q.v[j] = parts[t * 5 + j]; prod = sc_mul(prod, q); }
     }
     if (prod_inv) { u32 w[8]; sc_to_words(prod, w); memcpy(prod_inv, w, 32); }
