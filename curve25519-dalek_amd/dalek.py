@@ -7,6 +7,12 @@ error behaviour), batched, on top of Engine.  Reference entry points mirrored:
   CompressedEdwardsY::decompress / compress   edwards.rs:211 / :615
   x25519                                      x25519-dalek/src/x25519.rs:390
   verify_batch                                ed25519-dalek/src/batch.rs:146
+  VerifyingKey::verify / verify_strict        ed25519-dalek/src/verifying.rs:565 / :359   (verify_each)
+  SigningKey::sign                            ed25519-dalek/src/signing.rs:878-905        (sign_batch)
+  EdwardsPoint::multiscalar_mul               curve25519-dalek/src/edwards.rs:966-1000
+  VartimeEdwardsPrecomputation                curve25519-dalek/src/edwards.rs:1037-1076
+  RistrettoPoint::double_and_compress_batch   curve25519-dalek/src/ristretto.rs:564
+  Scalar::invert_batch                        curve25519-dalek/src/scalar.rs:802
 
 Values cross this layer as the reference's wire types: Scalar = 32 canonical LE bytes,
 CompressedEdwardsY / CompressedRistretto / MontgomeryPoint = 32 bytes.
@@ -97,3 +103,57 @@ def verify_batch(messages, signatures, verifying_keys, engine=None, z_mode=_e.Z_
         return None
     raise SignatureError({_e.ARRAY_LENGTH: "ArrayLength", _e.SCALAR_FORMAT: "ScalarFormat", _e.VERIFY: "Verify",
                           _e.NONE: "PointDecompression"}[st])
+
+
+def verify_each(messages, signatures, verifying_keys, strict=False, engine=None):
+    """Per-signature VerifyingKey::verify (verifying.rs:565) or verify_strict (:359): a list with None for
+    Ok(()) and a SignatureError for every failing signature."""
+    eng = engine or default_engine()
+    st = eng.verify_each(list(messages), list(signatures), list(verifying_keys), strict)
+    names = {_e.SCALAR_FORMAT: "ScalarFormat", _e.VERIFY: "Verify", _e.NONE: "PointDecompression"}
+    return [None if c == _e.OK else SignatureError(names[int(c)]) for c in st]
+
+
+def sign_batch(secret_keys, messages, engine=None):
+    """SigningKey::from_bytes(sk).sign(m) for every pair (signing.rs:878-905): -> (verifying keys, signatures)."""
+    eng = engine or default_engine()
+    pks, sigs = eng.sign_batch(list(secret_keys), list(messages))
+    return [pks[i].tobytes() for i in range(len(messages))], [sigs[i].tobytes() for i in range(len(messages))]
+
+
+def multiscalar_mul(scalars, points, engine=None):
+    """EdwardsPoint::multiscalar_mul (edwards.rs:966-1000), points as CompressedEdwardsY: regular schedule."""
+    if len(scalars) != len(points):
+        raise AssertionError("multiscalar_mul: scalars and points must have equal length")
+    eng = engine or default_engine()
+    st, out = eng.msm_consttime(_cat(scalars, 32), _cat(points, 32), _e.FMT_EDWARDS_Y, _e.FMT_EDWARDS_Y)
+    return None if st == _e.NONE else out
+
+
+class VartimeEdwardsPrecomputation:
+    """edwards.rs:1037-1076 (VartimePrecomputedMultiscalarMul, traits.rs:304-419); points as CompressedEdwardsY."""
+
+    def __init__(self, static_points, engine=None):
+        self.eng = engine or default_engine()
+        self.h = self.eng.precomp_create(_cat(static_points, 32), _e.FMT_EDWARDS_Y)
+
+    def __len__(self):
+        return self.eng.precomp_len(self.h)
+
+    def is_empty(self):
+        return len(self) == 0
+
+    def vartime_mixed_multiscalar_mul(self, static_scalars, dynamic_scalars, dynamic_points):
+        if len(dynamic_scalars) != len(dynamic_points):
+            raise AssertionError("dynamic scalars and points must have equal length")   # precomputed_straus.rs:87
+        st, out = self.eng.precomp_msm_vartime(self.h, _cat(static_scalars, 32), _cat(dynamic_scalars, 32), _cat(dynamic_points, 32),
+                                               _e.FMT_EDWARDS_Y, _e.FMT_EDWARDS_Y)
+        return None if st == _e.NONE else out
+
+    def vartime_multiscalar_mul(self, static_scalars):
+        return self.vartime_mixed_multiscalar_mul(static_scalars, [], [])
+
+    def close(self):
+        if self.h:
+            self.eng.precomp_destroy(self.h)
+            self.h = None
