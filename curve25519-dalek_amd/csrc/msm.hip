@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) 
     }
     ord_hist[threadIdx.x] = p[threadIdx.x] - v;
 }
-__global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ totals, u64 nb, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
+__global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ totals, u64 nb, u32 gid_off, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
     __shared__ u32 h[256], basep[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -226,7 +226,7 @@ __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ t
     __syncthreads();
     if (h[threadIdx.x]) basep[threadIdx.x] = atomicAdd(&ord_cursor[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
-    if (gid < nb) perm[basep[bin] + local] = (u32)gid;
+    if (gid < nb) perm[basep[bin] + local] = (u32)gid + gid_off;
 }
 
 // Buckets longer than LONG_CAP are left to the wave-cooperative path below, so that no lane ever walks a
@@ -236,9 +236,9 @@ constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mea
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
-                                                    const u32 *__restrict__ perm, u64 n, msm_geom g, u32 *__restrict__ buckets) {
+                                                    const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
     u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (u64)g.nwin * g.half) return;
+    if (tid >= count) return;
     const u64 gid = perm[tid];
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
     u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
@@ -281,11 +281,12 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
 // ---- long buckets -------------------------------------------------------------------------------------
 // work list: one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
 struct long_item { u32 gid, lo, hi, first; };
-__global__ void __launch_bounds__(256) k_find_long(const u32 *__restrict__ base, msm_geom g, u32 max_items, long_item *__restrict__ items,
+__global__ void __launch_bounds__(256) k_find_long(const u32 *__restrict__ base, msm_geom g, u64 gid_off, u64 count, u32 max_items, long_item *__restrict__ items,
                                                    u32 *__restrict__ counters /* [0]=#items [1]=#long buckets */, u32 *__restrict__ long_gids,
                                                    u32 *__restrict__ long_first) {
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (u64)g.nwin * g.half) return;
+    if (gid >= count) return;
+    gid += gid_off;
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
     u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
     u32 cnt = hi - lo;
@@ -583,7 +584,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     size_t oD = carve((size_t)g.nwin * n * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
     size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oT = carve(nb * 4);
     size_t lvl_pts = plan.empty() ? (size_t)g.nwin : (size_t)g.nwin * (plan[0].m_in / plan[0].L);
-    size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256 + 1024), oPerm = carve(nb * 4);
+    size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256 + 2048), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * n;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / LONG_CAP + 1);
@@ -597,7 +598,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
+    HIPCHK(hipMemsetAsync(flags, 0, 256 + 2048, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
     size_t lds = (size_t)g.half * 4;
     static int xswap = -1;   // tuning knob: C25519_XCD_SWAP = 0 | 1
@@ -614,42 +615,70 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
     if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
-    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist);
-    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
-    hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist, perm);
-    if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    {
-        static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2
-        if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 2; if (pipe < 0 || pipe > 2) pipe = 2; }
-        if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
-        else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
-        else hipLaunchKernelGGL(k_accumulate<2>, dim3(div_up64(nb, 256)), dim3(256), 0, st, d_pts, sorted, base, perm, n, g, buckets);
-    }
-    {
-        long_item *items = (long_item *)(ws + oLI);
-        uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
-        hipLaunchKernelGGL(k_find_long, dim3(div_up64(nb, 256)), dim3(256), 0, st, base, g, max_items, items, counters, lgids, lfirst);
-        hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 2048u)), dim3(64), 0, st, d_pts, sorted, n, g, items, counters, max_items, segs);
-        hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 1024u)), dim3(64), 0, st, base, g, counters, max_items, lgids, lfirst, segs, buckets);
-    }
-    if (ring) HIPCHK(hipEventRecord(ring[1], st));
-    // reduction levels
-    const uint32_t *S_in = buckets, *P_in = nullptr;
+    // Window groups: while group g+1 accumulates (VALU-bound, the whole chip), the latency-bound reduction
+    // levels of group g (a few thousand lanes) run on the second stream.
+    static int groups = -1;   // tuning knob: C25519_MSM_GROUPS = 1 | 2
+    if (groups < 0) { const char *e = getenv("C25519_MSM_GROUPS"); groups = e ? atoi(e) : 1; if (groups != 2) groups = 1; }   // measured: 2 groups cost more (two kernel tails) than the overlap returns
+    const int G = (groups == 2 && g.nwin >= 8 && n >= 65536) ? 2 : 1;
+    static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2
+    if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 2; if (pipe < 0 || pipe > 2) pipe = 2; }
+    long_item *items = (long_item *)(ws + oLI);
+    uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS);
     uint32_t *bufs[2] = {(uint32_t *)(ws + oR0), (uint32_t *)(ws + oR1)};
-    int which = 0;
-    for (size_t li = 0; li < plan.size(); li++) {
-        int m_out = plan[li].m_in / plan[li].L;
-        uint32_t *S_out = bufs[which], *P_out = bufs[which] + lvl_pts * 40;
-        hipLaunchKernelGGL(k_reduce_level, dim3(div_up64((uint64_t)g.nwin * m_out, 128)), dim3(128), 0, st, S_in, P_in, plan[li].m_in, plan[li].L,
-                           plan[li].shift, g.nwin, S_out, P_out);
-        S_in = S_out; P_in = P_out; which ^= 1;
+    const uint32_t *S_fin[2] = {nullptr, nullptr}, *P_fin[2] = {nullptr, nullptr};
+    int k_lo[3] = {0, G == 2 ? g.nwin / 2 : g.nwin, g.nwin};
+    if (ring) HIPCHK(hipEventRecord(ring[0], st));
+    for (int grp = 0; grp < G; grp++) {
+        const int k0 = k_lo[grp], k1 = k_lo[grp + 1], nw = k1 - k0;
+        const uint64_t goff = (uint64_t)k0 * g.half, cnt = (uint64_t)nw * g.half;
+        uint32_t *oh = ord_hist + 256 * grp, *pg = perm + goff, *counters = flags + 8 + 4 * grp;
+        hipLaunchKernelGGL(k_order_hist, dim3(div_up64(cnt, 256)), dim3(256), 0, st, totals + goff, cnt, oh);
+        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, oh);
+        hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(cnt, 256)), dim3(256), 0, st, totals + goff, cnt, (uint32_t)goff, oh, pg);
+        // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_find_long, dim3(div_up64(cnt, 256)), dim3(256), 0, ctx->aux, base, g, goff, cnt, max_items, items, counters, lgids, lfirst);
+        hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, sorted, n, g, items, counters, max_items, segs);
+        hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 1024u)), dim3(64), 0, ctx->aux, base, g, counters, max_items, lgids, lfirst, segs, buckets);
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
+        if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
+        else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
+        else hipLaunchKernelGGL(k_accumulate<2>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
+        if (grp == G - 1 && ring) HIPCHK(hipEventRecord(ring[1], st));
+        // reduction levels of this group: on the aux stream unless it is the last group
+        hipStream_t rs = st;
+        if (grp < G - 1) {
+            rs = ctx->aux;
+            HIPCHK(hipEventRecord(ctx->ev_fork2, st));
+            HIPCHK(hipStreamWaitEvent(rs, ctx->ev_fork2, 0));
+        }
+        const uint32_t *S_in = buckets + goff * 40, *P_in = nullptr;
+        const size_t gl = (size_t)nw * (plan.empty() ? 1 : plan[0].m_in / plan[0].L);       // points per level buffer of this group
+        uint32_t *gb[2] = {bufs[0] + (size_t)k0 * (lvl_pts / g.nwin) * 80, bufs[1] + (size_t)k0 * (lvl_pts / g.nwin) * 80};
+        int which = 0;
+        for (size_t li = 0; li < plan.size(); li++) {
+            int m_out = plan[li].m_in / plan[li].L;
+            uint32_t *S_out = gb[which], *P_out = gb[which] + gl * 40;
+            hipLaunchKernelGGL(k_reduce_level, dim3(div_up64((uint64_t)nw * m_out, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in, plan[li].L,
+                               plan[li].shift, nw, S_out, P_out);
+            S_in = S_out; P_in = P_out; which ^= 1;
+        }
+        S_fin[grp] = S_in; P_fin[grp] = P_in;
+        if (grp < G - 1) HIPCHK(hipEventRecord(ctx->ev_join2, rs));
     }
     HIPCHK(hipGetLastError());
+    if (G == 2) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join2, 0));
     // window totals -> host, Horner fold (pippenger.rs:159)
     std::vector<uint32_t> hS((size_t)g.nwin * 40), hP((size_t)g.nwin * 40);
     uint32_t hflags[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(hS.data(), S_in, hS.size() * 4, hipMemcpyDeviceToHost, st));
-    if (P_in) HIPCHK(hipMemcpyAsync(hP.data(), P_in, hP.size() * 4, hipMemcpyDeviceToHost, st));
+    const bool haveP = !plan.empty();
+    for (int grp = 0; grp < G; grp++) {
+        const int k0 = k_lo[grp], nw = k_lo[grp + 1] - k0;
+        HIPCHK(hipMemcpyAsync(hS.data() + (size_t)k0 * 40, S_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
+        if (haveP) HIPCHK(hipMemcpyAsync(hP.data() + (size_t)k0 * 40, P_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
+    }
     HIPCHK(hipMemcpyAsync(hflags, flags, 8, hipMemcpyDeviceToHost, st));
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     HIPCHK(hipStreamSynchronize(st));
@@ -657,7 +686,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     ge_p3 total = ge_identity();
     for (int k = g.nwin - 1; k >= 0; k--) {
         ge_p3 col = host_p40(&hS[(size_t)k * 40]);                    // sum_b B_b
-        if (P_in) col = ge_add(col, host_p40(&hP[(size_t)k * 40]));   // + sum_b b*B_b
+        if (haveP) col = ge_add(col, host_p40(&hP[(size_t)k * 40]));  // + sum_b b*B_b
         if (k != g.nwin - 1) total = ge_mul_by_pow_2(total, g.c);
         total = ge_add(total, col);
     }
