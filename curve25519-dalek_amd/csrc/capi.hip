@@ -135,6 +135,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
     int w = (int)(flags & 0xf);
@@ -163,6 +164,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->aux) { hipStreamSynchronize(ctx->aux); hipStreamDestroy(ctx->aux); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_sort) hipEventDestroy(ctx->ev_sort);
     if (ctx->ev_fork2) hipEventDestroy(ctx->ev_fork2);
     if (ctx->ev_join2) hipEventDestroy(ctx->ev_join2);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);

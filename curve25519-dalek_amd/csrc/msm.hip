@@ -417,23 +417,39 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
     for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
-// device z-mode, step 1: leaf_i = SHA-512(hram_i || s_i || LE64(i))
-__global__ void __launch_bounds__(256) k_zleaf(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, uint8_t *__restrict__ leaf) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * i;
-    u32 s[8];
-    load8(sigs, 2 * i + 1, s);
-    u64 hs[8], w[16];   // 104-byte message: one block
+// device z-mode, step 1: first tree level straight over the (hram_i, s_i) pairs -- hram_i already commits to
+// (R_i, A_i, M_i), so node_j = SHA-512(hram_16j || s_16j || ... || hram_16j+15 || s_16j+15 || LE64(n)) binds every
+// batch input with 13/16 compressions per signature (absent children = zero bytes; position = place in the tree)
+__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, uint8_t *__restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 m_out = (n + 15) / 16;
+    if (j >= m_out) return;
+    u64 hs[8], w[16];
     sha512_init(hs);
-    for (int j = 0; j < 8; j++) w[j] = bswap64(h[j]);
-    for (int j = 0; j < 4; j++) w[8 + j] = bswap64((u64)s[2 * j] | ((u64)s[2 * j + 1] << 32));
-    w[12] = bswap64(i); w[13] = 0x8000000000000000ull; w[14] = 0; w[15] = 104 * 8;
+#pragma unroll 1
+    for (int grp = 0; grp < 4; grp++) {                   // 4 children x 96 B = 3 blocks
+        u64 c0 = 16 * j + 4 * grp;
+#pragma unroll
+        for (int blk = 0; blk < 3; blk++) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int k = 16 * blk + q, child = k / 12, off = k % 12;
+                u64 c = c0 + child, v = 0;
+                if (c < n) v = off < 8 ? reinterpret_cast<const u64 *>(hram)[8 * c + off]
+                                       : reinterpret_cast<const u64 *>(sigs)[8 * c + 4 + (off - 8)];
+                w[q] = bswap64(v);
+            }
+            sha512_compress(hs, w);
+        }
+    }
+    w[0] = bswap64(n); w[1] = 0x8000000000000000ull;
+    for (int q = 2; q < 15; q++) w[q] = 0;
+    w[15] = (u64)(1536 + 8) * 8;
     sha512_compress(hs, w);
-    u64 *o = reinterpret_cast<u64 *>(leaf) + 8 * i;
-    for (int j = 0; j < 8; j++) o[j] = bswap64(hs[j]);
+    u64 *o = reinterpret_cast<u64 *>(out) + 8 * j;
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
 }
-// step 2: 16-ary Merkle level: out[j] = SHA-512(in[16j] || ... || in[16j+15]) (missing children skipped)
+// step 2: upper 16-ary Merkle levels: out[j] = SHA-512(in[16j] || ... || in[16j+15]) (missing children skipped)
 __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (m_in + 15) / 16;
@@ -560,7 +576,10 @@ static int pick_window(uint64_t n) {
 }
 
 // Sum over `nterms` (scalars at d_scalars, packed affine Niels points at d_pts) -> R.
-int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring) {
+// sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are enqueued
+// (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
+// second stream while the main stream still prepares the points; msm_core joins the two itself.
+int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream) {
     msm_geom g;
     g.c = pick_window(n);
     g.nwin = (256 + g.c - 1) / g.c;
@@ -597,7 +616,13 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
-    hipStream_t st = ctx->stream;
+    static const bool overlap = [] { const char *e = getenv("C25519_SORT_OVERLAP"); return e && atoi(e) != 0; }();   // measured: no gain (MSM 3.15 -> 3.35 ms, verify neutral) -- every kernel already fills the chip
+    if (!overlap && sort_stream && sort_stream != ctx->stream) {    // A/B knob: serialise (main waits for the scalars, sorts itself)
+        HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
+        sort_stream = nullptr;
+    }
+    hipStream_t st = sort_stream ? sort_stream : ctx->stream;      // sort phase
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 2048, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
     size_t lds = (size_t)g.half * 4;
@@ -615,6 +640,11 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
     if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    if (sort_stream && sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
+        HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
+    }
+    st = ctx->stream;
     // Window groups: while group g+1 accumulates (VALU-bound, the whole chip), the latency-bound reduction
     // levels of group g (a few thousand lanes) run on the second stream.
     static int groups = -1;   // tuning knob: C25519_MSM_GROUPS = 1 | 2
@@ -722,14 +752,17 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipMemsetAsync(d_bad, 0, 16, ctx->stream));
+    // points are normalised on the main stream while the scalars are recoded and sorted on the second one
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, d_bad))) return r;
-    uint32_t bad = 0;
+    r = msm_core(ctx, d_scalars, n, d_pts, R, ring, ctx->aux);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (r != C25519_OK) return r;
+    uint32_t bad = 0;                                  // msm_core has synchronised: prep's counter is final
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (bad) { HIPCHK(hipEventRecord(ring[0], ctx->stream)); HIPCHK(hipEventRecord(ring[1], ctx->stream)); HIPCHK(hipEventRecord(ring[2], ctx->stream)); HIPCHK(hipEventRecord(ctx->ev1, ctx->stream)); return C25519_NONE; }
-    r = msm_core(ctx, d_scalars, n, d_pts, R, ring);
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    return r;
+    return bad ? C25519_NONE : C25519_OK;
 }
 
 EXPORT int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160) {
@@ -819,13 +852,13 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
         HIPCHK(hipMemcpyAsync(z16, hz.data(), n * 16, hipMemcpyHostToDevice, sa));
         HIPCHK(hipStreamSynchronize(sa));
     } else {
-        hipLaunchKernelGGL(k_zleaf, dim3(nblk), dim3(256), 0, sa, hram, d_sigs, n, t0);
-        uint64_t mm = n; uint8_t *a = t0, *b = t1;
-        do {
+        uint64_t mm = (n + 15) / 16; uint8_t *a = t0, *b = t1;
+        hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, a);
+        while (mm > 1) {
             uint64_t mo = (mm + 15) / 16;
             hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, b);
             mm = mo; std::swap(a, b);
-        } while (mm > 1);
+        }
         hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, a, (n + 3) / 4, z16);
         HIPCHK(hipGetLastError());
     }
@@ -842,27 +875,22 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     uint64_t *hp = (uint64_t *)ctx->h_pinned;
     uint32_t *cnt = (uint32_t *)((uint8_t *)ctx->h_pinned + (size_t)nblk * 40);
     HIPCHK(hipMemcpyAsync(hp, partial, (size_t)nblk * 40, hipMemcpyDeviceToHost, sa));
-    HIPCHK(hipStreamSynchronize(sa));                  // chain (A) done: scalars are in place
-    HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));                  // chain (S) done: points are in place, counters final
-    int32_t verdict = -1;
-    if (cnt[0]) verdict = C25519_NONE;                  // a key that VerifyingKey::from_bytes rejects
-    else if (cnt[2]) verdict = C25519_SCALAR_FORMAT;    // batch.rs:208-211
-    else if (cnt[1]) verdict = C25519_VERIFY;           // batch.rs:244 (R fails to decompress)
-    if (verdict >= 0) {
-        HIPCHK(hipEventRecord(ring[0], st)); HIPCHK(hipEventRecord(ring[1], st)); HIPCHK(hipEventRecord(ring[2], st));
-        HIPCHK(hipEventRecord(ctx->ev1, st));
-        return verdict;
-    }
+    HIPCHK(hipStreamSynchronize(sa));                  // chain (A) done: z_i and z_i*h_i are in place
     sc52 bsum = sc_zero();
     for (unsigned b = 0; b < nblk; b++) { sc52 p; for (int j = 0; j < 5; j++) p.v[j] = hp[(size_t)b * 5 + j]; bsum = sc_add(bsum, p); }
     u32 bw[8];
     sc_to_words(sc_neg(bsum), bw);                       // -sum z_i s_i (batch.rs:240)
-    HIPCHK(hipMemcpyAsync(msc, bw, 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(msc, bw, 32, hipMemcpyHostToDevice, sa));
+    // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     ge_p3 R;
-    r = msm_core(ctx, msc, m, d_pts, R, ring);
+    r = msm_core(ctx, msc, m, d_pts, R, ring, sa);
     HIPCHK(hipEventRecord(ctx->ev1, st));
     if (r != C25519_OK) return r;
+    HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (cnt[0]) return C25519_NONE;                     // a key that VerifyingKey::from_bytes rejects
+    if (cnt[2]) return C25519_SCALAR_FORMAT;            // batch.rs:208-211
+    if (cnt[1]) return C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
     return ge_is_identity(R) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
 }
 

@@ -104,10 +104,10 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
 }
 
 // P40 -> raw160 / P32 (for the batched compressor)
-__global__ void __launch_bounds__(256) k_p40_to_raw(const u32 *__restrict__ in40, u64 n, uint8_t *__restrict__ out_raw) {
+__global__ void __launch_bounds__(256) k_p40_to_raw(const u32 *__restrict__ in40, const u32 *__restrict__ b40, u64 n, uint8_t *__restrict__ out_raw) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
-    ge_p3 p = p40_load(in40, idx);
+    ge_p3 p = b40 ? ge_add(p40_load(in40, idx), p40_load(b40, idx)) : p40_load(in40, idx);
     u64 l[20];
     const feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
     for (int c = 0; c < 4; c++) { u32 cl[10]; fe_canonical_limbs(*f[c], cl); for (int i = 0; i < 5; i++) l[5 * c + i] = (u64)cl[2 * i] | ((u64)cl[2 * i + 1] << 26); }
@@ -281,7 +281,7 @@ EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, c
     if ((r = var_base_launch(ctx, d_scalars, d_points, n, in_fmt, false, p40, okbuf))) return r;
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     if (out_fmt == C25519_FMT_RAW160) {
-        hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, n, d_out);
+        hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, d_out);
     } else {
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
         hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, (uint32_t *)ctx->scratch.p);
@@ -302,6 +302,54 @@ EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const u
     HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream));
     uint8_t *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
     if ((r = c25519_mul_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, out_fmt, dout, dok))) return r;
+    HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
+    if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+
+// ---- double base: out[i] = a[i] * A[i] + b[i] * B ----------------------------------------------------------
+EXPORT int32_t c25519_double_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_a, const uint8_t *d_A, const uint8_t *d_b, uint64_t n, int in_fmt, int out_fmt,
+                                            uint8_t *d_out, uint8_t *d_ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RAW160) { ctx->err = "double_base: out_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_e, 2 * n * 160 + n + 256))) return r;
+    uint32_t *P40 = (uint32_t *)ctx->tmp_e.p, *Q40 = P40 + n * 40;
+    uint8_t *okbuf = d_ok ? d_ok : (uint8_t *)ctx->tmp_e.p + 2 * n * 160;
+    hipStream_t st = ctx->stream;
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    HIPCHK(hipEventRecord(ring[0], st));
+    if ((r = var_base_launch(ctx, d_a, d_A, n, in_fmt, false, P40, okbuf))) return r;                 // a * A
+    HIPCHK(hipEventRecord(ring[1], st));
+    HIPCHK(launch_mul_base_p40(ctx->w, d_b, n, ctx->d_table, Q40, ctx->num_cus, st));                 // b * B
+    if (out_fmt == C25519_FMT_RAW160) {
+        hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, st, P40, Q40, n, d_out);
+    } else {
+        if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+        hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, st, P40, Q40, n, (uint32_t *)ctx->scratch.p);
+        HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, st));
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(ring[2], st));
+    HIPCHK(hipEventRecord(ctx->ev1, st));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_double_base_batch(c25519_ctx *ctx, const uint8_t *a, const uint8_t *A, const uint8_t *b, uint64_t n, int in_fmt, int out_fmt,
+                                        uint8_t *out, uint8_t *ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, 2 * n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * osz + n + 16))) return r;
+    if (n == 0) return C25519_OK;
+    uint8_t *da = (uint8_t *)ctx->tmp_a.p, *db = da + n * 32;
+    HIPCHK(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, A, n * psz, hipMemcpyHostToDevice, ctx->stream));
+    uint8_t *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
+    if ((r = c25519_double_base_batch_dev(ctx, da, (const uint8_t *)ctx->tmp_b.p, db, n, in_fmt, out_fmt, dout, dok))) return r;
     HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
     if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -65,6 +65,16 @@ class EdwardsPoint:
         st, out = eng.msm_vartime(_cat(scalars, 32), _cat(points, 32), _e.FMT_EDWARDS_Y, _e.FMT_EDWARDS_Y)
         return None if st == _e.NONE else out
 
+    @staticmethod
+    def vartime_double_scalar_mul_basepoint(a, A, b, engine=None):
+        """[a_i * A_i + b_i * B] (edwards.rs:1099-1106 over vartime_double_base.rs:23-72), batched: A_i as
+        160-byte raw EdwardsPoints, results as CompressedEdwardsY bytes."""
+        if not (len(a) == len(A) == len(b)):
+            raise AssertionError("vartime_double_scalar_mul_basepoint: a, A, b must have equal length")
+        eng = engine or default_engine()
+        out, _ = eng.double_base_batch(_cat(a, 32), _cat(A, 160), _cat(b, 32), _e.FMT_RAW160, _e.FMT_EDWARDS_Y)
+        return [out[i].tobytes() for i in range(out.shape[0])]
+
 
 class RistrettoPoint:
     @staticmethod

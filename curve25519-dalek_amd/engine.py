@@ -66,6 +66,8 @@ def load_library():
         "ed25519_verify_batch": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32]),
         "c25519_mul_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_mul_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_double_base_batch_dev": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_double_base_batch": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "ed25519_verify_each_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_each": (i32, [vp, vp, vp, vp, vp, u64, C.c_int, vp]),
         "ed25519_keygen_batch_dev": (i32, [vp, vp, u64, vp]),
@@ -94,7 +96,7 @@ ABI_SYMBOLS = [
     "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "c25519_microbench",
-    "c25519_mul_batch_dev", "c25519_mul_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
+    "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
     "c25519_precomp_create", "c25519_precomp_destroy", "c25519_precomp_len", "c25519_precomp_msm_vartime",
@@ -244,6 +246,15 @@ class Engine:
         self._chk(self.lib.c25519_mul_batch_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out_fmt, out.data_ptr(), ok.data_ptr()))
         return out, ok
 
+    def double_base_batch_t(self, a, A, b, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        n = self._t(a, 32)
+        assert self._t(A, _PT[in_fmt]) == n and self._t(b, 32) == n
+        out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
+        ok = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_double_base_batch_dev(self.ctx, a.data_ptr(), A.data_ptr(), b.data_ptr(), n, in_fmt, out_fmt, out.data_ptr(), ok.data_ptr()))
+        return out, ok
+
     def verify_each_t(self, msgs, msg_off, sigs, pks, strict=False):
         n = self._t(sigs, 64)
         assert self._t(pks, 32) == n and msg_off.numel() == n + 1
@@ -328,6 +339,15 @@ class Engine:
         out = np.empty((n, _PT[out_fmt]), dtype=np.uint8); ok = np.empty((n,), dtype=np.uint8)
         self._bind_stream()
         self._chk(self.lib.c25519_mul_batch(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out.ctypes.data, ok.ctypes.data))
+        return out, ok
+
+    def double_base_batch(self, a, A, b, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        """out[i] = a[i]*A[i] + b[i]*B (vartime_double_scalar_mul_basepoint, edwards.rs:1099)."""
+        sa = _np8(a, 32); p = _np8(A, _PT[in_fmt]); sb = _np8(b, 32); n = sa.shape[0]
+        assert p.shape[0] == n and sb.shape[0] == n
+        out = np.empty((n, _PT[out_fmt]), dtype=np.uint8); ok = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_double_base_batch(self.ctx, sa.ctypes.data, p.ctypes.data, sb.ctypes.data, n, in_fmt, out_fmt, out.ctypes.data, ok.ctypes.data))
         return out, ok
 
     @staticmethod

@@ -139,6 +139,13 @@ int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_
 int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
 int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
 
+/* ---- double base: out[i] = a[i] * A[i] + b[i] * B ---------------------------------------------------------
+ * replaces backend::vartime_double_base_mul (backend.rs:267 -> scalar_mul/vartime_double_base.rs:23-72;
+ * EdwardsPoint::vartime_double_scalar_mul_basepoint, edwards.rs:1099-1106), the single-signature kernel,
+ * batched: a radix-16 ladder on A_i plus the fixed-base table on B.  Formats and `ok` as c25519_mul_batch. */
+int32_t c25519_double_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_a, const uint8_t *d_A, const uint8_t *d_b, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
+int32_t c25519_double_base_batch(c25519_ctx *ctx, const uint8_t *a, const uint8_t *A, const uint8_t *b, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
+
 /* ---- per-signature verification: status[i] for every signature ----------------------------------------
  * replaces VerifyingKey::verify (verifying.rs:565 -> raw_verify :203 -> RCompute::finish :549-556 over
  * vartime_double_base::mul, scalar_mul/vartime_double_base.rs:23-72) and, with strict != 0,

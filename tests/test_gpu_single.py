@@ -65,6 +65,39 @@ def test_mul_batch_vs_oracle(eng, orc):
     assert eng.mul_batch(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8), 0, 0)[0].shape == (0, 32)
 
 
+def test_double_base_batch_vs_oracle(eng, orc, golden):
+    """a*A + b*B against vartime_double_base.rs:23-72 (oracle restatement) and the reference's own
+    A_TIMES_BASEPOINT / DOUBLE_SCALAR_MULT_RESULT constants (edwards.rs:1797-1818)."""
+    import curve25519_dalek_amd.dalek as dalek
+    n = 400
+    a = util.rand_scalars(71, n); b = util.rand_scalars(72, n)
+    edge = util.edge_scalars()
+    edge = edge[[int.from_bytes(e.tobytes(), "little") < 2**255 for e in edge]]
+    a[:edge.shape[0]] = edge; b[:edge.shape[0]] = edge[::-1]
+    A = eng.mul_base_batch(util.rand_scalars(73, n), out_fmt=2)                 # raw points with Z != 1
+    out, ok = eng.double_base_batch(a, A, b, in_fmt=2, out_fmt=0)
+    assert ok.all()
+    for i in list(range(0, 40)) + list(range(40, n, 9)):
+        want = orc.ed_compress(orc.ed_double_scalar_mul_basepoint(a[i].tobytes(), A[i].tobytes(), b[i].tobytes()))
+        assert out[i].tobytes() == want, i
+    raw, _ = eng.double_base_batch(a[:64], A[:64], b[:64], in_fmt=2, out_fmt=2)
+    assert [orc.ed_compress(raw[i].tobytes()) for i in range(64)] == [out[i].tobytes() for i in range(64)]
+    # compressed inputs, one that does not decode
+    enc = eng.compress_batch(A[:50])
+    bad = util.rand_bytes(74, 4000); bad = bad[orc.ed_decompress_ok_batch(bad) == 0][:1]
+    enc = np.concatenate([enc, bad])
+    got, ok = eng.double_base_batch(a[:51], enc, b[:51], in_fmt=0, out_fmt=0)
+    assert ok[:50].all() and not ok[50]
+    assert [got[i].tobytes() for i in range(50)] == [out[i].tobytes() for i in range(50)]
+    # reference constants: A_SCALAR * (A_TIMES_BASEPOINT) + B_SCALAR * B = DOUBLE_SCALAR_MULT_RESULT
+    f = "curve25519-dalek/src/edwards.rs"
+    asc = golden.bytes(f, "A_SCALAR"); bsc = golden.bytes(f, "B_SCALAR")
+    atb = golden.bytes(f, "A_TIMES_BASEPOINT"); res = golden.bytes(f, "DOUBLE_SCALAR_MULT_RESULT")
+    P = orc.ed_decompress(bytes(atb))
+    assert dalek.EdwardsPoint.vartime_double_scalar_mul_basepoint([bytes(asc)], [P], [bytes(bsc)], engine=eng) == [bytes(res)]
+    assert eng.double_base_batch(np.zeros((0, 32), np.uint8), np.zeros((0, 160), np.uint8), np.zeros((0, 32), np.uint8))[0].shape[0] == 0
+
+
 def test_verify_each_testvectors(eng, orc):
     tv = _testvectors()
     pks, msgs, sigs = [t[1] for t in tv], [t[2] for t in tv], [t[3] for t in tv]
