@@ -29,6 +29,15 @@ ALGO = {
     "verify": {"bytes": 128, "unit": "verifies/s", "metric": "Ed25519 batch verifies/sec (verify_batch)"},
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# The roof that actually binds: 32x32->64 multiply-accumulate issue (v_mad_u64_u32).
+# Field work per unit as implemented, counted from the kernels: M = fe_mul = 100 MACs, S = fe_sq = 55 MACs;
+# "ref" = the reference algorithm's count from SURVEY.md 8d (M = 100, S = 60 in its 5x51 schoolbook terms).
+VALU = {
+    "fixed_base": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) + 5M compress + 1/16 inversion"},
+    "x25519": {"M": 1303, "S": 1036, "ref": 231000, "what": "255 x (5M + 4S + 10-product a24 mul) + 3M + 1/16 inversion"},
+    "msm": {"M": 121, "S": 0, "ref": 26500, "what": "16 windows x 7M bucket adds + 8M normalise + ~1M reduce (c = 16)"},
+    "verify": {"M": 210, "S": 510, "ref": 74400, "what": "2 x decompress (255S + 21M) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
+}
 
 
 def host_cores():
@@ -152,6 +161,9 @@ def main():
             if result["st"] != 0:
                 raise SystemExit("PARITY FAILURE: valid batch rejected (status %d)" % result["st"])
 
+    # live peak of the binding unit on THIS box (box-to-box spread is ~10 %): v_mad_u64_u32 issue rate, measured
+    # before the timed region by the library's own probe kernel (c25519_microbench, kernels.hip)
+    mac_peak = max(eng.microbench(0, 4000) for _ in range(2)) * 1e9
     for _ in range(args.warmup):
         run()
     barrier()
@@ -244,6 +256,13 @@ def main():
                          "note": "integer (VALU v_mad_u64_u32) bound kernel: HBM fraction is tiny by construction; see DESIGN.md"},
             "cpu_baseline": cpu_baseline,
         }
+        v = VALU[wl]
+        mac_impl = 100 * v["M"] + 55 * v["S"]
+        per_gpu = units / dt / world
+        res["valu"] = {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": v["ref"],
+                       "field_ops_per_unit": "%d M + %d S: %s" % (v["M"], v["S"], v["what"]),
+                       "achieved": per_gpu * mac_impl / 1e12, "peak": mac_peak / 1e12, "unit": "TMAC/s (per GPU)",
+                       "frac": per_gpu * mac_impl / mac_peak, "peak_source": "c25519_microbench(0) on this GPU, this run"}
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()

@@ -368,7 +368,9 @@ EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     hipEventRecord(ctx->ev1, ctx->stream);
     float ms = c25519_last_kernel_ms(ctx);
     if (ms <= 0) return -1.0;
-    double per_lane = (which == 0 || which == 4 || which == 5) ? 8.0 * iters : 2.0 * iters;
+    // 6, 7: the mixed probes count their v_mad_u64_u32 only (8 per iteration), so the result reads as
+    // "MAC rate with R simple integer ops issued beside every MAC"
+    double per_lane = (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
     double total = per_lane * 256.0 * grid;
     return total / (ms * 1e-3) / 1e9;
 }

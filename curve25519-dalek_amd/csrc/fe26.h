@@ -149,7 +149,40 @@ C25519_HD feT fe_carry64(u64 h[10]) {
     return r;
 }
 
-#define C25519_MAD(acc, a, b) acc += (u64)(a) * (u64)(b)
+// Chained form: column k+1 starts from the carry out of column k, so the carry rides in as the 64-bit addend of
+// the column's first v_mad_u64_u32 instead of costing a separate 64-bit add (9 VOP3 issue slots per product).
+// fe_finish64 takes columns that already contain their carry-in.
+// Worth +4 % on the register-resident, high-occupancy kernels (comb, Montgomery ladder: kernels.hip sets
+// C25519_CHAIN 1); the gather/latency-bound kernels want the ten independent column sums for ILP instead
+// (k_var_base -15 %, k_reduce_level -19 %, k_long_segments -15 % when chained), hence off by default.
+#ifndef C25519_CHAIN
+#define C25519_CHAIN 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C25519_CHAIN
+#define C25519_PIN(x) asm("" : "+v"(x))
+#else
+#define C25519_PIN(x)
+#endif
+#define C25519_MAD(acc, a, b) acc += (u64)(a) * (u64)(b); C25519_PIN(acc)
+
+#if C25519_CHAIN
+// (the empty asm pins "carry + first product" as one value, otherwise LLVM reassociates the carry to the end
+// of the column sum and the separate add comes back)
+#define C25519_COL(k, a, b) h[k] = (h[(k) - 1] >> (((k) & 1) ? 26 : 25)) + (u64)(a) * (u64)(b); C25519_PIN(h[k])
+C25519_HD feT fe_finish64(const u64 h[10]) {
+    feT r;
+    for (int i = 0; i < 10; i++) r.v[i] = (u32)h[i] & ((i & 1) ? M25 : M26);
+    u64 c = h[9] >> 25;
+    u64 t = (u64)r.v[0] + 19ull * c;
+    r.v[0] = (u32)t & M26;
+    r.v[1] += (u32)(t >> 26);
+    C25519_BOUND(r.v, T_EVEN, T_ODD, "fe_finish64");
+    return r;
+}
+#else
+#define C25519_COL(k, a, b) h[k] = (u64)(a) * (u64)(b)
+#define fe_finish64 fe_carry64
+#endif
 
 // field.rs:111-214 restated for 10 limbs: h_k = sum_{i+j=k} f_i g_j [x2 if i,j odd]
 //                                              + 19 sum_{i+j=k+10} f_i g_j [x2 if i,j odd]
@@ -168,43 +201,43 @@ C25519_HD feT fe_mul(const feW &f, const feL &g) {
     C25519_MAD(h[0], f1_2, g9_19); C25519_MAD(h[0], f2, g8_19); C25519_MAD(h[0], f3_2, g7_19);
     C25519_MAD(h[0], f4, g6_19); C25519_MAD(h[0], f5_2, g5_19); C25519_MAD(h[0], f6, g4_19);
     C25519_MAD(h[0], f7_2, g3_19); C25519_MAD(h[0], f8, g2_19); C25519_MAD(h[0], f9_2, g1_19);
-    h[1] = (u64)f0 * g1;
+    C25519_COL(1, f0, g1);
     C25519_MAD(h[1], f1, g0); C25519_MAD(h[1], f2, g9_19); C25519_MAD(h[1], f3, g8_19);
     C25519_MAD(h[1], f4, g7_19); C25519_MAD(h[1], f5, g6_19); C25519_MAD(h[1], f6, g5_19);
     C25519_MAD(h[1], f7, g4_19); C25519_MAD(h[1], f8, g3_19); C25519_MAD(h[1], f9, g2_19);
-    h[2] = (u64)f0 * g2;
+    C25519_COL(2, f0, g2);
     C25519_MAD(h[2], f1_2, g1); C25519_MAD(h[2], f2, g0); C25519_MAD(h[2], f3_2, g9_19);
     C25519_MAD(h[2], f4, g8_19); C25519_MAD(h[2], f5_2, g7_19); C25519_MAD(h[2], f6, g6_19);
     C25519_MAD(h[2], f7_2, g5_19); C25519_MAD(h[2], f8, g4_19); C25519_MAD(h[2], f9_2, g3_19);
-    h[3] = (u64)f0 * g3;
+    C25519_COL(3, f0, g3);
     C25519_MAD(h[3], f1, g2); C25519_MAD(h[3], f2, g1); C25519_MAD(h[3], f3, g0);
     C25519_MAD(h[3], f4, g9_19); C25519_MAD(h[3], f5, g8_19); C25519_MAD(h[3], f6, g7_19);
     C25519_MAD(h[3], f7, g6_19); C25519_MAD(h[3], f8, g5_19); C25519_MAD(h[3], f9, g4_19);
-    h[4] = (u64)f0 * g4;
+    C25519_COL(4, f0, g4);
     C25519_MAD(h[4], f1_2, g3); C25519_MAD(h[4], f2, g2); C25519_MAD(h[4], f3_2, g1);
     C25519_MAD(h[4], f4, g0); C25519_MAD(h[4], f5_2, g9_19); C25519_MAD(h[4], f6, g8_19);
     C25519_MAD(h[4], f7_2, g7_19); C25519_MAD(h[4], f8, g6_19); C25519_MAD(h[4], f9_2, g5_19);
-    h[5] = (u64)f0 * g5;
+    C25519_COL(5, f0, g5);
     C25519_MAD(h[5], f1, g4); C25519_MAD(h[5], f2, g3); C25519_MAD(h[5], f3, g2);
     C25519_MAD(h[5], f4, g1); C25519_MAD(h[5], f5, g0); C25519_MAD(h[5], f6, g9_19);
     C25519_MAD(h[5], f7, g8_19); C25519_MAD(h[5], f8, g7_19); C25519_MAD(h[5], f9, g6_19);
-    h[6] = (u64)f0 * g6;
+    C25519_COL(6, f0, g6);
     C25519_MAD(h[6], f1_2, g5); C25519_MAD(h[6], f2, g4); C25519_MAD(h[6], f3_2, g3);
     C25519_MAD(h[6], f4, g2); C25519_MAD(h[6], f5_2, g1); C25519_MAD(h[6], f6, g0);
     C25519_MAD(h[6], f7_2, g9_19); C25519_MAD(h[6], f8, g8_19); C25519_MAD(h[6], f9_2, g7_19);
-    h[7] = (u64)f0 * g7;
+    C25519_COL(7, f0, g7);
     C25519_MAD(h[7], f1, g6); C25519_MAD(h[7], f2, g5); C25519_MAD(h[7], f3, g4);
     C25519_MAD(h[7], f4, g3); C25519_MAD(h[7], f5, g2); C25519_MAD(h[7], f6, g1);
     C25519_MAD(h[7], f7, g0); C25519_MAD(h[7], f8, g9_19); C25519_MAD(h[7], f9, g8_19);
-    h[8] = (u64)f0 * g8;
+    C25519_COL(8, f0, g8);
     C25519_MAD(h[8], f1_2, g7); C25519_MAD(h[8], f2, g6); C25519_MAD(h[8], f3_2, g5);
     C25519_MAD(h[8], f4, g4); C25519_MAD(h[8], f5_2, g3); C25519_MAD(h[8], f6, g2);
     C25519_MAD(h[8], f7_2, g1); C25519_MAD(h[8], f8, g0); C25519_MAD(h[8], f9_2, g9_19);
-    h[9] = (u64)f0 * g9;
+    C25519_COL(9, f0, g9);
     C25519_MAD(h[9], f1, g8); C25519_MAD(h[9], f2, g7); C25519_MAD(h[9], f3, g6);
     C25519_MAD(h[9], f4, g5); C25519_MAD(h[9], f5, g4); C25519_MAD(h[9], f6, g3);
     C25519_MAD(h[9], f7, g2); C25519_MAD(h[9], f8, g1); C25519_MAD(h[9], f9, g0);
-    return fe_carry64(h);
+    return fe_finish64(h);
 }
 
 // field.rs:454-559 (pow2k body) restated for 10 limbs: 55 products.
@@ -219,34 +252,34 @@ C25519_HD feT fe_sq(const feL &f) {
     h[0] = (u64)f0 * f0;
     C25519_MAD(h[0], f1_2, f9_38); C25519_MAD(h[0], f2_2, f8_19); C25519_MAD(h[0], f3_2, f7_38);
     C25519_MAD(h[0], f4_2, f6_19); C25519_MAD(h[0], f5, f5_38);
-    h[1] = (u64)f0_2 * f1;
+    C25519_COL(1, f0_2, f1);
     C25519_MAD(h[1], f2, f9_38); C25519_MAD(h[1], f3_2, f8_19); C25519_MAD(h[1], f4, f7_38);
     C25519_MAD(h[1], f5_2, f6_19);
-    h[2] = (u64)f0_2 * f2;
+    C25519_COL(2, f0_2, f2);
     C25519_MAD(h[2], f1_2, f1); C25519_MAD(h[2], f3_2, f9_38); C25519_MAD(h[2], f4_2, f8_19);
     C25519_MAD(h[2], f5_2, f7_38); C25519_MAD(h[2], f6, f6_19);
-    h[3] = (u64)f0_2 * f3;
+    C25519_COL(3, f0_2, f3);
     C25519_MAD(h[3], f1_2, f2); C25519_MAD(h[3], f4, f9_38); C25519_MAD(h[3], f5_2, f8_19);
     C25519_MAD(h[3], f6, f7_38);
-    h[4] = (u64)f0_2 * f4;
+    C25519_COL(4, f0_2, f4);
     C25519_MAD(h[4], f1_2, f3_2); C25519_MAD(h[4], f2, f2); C25519_MAD(h[4], f5_2, f9_38);
     C25519_MAD(h[4], f6_2, f8_19); C25519_MAD(h[4], f7, f7_38);
-    h[5] = (u64)f0_2 * f5;
+    C25519_COL(5, f0_2, f5);
     C25519_MAD(h[5], f1_2, f4); C25519_MAD(h[5], f2_2, f3); C25519_MAD(h[5], f6, f9_38);
     C25519_MAD(h[5], f7_2, f8_19);
-    h[6] = (u64)f0_2 * f6;
+    C25519_COL(6, f0_2, f6);
     C25519_MAD(h[6], f1_2, f5_2); C25519_MAD(h[6], f2_2, f4); C25519_MAD(h[6], f3_2, f3);
     C25519_MAD(h[6], f7_2, f9_38); C25519_MAD(h[6], f8, f8_19);
-    h[7] = (u64)f0_2 * f7;
+    C25519_COL(7, f0_2, f7);
     C25519_MAD(h[7], f1_2, f6); C25519_MAD(h[7], f2_2, f5); C25519_MAD(h[7], f3_2, f4);
     C25519_MAD(h[7], f8, f9_38);
-    h[8] = (u64)f0_2 * f8;
+    C25519_COL(8, f0_2, f8);
     C25519_MAD(h[8], f1_2, f7_2); C25519_MAD(h[8], f2_2, f6); C25519_MAD(h[8], f3_2, f5_2);
     C25519_MAD(h[8], f4, f4); C25519_MAD(h[8], f9, f9_38);
-    h[9] = (u64)f0_2 * f9;
+    C25519_COL(9, f0_2, f9);
     C25519_MAD(h[9], f1_2, f8); C25519_MAD(h[9], f2_2, f7); C25519_MAD(h[9], f3_2, f6);
     C25519_MAD(h[9], f4_2, f5);
-    return fe_carry64(h);
+    return fe_finish64(h);
 }
 
 // f * small constant c (c < 2^20), e.g. a24 = 121666 in the Montgomery ladder

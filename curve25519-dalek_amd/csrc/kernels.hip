@@ -2,6 +2,7 @@
 // Launchers at the bottom are the only symbols the host side (capi.hip) uses.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
+#define C25519_CHAIN 1   // chained-carry fe_mul / fe_sq (fe26.h): +4 % on the comb and the ladder
 #include "devio.h"
 #include "kernels.h"
 
@@ -326,6 +327,33 @@ __global__ void __launch_bounds__(256) k_probe_add(u32 *out, int iters, u32 seed
     u32 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
     if (r == 0x12345678u) out[0] = r;
 }
+// plain two-operand adds (VOP2 encoding)
+__global__ void __launch_bounds__(256) k_probe_add2(u32 *out, int iters, u32 seed) {
+    u32 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    for (int i = 0; i < iters; i++) {
+        a0 += a1; a1 += a2; a2 += a3; a3 += a4; a4 += a5; a5 += a6; a6 += a7; a7 += a0;
+    }
+    u32 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345678u) out[0] = r;
+}
+// co-issue probe: 8 independent v_mad_u64_u32 chains interleaved with 8*R independent v_xad_u32 chains
+template <int R>
+__global__ void __launch_bounds__(256) k_probe_mix(u32 *out, int iters, u32 seed) {
+    u32 b = seed | 1u;
+    u64 a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    u32 c[8 * R];
+    for (int j = 0; j < 8 * R; j++) c[j] = threadIdx.x * (2 * j + 3) + out[j & 7];
+    for (int i = 0; i < iters; i++) {
+        a0 = (u64)(u32)a1 * b + a0; a1 = (u64)(u32)a2 * b + a1; a2 = (u64)(u32)a3 * b + a2; a3 = (u64)(u32)a4 * b + a3;
+        a4 = (u64)(u32)a5 * b + a4; a5 = (u64)(u32)a6 * b + a5; a6 = (u64)(u32)a7 * b + a6; a7 = (u64)(u32)a0 * b + a7;
+#pragma unroll
+        for (int j = 0; j < 8 * R; j++) c[j] += c[(j + 1) % (8 * R)] ^ b;
+    }
+    u64 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    u32 q = 0;
+    for (int j = 0; j < 8 * R; j++) q ^= c[j];
+    if ((u32)r == 0x12345678u && q == 0x9abcdef0u) out[0] = (u32)(r >> 32);
+}
 __global__ void __launch_bounds__(256) k_probe_mullo(u32 *out, int iters, u32 seed) {
     u32 b = seed | 1u;
     u32 a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
@@ -525,6 +553,9 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 3: hipLaunchKernelGGL(k_probe_femul51, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 4: hipLaunchKernelGGL(k_probe_add, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 5: hipLaunchKernelGGL(k_probe_mullo, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 8: hipLaunchKernelGGL(k_probe_add2, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 6: hipLaunchKernelGGL(k_probe_mix<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 7: hipLaunchKernelGGL(k_probe_mix<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

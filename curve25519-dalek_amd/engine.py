@@ -22,7 +22,8 @@ class EngineError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libc25519hip.so")
+    # C25519_HIP_LIB: developer knob for A/B runs of two builds of the same library
+    return os.environ.get("C25519_HIP_LIB") or os.path.join(_HERE, "lib", "libc25519hip.so")
 
 
 def load_library():

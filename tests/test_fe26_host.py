@@ -31,13 +31,14 @@ def b2i(b):
     return int.from_bytes(b, "little")
 
 
-@pytest.fixture(scope="module")
-def host():
+@pytest.fixture(scope="module", params=[0, 1], ids=["columns", "chained"])
+def host(request):
+    """Both forms of fe_mul / fe_sq (fe26.h C25519_CHAIN: independent column sums, chained carries)."""
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
-    so = os.path.join(ROOT, "tests", "host", "libfe26host.so")
+    so = os.path.join(ROOT, "tests", "host", "libfe26host%d.so" % request.param)
     deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "sc_sha.h", "transcript_host.h", "constants_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, src])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DC25519_CHAIN=%d" % request.param, "-o", so, src])
     return C.CDLL(so)
 
 
