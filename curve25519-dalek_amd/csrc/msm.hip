@@ -740,29 +740,50 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
     return C25519_OK;
 }
 
-static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
-    HIPCHK(hipSetDevice(ctx->device));
+// One bucket-method pass over at most MSM_PASS_MAX terms.
+static int32_t msm_partial_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     R = ge_identity();
-    if (n == 0) return C25519_OK;
-    if (n >= (1ull << 31)) { ctx->err = "msm: n must be < 2^31"; return -(int32_t)hipErrorInvalidValue; }
     int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * 96 + 256);
     if (r) return r;
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     uint32_t *d_bad = (uint32_t *)ctx->d_flag;
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
-    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipMemsetAsync(d_bad, 0, 16, ctx->stream));
     // points are normalised on the main stream while the scalars are recoded and sorted on the second one
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, d_bad))) return r;
     r = msm_core(ctx, d_scalars, n, d_pts, R, ring, ctx->aux);
-    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     if (r != C25519_OK) return r;
     uint32_t bad = 0;                                  // msm_core has synchronised: prep's counter is final
     HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return bad ? C25519_NONE : C25519_OK;
+}
+// The window width stops at c = 16 (the per-window histogram lives in LDS), so beyond ~2^22 terms the lists per
+// bucket only get longer: larger inputs are cut into passes of about 2^21 terms -- the same decomposition the
+// multi-GPU path uses across ranks -- whose partial sums are added on the host.  This also bounds
+// the workspace (~0.5 GB) for any n.
+static const uint64_t MSM_PASS_MAX = 3ull << 20, MSM_PASS = 1ull << 21;
+static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
+    HIPCHK(hipSetDevice(ctx->device));
+    R = ge_identity();
+    if (n == 0) return C25519_OK;
+    if (n >= (1ull << 40)) { ctx->err = "msm: n must be < 2^40"; return -(int32_t)hipErrorInvalidValue; }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const uint64_t passes = n <= MSM_PASS_MAX ? 1 : (n + MSM_PASS - 1) / MSM_PASS, per = (n + passes - 1) / passes;
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    bool none = false;
+    for (uint64_t lo = 0; lo < n; lo += per) {
+        const uint64_t cnt = std::min(per, n - lo);
+        ge_p3 part;
+        int32_t r = msm_partial_pass(ctx, d_scalars + lo * 32, d_points + lo * psz, cnt, in_fmt, part);
+        if (r < 0) return r;
+        if (r == C25519_NONE) none = true;             // keep going: the status must not depend on the split
+        else R = passes == 1 ? part : ge_add(R, part);
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return none ? C25519_NONE : C25519_OK;
 }
 
 EXPORT int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160) {
@@ -804,13 +825,9 @@ EXPORT int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160,
 // ---- verify_batch ---------------------------------------------------------------------------------------
 #include "transcript_host.h"
 
-EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
-                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
-    (void)msgs_len;
-    HIPCHK(hipSetDevice(ctx->device));
-    if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
-    if (2 * n + 1 >= (1ull << 31)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
-    if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
+// One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms).
+static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off,
+                                 const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -827,7 +844,6 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     uint32_t *d_cnt = (uint32_t *)ctx->d_flag;      // [0] bad A, [1] bad R, [2] bad s
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
-    HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
     // Two independent chains: (S) decompress A_i and R_i -- VALU-bound, ~30 % of the call; (A) hash,
     // derive z_i, batch scalars -- partly latency-bound (the Merkle levels).  They run on two streams
@@ -884,7 +900,6 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     ge_p3 R;
     r = msm_core(ctx, msc, m, d_pts, R, ring, sa);
-    HIPCHK(hipEventRecord(ctx->ev1, st));
     if (r != C25519_OK) return r;
     HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -892,6 +907,29 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     if (cnt[2]) return C25519_SCALAR_FORMAT;            // batch.rs:208-211
     if (cnt[1]) return C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
     return ge_is_identity(R) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
+}
+// Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
+// 2^20 signatures each (same reason as MSM_PASS_MAX; every pass derives its own z_i).  All passes run even after
+// a failure so that the reference's precedence -- key decoding, then ScalarFormat for ANY non-canonical s
+// (batch.rs:208-211), then Verify -- does not depend on where the batch was cut.
+static const uint64_t VERIFY_PASS_MAX = 3ull << 19, VERIFY_PASS = 1ull << 20;
+EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
+    (void)msgs_len;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
+    if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
+    if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
+    bool seen[5] = {false, false, false, false, false};
+    for (uint64_t lo = 0; lo < n; lo += per) {
+        int32_t r = verify_batch_pass(ctx, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, std::min(per, n - lo), z_mode);
+        if (r < 0) return r;
+        seen[r] = true;
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
 }
 
 EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,

@@ -142,3 +142,40 @@ def test_msm_full_size_2p21(eng, orc):
     st, got = eng.msm_vartime_t(dx, denc, in_fmt=0, out_fmt=0)
     assert st == 0 and got == want
     print("MSM 2^21 compressed-in: last call %.3f ms (accumulate %.3f ms)" % (eng.last_kernel_ms(), eng.phase_ms(0, 0)))
+
+
+def _sumsq_device(dx):
+    """sum x_i^2 mod l for an (n, 32) uint8 CUDA tensor: exact 16-bit-limb Gram matrix on the device
+    (every entry < 2^24 * 2^32), recombined with Python integers."""
+    import torch
+    a = dx.view(torch.int16).to(torch.int64) & 0xFFFF                   # (n, 16) little-endian 16-bit limbs
+    tot = 0
+    for j in range(16):
+        col = (a[:, j:j + 1] * a).sum(0).cpu().tolist()
+        for k in range(16):
+            tot += int(col[k]) << (16 * (j + k))
+    return tot % L
+
+
+def test_msm_config4_2p24_terms(eng, orc):
+    """BASELINE configs[3] at its full size on ONE GPU: 2^24 terms as 8 shards of 2^21 (the decomposition the
+    8-GPU run uses, SURVEY.md 8e: per-shard partial sums, 160-byte partials, one fold) and as a single call.
+    Points x_i*B are generated on the device; expected = (sum x_i^2 mod l) * B."""
+    import torch
+    n, shards = 1 << 24, 8
+    g = torch.Generator(device="cuda"); g.manual_seed(424242)
+    dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dx[:, 31] &= 0x0F
+    assert _sumsq_device(dx[:1000]) == sumsq(dx[:1000].cpu().numpy())   # the checker itself
+    want = orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+    draw = eng.mul_base_batch_t(dx, out_fmt=2)
+    parts = []
+    per = n // shards
+    for r in range(shards):
+        st, p = eng.msm_partial_t(dx[r * per:(r + 1) * per], draw[r * per:(r + 1) * per], in_fmt=2)
+        assert st == 0
+        parts.append(p)
+    assert eng.fold_partials(parts, out_fmt=0) == want
+    st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    print("MSM 2^24 single call: %.3f ms" % eng.last_kernel_ms())

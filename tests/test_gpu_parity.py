@@ -92,6 +92,24 @@ def test_x25519_vs_oracle(eng, orc, golden):
     assert eng.x25519_batch(np.zeros((0, 32), np.uint8), np.zeros((0, 32), np.uint8)).shape == (0, 32)
 
 
+def test_x25519_full_size_2p20_diffie_hellman(eng, orc, torch):
+    """BASELINE configs[4] at full size: 2^20 independent ladders.  Size-independent property: Diffie-Hellman
+    commutes, x25519(a, x25519(b, 9)) == x25519(b, x25519(a, 9)) for every pair (x25519_tests.rs:13-31 does this
+    for one pair); plus a 4096-sample slice against the oracle."""
+    n = 1 << 20
+    g = torch.Generator(device="cuda"); g.manual_seed(7748)
+    da = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    db = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    nine = torch.zeros((n, 32), dtype=torch.uint8, device="cuda"); nine[:, 0] = 9
+    pa, pb = eng.x25519_batch_t(da, nine), eng.x25519_batch_t(db, nine)
+    sab, sba = eng.x25519_batch_t(da, pb), eng.x25519_batch_t(db, pa)
+    assert torch.equal(sab, sba)
+    assert int((sab != 0).any(dim=1).sum()) == n                       # no contributory failure on honest keys
+    idx = torch.arange(0, n, n // 4096, device="cuda")
+    want = orc.x25519_batch(da[idx].cpu().numpy(), pb[idx].cpu().numpy(), threads=8)
+    assert np.array_equal(sab[idx].cpu().numpy(), want)
+
+
 def test_decompress_compress_vs_oracle(eng, orc):
     n = 4000
     enc = util.rand_bytes(41, n)

@@ -121,3 +121,32 @@ def test_verify_batch_full_size_2p20(eng, orc):
     assert eng.verify_batch_t(dm, doff, ds2, dp, 1) == VERIFY
     ds3 = ds.clone(); ds3[12345, 63] |= 0x20       # s >= 2^253 > l
     assert eng.verify_batch_t(dm, doff, ds3, dp, 1) == SCALAR_FORMAT
+
+
+def test_verify_batch_multi_pass_precedence(eng, orc):
+    """Batches beyond ~1.5 * 2^20 signatures are checked in several passes (msm.hip VERIFY_PASS_MAX): the verdict
+    and the reference's error precedence (batch.rs:208-211 before :244-250) must not depend on where the batch
+    is cut.  Signatures come from the device signer (byte-exact vs TESTVECTORS in test_gpu_single.py), a slice is
+    re-checked by the oracle."""
+    import torch
+    n = (5 << 19) + 12345                                    # 3 passes of ~0.87 M
+    g = torch.Generator(device="cuda"); g.manual_seed(2520)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dm = torch.randint(0, 256, (n * 40,), dtype=torch.uint8, device="cuda", generator=g)
+    doff = torch.arange(0, 40 * (n + 1), 40, dtype=torch.int64).cuda()
+    dp, ds = eng.sign_batch_t(seeds, dm, doff)
+    idx = [0, 1, n // 2, n - 1]
+    for i in idx:
+        m = dm[40 * i:40 * (i + 1)].cpu().numpy().tobytes()
+        assert orc.ed25519_verify(dp[i].cpu().numpy().tobytes(), m, ds[i].cpu().numpy().tobytes()) == 0
+    for z_mode in (1, 0):
+        assert eng.verify_batch_t(dm, doff, ds, dp, z_mode) == OK
+    first, last = 1000, n - 1000                              # in the first and in the last pass
+    bad = ds.clone(); bad[first, 3] ^= 1
+    assert eng.verify_batch_t(dm, doff, bad, dp, 1) == VERIFY
+    bad = ds.clone(); bad[last, 3] ^= 1
+    assert eng.verify_batch_t(dm, doff, bad, dp, 1) == VERIFY
+    bad = ds.clone(); bad[first, 3] ^= 1; bad[last, 63] |= 0x20            # Verify in pass 1, ScalarFormat in pass 3
+    assert eng.verify_batch_t(dm, doff, bad, dp, 1) == SCALAR_FORMAT
+    bad = ds.clone(); bad[last, 3] ^= 1; bad[first, 63] |= 0x20
+    assert eng.verify_batch_t(dm, doff, bad, dp, 1) == SCALAR_FORMAT
