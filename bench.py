@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # Field work per unit as implemented, counted from the kernels: M = fe_mul = 100 MACs, S = fe_sq = 55 MACs;
 # "ref" = the reference algorithm's count from SURVEY.md 8d (M = 100, S = 60 in its 5x51 schoolbook terms).
 VALU = {
-    "fixed_base": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) + 5M compress + 1/16 inversion"},
+    "fixed_base": {"M": 118, "S": 16, "ref": 47100, "what": "16 madd x 7M (radix-2^16 tables in HBM) + 5M compress + 1/16 inversion"},
+    "fixed_base_comb": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) (LDS comb) + 5M compress + 1/16 inversion"},
     "x25519": {"M": 1303, "S": 1036, "ref": 231000, "what": "255 x (5M + 4S + 10-product a24 mul) + 3M + 1/16 inversion"},
     "msm": {"M": 121, "S": 0, "ref": 26500, "what": "16 windows x 7M bucket adds + 8M normalise + ~1M reduce (c = 16)"},
     "verify": {"M": 210, "S": 510, "ref": 74400, "what": "2 x decompress (255S + 21M) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
@@ -78,7 +79,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
-    eng = pkg.Engine(local_rank)
+    eng = pkg.Engine(local_rank, window=int(os.environ.get("C25519_WINDOW", "0")))
 
     wl = args.workload
     log2n = args.log2n if args.log2n is not None else {"fixed_base": 20, "x25519": 20, "msm": 21, "verify": 20}[wl]
@@ -256,7 +257,7 @@ def main():
                          "note": "integer (VALU v_mad_u64_u32) bound kernel: HBM fraction is tiny by construction; see DESIGN.md"},
             "cpu_baseline": cpu_baseline,
         }
-        v = VALU[wl]
+        v = VALU["fixed_base_comb" if (wl == "fixed_base" and os.environ.get("C25519_WINDOW", "0") == "9") else wl]
         mac_impl = 100 * v["M"] + 55 * v["S"]
         per_gpu = units / dt / world
         res["valu"] = {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": v["ref"],

@@ -11,6 +11,8 @@
 #include "ge26.h"
 #include "kernels.h"
 #include "ctx.h"
+#include "sc_sha.h"
+#include "msm_internal.h"
 
 using namespace c25519;
 
@@ -115,6 +117,43 @@ static void build_comb_table(std::vector<uint32_t> &out) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ---- wide-window fixed-base table (k_mul_base_wide): entry e of window j = e * 2^(C j) * B.  The table is made
+// on the device by the engine itself: the host writes the scalars e * 2^(C j) mod l (repeated sc_add), the comb
+// kernel multiplies them by B, and the batched normaliser of the MSM path packs them as affine Niels points.
+static int32_t build_wide_table(c25519_ctx *ctx, int C) {
+    const int nw = (256 + C - 1) / C, rem = 256 - C * (nw - 1);
+    const uint64_t HALF = 1ull << (C - 1), ENT = HALF + 1, N = (uint64_t)(nw - 1) * ENT + (1ull << rem) + 1;
+    std::vector<uint8_t> sc((size_t)N * 32);
+    sc52 p2 = sc_zero(); p2.v[0] = 1;
+    for (int j = 0; j < nw; j++) {
+        const uint64_t cnt = (j == nw - 1) ? (1ull << rem) + 1 : ENT;
+        sc52 acc = sc_zero();
+        for (uint64_t e = 0; e < cnt; e++) {
+            u32 wds[8];
+            sc_to_words(acc, wds);
+            memcpy(&sc[((size_t)j * ENT + e) * 32], wds, 32);
+            acc = sc_add(acc, p2);
+        }
+        for (int k = 0; k < C; k++) p2 = sc_add(p2, p2);
+    }
+    uint8_t *d_sc = nullptr, *d_raw = nullptr;
+    uint32_t *d_wide = nullptr;
+    HIPCHK(hipMalloc(&d_sc, N * 32));
+    HIPCHK(hipMalloc(&d_raw, N * 160));
+    HIPCHK(hipMalloc(&d_wide, N * 96));
+    HIPCHK(hipMemcpyAsync(d_sc, sc.data(), N * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_mul_base(ctx->w, d_sc, N, ctx->d_table, nullptr, d_raw, ctx->num_cus, ctx->stream));
+    int32_t r = prep_points(ctx, d_raw, N, C25519_FMT_RAW160, d_wide, 0, (uint32_t *)ctx->d_flag);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipFree(d_sc));
+    HIPCHK(hipFree(d_raw));
+    HIPCHK(hipFree(ctx->d_table));
+    ctx->d_table = d_wide;
+    ctx->w = C;
+    return C25519_OK;
+}
+
 EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -138,8 +177,9 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
-    int w = (int)(flags & 0xf);
-    ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position window tables; default 9: signed comb
+    int w = (int)(flags & 0x1f);
+    const int wide = (w >= 10 && w <= 20) ? w : (w == 0 ? 16 : 0);   // default: radix 2^16 (measured best table size / speed point)
+    ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position LDS window tables; 9: signed comb (also bootstraps the wide table)
     std::vector<uint32_t> tab;
     if (ctx->w == 9) build_comb_table(tab); else build_basepoint_table(ctx->w, tab);
     if (hipMalloc(&ctx->d_table, tab.size() * 4) != hipSuccess ||
@@ -147,6 +187,11 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
         hipMalloc(&ctx->d_flag, 256) != hipSuccess) {
         fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
         delete ctx;
+        return nullptr;
+    }
+    if (wide && build_wide_table(ctx, wide) != C25519_OK) {
+        fprintf(stderr, "c25519_ctx_create: building the radix-2^%d fixed-base table failed: %s\n", wide, ctx->err.c_str());
+        c25519_ctx_destroy(ctx);
         return nullptr;
     }
     return ctx;

@@ -32,6 +32,17 @@ C25519_HD ge_p3 ge_basepoint() {
     ge_p3 r; r.X = fe_const(x); r.Y = fe_const(y); r.Z = fe_one(); r.T = fe_const(t); return r;
 }
 
+// Loop-carried points: LLVM hoists the zero-extension of the u32 limbs across the loop PHI and then carries
+// them as 64-bit values, which turns every product with such a limb into a 64 x 32 multiply (two
+// v_mad_u64_u32 and two moves instead of one: +7 % multiplier work in k_mul_base_wide).  An empty asm on every
+// limb at the loop boundary keeps them 32-bit registers.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void fe_pin(feT &a) { for (int i = 0; i < 10; i++) asm("" : "+v"(a.v[i])); }
+#else
+inline void fe_pin(feT &) {}
+#endif
+C25519_HD void ge_pin(ge_p3 &p) { fe_pin(p.X); fe_pin(p.Y); fe_pin(p.Z); fe_pin(p.T); }
+
 // CompletedPoint -> EdwardsPoint, curve_models.rs:365-373 (4 M).  The wide operand goes first.
 C25519_HD ge_p3 ge_p1p1_to_p3(const ge_p1p1 &p) {
     ge_p3 r;

@@ -138,6 +138,84 @@ __global__ void __launch_bounds__(BS) k_mul_base_comb(const uint8_t *__restrict_
 }
 
 // ================================================================================================
+// K1w fixed base with WIDE signed windows: s = sum_j d_j 2^(C j), d_j in (-2^(C-1), 2^(C-1)], and one table of
+//     e * 2^(C j) * B per digit position (the reference's EdwardsBasepointTable structure, edwards.rs:1131-1141,
+//     with radix 2^C instead of 16): ceil(256 / C) mixed additions, no doublings.  The table does not fit LDS --
+//     it lives in HBM and is served by L2 (C <= 12: <= 4.3 MB) or the 256 MB MALL (C = 16: 53 MB), so each
+//     addition costs one 96-byte gather, prefetched one window ahead.  The top window is unsigned (it absorbs
+//     the last carry and bit 255) and has its own length.
+//     Layout: windows 0 .. nw-2: 2^(C-1)+1 entries each (entry 0 = identity), then 2^rem + 1 entries.
+// ================================================================================================
+template <int OUT>
+__global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict__ scalars, u64 n, const u32 *__restrict__ tab, int C, int nw,
+                                                       u32 *__restrict__ scratch, uint8_t *__restrict__ out_raw) {
+    const u64 idx = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    u32 s[8];
+    load8(scalars, idx, s);
+    const u32 HALF = 1u << (C - 1), MASK = (HALF << 1) - 1u, ENT = HALF + 1;
+    // The table entry of window j+1 is fetched while the addition of window j runs.  Holding it in registers would
+    // cost 24 VGPRs for the whole iteration; instead each wave DMAs it straight into its own 6 x 1 KiB LDS slots
+    // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave base + 16 * lane) and reads it back
+    // at the top of the next iteration.  Every lane only ever touches its own slot, so no barrier is involved:
+    // the wave's own vmcnt(0) orders DMA -> ds_read, and lgkmcnt(0) orders ds_read -> the next DMA into the slot.
+    __shared__ uint4 stage[6 * 256];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    uint4 *wave_slot = stage + (threadIdx.x & ~63u);
+    uint4 *my_slot = stage + threadIdx.x;
+    // the scalar is a shift register: the current window is always its low C bits
+    u32 d = s[0] & MASK;
+    bool neg = d > HALF;
+    u32 carry = neg ? 1u : 0u;
+    u32 mag = neg ? (MASK + 1u - d) : d;
+    const uint4 *e = reinterpret_cast<const uint4 *>(tab) + (u64)mag * 6;
+#define C25519_STAGE_ENTRY(src)                                                                                          \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 0), (lds_void *)(wave_slot + 0 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 1), (lds_void *)(wave_slot + 1 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 2), (lds_void *)(wave_slot + 2 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 3), (lds_void *)(wave_slot + 3 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 4), (lds_void *)(wave_slot + 4 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 5), (lds_void *)(wave_slot + 5 * 256), 16, 0, 0)
+    C25519_STAGE_ENTRY(e);
+    ge_p3 P = ge_identity();
+#pragma unroll 1
+    for (int j = 0; j < nw; j++) {
+        const bool cur_neg = neg;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // entry j has landed in the slot
+        uint4 q0 = my_slot[0 * 256], q1 = my_slot[1 * 256], q2 = my_slot[2 * 256], q3 = my_slot[3 * 256], q4 = my_slot[4 * 256], q5 = my_slot[5 * 256];
+        u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                      q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+#pragma unroll
+        for (int i = 0; i < 24; i++) asm volatile("" : "+v"(tw[i]));   // the reads are complete (lgkmcnt) before ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j + 1 < nw) {                                           // ... the slot is refilled with entry j+1
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = __funnelshift_r(s[i], s[i + 1], C);
+            s[7] >>= C;
+            d = (s[0] & MASK) + carry;
+            const bool top = (j + 2 == nw);
+            neg = !top && d > HALF;
+            carry = neg ? 1u : 0u;
+            mag = neg ? (MASK + 1u - d) : d;
+            e = reinterpret_cast<const uint4 *>(tab) + ((u64)(j + 1) * ENT + mag) * 6;
+            C25519_STAGE_ENTRY(e);
+        }
+        aniels_words_cneg(tw, cur_neg);
+        P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
+        ge_pin(P);
+    }
+#undef C25519_STAGE_ENTRY
+    if (OUT == 1) raw160_store(out_raw, idx, P);
+    else if (OUT == 2) {
+        uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
+        u32 t[40];
+        for (int i = 0; i < 10; i++) { t[i] = P.X.v[i]; t[10 + i] = P.Y.v[i]; t[20 + i] = P.Z.v[i]; t[30 + i] = P.T.v[i]; }
+        for (int i = 0; i < 10; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+    } else p32_store(scratch, idx, P.X, P.Y, P.Z);
+}
+
+// ================================================================================================
 // K3  batched compression (edwards.rs:634-647 compress_batch_alloc): Montgomery's trick
 //     (field.rs:225-273) with each lane owning CH projective points: 3 M per point + one field
 //     inversion per lane.  Lane t owns points t, t+T, t+2T, ... so a wave's loads stay adjacent.
@@ -148,27 +226,36 @@ __global__ void __launch_bounds__(256) k_compress_p32(const u32 *__restrict__ sc
                                                       uint8_t *__restrict__ out) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    // one wave per SIMD at n = 2^20: nothing else hides the load latency, so every record is fetched one step ahead
     feT acc = fe_one();
+    feT Zc = p32_load_z(scratch, t);
+    int cnt = 0;
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
         u64 idx = t + (u64)j * T;
         if (idx >= n) break;
+        cnt = j + 1;
+        const u64 nxt = idx + T;
+        feT Zn = (j + 1 < CH && nxt < n) ? p32_load_z(scratch, nxt) : Zc;
         fe48_store(prefix, idx, acc);
-        acc = fe_mul(acc, p32_load_z(scratch, idx));
+        acc = fe_mul(acc, Zc);
+        Zc = Zn;
     }
     feT inv = fe_invert(acc);
+    u64 idx = t + (u64)(cnt - 1) * T;
+    feT Z = p32_load_z(scratch, idx), pre = fe48_load(prefix, idx), X, Y;
+    p32_load_xy(scratch, idx, X, Y);
 #pragma unroll 1
-    for (int j = CH - 1; j >= 0; j--) {
-        u64 idx = t + (u64)j * T;
-        if (idx >= n) continue;
-        feT Z = p32_load_z(scratch, idx);
-        feT zi = fe_mul(inv, fe48_load(prefix, idx));
+    for (int j = cnt - 1; j >= 0; j--) {
+        const u64 cur = t + (u64)j * T, prv = j > 0 ? cur - T : cur;
+        feT Zp = p32_load_z(scratch, prv), prep = fe48_load(prefix, prv), Xp, Yp;
+        p32_load_xy(scratch, prv, Xp, Yp);
+        feT zi = fe_mul(inv, pre);
         inv = fe_mul(inv, Z);
-        feT X, Y;
-        p32_load_xy(scratch, idx, X, Y);
         u32 w[8];
         ge_affine_compress(fe_mul(X, zi), fe_mul(Y, zi), w);
-        store8(out, idx, w);
+        store8(out, cur, w);
+        Z = Zp; pre = prep; X = Xp; Y = Yp;
     }
 }
 
@@ -476,8 +563,15 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t 
     case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, scratch, out_raw, num_cus, st);
     case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, scratch, out_raw, num_cus, st);
-    default: return hipErrorInvalidValue;
+    default: break;
     }
+    if (w >= 10 && w <= 20) {
+        const int nw = (256 + w - 1) / w;
+        if (out_raw) hipLaunchKernelGGL(k_mul_base_wide<1>, dim3(div_up(n, 256)), dim3(256), 0, st, scalars, n, tab, w, nw, scratch, out_raw);
+        else hipLaunchKernelGGL(k_mul_base_wide<0>, dim3(div_up(n, 256)), dim3(256), 0, st, scalars, n, tab, w, nw, scratch, out_raw);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st) {
@@ -487,8 +581,13 @@ hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint3
     case 4: return launch_mul_base_w<4, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
     case 5: return launch_mul_base_w<5, 512>(scalars, n, tab, out40, nullptr, num_cus, st, true);
     case 6: return launch_mul_base_w<6, 1024>(scalars, n, tab, out40, nullptr, num_cus, st, true);
-    default: return hipErrorInvalidValue;
+    default: break;
     }
+    if (w >= 10 && w <= 20) {
+        hipLaunchKernelGGL(k_mul_base_wide<2>, dim3(div_up(n, 256)), dim3(256), 0, st, scalars, n, tab, w, (256 + w - 1) / w, out40, (uint8_t *)nullptr);
+        return hipGetLastError();
+    }
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, u64 n, uint8_t *out, hipStream_t st) {

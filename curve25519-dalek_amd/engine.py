@@ -125,7 +125,7 @@ class Engine:
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible to PyTorch-ROCm: the engine has no CPU fallback")
         self.device = torch.device("cuda", device)
-        self.ctx = self.lib.c25519_ctx_create(device, window & 0xf)
+        self.ctx = self.lib.c25519_ctx_create(device, window & 0x1f)
         if not self.ctx:
             raise EngineError("c25519_ctx_create(%d) failed" % device)
         self._bind_stream()
