@@ -37,7 +37,8 @@ VALU = {
     "fixed_base_comb": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) (LDS comb) + 5M compress + 1/16 inversion"},
     "x25519": {"M": 1303, "S": 1036, "ref": 231000, "what": "255 x (5M + 4S + 10-product a24 mul) + 3M + 1/16 inversion"},
     "msm": {"M": 121, "S": 0, "ref": 26500, "what": "16 windows x 7M bucket adds + 8M normalise + ~1M reduce (c = 16)"},
-    "verify": {"M": 210, "S": 510, "ref": 74400, "what": "2 x decompress (255S + 21M) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
+    "verify": {"M": 197, "S": 255, "ref": 57000, "what": "decompress R (255S + 21M) + normalise A (8M) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
+    "verify_bytes": {"M": 210, "S": 510, "ref": 74400, "what": "decompress R and A (2 x (255S + 21M)) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
 }
 
 
@@ -64,6 +65,9 @@ def main():
     ap.add_argument("--workload", default="fixed_base", choices=sorted(ALGO))
     ap.add_argument("--log2n", type=int, default=None, help="units per GPU = 2^log2n (default: the BASELINE size)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keys-as-bytes", action="store_true",
+                    help="verify: pass only the 32-byte keys (A_i is decompressed inside the call); default: the keys' points "
+                         "are cached like the reference's VerifyingKey (verifying.rs:64-71, batch.rs:236)")
     args = ap.parse_args()
 
     import numpy as np
@@ -117,50 +121,47 @@ def main():
             assert st == 0
             result["out"] = out
     elif wl == "verify":
-        from oracle import orc as _orc       # input GENERATOR only (signing is not on the measured path)
-        seeds = np.random.default_rng(1000 + rank).integers(0, 256, size=(n, 32), dtype=np.uint8)
-        mh = np.random.default_rng(2000 + rank).integers(0, 256, size=(n, 32), dtype=np.uint8)
-        pk_h, sig_h = _orc.ed25519_keygen_sign_batch(seeds, mh, threads=host_cores())
-        d_msgs = torch.from_numpy(mh.reshape(-1)).to(dev)
+        # inputs: 2^k independent keypairs and 32-byte messages, signed by the engine's own batched signer
+        # (byte-exact against the reference's TESTVECTORS in tests/test_gpu_single.py; not on the measured path)
+        seeds, d_msgs = rnd(n), rnd(n).reshape(-1)
         d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
-        d_sigs, d_pks = torch.from_numpy(sig_h).to(dev), torch.from_numpy(pk_h).to(dev)
+        d_pks, d_sigs = eng.sign_batch_t(seeds, d_msgs, d_off)
+        d_pk_points = None
+        if not args.keys_as_bytes:
+            _, d_pk_points, ok = eng.decompress_batch_t(d_pks)       # VerifyingKey::from_bytes, done once per key
+            assert bool(ok.all())
         result = {}
 
         def run():
-            result["st"] = eng.verify_batch_t(d_msgs, d_off, d_sigs, d_pks, pkg.engine.Z_DEVICE)
+            result["st"] = eng.verify_batch_t(d_msgs, d_off, d_sigs, d_pks, pkg.engine.Z_DEVICE, pk_points=d_pk_points)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- parity spot-check against the oracle, outside the timed region (rank 0) ----------------
+    # ---- sanity outside the timed region.  The oracle (test infrastructure) is used ONLY in the cpu_baseline leg:
+    # there its outputs on the sample are also compared with the GPU's.  Here: product-only checks. -------------
     cpu_baseline = None
+    use_oracle = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     run()
     torch.cuda.synchronize(dev)
-    if rank == 0:
-        from oracle import orc
-        cores = host_cores()
-        if wl in ("fixed_base", "x25519"):
-            idx = torch.randperm(n, device=dev, generator=gen)[:1024].cpu().numpy()
-            if wl == "fixed_base":
-                want = orc.mul_base_compress_batch(scalars[idx].cpu().numpy(), threads=cores)
-            else:
-                want = orc.x25519_batch(ks[idx].cpu().numpy(), us[idx].cpu().numpy(), threads=cores)
-            if not np.array_equal(out[idx].cpu().numpy(), want):
-                raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
-        elif wl == "msm" and world == 1:
-            L = 2**252 + 27742317777372353535851937790883648493
-            xb, yb = xs.cpu().numpy(), ys.cpu().numpy()
-            acc = 0
-            for i in range(n):
-                acc += int.from_bytes(xb[i].tobytes(), "little") * int.from_bytes(yb[i].tobytes(), "little")
-            want = orc.ed_compress(orc.ed_mul_base((acc % L).to_bytes(32, "little")))
-            if result["out"] != want:
-                raise SystemExit("PARITY FAILURE: MSM result differs from (sum x_i y_i) B")
-        elif wl == "verify":
-            if result["st"] != 0:
-                raise SystemExit("PARITY FAILURE: valid batch rejected (status %d)" % result["st"])
+    if wl == "verify" and result["st"] != 0:
+        raise SystemExit("SELF-CHECK FAILURE: valid batch rejected (status %d)" % result["st"])
+    if wl == "msm" and world == 1:
+        # (sum x_i y_i mod l) * B through the engine's fixed-base kernel must equal the MSM over P_i = y_i * B
+        L = 2**252 + 27742317777372353535851937790883648493
+        def limbs(t):
+            return (t.view(torch.int16).to(torch.int64) & 0xFFFF)
+        ax, ay = limbs(xs), limbs(ys)
+        acc = 0
+        for j in range(16):
+            col = (ax[:, j:j + 1] * ay).sum(0).cpu().tolist()           # exact: each entry < 2^21 * 2^32
+            for k in range(16):
+                acc += int(col[k]) << (16 * (j + k))
+        want = eng.mul_base_batch(np.frombuffer((acc % L).to_bytes(32, "little"), np.uint8).reshape(1, 32))[0].tobytes()
+        if result["out"] != want:
+            raise SystemExit("SELF-CHECK FAILURE: MSM result differs from (sum x_i y_i) B")
 
     # live peak of the binding unit on THIS box (box-to-box spread is ~10 %): v_mad_u64_u32 issue rate, measured
     # before the timed region by the library's own probe kernel (c25519_microbench, kernels.hip)
@@ -184,9 +185,29 @@ def main():
     dom_ms = sum(eng.phase_ms(b, 0) for b in range(k)) / k
     rest_ms = sum(eng.phase_ms(b, 1) for b in range(k)) / k
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if use_oracle:
         from oracle import orc
         cores = host_cores()
+        # parity of the GPU outputs against the oracle on the sample it is about to be timed on
+        if wl in ("fixed_base", "x25519"):
+            idx = torch.randperm(n, device=dev, generator=gen)[:1024].cpu().numpy()
+            if wl == "fixed_base":
+                want = orc.mul_base_compress_batch(scalars[idx].cpu().numpy(), threads=cores)
+            else:
+                want = orc.x25519_batch(ks[idx].cpu().numpy(), us[idx].cpu().numpy(), threads=cores)
+            if not np.array_equal(out[idx].cpu().numpy(), want):
+                raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
+        elif wl == "msm":
+            m = 2048
+            want = orc.ed_compress(orc.ed_msm([xs[i].cpu().numpy().tobytes() for i in range(m)], [pts[i].cpu().numpy().tobytes() for i in range(m)]))
+            st, got = eng.msm_vartime_t(xs[:m].contiguous(), pts[:m].contiguous(), pkg.engine.FMT_RAW160, pkg.engine.FMT_EDWARDS_Y)
+            if st != 0 or got != want:
+                raise SystemExit("PARITY FAILURE: MSM result differs from the oracle's")
+        else:
+            mh = d_msgs.reshape(n, 32).cpu().numpy(); sig_h = d_sigs.cpu().numpy(); pk_h = d_pks.cpu().numpy()
+            for i in range(0, n, n // 64):
+                if orc.ed25519_verify(pk_h[i].tobytes(), mh[i].tobytes(), sig_h[i].tobytes()) != 0:
+                    raise SystemExit("PARITY FAILURE: the oracle rejects a signature the engine accepts")
         if wl in ("fixed_base", "x25519"):
             # embarrassingly parallel in the reference too: one slice per host core
             probe = min(n, 1024 * cores)
@@ -248,7 +269,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
-            "config": {"workload": "%s: 2^%d units per GPU, inputs resident in HBM, canonical 32-byte outputs" % (wl, log2n),
+            "config": {"workload": "%s: 2^%d units per GPU, inputs resident in HBM, canonical 32-byte outputs%s" % (
+                wl, log2n, "" if wl != "verify" else (", keys as 32 bytes (decompressed inside)" if args.keys_as_bytes else ", keys = VerifyingKey (bytes + cached point), as in the reference")),
                        "units_per_gpu": n, "parallelism": ("sharded terms, all_gather of 160-B partials x%d" if wl == "msm" else "replicas x%d") % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
@@ -257,7 +279,8 @@ def main():
                          "note": "integer (VALU v_mad_u64_u32) bound kernel: HBM fraction is tiny by construction; see DESIGN.md"},
             "cpu_baseline": cpu_baseline,
         }
-        v = VALU["fixed_base_comb" if (wl == "fixed_base" and os.environ.get("C25519_WINDOW", "0") == "9") else wl]
+        v = VALU["fixed_base_comb" if (wl == "fixed_base" and os.environ.get("C25519_WINDOW", "0") == "9") else
+                 "verify_bytes" if (wl == "verify" and args.keys_as_bytes) else wl]
         mac_impl = 100 * v["M"] + 55 * v["S"]
         per_gpu = units / dt / world
         res["valu"] = {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": v["ref"],

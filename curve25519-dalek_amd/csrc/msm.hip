@@ -826,8 +826,10 @@ EXPORT int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160,
 #include "transcript_host.h"
 
 // One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms).
+// d_pk_points (may be NULL): the keys' decompressed points, n x 160 raw -- what VerifyingKey carries beside its bytes
+// (verifying.rs:64-71), so that, like the reference (batch.rs:236), the batch does not decompress A_i again.
 static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off,
-                                 const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
+                                 const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -853,7 +855,8 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
-    hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_pks, (uint64_t)1, n, d_pts, n + 1, d_cnt + 0);
+    if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 0))) return r; }
+    else hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_pks, (uint64_t)1, n, d_pts, n + 1, d_cnt + 0);
     hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_sigs, (uint64_t)2, n, d_pts, (uint64_t)1, d_cnt + 1);
     // (A)
     hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, d_sigs, d_pks, n, hram, d_cnt + 2);
@@ -913,8 +916,8 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
 // a failure so that the reference's precedence -- key decoding, then ScalarFormat for ANY non-canonical s
 // (batch.rs:208-211), then Verify -- does not depend on where the batch was cut.
 static const uint64_t VERIFY_PASS_MAX = 3ull << 19, VERIFY_PASS = 1ull << 20;
-EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
-                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
+EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                             const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
     (void)msgs_len;
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
@@ -924,7 +927,8 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
     bool seen[5] = {false, false, false, false, false};
     for (uint64_t lo = 0; lo < n; lo += per) {
-        int32_t r = verify_batch_pass(ctx, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, std::min(per, n - lo), z_mode);
+        int32_t r = verify_batch_pass(ctx, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr,
+                                      std::min(per, n - lo), z_mode);
         if (r < 0) return r;
         seen[r] = true;
     }
@@ -932,19 +936,29 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
     return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
 }
 
-EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
-                                    uint64_t n, uint32_t z_mode) {
+EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
+    return ed25519_verify_batch_keys_dev(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, nullptr, n, z_mode);
+}
+EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                         const uint8_t *pk_points, uint64_t n, uint32_t z_mode) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
     uint64_t mlen = msg_off[n];
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||
-        (r = ctx_reserve(ctx, ctx->scratch, n * 32 + 16)))
+        (r = ctx_reserve(ctx, ctx->scratch, n * 32 + (pk_points ? n * 160 : 0) + 16)))
         return r;
     if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->tmp_c.p, sigs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->scratch.p, pks, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    return ed25519_verify_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, (const uint8_t *)ctx->tmp_c.p,
-                                    (const uint8_t *)ctx->scratch.p, n, z_mode);
+    uint8_t *d_pk = (uint8_t *)ctx->scratch.p, *d_pp = pk_points ? d_pk + n * 32 : nullptr;
+    HIPCHK(hipMemcpyAsync(d_pk, pks, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (pk_points) HIPCHK(hipMemcpyAsync(d_pp, pk_points, n * 160, hipMemcpyHostToDevice, ctx->stream));
+    return ed25519_verify_batch_keys_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, (const uint8_t *)ctx->tmp_c.p,
+                                         d_pk, d_pp, n, z_mode);
+}
+EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                    uint64_t n, uint32_t z_mode) {
+    return ed25519_verify_batch_keys(ctx, msgs, msg_off, sigs, pks, nullptr, n, z_mode);
 }

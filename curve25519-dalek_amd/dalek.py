@@ -103,12 +103,42 @@ def x25519(ks, us, engine=None):
     return [out[i].tobytes() for i in range(out.shape[0])]
 
 
+class VerifyingKey:
+    """ed25519-dalek/src/verifying.rs:64-71: the 32 key bytes together with the decompressed point, so that
+    verify_batch does not decompress A_i again (batch.rs:236)."""
+    __slots__ = ("compressed", "point")
+
+    def __init__(self, compressed, point):
+        self.compressed, self.point = bytes(compressed), bytes(point)
+
+    @staticmethod
+    def from_bytes(keys, engine=None):
+        """VerifyingKey::from_bytes (verifying.rs:167-175), batched: a list of VerifyingKey; raises
+        SignatureError("PointDecompression") if any key does not decode."""
+        eng = engine or default_engine()
+        _, pts, ok = eng.decompress_batch(_cat(keys, 32), _e.FMT_EDWARDS_Y)
+        if len(keys) and not ok.all():
+            raise SignatureError("PointDecompression")
+        return [VerifyingKey(keys[i], pts[i].tobytes()) for i in range(len(keys))]
+
+    def as_bytes(self):
+        return self.compressed
+
+    def __bytes__(self):
+        return self.compressed
+
+
 def verify_batch(messages, signatures, verifying_keys, engine=None, z_mode=_e.Z_TRANSCRIPT):
     """ed25519-dalek/src/batch.rs:146: returns None on success, raises SignatureError otherwise
     (ArrayLength / ScalarFormat / Verify in the reference's precedence; PointDecompression for a key
-    that would have failed VerifyingKey::from_bytes, verifying.rs:167)."""
+    that would have failed VerifyingKey::from_bytes, verifying.rs:167).  verifying_keys: 32-byte strings, or
+    VerifyingKey objects (then their cached points are used, as in the reference)."""
     eng = engine or default_engine()
-    st = eng.verify_batch(list(messages), list(signatures), list(verifying_keys), z_mode)
+    keys = list(verifying_keys)
+    pk_points = None
+    if keys and all(isinstance(k, VerifyingKey) for k in keys):
+        pk_points = _cat([k.point for k in keys], 160)
+    st = eng.verify_batch(list(messages), list(signatures), [bytes(k) for k in keys], z_mode, pk_points=pk_points)
     if st == _e.OK:
         return None
     raise SignatureError({_e.ARRAY_LENGTH: "ArrayLength", _e.SCALAR_FORMAT: "ScalarFormat", _e.VERIFY: "Verify",

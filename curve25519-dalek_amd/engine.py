@@ -65,6 +65,8 @@ def load_library():
         "c25519_fold_partials": (i32, [vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_batch_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32]),
+        "ed25519_verify_batch_keys_dev": (i32, [vp, vp, vp, u64, vp, vp, vp, u64, C.c_uint32]),
+        "ed25519_verify_batch_keys": (i32, [vp, vp, vp, vp, vp, vp, u64, C.c_uint32]),
         "c25519_mul_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_mul_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_double_base_batch_dev": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
@@ -96,7 +98,7 @@ ABI_SYMBOLS = [
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_mul_base_batch_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
-    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "c25519_microbench",
+    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
@@ -229,13 +231,17 @@ class Engine:
         self._chk(self.lib.c25519_fold_partials(self.ctx, blob, len(partials), out_fmt, out))
         return out.raw
 
-    def verify_batch_t(self, msgs, msg_off, sigs, pks, z_mode=Z_DEVICE):
-        """msgs: uint8 CUDA tensor of the concatenated messages; msg_off: int64/uint64 CUDA tensor (n+1)."""
+    def verify_batch_t(self, msgs, msg_off, sigs, pks, z_mode=Z_DEVICE, pk_points=None):
+        """msgs: uint8 CUDA tensor of the concatenated messages; msg_off: int64/uint64 CUDA tensor (n+1);
+        pk_points: optional (n, 160) raw points of the keys (VerifyingKey.point), skips their decompression."""
         n = self._t(sigs, 64)
         assert self._t(pks, 32) == n and msg_off.numel() == n + 1
+        if pk_points is not None:
+            assert self._t(pk_points, 160) == n
         self._bind_stream()
-        return self._chk(self.lib.ed25519_verify_batch_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(),
-                                                           sigs.data_ptr(), pks.data_ptr(), n, z_mode),
+        return self._chk(self.lib.ed25519_verify_batch_keys_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(),
+                                                                sigs.data_ptr(), pks.data_ptr(), pk_points.data_ptr() if pk_points is not None else None,
+                                                                n, z_mode),
                          (OK, NONE, SCALAR_FORMAT, VERIFY))
 
     def mul_batch_t(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
@@ -319,8 +325,9 @@ class Engine:
         st = self._chk(self.lib.c25519_msm_vartime(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out), (OK, NONE))
         return st, out.raw
 
-    def verify_batch(self, msgs, sigs, pks, z_mode=Z_TRANSCRIPT):
-        """msgs: list of bytes; sigs: list of 64-byte; pks: list of 32-byte.  Status code out."""
+    def verify_batch(self, msgs, sigs, pks, z_mode=Z_TRANSCRIPT, pk_points=None):
+        """msgs: list of bytes; sigs: list of 64-byte; pks: list of 32-byte; pk_points: optional (n, 160) uint8
+        array of the keys' decompressed points (VerifyingKey.point).  Status code out."""
         if not (len(msgs) == len(sigs) == len(pks)):
             return ARRAY_LENGTH  # batch.rs:152-165
         n = len(msgs)
@@ -331,7 +338,12 @@ class Engine:
         s = _np8(b"".join(sigs) if n else b"", 64) if n else np.zeros((0, 64), np.uint8)
         p = _np8(b"".join(pks) if n else b"", 32) if n else np.zeros((0, 32), np.uint8)
         self._bind_stream()
-        return self._chk(self.lib.ed25519_verify_batch(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, z_mode),
+        pp = None
+        if pk_points is not None:
+            pp = _np8(pk_points, 160)
+            assert pp.shape[0] == n
+        return self._chk(self.lib.ed25519_verify_batch_keys(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data,
+                                                            pp.ctypes.data if pp is not None else None, n, z_mode),
                          (OK, NONE, SCALAR_FORMAT, VERIFY))
 
     def mul_batch(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):

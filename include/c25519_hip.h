@@ -134,6 +134,14 @@ int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const u
                                  const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                              const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint32_t z_mode);
+/* The same check for callers that hold VerifyingKey values: the reference's VerifyingKey keeps the decompressed
+ * point beside the 32 key bytes (verifying.rs:64-71, built once by from_bytes :167-175), so its verify_batch
+ * never decompresses A_i (batch.rs:236 uses pk.point directly).  pk_points: n x 160 raw
+ * EdwardsPoints matching pks (e.g. from c25519_decompress_batch), or NULL = decompress the key bytes here. */
+int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                      const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode);
+int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
+                                  const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_points, uint64_t n, uint32_t z_mode);
 
 /* ---- variable base: out[i] = scalars[i] * points[i] ------------------------------------------------
  * replaces backend::variable_base_mul (backend.rs:253 -> scalar_mul/variable_base.rs:11-47;

@@ -150,3 +150,42 @@ def test_verify_batch_multi_pass_precedence(eng, orc):
     assert eng.verify_batch_t(dm, doff, bad, dp, 1) == SCALAR_FORMAT
     bad = ds.clone(); bad[last, 3] ^= 1; bad[first, 63] |= 0x20
     assert eng.verify_batch_t(dm, doff, bad, dp, 1) == SCALAR_FORMAT
+
+
+def test_verify_batch_with_cached_key_points(eng, orc):
+    """VerifyingKey carries its decompressed point (verifying.rs:64-71) and the reference's verify_batch uses it
+    (batch.rs:236): same verdicts with and without the cached points, host and device entry points."""
+    import torch
+    import curve25519_dalek_amd.dalek as dalek
+    n = 5000
+    seeds = util.rand_bytes(910, n); msgs = util.rand_bytes(911, n, 47)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    M = [msgs[i].tobytes() for i in range(n)]; S = [sigs[i].tobytes() for i in range(n)]; P = [pks[i].tobytes() for i in range(n)]
+    vks = dalek.VerifyingKey.from_bytes(P, engine=eng)
+    assert vks[7].as_bytes() == P[7] and orc.ed_compress(vks[7].point) == P[7]
+    for z_mode in (0, 1):
+        assert dalek.verify_batch(M, S, vks, engine=eng, z_mode=z_mode) is None
+    bad = list(S); b = bytearray(bad[n // 2]); b[1] ^= 4; bad[n // 2] = bytes(b)
+    with pytest.raises(dalek.SignatureError, match="Verify"):
+        dalek.verify_batch(M, bad, vks, engine=eng, z_mode=1)
+    bad = list(S); b = bytearray(bad[3]); b[63] |= 0x20; bad[3] = bytes(b)
+    with pytest.raises(dalek.SignatureError, match="ScalarFormat"):
+        dalek.verify_batch(M, bad, vks, engine=eng, z_mode=1)
+    with pytest.raises(dalek.SignatureError, match="PointDecompression"):
+        dalek.VerifyingKey.from_bytes(P[:5] + [(2).to_bytes(32, "little")], engine=eng)
+    # a key whose cached point is another key's: the batch equation must fail (the points are really used)
+    swapped = list(vks); swapped[10] = dalek.VerifyingKey(P[10], vks[11].point)
+    with pytest.raises(dalek.SignatureError, match="Verify"):
+        dalek.verify_batch(M, S, swapped, engine=eng, z_mode=1)
+    # device-resident, full size, with timing
+    n = 1 << 20
+    seeds = util.rand_bytes(400, n); msgs = util.rand_bytes(401, n, 32)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    dm = torch.from_numpy(msgs.reshape(-1)).cuda(); doff = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64).cuda()
+    ds = torch.from_numpy(sigs).cuda(); dp = torch.from_numpy(pks).cuda()
+    _, dpts, ok = eng.decompress_batch_t(dp)
+    assert bool(ok.all())
+    assert eng.verify_batch_t(dm, doff, ds, dp, 1, pk_points=dpts) == OK
+    print("verify_batch 2^20 with cached key points: %.3f ms" % eng.last_kernel_ms())
+    ds2 = ds.clone(); ds2[99, 7] ^= 1
+    assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts) == VERIFY
