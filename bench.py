@@ -242,7 +242,7 @@ def main():
         # HBM bytes per launch of the dominant kernel from the committed PMC profile of this workload
         # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_all.sh; FETCH_SIZE doubled per the
         # gfx950 correction in MI355X_MICROARCH.md).  null if no profile has been committed yet.
-        dom_kernel = {"fixed_base": "k_mul_base", "x25519": "k_x25519", "msm": "k_accumulate", "verify": "k_prep_compressed"}[wl]
+        dom_kernel = {"fixed_base": "k_mul_base_comb" if os.environ.get("C25519_WINDOW", "0") == "9" else "k_mul_base_wide", "x25519": "k_x25519", "msm": "k_accumulate", "verify": "k_accumulate"}[wl]
         import glob
         for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.txt" % wl)), reverse=True):
             fetch = write = None

@@ -417,9 +417,11 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
     for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
-// device z-mode, step 1: first tree level straight over the (hram_i, s_i) pairs -- hram_i already commits to
-// (R_i, A_i, M_i), so node_j = SHA-512(hram_16j || s_16j || ... || hram_16j+15 || s_16j+15 || LE64(n)) binds every
-// batch input with 13/16 compressions per signature (absent children = zero bytes; position = place in the tree)
+// device z-mode.  Tree nodes are 32 bytes (the first half of a SHA-512 digest: 128-bit collision resistance, the
+// level of the 128-bit z_i themselves), which halves the hashing and the latency of the narrow upper levels.
+// step 1: first level straight over the signatures -- hram_i = H(R_i || A_i || M_i) already commits to
+// (R_i, A_i, M_i), so node_j = SHA-512(hram_16j[0..32] || s_16j || ... || hram_16j+15[0..32] || s_16j+15 || LE64(n))
+// binds every batch input with 9/16 compressions per signature (absent children = zero bytes; position = place)
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (n + 15) / 16;
@@ -427,51 +429,48 @@ __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__
     u64 hs[8], w[16];
     sha512_init(hs);
 #pragma unroll 1
-    for (int grp = 0; grp < 4; grp++) {                   // 4 children x 96 B = 3 blocks
-        u64 c0 = 16 * j + 4 * grp;
+    for (int blk = 0; blk < 8; blk++) {                   // 2 children x 64 B per block
 #pragma unroll
-        for (int blk = 0; blk < 3; blk++) {
+        for (int half = 0; half < 2; half++) {
+            const u64 c = 16 * j + 2 * blk + half;
+            const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
 #pragma unroll
-            for (int q = 0; q < 16; q++) {
-                const int k = 16 * blk + q, child = k / 12, off = k % 12;
-                u64 c = c0 + child, v = 0;
-                if (c < n) v = off < 8 ? reinterpret_cast<const u64 *>(hram)[8 * c + off]
-                                       : reinterpret_cast<const u64 *>(sigs)[8 * c + 4 + (off - 8)];
-                w[q] = bswap64(v);
-            }
-            sha512_compress(hs, w);
+            for (int q = 0; q < 4; q++) { w[8 * half + q] = c < n ? bswap64(h[q]) : 0ull; w[8 * half + 4 + q] = c < n ? bswap64(sg[q]) : 0ull; }
         }
+        sha512_compress(hs, w);
     }
     w[0] = bswap64(n); w[1] = 0x8000000000000000ull;
     for (int q = 2; q < 15; q++) w[q] = 0;
-    w[15] = (u64)(1536 + 8) * 8;
+    w[15] = (u64)(1024 + 8) * 8;
     sha512_compress(hs, w);
-    u64 *o = reinterpret_cast<u64 *>(out) + 8 * j;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
+    u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
+    for (int q = 0; q < 4; q++) o[q] = bswap64(hs[q]);
 }
-// step 2: upper 16-ary Merkle levels: out[j] = SHA-512(in[16j] || ... || in[16j+15]) (missing children skipped)
+// step 2: upper 16-ary Merkle levels: out[j] = SHA-512(in[16j] || ... || in[16j+15] || LE64(m_in))[0..32]
 __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (m_in + 15) / 16;
     if (j >= m_out) return;
-    // message = 16 children x 64 bytes (absent children = zero bytes) || LE64(m_in): 8 full blocks + 1
+    // message = 16 children x 32 bytes (absent children = zero bytes) || LE64(m_in): 4 full blocks + 1
     u64 hs[8], w[16];
     sha512_init(hs);
 #pragma unroll 1
-    for (int blk = 0; blk < 8; blk++) {
-        for (int half = 0; half < 2; half++) {
-            u64 c = 16 * j + 2 * blk + half;
-            const u64 *h = reinterpret_cast<const u64 *>(in) + 8 * c;
-            for (int q = 0; q < 8; q++) w[8 * half + q] = c < m_in ? bswap64(h[q]) : 0ull;
+    for (int blk = 0; blk < 4; blk++) {
+#pragma unroll
+        for (int ch = 0; ch < 4; ch++) {
+            const u64 c = 16 * j + 4 * blk + ch;
+            const u64 *h = reinterpret_cast<const u64 *>(in) + 4 * c;
+#pragma unroll
+            for (int q = 0; q < 4; q++) w[4 * ch + q] = c < m_in ? bswap64(h[q]) : 0ull;
         }
         sha512_compress(hs, w);
     }
     w[0] = bswap64(m_in); w[1] = 0x8000000000000000ull;
     for (int q = 2; q < 15; q++) w[q] = 0;
-    w[15] = (u64)(1024 + 8) * 8;
+    w[15] = (u64)(512 + 8) * 8;
     sha512_compress(hs, w);
-    u64 *o = reinterpret_cast<u64 *>(out) + 8 * j;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
+    u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
+    for (int q = 0; q < 4; q++) o[q] = bswap64(hs[q]);
 }
 // step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)); n4 = ceil(n/4) lanes,
 // z16 has room for 4*n4 entries
@@ -479,12 +478,12 @@ __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ roo
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
-    u64 hs[8], w[16];   // 72-byte message: one block
+    u64 hs[8], w[16];   // 40-byte message: one block
     sha512_init(hs);
-    for (int q = 0; q < 8; q++) w[q] = bswap64(h[q]);
-    w[8] = bswap64(i); w[9] = 0x8000000000000000ull;
-    for (int q = 10; q < 15; q++) w[q] = 0;
-    w[15] = 72 * 8;
+    for (int q = 0; q < 4; q++) w[q] = bswap64(h[q]);
+    w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
+    for (int q = 6; q < 15; q++) w[q] = 0;
+    w[15] = 40 * 8;
     sha512_compress(hs, w);
     u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
     for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
