@@ -390,6 +390,55 @@ __global__ void __launch_bounds__(128) k_reduce_level(const u32 *__restrict__ S_
     p40_store(P_out, gid, acc);
 }
 
+// The same level computed by EIGHT lanes per segment (lane j holds entry j): a 3-step suffix scan gives the running
+// sums, two 3-step butterflies give sum_j j*S_j and sum_j P_j -- 10 dependent additions instead of 22.  The upper
+// levels have so few segments that they are pure latency (one wave per SIMD or less), so the 8x lane count is free
+// there; the first level keeps k_reduce_level (its 8x lanes would be real work).
+__device__ __forceinline__ ge_p3 p3_shfl_down8(const ge_p3 &a, int d, int j) {
+    ge_p3 o;
+    for (int i = 0; i < 10; i++) {
+        o.X.v[i] = __shfl_down(a.X.v[i], d, 8); o.Y.v[i] = __shfl_down(a.Y.v[i], d, 8);
+        o.Z.v[i] = __shfl_down(a.Z.v[i], d, 8); o.T.v[i] = __shfl_down(a.T.v[i], d, 8);
+    }
+    const bool in = j + d < 8;
+    const ge_p3 id = ge_identity();
+    for (int i = 0; i < 10; i++) {
+        o.X.v[i] = in ? o.X.v[i] : id.X.v[i]; o.Y.v[i] = in ? o.Y.v[i] : id.Y.v[i];
+        o.Z.v[i] = in ? o.Z.v[i] : id.Z.v[i]; o.T.v[i] = in ? o.T.v[i] : id.T.v[i];
+    }
+    return o;
+}
+__device__ __forceinline__ ge_p3 p3_sum8(ge_p3 a) {          // every lane of the group ends with the group total
+#pragma unroll 1
+    for (int d = 4; d > 0; d >>= 1) {
+        ge_p3 o;
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_xor(a.X.v[i], d, 8); o.Y.v[i] = __shfl_xor(a.Y.v[i], d, 8);
+            o.Z.v[i] = __shfl_xor(a.Z.v[i], d, 8); o.T.v[i] = __shfl_xor(a.T.v[i], d, 8);
+        }
+        a = ge_add(a, o);
+    }
+    return a;
+}
+__global__ void __launch_bounds__(128) k_reduce_level_coop(const u32 *__restrict__ S_in, const u32 *__restrict__ P_in, int m_in, int L, int shift,
+                                                           int nwin, u32 *__restrict__ S_out, u32 *__restrict__ P_out) {
+    const int m_out = m_in / L;
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, gid = t >> 3;
+    const int j = (int)(t & 7);
+    const bool active = gid < (u64)nwin * m_out;              // whole 8-lane groups are active or not; nobody returns early
+    const int k = active ? (int)(gid / m_out) : 0, seg = active ? (int)(gid % m_out) : 0;
+    const u64 in0 = (u64)k * m_in + (u64)seg * L;
+    const bool have = active && j < L;
+    ge_p3 run = have ? p40_load(S_in, in0 + j) : ge_identity();
+    ge_p3 psum = (have && P_in) ? p40_load(P_in, in0 + j) : ge_identity();
+#pragma unroll 1
+    for (int d = 1; d < 8; d <<= 1) run = ge_add(run, p3_shfl_down8(run, d, j));      // run_j = sum_{i >= j} S_i
+    ge_p3 acc = p3_sum8(j >= 1 ? run : ge_identity());                                  // sum_{j >= 1} run_j = sum_i i * S_i
+    if (shift > 0) acc = ge_mul_by_pow_2(acc, shift);
+    if (P_in) acc = ge_add(acc, p3_sum8(psum));
+    if (active && j == 0) { p40_store(S_out, gid, run); p40_store(P_out, gid, acc); }
+}
+
 // ================================================================================================
 // verify_batch kernels
 // ================================================================================================
@@ -690,8 +739,13 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
         for (size_t li = 0; li < plan.size(); li++) {
             int m_out = plan[li].m_in / plan[li].L;
             uint32_t *S_out = gb[which], *P_out = gb[which] + gl * 40;
-            hipLaunchKernelGGL(k_reduce_level, dim3(div_up64((uint64_t)nw * m_out, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in, plan[li].L,
-                               plan[li].shift, nw, S_out, P_out);
+            static const int coop = [] { const char *e = getenv("C25519_REDUCE_COOP"); return e ? atoi(e) : 1; }();
+            if (coop && (uint64_t)nw * m_out * 8 <= (1u << 17))     // <= 2 waves per SIMD even with 8 lanes per segment: latency-bound
+                hipLaunchKernelGGL(k_reduce_level_coop, dim3(div_up64((uint64_t)nw * m_out * 8, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in,
+                                   plan[li].L, plan[li].shift, nw, S_out, P_out);
+            else
+                hipLaunchKernelGGL(k_reduce_level, dim3(div_up64((uint64_t)nw * m_out, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in, plan[li].L,
+                                   plan[li].shift, nw, S_out, P_out);
             S_in = S_out; P_in = P_out; which ^= 1;
         }
         S_fin[grp] = S_in; P_fin[grp] = P_in;
