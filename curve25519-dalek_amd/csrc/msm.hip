@@ -187,6 +187,42 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
     }
 }
 
+// Scatter in bucket-range slices.  A window's sorted list is 4n bytes (8 MB at n = 2^21) and every 128-byte line of it
+// collects its 32 entries from 32 different chunk blocks over the whole kernel: written in one sweep, the lines leave
+// the 4 MB L2 of the XCD half-filled and every 4-byte store reaches HBM as its own 32-byte sector (measured WRITE_SIZE
+// 1.1 GB for 134 MB of payload).  Here a block keeps its chunk's digits in LDS (2 bytes x 65536) and sweeps them
+// `parts` times, each time scattering only the buckets of one slice: the 32 chunk blocks of a window run on the same
+// XCD at the same time (blockIdx.x = window, linear workgroup id mod 8 = XCD) and move through the slices roughly
+// together, so the region being written (4n/parts bytes) stays in that L2 until its lines are complete.
+__global__ void __launch_bounds__(1024) k_scatter_sliced(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, int parts,
+                                                         const u32 *__restrict__ starts, const u32 *__restrict__ base, u32 *__restrict__ sorted) {
+    extern __shared__ u32 sm[];
+    const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y;
+    const int per = g.half / parts;
+    u32 *cursor = sm;
+    uint16_t *dig = reinterpret_cast<uint16_t *>(sm + per);
+    const u64 lo = (u64)j * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const u32 cnt = hi > lo ? (u32)(hi - lo) : 0u;
+    for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) dig[i] = D[(u64)k * n + lo + i];
+    const u32 *st = starts + ((u64)k * nchunk + j) * g.half;
+    const u32 *bs = base + (u64)k * (g.half + 1);
+#pragma unroll 1
+    for (int q = 0; q < parts; q++) {
+        const int b0 = q * per;
+        __syncthreads();
+        for (int i = threadIdx.x; i < per; i += blockDim.x) cursor[i] = st[b0 + i] + bs[b0 + i];
+        __syncthreads();
+        for (u32 i = threadIdx.x; i < cnt; i += blockDim.x) {
+            int d = digit_of(dig[i], k, g);
+            int bk = (d > 0 ? d : -d) - 1 - b0;
+            if (d != 0 && bk >= 0 && bk < per) {
+                u32 pos = atomicAdd(&cursor[bk], 1u);
+                sorted[(u64)k * n + pos] = (u32)(lo + i) | (d < 0 ? 0x80000000u : 0u);
+            }
+        }
+    }
+}
+
 // ================================================================================================
 // bucket accumulation: one lane per (window, bucket)   [pippenger.rs:122-136, as gather lists]
 // ================================================================================================
@@ -639,6 +675,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     }
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
+    if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
     uint64_t chunk = (n + nchunk - 1) / nchunk;
     const uint64_t nb = (uint64_t)g.nwin * g.half;
     // level plan for the reduction
@@ -686,7 +723,12 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     else hipLaunchKernelGGL(k_hist<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
     hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
     hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
-    if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    static const int sparts = [] { const char *e = getenv("C25519_SCATTER_PARTS"); int v = e ? atoi(e) : 8; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }();
+    const size_t lds_sliced = (size_t)g.half / sparts * 4 + (size_t)chunk * 2;
+    if (sparts > 1 && g.half >= 1024 * sparts && lds_sliced <= 160 * 1024) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced));
+        hipLaunchKernelGGL(k_scatter_sliced, dim3(g.nwin, nchunk), dim3(1024), lds_sliced, st, D, n, g, chunk, sparts, counts, base, sorted);
+    } else if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     if (sort_stream && sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
         HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
