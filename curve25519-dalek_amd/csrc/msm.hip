@@ -116,7 +116,9 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
     }
 }
 // signed digit of window k from the stored value
-__device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) { return (k == g.nwin - 1) ? (int)v : (int)v - g.half; }
+// (a top digit above `half` can only come from a scalar with bit 255 set: k_digits has flagged it and the call fails;
+// it is dropped here so that no kernel indexes past its tables)
+__device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) { return (k == g.nwin - 1) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - g.half; }
 
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
 template <bool XCD_SWAP>
@@ -183,6 +185,183 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
         if (d != 0) {
             u32 pos = atomicAdd(&cursor[(d > 0 ? d : -d) - 1], 1u);
             sorted[(u64)k * n + pos] = (u32)t | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ================================================================================================
+// Two-pass partition sort (wide windows, c >= 13).  A direct scatter writes every 4-byte entry to its own cache line.
+// Here pass 1 splits each chunk of a window into SLICES of 256 buckets through an LDS staging buffer, so that what
+// goes to HBM are contiguous runs; pass 2 gives each (window, slice) bin -- ~16 K entries, all of it in LDS -- to one
+// block that counting-sorts it by the low 8 bucket bits and writes the final list, the bucket totals and the bucket
+// offsets, all coalesced.  Intermediate entry: bucket_low8 << 24 | sign << 23 | term index (n <= 2^23).
+// ================================================================================================
+constexpr int PART_BPS = 256;            // buckets per slice
+constexpr int PART_CHUNK = 16384;        // terms per pass-1 block (64 KB of staging: two blocks per CU)
+constexpr int PART_CAP = 18432;          // bin capacity of the LDS path of pass 2 (mean 16384 at n = 2^21; larger bins take the global path)
+
+__device__ __forceinline__ bool part_entry(u32 v, int k, const msm_geom &g, u32 t, u32 &slice, u32 &entry) {
+    int d = digit_of(v, k, g);
+    if (d == 0) return false;
+    u32 b = (u32)((d > 0 ? d : -d) - 1);
+    slice = b / PART_BPS;
+    entry = ((b % PART_BPS) << 24) | (d < 0 ? (1u << 23) : 0u) | t;
+    return true;
+}
+// cc[(k*SL + s)*nchunk + j] = number of non-zero digits of chunk j, window k, that fall into slice s
+__global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, u32 *__restrict__ cc) {
+    extern __shared__ u32 sm[];                               // [4][SL]
+    const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < 4 * SL; i += 256) sm[i] = 0;
+    __syncthreads();
+    const u64 lo = (u64)j * PART_CHUNK, hi = lo + PART_CHUNK < n ? lo + PART_CHUNK : n;
+    const uint16_t *Dk = D + (u64)k * n;
+    if ((((u64)k * n) & 7) == 0 && hi - lo == PART_CHUNK) {           // full, 16-byte aligned chunk: eight digits per load
+        const uint4 *q = reinterpret_cast<const uint4 *>(Dk + lo);
+        for (int i = threadIdx.x; i < PART_CHUNK / 8; i += 256) {
+            uint4 v = q[i];
+            u32 x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                u32 sl, e;
+                if (part_entry((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
+            }
+        }
+    } else {
+        for (u64 t = lo + threadIdx.x; t < hi; t += 256) {
+            u32 sl, e;
+            if (part_entry(Dk[t], k, g, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
+        }
+    }
+    __syncthreads();
+    for (int sidx = threadIdx.x; sidx < SL; sidx += 256)
+        cc[((u64)k * SL + sidx) * nchunk + j] = sm[sidx] + sm[SL + sidx] + sm[2 * SL + sidx] + sm[3 * SL + sidx];
+}
+// one block per window: exclusive scan of cc in (slice, chunk) order, in place; bin_base[k][s] (SL+1 entries); base[k][half]
+__global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL, int nchunk, msm_geom g, u32 *__restrict__ bin_base, u32 *__restrict__ base) {
+    __shared__ u32 part[1024];
+    const int k = blockIdx.x, tid = threadIdx.x, M = SL * nchunk;
+    u32 *v = cc + (u64)k * M;
+    const int per = (M + 1023) / 1024, i0 = tid * per, i1 = i0 + per < M ? i0 + per : M;
+    u32 sum = 0;
+    for (int i = i0; i < i1; i++) sum += v[i];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        u32 x = tid >= off ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += x;
+        __syncthreads();
+    }
+    u32 run = part[tid] - sum;
+    for (int i = i0; i < i1; i++) {
+        u32 c = v[i]; v[i] = run;
+        if (i % nchunk == 0) bin_base[(u64)k * (SL + 1) + i / nchunk] = run;
+        run += c;
+    }
+    if (tid == 1023) { bin_base[(u64)k * (SL + 1) + SL] = part[1023]; base[(u64)k * (g.half + 1) + g.half] = part[1023]; }
+}
+// pass 1: chunk j of window k -> runs per slice in P1[k][..]
+__global__ void __launch_bounds__(1024) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
+    extern __shared__ u32 sm[];
+    u32 *cnt = sm;                         // [16][SL]: per-wave counts, then per-wave cursors
+    u32 *ls = sm + 16 * SL;                // [SL + 1]: start of each slice in the staging buffer
+    u32 *stot = ls + SL + 1;               // [SL]
+    u32 *stage = stot + SL;                // [PART_CHUNK]
+    const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16 * SL; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    const u64 lo = (u64)j * PART_CHUNK, hi = lo + PART_CHUNK < n ? lo + PART_CHUNK : n;
+    for (u64 t = lo + threadIdx.x; t < hi; t += 1024) {
+        u32 sl, e;
+        if (part_entry(D[(u64)k * n + t], k, g, (u32)t, sl, e)) atomicAdd(&cnt[w * SL + sl], 1u);
+    }
+    __syncthreads();
+    for (int sidx = threadIdx.x; sidx < SL; sidx += 1024) {          // per slice: exclusive prefix over the 16 waves
+        u32 run = 0;
+        for (int ww = 0; ww < 16; ww++) { u32 c = cnt[ww * SL + sidx]; cnt[ww * SL + sidx] = run; run += c; }
+        stot[sidx] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { u32 run = 0; for (int sidx = 0; sidx < SL; sidx++) { ls[sidx] = run; run += stot[sidx]; } ls[SL] = run; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 16 * SL; i += 1024) cnt[i] += ls[i % SL];
+    __syncthreads();
+    for (u64 t = lo + threadIdx.x; t < hi; t += 1024) {
+        u32 sl, e;
+        if (part_entry(D[(u64)k * n + t], k, g, (u32)t, sl, e)) stage[atomicAdd(&cnt[w * SL + sl], 1u)] = e;
+    }
+    __syncthreads();
+    for (int sidx = w; sidx < SL; sidx += 16) {                       // each wave copies whole runs
+        const u32 len = stot[sidx], src = ls[sidx];
+        u32 *dst = P1 + (u64)k * n + gofs[((u64)k * SL + sidx) * nchunk + j];
+        for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
+    }
+}
+// pass 2: bin (window k, slice s) -> final order, bucket totals and bucket offsets.  The bin's entries live in
+// registers (18 per thread), LDS holds only the sorted copy: 74 KB per block, two blocks per CU.
+constexpr int PART_R = PART_CAP / 1024;
+__global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
+                                                u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted) {
+    extern __shared__ u32 sm[];
+    u32 *cnt = sm, *cur = sm + PART_BPS, *out = sm + 2 * PART_BPS;
+    const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
+    const u32 b0 = bin_base[(u64)k * (SL + 1) + sidx], m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0;
+    const u32 *src = P1 + (u64)k * n + b0;
+    u32 *dst = sorted + (u64)k * n + b0;
+    const bool fits = m <= (u32)PART_CAP;
+    if (tid < PART_BPS) cnt[tid] = 0;
+    __syncthreads();
+    u32 e[PART_R];
+    if (fits) {
+#pragma unroll
+        for (int r = 0; r < PART_R; r++) { const u32 i = tid + 1024u * r; e[r] = i < m ? src[i] : 0u; }
+#pragma unroll
+        for (int r = 0; r < PART_R; r++) if (tid + 1024u * r < m) atomicAdd(&cnt[e[r] >> 24], 1u);
+    } else {
+        for (u32 i = tid; i < m; i += 1024) atomicAdd(&cnt[src[i] >> 24], 1u);
+    }
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan of the 256 bucket counts by one wave
+        u32 c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
+        u32 sum = c0 + c1 + c2 + c3, inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { u32 x = __shfl_up(inc, off, 64); if (tid >= off) inc += x; }
+        u32 run = inc - sum;
+        cur[4 * tid] = run; cur[4 * tid + 1] = run + c0; cur[4 * tid + 2] = run + c0 + c1; cur[4 * tid + 3] = run + c0 + c1 + c2;
+    }
+    __syncthreads();
+    if (tid < PART_BPS) {
+        const u64 b = (u64)sidx * PART_BPS + tid;
+        totals[(u64)k * g.half + b] = cnt[tid];
+        base[(u64)k * (g.half + 1) + b] = b0 + cur[tid];
+    }
+    __syncthreads();
+    if (fits) {
+#pragma unroll
+        for (int r = 0; r < PART_R; r++)
+            if (tid + 1024u * r < m) out[atomicAdd(&cur[e[r] >> 24], 1u)] = (e[r] & 0x7fffffu) | ((e[r] & (1u << 23)) << 8);
+        __syncthreads();
+        for (u32 i = tid; i < m; i += 1024) dst[i] = out[i];
+    } else {
+        // oversize bin = heavily skewed digits (e.g. one bucket holding most of the window).  Entries go straight to
+        // their final place; lanes of a wave that share the first lane's bucket take their slots with ONE atomic.
+        for (u32 i0 = 0; i0 < m; i0 += 1024) {
+            const u32 i = i0 + tid;
+            const bool have = i < m;
+            const u32 ev = have ? src[i] : 0u, bk = ev >> 24;
+            const u32 lead_bk = __shfl(bk, __ffsll((long long)__ballot(have)) - 1, 64);
+            const unsigned long long same = __ballot(have && bk == lead_bk);
+            u32 pos = 0;
+            if (have && bk == lead_bk) {
+                const int leader = __ffsll((long long)same) - 1, lane = tid & 63;
+                u32 first = 0;
+                if (lane == leader) first = atomicAdd(&cur[bk], (u32)__popcll(same));
+                first = __shfl(first, leader, 64);
+                pos = first + (u32)__popcll(same & ((1ull << lane) - 1ull));
+            } else if (have) {
+                pos = atomicAdd(&cur[bk], 1u);
+            }
+            if (have) dst[pos] = (ev & 0x7fffffu) | ((ev & (1u << 23)) << 8);
         }
     }
 }
@@ -570,8 +749,11 @@ __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ roo
     for (int q = 6; q < 15; q++) w[q] = 0;
     w[15] = 40 * 8;
     sha512_compress(hs, w);
+    // z_i < 2^127: with the signed recoding s' = s + sum HALF 2^(ck) a 127-bit value never carries out of its eighth
+    // 16-bit window, so the R_i terms leave windows 8..15 empty; a full 128-bit z_i would put about half of all R_i
+    // into ONE bucket of window 8 (carry digit +1).  A forged batch then passes with probability 2^-127 instead of 2^-128.
     u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]) & ((q & 1) ? 0x7fffffffffffffffull : ~0ull);
 }
 // scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = z_i, [1+n+i] = z_i*h_i;
 // per-block partial sums of z_i*s_i (mod l) to `partial`
@@ -695,6 +877,12 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
     size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     size_t oLS = carve((size_t)max_items * 160);
+    // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
+    static const int sort2 = [] { const char *e = getenv("C25519_SORT2"); return e ? atoi(e) : 1; }();
+    const bool use_part = sort2 && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
+    const int SL = g.half / PART_BPS, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
+    size_t oP1 = 0, oCC = 0, oBB = 0;
+    if (use_part) { oP1 = carve((size_t)g.nwin * n * 4); oCC = carve((size_t)g.nwin * SL * pchunks * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
     if (r) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
@@ -710,6 +898,16 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;      // sort phase
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 2048, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
+    if (use_part) {
+        uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
+        const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS + PART_CAP) * 4;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, cc);
+        hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(1024), 0, st, cc, SL, pchunks, g, bin_base, base);
+        hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, cc, P1);
+        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted);
+    } else {
     size_t lds = (size_t)g.half * 4;
     static int xswap = -1;   // tuning knob: C25519_XCD_SWAP = 0 | 1
     if (xswap < 0) { const char *e = getenv("C25519_XCD_SWAP"); xswap = e ? atoi(e) : 1; }
@@ -730,6 +928,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
         hipLaunchKernelGGL(k_scatter_sliced, dim3(g.nwin, nchunk), dim3(1024), lds_sliced, st, D, n, g, chunk, sparts, counts, base, sorted);
     } else if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+    }
     if (sort_stream && sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
         HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
