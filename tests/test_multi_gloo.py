@@ -76,3 +76,37 @@ def test_fold_partials_without_gpu():
     assert pkg.multi.fold_partials([a], pkg.engine.FMT_RISTRETTO) == orc.ris_compress(a)
     raw = pkg.multi.fold_partials([a, b], pkg.engine.FMT_RAW160)
     assert orc.ed_compress(raw) == orc.ed_compress(orc.ed_add(a, b))
+
+
+def _verdict_worker(rank, world, port, statuses, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import curve25519_dalek_amd as pkg
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    out = [pkg.multi.combine_verdicts(case[rank]) for case in statuses]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_verify_verdict_precedence_gloo():
+    """verify_batch over two ranks: the batch verdict is the worst shard verdict in the reference's order
+    (batch.rs:208-211 ScalarFormat before :244-250 Verify), identical on every rank."""
+    OK, NONE, SCALAR_FORMAT, VERIFY = 0, 1, 2, 3
+    cases = [(OK, OK), (OK, VERIFY), (VERIFY, OK), (VERIFY, SCALAR_FORMAT), (SCALAR_FORMAT, VERIFY), (OK, SCALAR_FORMAT),
+             (NONE, SCALAR_FORMAT), (VERIFY, NONE), (VERIFY, VERIFY)]
+    want = [OK, VERIFY, VERIFY, SCALAR_FORMAT, SCALAR_FORMAT, SCALAR_FORMAT, NONE, NONE, VERIFY]
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verdict_worker, args=(r, world, port, cases, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, out in res:
+        assert out == want
