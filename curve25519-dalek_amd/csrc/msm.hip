@@ -94,7 +94,15 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 // ================================================================================================
 // digits + counting sort
 // ================================================================================================
-struct msm_geom { int c, nwin, half; u32 addk[8]; };
+// Window layout.  Scalars are reduced mod l (< 2^253, scalar.rs:193-205) in every MSM the reference performs, so the
+// 253 bits are shared out EVENLY: equal windows of c bits would leave a 13-bit rump at the top (c = 16) whose few
+// buckets collect 16x longer lists than the others.  From the top: an overflow window for bits 253..255 (empty unless
+// a caller passes an unreduced scalar, which stays correct), one UNSIGNED window of c-1 bits (its digits 1..2^(c-1)
+// fill all `half` buckets and it produces no carry), and below it signed windows of c or c-1 bits.
+//   digit k = bits [pos[k], pos[k] + wid[k]) of s' = s + addk, minus 2^(wid[k]-1) for the signed windows,
+//   addk = sum over signed windows of 2^(pos[k] + wid[k] - 1).
+constexpr int MSM_MAX_WIN = 56;
+struct msm_geom { int c, nwin, half; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
 
 // D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
 __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
@@ -106,19 +114,19 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
     u64 carry = 0;
     for (int i = 0; i < 8; i++) { u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = v >> 32; }
     s[8] = (u32)carry;
-    const u32 mask = (1u << g.c) - 1u;
     for (int k = 0; k < g.nwin; k++) {
-        int bit = k * g.c, wi = bit >> 5, sh = bit & 31;
+        int bit = g.pos[k], wi = bit >> 5, sh = bit & 31;
         u64 two = (u64)s[wi] | ((u64)(wi + 1 <= 8 ? s[wi + 1] : 0u) << 32);
-        u32 v = (u32)(two >> sh);
-        if (k != g.nwin - 1) v &= mask;          // top window keeps every remaining bit (unsigned digit)
+        u32 v = (u32)(two >> sh) & ((1u << g.wid[k]) - 1u);
         D[(u64)k * n + t] = (uint16_t)v;
     }
 }
 // signed digit of window k from the stored value
 // (a top digit above `half` can only come from a scalar with bit 255 set: k_digits has flagged it and the call fails;
 // it is dropped here so that no kernel indexes past its tables)
-__device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) { return (k == g.nwin - 1) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - g.half; }
+__device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) {
+    return (k >= g.nwin - 2) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - (1 << (g.wid[k] - 1));     // the top two windows are unsigned
+}
 
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
 template <bool XCD_SWAP>
@@ -848,11 +856,20 @@ static int pick_window(uint64_t n) {
 int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream) {
     msm_geom g;
     g.c = pick_window(n);
-    g.nwin = (256 + g.c - 1) / g.c;
     g.half = 1 << (g.c - 1);
-    {   // addk = sum_{k < nwin-1} half << (c k)
+    {   // see msm_geom: signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit window, then bits 253..255
+        const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
         uint32_t a[9] = {0};
-        for (int k = 0; k < g.nwin - 1; k++) { int bit = k * g.c + g.c - 1; a[bit >> 5] |= 1u << (bit & 31); }
+        int bit = 0;
+        for (int k = 0; k < nsig; k++) {
+            g.pos[k] = (unsigned char)bit; g.wid[k] = (unsigned char)(wbase + (k < wrem ? 1 : 0));
+            bit += g.wid[k];
+            a[(bit - 1) >> 5] |= 1u << ((bit - 1) & 31);
+        }
+        g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 1);          // bit == 253 - (c-1)
+        g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
+        g.nwin = nsig + 2;
+        for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
         for (int i = 0; i < 8; i++) g.addk[i] = a[i];
     }
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
@@ -1011,7 +1028,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     for (int k = g.nwin - 1; k >= 0; k--) {
         ge_p3 col = host_p40(&hS[(size_t)k * 40]);                    // sum_b B_b
         if (haveP) col = ge_add(col, host_p40(&hP[(size_t)k * 40]));  // + sum_b b*B_b
-        if (k != g.nwin - 1) total = ge_mul_by_pow_2(total, g.c);
+        if (k != g.nwin - 1) total = ge_mul_by_pow_2(total, g.pos[k + 1] - g.pos[k]);
         total = ge_add(total, col);
     }
     R = total;
