@@ -179,3 +179,42 @@ def test_msm_config4_2p24_terms(eng, orc):
     st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == want
     print("MSM 2^24 single call: %.3f ms" % eng.last_kernel_ms())
+
+
+def test_msm_two_passes_odd_size(eng, orc):
+    """3*2^20 + 17 terms: two passes of unequal length (msm.hip MSM_PASS_MAX), partial sums added on the host."""
+    import torch
+    n = (3 << 20) + 17
+    g = torch.Generator(device="cuda"); g.manual_seed(31337)
+    dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dx[:, 31] &= 0x0F
+    draw = eng.mul_base_batch_t(dx, out_fmt=2)
+    st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+
+
+@pytest.mark.parametrize("log2n", [13, 17, 20])
+def test_msm_maximally_skewed_digits(eng, orc, log2n):
+    """Every term carries the SAME scalar, so each window has one bucket holding all n entries: the oversize-bin branch
+    of the partition sort, the long-bucket path and the one-pass sort of small inputs.  Points are distinct
+    (P_i = y_i B); expected = s * (sum y_i) * B.  A second batch repeats one point n times (n * s * P)."""
+    import torch
+    n = 1 << log2n
+    s_int = (L - 12345) // 3
+    s = np.frombuffer(i2b(s_int), np.uint8)
+    g = torch.Generator(device="cuda"); g.manual_seed(4242 + log2n)
+    dy = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dy[:, 31] &= 0x0F
+    dP = eng.mul_base_batch_t(dy, out_fmt=2)
+    ds = torch.from_numpy(np.tile(s, (n, 1))).cuda()
+    ysum = 0
+    yb = dy.cpu().numpy()
+    for i in range(n):
+        ysum += int.from_bytes(yb[i].tobytes(), "little")
+    want = orc.ed_compress(orc.ed_mul_base(i2b(s_int * ysum % L)))
+    st, got = eng.msm_vartime_t(ds, dP, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    same = dP[:1].repeat(n, 1).contiguous()
+    want2 = orc.ed_compress(orc.ed_mul(dP[0].cpu().numpy().tobytes(), i2b(s_int * n % L)))
+    st, got = eng.msm_vartime_t(ds, same, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want2
