@@ -140,7 +140,7 @@ static int32_t build_wide_table(c25519_ctx *ctx, int C) {
     uint32_t *d_wide = nullptr;
     HIPCHK(hipMalloc(&d_sc, N * 32));
     HIPCHK(hipMalloc(&d_raw, N * 160));
-    HIPCHK(hipMalloc(&d_wide, N * 96));
+    HIPCHK(hipMalloc(&d_wide, N * 128));       // one 128-byte limb entry per table slot: the MSM's point format (devio.h pts_store)
     HIPCHK(hipMemcpyAsync(d_sc, sc.data(), N * 32, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(launch_mul_base(ctx->w, d_sc, N, ctx->d_table, nullptr, d_raw, ctx->num_cus, ctx->stream));
     int32_t r = prep_points(ctx, d_raw, N, C25519_FMT_RAW160, d_wide, 0, (uint32_t *)ctx->d_flag);

@@ -93,22 +93,30 @@ __device__ __forceinline__ ge_p3 raw160_load(const uint8_t *in, u64 idx) {
     return p;
 }
 
-// ---- packed affine Niels point: 24 u32 = canonical (y+x, y-x, 2dxy) --------------------------------
-__device__ __forceinline__ void pts96_store(u32 *pts, u64 idx, const feT &x, const feT &y) {
-    u32 w[24];
-    fe_to_words(fe_add(y, x), w);
-    fe_to_words(fe_sub(y, x), w + 8);
-    fe_to_words(fe_mul(fe_mul(x, y), fe_d2()), w + 16);
-    uint4 *q = reinterpret_cast<uint4 *>(pts) + 6 * idx;
-    for (int i = 0; i < 6; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+// ---- affine Niels point as stored for gathers: (y+x, y-x, 2dxy) as 3 x 10 tight LIMBS + 8 bytes of padding = 128 B,
+//      i.e. exactly one cache line per point and nothing to unpack; the sign of a signed digit is applied by
+//      ge_madd_signed_p3 (operand swap), not to the stored data --------------------------------------------------------
+constexpr int PTS_BYTES = 128, PTS_Q = PTS_BYTES / 16;
+__device__ __forceinline__ void pts_store(u32 *pts, u64 idx, const feT &x, const feT &y) {
+    feT a = fe_carry(fe_add(y, x)), b = fe_carry(fe_sub(y, x)), c = fe_mul(fe_mul(x, y), fe_d2());
+    u32 t[32];
+    for (int i = 0; i < 10; i++) { t[i] = a.v[i]; t[10 + i] = b.v[i]; t[20 + i] = c.v[i]; }
+    t[30] = 0; t[31] = 0;
+    uint4 *q = reinterpret_cast<uint4 *>(pts) + PTS_Q * idx;
+    for (int i = 0; i < PTS_Q; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
 }
-// load +P or -P (sign applied to the packed words, ge26.h aniels_words_cneg)
-__device__ __forceinline__ ge_aniels pts96_load(const u32 *pts, u64 idx, bool neg) {
-    const uint4 *q = reinterpret_cast<const uint4 *>(pts) + 6 * idx;
-    uint4 a = q[0], b = q[1], c = q[2], d = q[3], e = q[4], f = q[5];
-    u32 w[24] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w, e.x, e.y, e.z, e.w, f.x, f.y, f.z, f.w};
-    aniels_words_cneg(w, neg);
-    return aniels_from_words(w);
+__device__ __forceinline__ ge_aniels pts_from_q(const uint4 q[PTS_Q]) {
+    u32 t[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+                 q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
+    ge_aniels A;
+    for (int i = 0; i < 10; i++) { A.ypx.v[i] = t[i]; A.ymx.v[i] = t[10 + i]; A.xy2d.v[i] = t[20 + i]; }
+    return A;
+}
+__device__ __forceinline__ ge_aniels pts_load(const u32 *pts, u64 idx) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * idx;
+    uint4 q[PTS_Q];
+    for (int i = 0; i < PTS_Q; i++) q[i] = src[i];
+    return pts_from_q(q);
 }
 // extended point as 40 u32 tight limbs (bucket sums, partial results)
 __device__ __forceinline__ void p40_store(u32 *base, u64 idx, const ge_p3 &p) {

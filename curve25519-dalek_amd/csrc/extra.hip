@@ -165,7 +165,7 @@ EXPORT c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *sta
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     c25519_precomp *p = new c25519_precomp{nullptr, n};
-    if (hipMalloc(&p->d_pts, (n ? n : 1) * 96) != hipSuccess) { delete p; return nullptr; }
+    if (hipMalloc(&p->d_pts, (n ? n : 1) * PTS_BYTES) != hipSuccess) { delete p; return nullptr; }
     if (n == 0) return p;
     if (ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) { hipFree(p->d_pts); delete p; return nullptr; }
     uint32_t *bad = (uint32_t *)ctx->d_flag;
@@ -197,14 +197,14 @@ EXPORT int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp 
     if (m == 0) { host_encode(R, out_fmt, out); return C25519_OK; }
     size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
-    if ((r = ctx_reserve(ctx, ctx->tmp_a, m * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n_dyn * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_e, m * 96 + 256))) return r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, m * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n_dyn * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
     uint8_t *d_sc = (uint8_t *)ctx->tmp_a.p;
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p, *bad = (uint32_t *)ctx->d_flag;
     hipStream_t st = ctx->stream;
     HIPCHK(hipMemsetAsync(bad, 0, 16, st));
     if (ns) {
         HIPCHK(hipMemcpyAsync(d_sc, static_scalars, ns * 32, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_pts, p->d_pts, ns * 96, hipMemcpyDeviceToDevice, st));
+        HIPCHK(hipMemcpyAsync(d_pts, p->d_pts, ns * PTS_BYTES, hipMemcpyDeviceToDevice, st));
     }
     if (n_dyn) {
         HIPCHK(hipMemcpyAsync(d_sc + ns * 32, dyn_scalars, n_dyn * 32, hipMemcpyHostToDevice, st));

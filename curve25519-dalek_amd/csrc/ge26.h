@@ -98,6 +98,31 @@ C25519_HD ge_p1p1 ge_madd(const ge_p3 &p, const ge_aniels &q) {
     r.T = fe_sub_w(Z2, TT);
     return r;
 }
+// P + (neg ? -Q : Q) straight to extended coordinates, for table entries kept as LIMBS (no unpacking, no negation
+// arithmetic): -Q = (y-x, y+x, -2dxy) swaps the first two entries, and the sign of TT = T * 2dxy only decides which of
+// Z2 + TT / Z2 - TT plays Z and which plays T of the completed point.  Both are needed anyway; Z3 = (Z2+TT)(Z2-TT)
+// either way, and the wide one of the pair is always put first in its product, so 40 selects replace the
+// conditional subtraction p - v and the three unpackings.  7 M like ge_madd + ge_p1p1_to_p3.
+C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) {
+    feT qa, qb;
+    for (int i = 0; i < 10; i++) { qa.v[i] = neg ? q.ymx.v[i] : q.ypx.v[i]; qb.v[i] = neg ? q.ypx.v[i] : q.ymx.v[i]; }
+    feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
+    feT PP = fe_mul(YpX, qa), MM = fe_mul(YmX, qb);
+    feT TT = fe_mul(p.T, q.xy2d);
+    feL Z2 = fe_add(p.Z, p.Z);
+    feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
+    feL zp = fe_add_lt(Z2, TT);            // Z of the completed point for +Q, T for -Q   (loose)
+    feW zm = fe_sub_w(Z2, TT);             // T of the completed point for +Q, Z for -Q   (wide)
+    feW fx, fy;                            // the factor of X (the completed T) and of Y (the completed Z)
+    for (int i = 0; i < 10; i++) { fx.v[i] = neg ? zp.v[i] : zm.v[i]; fy.v[i] = neg ? zm.v[i] : zp.v[i]; }
+    ge_p3 r;
+    r.X = fe_mul(fx, X);
+    r.Y = fe_mul(fy, Y);
+    r.Z = fe_mul(zm, zp);
+    r.T = fe_mul(X, Y);
+    return r;
+}
+
 // w[0..7] = y+x, w[8..15] = y-x, w[16..23] = 2dxy as canonical 255-bit words.  neg: swap the first
 // two and replace the third by p - v (v = 0 gives p, a non-canonical but valid representative of 0).
 C25519_HD void aniels_words_cneg(u32 w[24], bool neg) {

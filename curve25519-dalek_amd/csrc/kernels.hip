@@ -141,9 +141,10 @@ __global__ void __launch_bounds__(BS) k_mul_base_comb(const uint8_t *__restrict_
 // K1w fixed base with WIDE signed windows: s = sum_j d_j 2^(C j), d_j in (-2^(C-1), 2^(C-1)], and one table of
 //     e * 2^(C j) * B per digit position (the reference's EdwardsBasepointTable structure, edwards.rs:1131-1141,
 //     with radix 2^C instead of 16): ceil(256 / C) mixed additions, no doublings.  The table does not fit LDS --
-//     it lives in HBM and is served by L2 (C <= 12: <= 4.3 MB) or the 256 MB MALL (C = 16: 53 MB), so each
-//     addition costs one 96-byte gather, prefetched one window ahead.  The top window is unsigned (it absorbs
-//     the last carry and bit 255) and has its own length.
+//     it lives in HBM and is served by L2 (C <= 12: <= 5.8 MB) or the 256 MB MALL (C = 16: 71 MB), so each
+//     addition costs one 128-byte gather -- exactly one cache line: an entry is (y+x, y-x, 2dxy) as 3 x 10 LIMBS
+//     + 8 bytes of padding, ready for ge_madd_signed_p3 without unpacking -- prefetched one window ahead.  The top
+//     window is unsigned (it absorbs the last carry and bit 255) and has its own length.
 //     Layout: windows 0 .. nw-2: 2^(C-1)+1 entries each (entry 0 = identity), then 2^rem + 1 entries.
 // ================================================================================================
 template <int OUT>
@@ -155,11 +156,11 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
     load8(scalars, idx, s);
     const u32 HALF = 1u << (C - 1), MASK = (HALF << 1) - 1u, ENT = HALF + 1;
     // The table entry of window j+1 is fetched while the addition of window j runs.  Holding it in registers would
-    // cost 24 VGPRs for the whole iteration; instead each wave DMAs it straight into its own 6 x 1 KiB LDS slots
+    // cost 30 VGPRs for the whole iteration; instead each wave DMAs it straight into its own 8 x 1 KiB LDS slots
     // (global_load_lds_dwordx4: per-lane global address, LDS destination = wave base + 16 * lane) and reads it back
     // at the top of the next iteration.  Every lane only ever touches its own slot, so no barrier is involved:
     // the wave's own vmcnt(0) orders DMA -> ds_read, and lgkmcnt(0) orders ds_read -> the next DMA into the slot.
-    __shared__ uint4 stage[6 * 256];
+    __shared__ uint4 stage[8 * 256];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     uint4 *wave_slot = stage + (threadIdx.x & ~63u);
@@ -169,25 +170,29 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
     bool neg = d > HALF;
     u32 carry = neg ? 1u : 0u;
     u32 mag = neg ? (MASK + 1u - d) : d;
-    const uint4 *e = reinterpret_cast<const uint4 *>(tab) + (u64)mag * 6;
+    const uint4 *e = reinterpret_cast<const uint4 *>(tab) + (u64)mag * 8;
 #define C25519_STAGE_ENTRY(src)                                                                                          \
     __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 0), (lds_void *)(wave_slot + 0 * 256), 16, 0, 0);              \
     __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 1), (lds_void *)(wave_slot + 1 * 256), 16, 0, 0);              \
     __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 2), (lds_void *)(wave_slot + 2 * 256), 16, 0, 0);              \
     __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 3), (lds_void *)(wave_slot + 3 * 256), 16, 0, 0);              \
     __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 4), (lds_void *)(wave_slot + 4 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 5), (lds_void *)(wave_slot + 5 * 256), 16, 0, 0)
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 5), (lds_void *)(wave_slot + 5 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 6), (lds_void *)(wave_slot + 6 * 256), 16, 0, 0);              \
+    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 7), (lds_void *)(wave_slot + 7 * 256), 16, 0, 0)
     C25519_STAGE_ENTRY(e);
     ge_p3 P = ge_identity();
 #pragma unroll 1
     for (int j = 0; j < nw; j++) {
         const bool cur_neg = neg;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // entry j has landed in the slot
-        uint4 q0 = my_slot[0 * 256], q1 = my_slot[1 * 256], q2 = my_slot[2 * 256], q3 = my_slot[3 * 256], q4 = my_slot[4 * 256], q5 = my_slot[5 * 256];
-        u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-                      q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+        uint4 q[8];
 #pragma unroll
-        for (int i = 0; i < 24; i++) asm volatile("" : "+v"(tw[i]));   // the reads are complete (lgkmcnt) before ...
+        for (int i = 0; i < 8; i++) q[i] = my_slot[i * 256];
+        u32 tw[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+                      q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
+#pragma unroll
+        for (int i = 0; i < 30; i++) asm volatile("" : "+v"(tw[i]));   // the reads are complete (lgkmcnt) before ...
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (j + 1 < nw) {                                           // ... the slot is refilled with entry j+1
 #pragma unroll
@@ -198,11 +203,13 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
             neg = !top && d > HALF;
             carry = neg ? 1u : 0u;
             mag = neg ? (MASK + 1u - d) : d;
-            e = reinterpret_cast<const uint4 *>(tab) + ((u64)(j + 1) * ENT + mag) * 6;
+            e = reinterpret_cast<const uint4 *>(tab) + ((u64)(j + 1) * ENT + mag) * 8;
             C25519_STAGE_ENTRY(e);
         }
-        aniels_words_cneg(tw, cur_neg);
-        P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
+        ge_aniels A;                                                // the table holds limbs: no unpacking
+#pragma unroll
+        for (int i = 0; i < 10; i++) { A.ypx.v[i] = tw[i]; A.ymx.v[i] = tw[10 + i]; A.xy2d.v[i] = tw[20 + i]; }
+        P = ge_madd_signed_p3(P, A, cur_neg);
         ge_pin(P);
     }
 #undef C25519_STAGE_ENTRY

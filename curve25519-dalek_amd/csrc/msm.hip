@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(256) k_prep_compressed(const uint8_t *__restri
     load8(in, i * stride_items, w);     // stride 1 for point arrays, 2 to pick R out of 64-byte signatures
     ge_p3 P;
     bool ok = (FMT == 0) ? ge_decompress(P, w) : ris_decompress(P, w);
-    pts96_store(pts, dst0 + i, P.X, P.Y);
+    pts_store(pts, dst0 + i, P.X, P.Y);
     if (!ok) atomicAdd(bad_count, 1u);
 }
 // raw 160-byte points: Montgomery-trick normalisation, CH points per lane (cf. k_compress_p32)
@@ -84,11 +84,11 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
         feT Z = raw160_fe(in, idx, 2);
         feT zi = fe_mul(inv, pre);
         inv = fe_mul(inv, Z);
-        pts96_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
+        pts_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
     }
 }
 __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) { ge_p3 B = ge_basepoint(); pts96_store(pts, dst, B.X, B.Y); }
+    if (threadIdx.x == 0 && blockIdx.x == 0) { ge_p3 B = ge_basepoint(); pts_store(pts, dst, B.X, B.Y); }
 }
 
 // ================================================================================================
@@ -472,8 +472,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
 #pragma unroll 1
         for (u32 i = lo; i < hi; i++) {
             u32 e = list[i];
-            ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
-            acc = ge_p1p1_to_p3(ge_madd(acc, A));
+            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
         }
     } else if (PIPE == 1) {
         u32 e_next = lo < hi ? list[lo] : 0u;
@@ -481,21 +480,18 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
         for (u32 i = lo; i < hi; i++) {
             u32 e = e_next;
             if (i + 1 < hi) e_next = list[i + 1];
-            ge_aniels A = pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0);
-            acc = ge_p1p1_to_p3(ge_madd(acc, A));
+            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
         }
     } else {
-        uint4 q[6];
+        uint4 q[PTS_Q];
         u32 e = 0;
-        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + 6 * (u64)(e & 0x7fffffffu); for (int j = 0; j < 6; j++) q[j] = src[j]; }
+        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
 #pragma unroll 1
         for (u32 i = lo; i < hi; i++) {
-            u32 w[24] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w,
-                         q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w};
-            bool neg = (e >> 31) != 0;
-            if (i + 1 < hi) { e = list[i + 1]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + 6 * (u64)(e & 0x7fffffffu); for (int j = 0; j < 6; j++) q[j] = src[j]; }
-            aniels_words_cneg(w, neg);
-            acc = ge_p1p1_to_p3(ge_madd(acc, aniels_from_words(w)));
+            const ge_aniels A = pts_from_q(q);
+            const bool neg = (e >> 31) != 0;
+            if (i + 1 < hi) { e = list[i + 1]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+            acc = ge_madd_signed_p3(acc, A, neg);
         }
     }
     p40_store(buckets, gid, acc);
@@ -552,7 +548,7 @@ __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pt
 #pragma unroll 1
         for (u32 i = it.lo + threadIdx.x; i < it.hi; i += 64) {
             u32 e = list[i];
-            acc = ge_p1p1_to_p3(ge_madd(acc, pts96_load(pts, e & 0x7fffffffu, (e >> 31) != 0)));
+            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
         }
         acc = wave_sum(acc);
         if (threadIdx.x == 0) p40_store(seg_sums, item, acc);
@@ -1054,7 +1050,7 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 // One bucket-method pass over at most MSM_PASS_MAX terms.
 static int32_t msm_partial_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     R = ge_identity();
-    int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * 96 + 256);
+    int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256);
     if (r) return r;
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     uint32_t *d_bad = (uint32_t *)ctx->d_flag;
@@ -1144,7 +1140,7 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
-    if ((r = ctx_reserve(ctx, ctx->tmp_e, m * 96 + 256))) return r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
     // tmp_f: hram (64n) | z16 (16n) | msm scalars (32m) | leaf/tree (64n + 64n/16 + ..) | partial sums
     const unsigned nblk = div_up64(n, 256);
     size_t off = 0;

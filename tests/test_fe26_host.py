@@ -156,6 +156,13 @@ def test_point_formulas_vs_oracle(host, orc):
         qh = to_host(q)
         assert call(host, "h_ge_compress", call(host, "h_ge_madd", ah, qh, C.c_int(0), out=128)) == orc.ed_compress(orc.ed_add(ao, q))
         assert call(host, "h_ge_compress", call(host, "h_ge_madd", ah, qh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, q))
+        assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", ah, qh, C.c_int(0), out=128)) == orc.ed_compress(orc.ed_add(ao, q))
+        assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", ah, qh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, q))
+        # chained: the output of the signed form feeds the next addition (bounds of the next fe_mul operands)
+        acc = ah
+        for i in range(20):
+            acc = call(host, "h_ge_madd_signed", acc, qh, C.c_int(i & 1), out=128)
+        assert call(host, "h_ge_compress", acc, out=32) == orc.ed_compress(ao)
         for (bo, bh) in pts[8:11]:
             assert call(host, "h_ge_compress", call(host, "h_ge_add_cached_signed", ah, bh, C.c_int(0), out=128)) == orc.ed_compress(orc.ed_add(ao, bo))
             assert call(host, "h_ge_compress", call(host, "h_ge_add_cached_signed", ah, bh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, bo))
@@ -163,6 +170,7 @@ def test_point_formulas_vs_oracle(host, orc):
     ident = to_host(orc.ed_identity())
     for neg in (0, 1):
         assert call(host, "h_ge_compress", call(host, "h_ge_madd", pts[0][1], ident, C.c_int(neg), out=128)) == orc.ed_compress(pts[0][0])
+        assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", pts[0][1], ident, C.c_int(neg), out=128)) == orc.ed_compress(pts[0][0])
     # a long chain (the reference's overflow hunt, edwards.rs:2254-2261): 300 chained doublings+adds
     acc_h, acc_o = pts[0][1], pts[0][0]
     for i in range(300):
