@@ -482,6 +482,21 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
             if (i + 1 < hi) e_next = list[i + 1];
             acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
         }
+    } else if (PIPE == 3) {
+        // point i+1 AND index i+2 in flight during addition i: the gather of the next point never waits for its index
+        uint4 q[PTS_Q];
+        u32 e = 0, e1 = 0;
+        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+        if (lo + 1 < hi) e1 = list[lo + 1];
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            const ge_aniels A = pts_from_q(q);
+            const bool neg = (e >> 31) != 0;
+            e = e1;
+            if (i + 1 < hi) { const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+            if (i + 2 < hi) e1 = list[i + 2];
+            acc = ge_madd_signed_p3(acc, A, neg);
+        }
     } else {
         uint4 q[PTS_Q];
         u32 e = 0;
@@ -952,8 +967,8 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     static int groups = -1;   // tuning knob: C25519_MSM_GROUPS = 1 | 2
     if (groups < 0) { const char *e = getenv("C25519_MSM_GROUPS"); groups = e ? atoi(e) : 1; if (groups != 2) groups = 1; }   // measured: 2 groups cost more (two kernel tails) than the overlap returns
     const int G = (groups == 2 && g.nwin >= 8 && n >= 65536) ? 2 : 1;
-    static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2
-    if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 2; if (pipe < 0 || pipe > 2) pipe = 2; }
+    static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2 | 3 (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
+    if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 3; if (pipe < 0 || pipe > 3) pipe = 3; }
     long_item *items = (long_item *)(ws + oLI);
     uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS);
     uint32_t *bufs[2] = {(uint32_t *)(ws + oR0), (uint32_t *)(ws + oR1)};
@@ -976,6 +991,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
         HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
         if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
         else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
+        else if (pipe == 3) hipLaunchKernelGGL(k_accumulate<3>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
         else hipLaunchKernelGGL(k_accumulate<2>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
         if (grp == G - 1 && ring) HIPCHK(hipEventRecord(ring[1], st));
