@@ -270,7 +270,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL
     if (tid == 1023) { bin_base[(u64)k * (SL + 1) + SL] = part[1023]; base[(u64)k * (g.half + 1) + g.half] = part[1023]; }
 }
 // pass 1: chunk j of window k -> runs per slice in P1[k][..]
-__global__ void __launch_bounds__(1024) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
+__global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
     extern __shared__ u32 sm[];
     u32 *cnt = sm;                         // [16][SL]: per-wave counts, then per-wave cursors
     u32 *ls = sm + 16 * SL;                // [SL + 1]: start of each slice in the staging buffer
@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(1024) k_part1(const uint16_t *__restrict__ D, 
 // pass 2: bin (window k, slice s) -> final order, bucket totals and bucket offsets.  The bin's entries live in
 // registers (18 per thread), LDS holds only the sorted copy: 74 KB per block, two blocks per CU.
 constexpr int PART_R = PART_CAP / 1024;
-__global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
+__global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
                                                 u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted) {
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS, *out = sm + 2 * PART_BPS;

@@ -58,7 +58,7 @@ typedef struct c25519_ctx c25519_ctx;
  * EdwardsBasepointTable (edwards.rs:1131-1141, :1246-1282) sized for the 160 KiB LDS;
  * 9: signed 9-tooth x 6-table comb in LDS (31 additions + 4 doublings per scalar, 147 KB);
  * 10 .. 20: the EdwardsBasepointTable structure with radix 2^w and the table in HBM, served by L2 / MALL:
- * ceil(256/w) additions with one 96-byte gather each, no doublings (table 1.2 MB at w = 10, 53 MB at w = 16);
+ * ceil(256/w) additions with one 128-byte gather each, no doublings (table 1.7 MB at w = 10, 71 MB at w = 16);
  * 0 (default) = 16.  The table is computed on the device when the context is created.  Returns NULL
  * if there is no usable GPU: there is NO CPU fallback. */
 c25519_ctx *c25519_ctx_create(int device, uint32_t flags);
