@@ -177,6 +177,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
+    if (hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
     int w = (int)(flags & 0x1f);
     const int wide = (w >= 10 && w <= 20) ? w : (w == 0 ? 16 : 0);   // default: radix 2^16 (measured best table size / speed point)
     ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position LDS window tables; 9: signed comb (also bootstraps the wide table)
@@ -213,6 +214,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_fork2) hipEventDestroy(ctx->ev_fork2);
     if (ctx->ev_join2) hipEventDestroy(ctx->ev_join2);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->h_msm) hipHostFree(ctx->h_msm);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventDestroy(ctx->ring[i][j]);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;

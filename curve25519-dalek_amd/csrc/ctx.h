@@ -23,6 +23,7 @@ struct c25519_ctx {
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_sort = nullptr;
     void *h_pinned = nullptr; size_t h_pinned_cap = 0;   // pinned host staging for small read-backs
+    void *h_msm = nullptr;                               // 20 KB pinned: window totals + flags of msm_core
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
     devbuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
     std::string err;

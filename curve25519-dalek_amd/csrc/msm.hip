@@ -864,7 +864,8 @@ static int pick_window(uint64_t n) {
 // sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are enqueued
 // (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
 // second stream while the main stream still prepares the points; msm_core joins the two itself.
-int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream) {
+int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream,
+                 void *extra_dst, const void *extra_src, size_t extra_bytes) {
     msm_geom g;
     g.c = pick_window(n);
     g.half = 1 << (g.c - 1);
@@ -1024,15 +1025,18 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     HIPCHK(hipGetLastError());
     if (G == 2) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join2, 0));
     // window totals -> host, Horner fold (pippenger.rs:159)
-    std::vector<uint32_t> hS((size_t)g.nwin * 40), hP((size_t)g.nwin * 40);
-    uint32_t hflags[2] = {0, 0};
+    // (pinned staging: three small copies queue back to back instead of three staged pageable copies)
+    static_assert((size_t)MSM_MAX_WIN * 160 * 2 + 64 <= 20 * 1024, "h_msm too small");
+    uint32_t *hS = (uint32_t *)ctx->h_msm, *hP = hS + (size_t)MSM_MAX_WIN * 40, *hflags = hP + (size_t)MSM_MAX_WIN * 40;
+    hflags[0] = hflags[1] = 0;
     const bool haveP = !plan.empty();
     for (int grp = 0; grp < G; grp++) {
         const int k0 = k_lo[grp], nw = k_lo[grp + 1] - k0;
-        HIPCHK(hipMemcpyAsync(hS.data() + (size_t)k0 * 40, S_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
-        if (haveP) HIPCHK(hipMemcpyAsync(hP.data() + (size_t)k0 * 40, P_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(hS + (size_t)k0 * 40, S_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
+        if (haveP) HIPCHK(hipMemcpyAsync(hP + (size_t)k0 * 40, P_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
     }
     HIPCHK(hipMemcpyAsync(hflags, flags, 8, hipMemcpyDeviceToHost, st));
+    if (extra_bytes) HIPCHK(hipMemcpyAsync(extra_dst, extra_src, extra_bytes, hipMemcpyDeviceToHost, st));
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     HIPCHK(hipStreamSynchronize(st));
     if (hflags[0]) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
@@ -1225,10 +1229,8 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     HIPCHK(hipMemcpyAsync(msc, bw, 32, hipMemcpyHostToDevice, sa));
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     ge_p3 R;
-    r = msm_core(ctx, msc, m, d_pts, R, ring, sa);
+    r = msm_core(ctx, msc, m, d_pts, R, ring, sa, cnt, d_cnt, 16);      // the decode / canonical-s counters ride along with the last copy
     if (r != C25519_OK) return r;
-    HIPCHK(hipMemcpyAsync(cnt, d_cnt, 16, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
     if (cnt[0]) return C25519_NONE;                     // a key that VerifyingKey::from_bytes rejects
     if (cnt[2]) return C25519_SCALAR_FORMAT;            // batch.rs:208-211
     if (cnt[1]) return C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
