@@ -700,19 +700,29 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
     for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
-// device z-mode.  Tree nodes are 32 bytes (the first half of a SHA-512 digest: 128-bit collision resistance, the
-// level of the 128-bit z_i themselves), which halves the hashing and the latency of the narrow upper levels.
-// step 1: first level straight over the signatures -- hram_i = H(R_i || A_i || M_i) already commits to
-// (R_i, A_i, M_i), so node_j = SHA-512(hram_16j[0..32] || s_16j || ... || hram_16j+15[0..32] || s_16j+15 || LE64(n))
-// binds every batch input with 9/16 compressions per signature (absent children = zero bytes; position = place)
+// device z-mode.  The z_i must depend on every input bit of the batch (a per-signature or per-subtree derivation
+// allows a 2^64 meet-in-the-middle forgery), so they are derived from the root of a hash tree over the batch.  The tree
+// is built from the SHA-512 COMPRESSION FUNCTION on fixed-size inputs -- no length padding, hence no extra padding
+// block per node -- with the node's level and the level's node count folded into the chaining value (domain separation
+// and shape binding); nodes are the first 32 bytes of the output (128-bit collision resistance, the level of the z_i).
+// A tree of fixed shape over a collision-resistant compression function is binding, which is all that is needed.
+//   level 0: node_j = F_0(hram_16j[0..32] || s_16j || ... || hram_16j+15[0..32] || s_16j+15): 8 chained blocks per 16
+//            signatures; hram_i = H(R_i || A_i || M_i) already commits to (R_i, A_i, M_i).  Throughput-bound.
+//   level l: node_j = F_l(four children): ONE compression per node.  These levels are pure latency (one dependent
+//            SHA-512 compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
+__device__ __forceinline__ void ztree_iv(u64 hs[8], u32 level, u64 count) {
+    sha512_init(hs);
+    hs[0] ^= 0x7a5f747265650000ull | level;           // "z_tree" || level
+    hs[1] ^= count;                                    // number of nodes of the level being consumed
+}
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (n + 15) / 16;
     if (j >= m_out) return;
     u64 hs[8], w[16];
-    sha512_init(hs);
+    ztree_iv(hs, 0u, n);
 #pragma unroll 1
-    for (int blk = 0; blk < 8; blk++) {                   // 2 children x 64 B per block
+    for (int blk = 0; blk < 8; blk++) {                   // 2 signatures x 64 B per block (absent = zero bytes)
 #pragma unroll
         for (int half = 0; half < 2; half++) {
             const u64 c = 16 * j + 2 * blk + half;
@@ -722,38 +732,49 @@ __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__
         }
         sha512_compress(hs, w);
     }
-    w[0] = bswap64(n); w[1] = 0x8000000000000000ull;
-    for (int q = 2; q < 15; q++) w[q] = 0;
-    w[15] = (u64)(1024 + 8) * 8;
-    sha512_compress(hs, w);
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
-    for (int q = 0; q < 4; q++) o[q] = bswap64(hs[q]);
+    for (int q = 0; q < 4; q++) o[q] = hs[q];
 }
-// step 2: upper 16-ary Merkle levels: out[j] = SHA-512(in[16j] || ... || in[16j+15] || LE64(m_in))[0..32]
-__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, uint8_t *__restrict__ out) {
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 m_out = (m_in + 15) / 16;
-    if (j >= m_out) return;
-    // message = 16 children x 32 bytes (absent children = zero bytes) || LE64(m_in): 4 full blocks + 1
+// one 4-ary level: out[j] = F_level(in[4j] || in[4j+1] || in[4j+2] || in[4j+3])[0..32]
+__device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, u32 level, u64 *out4) {
     u64 hs[8], w[16];
-    sha512_init(hs);
-#pragma unroll 1
-    for (int blk = 0; blk < 4; blk++) {
+    ztree_iv(hs, level, m_in);
 #pragma unroll
-        for (int ch = 0; ch < 4; ch++) {
-            const u64 c = 16 * j + 4 * blk + ch;
-            const u64 *h = reinterpret_cast<const u64 *>(in) + 4 * c;
+    for (int ch = 0; ch < 4; ch++) {
+        const u64 c = 4 * j + ch;
 #pragma unroll
-            for (int q = 0; q < 4; q++) w[4 * ch + q] = c < m_in ? bswap64(h[q]) : 0ull;
-        }
-        sha512_compress(hs, w);
+        for (int q = 0; q < 4; q++) w[4 * ch + q] = c < m_in ? in[4 * c + q] : 0ull;
     }
-    w[0] = bswap64(m_in); w[1] = 0x8000000000000000ull;
-    for (int q = 2; q < 15; q++) w[q] = 0;
-    w[15] = (u64)(512 + 8) * 8;
     sha512_compress(hs, w);
+    for (int q = 0; q < 4; q++) out4[q] = hs[q];
+}
+__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, uint8_t *__restrict__ out) {
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (m_in + 3) / 4) return;
+    u64 r[4];
+    ztree_node4(reinterpret_cast<const u64 *>(in), m_in, j, level, r);
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
-    for (int q = 0; q < 4; q++) o[q] = bswap64(hs[q]);
+    for (int q = 0; q < 4; q++) o[q] = r[q];
+}
+// the last levels (m_in <= 1024 nodes) in ONE block: no launch gaps between levels that hold a handful of nodes
+__global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, uint8_t *__restrict__ root) {
+    __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
+    for (u64 i = threadIdx.x; i < m_in * 4; i += 256) buf0[i] = reinterpret_cast<const u64 *>(in)[i];
+    __syncthreads();
+    u64 *cur = buf0, *nxt = buf1;
+    u64 m = m_in;
+    while (m > 1) {
+        const u64 mo = (m + 3) / 4;                                  // <= 256 = blockDim
+        if (threadIdx.x < mo) {
+            u64 r[4];
+            ztree_node4(cur, m, threadIdx.x, level, r);
+            for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = r[q];
+        }
+        __syncthreads();
+        u64 *t = cur; cur = nxt; nxt = t;
+        m = mo; level++;
+    }
+    if (threadIdx.x < 4) reinterpret_cast<u64 *>(root)[threadIdx.x] = cur[threadIdx.x];
 }
 // step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)); n4 = ceil(n/4) lanes,
 // z16 has room for 4*n4 entries
@@ -808,6 +829,35 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
         __syncthreads();
     }
     if (threadIdx.x == 0) for (int j = 0; j < 5; j++) partial[(u64)blockIdx.x * 5 + j] = red[0][j];
+}
+
+// msm_scalars[0] = -(sum of the per-block partial sums) mod l: one block, strided sums then a tree
+__global__ void __launch_bounds__(256) k_bsum_finish(const u64 *__restrict__ partial, u32 nblk, uint8_t *__restrict__ msm_scalars) {
+    __shared__ u64 red[256][5];
+    sc52 acc = sc_zero();
+    for (u32 b = threadIdx.x; b < nblk; b += 256) {
+        sc52 p;
+        for (int j = 0; j < 5; j++) p.v[j] = partial[(u64)b * 5 + j];
+        acc = sc_add(acc, p);
+    }
+    for (int j = 0; j < 5; j++) red[threadIdx.x][j] = acc.v[j];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sc52 a, b;
+            for (int j = 0; j < 5; j++) { a.v[j] = red[threadIdx.x][j]; b.v[j] = red[threadIdx.x + off][j]; }
+            a = sc_add(a, b);
+            for (int j = 0; j < 5; j++) red[threadIdx.x][j] = a.v[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sc52 t;
+        for (int j = 0; j < 5; j++) t.v[j] = red[0][j];
+        u32 w[8];
+        sc_to_words(sc_neg(t), w);
+        store8(msm_scalars, 0, w);
+    }
 }
 
 hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st) {
@@ -1199,34 +1249,31 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
         HIPCHK(hipStreamSynchronize(sa));
     } else {
         uint64_t mm = (n + 15) / 16; uint8_t *a = t0, *b = t1;
+        uint32_t level = 1;
         hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, a);
-        while (mm > 1) {
-            uint64_t mo = (mm + 15) / 16;
-            hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, b);
-            mm = mo; std::swap(a, b);
+        while (mm > 1024) {
+            uint64_t mo = (mm + 3) / 4;
+            hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, b);
+            mm = mo; level++; std::swap(a, b);
         }
+        hipLaunchKernelGGL(k_ztree_tail, dim3(1), dim3(256), 0, sa, a, mm, level, b);      // leaves the 32-byte root at b
+        std::swap(a, b);
         hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, a, (n + 3) / 4, z16);
         HIPCHK(hipGetLastError());
     }
     hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hram, d_sigs, z16, n, msc, partial);
     HIPCHK(hipGetLastError());
-    // pinned staging: [partial sums nblk x 40 B][counters 16 B]
-    size_t need = (size_t)nblk * 40 + 64;
-    if (ctx->h_pinned_cap < need) {
+    // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block on
+    // the device, so the host does not have to wait for chain (A) before it can enqueue the MSM
+    hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
+    HIPCHK(hipGetLastError());
+    if (ctx->h_pinned_cap < 64) {
         if (ctx->h_pinned) HIPCHK(hipHostFree(ctx->h_pinned));
         ctx->h_pinned = nullptr; ctx->h_pinned_cap = 0;
-        HIPCHK(hipHostMalloc(&ctx->h_pinned, need + need / 4, hipHostMallocDefault));
-        ctx->h_pinned_cap = need + need / 4;
+        HIPCHK(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
+        ctx->h_pinned_cap = 4096;
     }
-    uint64_t *hp = (uint64_t *)ctx->h_pinned;
-    uint32_t *cnt = (uint32_t *)((uint8_t *)ctx->h_pinned + (size_t)nblk * 40);
-    HIPCHK(hipMemcpyAsync(hp, partial, (size_t)nblk * 40, hipMemcpyDeviceToHost, sa));
-    HIPCHK(hipStreamSynchronize(sa));                  // chain (A) done: z_i and z_i*h_i are in place
-    sc52 bsum = sc_zero();
-    for (unsigned b = 0; b < nblk; b++) { sc52 p; for (int j = 0; j < 5; j++) p.v[j] = hp[(size_t)b * 5 + j]; bsum = sc_add(bsum, p); }
-    u32 bw[8];
-    sc_to_words(sc_neg(bsum), bw);                       // -sum z_i s_i (batch.rs:240)
-    HIPCHK(hipMemcpyAsync(msc, bw, 32, hipMemcpyHostToDevice, sa));
+    uint32_t *cnt = (uint32_t *)ctx->h_pinned;          // pinned staging of the three counters
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     ge_p3 R;
     r = msm_core(ctx, msc, m, d_pts, R, ring, sa, cnt, d_cnt, 16);      // the decode / canonical-s counters ride along with the last copy
