@@ -48,7 +48,7 @@ extern "C" {
 
 /* ed25519_verify_batch z_mode: how the 128-bit batch coefficients z_i are derived */
 #define C25519_Z_TRANSCRIPT 0 /* byte-for-byte the reference's Merlin/STROBE transcript (batch.rs:168-222), host-sequential */
-#define C25519_Z_DEVICE 1     /* per-signature SHA-512 counter mode keyed by a digest of the whole batch, on device */
+#define C25519_Z_DEVICE 1     /* 127-bit z_i = SHA-512(root || counter) on the device, root = hash tree over every (H(R||A||M), s) of the batch */
 
 typedef struct c25519_ctx c25519_ctx;
 
