@@ -136,24 +136,24 @@ static int32_t build_wide_table(c25519_ctx *ctx, int C) {
         }
         for (int k = 0; k < C; k++) p2 = sc_add(p2, p2);
     }
-    uint8_t *d_sc = nullptr, *d_raw = nullptr;
-    uint32_t *d_wide = nullptr;
-    HIPCHK(hipMalloc(&d_sc, N * 32));
-    HIPCHK(hipMalloc(&d_raw, N * 160));
-    HIPCHK(hipMalloc(&d_wide, N * 128));       // one 128-byte limb entry per table slot: the MSM's point format (devio.h pts_store)
-    HIPCHK(hipMemcpyAsync(d_sc, sc.data(), N * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(launch_mul_base(ctx->w, d_sc, N, ctx->d_table, nullptr, d_raw, ctx->num_cus, ctx->stream));
-    int32_t r = prep_points(ctx, d_raw, N, C25519_FMT_RAW160, d_wide, 0, (uint32_t *)ctx->d_flag);
+    struct tmp { void *p = nullptr; ~tmp() { if (p) hipFree(p); } } t_sc, t_raw, t_wide;     // freed on every path
+    HIPCHK(hipMalloc(&t_sc.p, N * 32));
+    HIPCHK(hipMalloc(&t_raw.p, N * 160));
+    HIPCHK(hipMalloc(&t_wide.p, N * 128));     // one 128-byte limb entry per table slot: the MSM's point format (devio.h pts_store)
+    HIPCHK(hipMemcpyAsync(t_sc.p, sc.data(), N * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(launch_mul_base(ctx->w, (const uint8_t *)t_sc.p, N, ctx->d_table, nullptr, (uint8_t *)t_raw.p, ctx->num_cus, ctx->stream));
+    int32_t r = prep_points(ctx, (const uint8_t *)t_raw.p, N, C25519_FMT_RAW160, (uint32_t *)t_wide.p, 0, (uint32_t *)ctx->d_flag);
     if (r) return r;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipFree(d_sc));
-    HIPCHK(hipFree(d_raw));
+    if (ctx->prefix.p) { hipFree(ctx->prefix.p); ctx->prefix.p = nullptr; ctx->prefix.cap = 0; }    // the normaliser's scratch (48 B per entry)
     HIPCHK(hipFree(ctx->d_table));
-    ctx->d_table = d_wide;
+    ctx->d_table = (uint32_t *)t_wide.p;
+    t_wide.p = nullptr;
     ctx->w = C;
     return C25519_OK;
 }
 
+EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
 EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
@@ -165,19 +165,19 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     ctx->device = device;
     ctx->flags = flags;
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
     ctx->num_cus = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fprintf(stderr, "c25519_ctx_create: warning: device arch %s, kernels are built for gfx950 only\n", prop.gcnArchName);
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
     ctx->own_stream = true;
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
-    if (hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) != hipSuccess) { delete ctx; return nullptr; }
+    if (hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
     int w = (int)(flags & 0x1f);
     const int wide = (w >= 10 && w <= 20) ? w : (w == 0 ? 16 : 0);   // default: radix 2^16 (measured best table size / speed point)
     ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position LDS window tables; 9: signed comb (also bootstraps the wide table)
@@ -187,7 +187,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
         hipMemcpy(ctx->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->d_flag, 256) != hipSuccess) {
         fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
-        delete ctx;
+        c25519_ctx_destroy(ctx);
         return nullptr;
     }
     if (wide && build_wide_table(ctx, wide) != C25519_OK) {
@@ -201,12 +201,13 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
     devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->d_table) hipFree(ctx->d_table);
     if (ctx->d_flag) hipFree(ctx->d_flag);
-    hipEventDestroy(ctx->ev0); hipEventDestroy(ctx->ev1);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->aux) { hipStreamSynchronize(ctx->aux); hipStreamDestroy(ctx->aux); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
@@ -215,8 +216,8 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_join2) hipEventDestroy(ctx->ev_join2);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
-    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventDestroy(ctx->ring[i][j]);
-    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);
+    if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
