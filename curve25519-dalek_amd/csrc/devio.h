@@ -142,4 +142,10 @@ __device__ __forceinline__ feT raw160_fe(const uint8_t *in, u64 idx, int which) 
     return fe_from_limbs51(l);
 }
 
+// Z of a raw point stored as exactly (1, 0, 0, 0, 0): what CompressedEdwardsY::decompress leaves (edwards.rs:256)
+__device__ __forceinline__ bool raw160_z_is_one(const uint8_t *in, u64 idx) {
+    const u64 *p = reinterpret_cast<const u64 *>(in + idx * 160 + 80);
+    return (p[0] == 1) & ((p[1] | p[2] | p[3] | p[4]) == 0);
+}
+
 }  // namespace c25519

@@ -62,16 +62,20 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     feT acc = fe_one();
+    bool affine = true;                 // every Z of this lane is literally 1 (points straight from a decompression,
+                                        // e.g. VerifyingKey.point): the shared inversion is skipped
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
         u64 idx = t + (u64)j * T;
         if (idx >= n) break;
+        affine = affine && raw160_z_is_one(in, idx);
         uint4 *q = reinterpret_cast<uint4 *>(prefix) + 3 * idx;
         q[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]); q[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
         q[2] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
         acc = fe_mul(acc, raw160_fe(in, idx, 2));
     }
-    feT inv = fe_invert(acc);
+    feT inv = fe_one();
+    if (!affine) inv = fe_invert(acc);
 #pragma unroll 1
     for (int j = CH - 1; j >= 0; j--) {
         u64 idx = t + (u64)j * T;
