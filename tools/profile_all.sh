@@ -28,7 +28,7 @@ for w in fixed_base verify x25519 msm; do
   i=0
   for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS GRBM_GUI_ACTIVE" "VALUBusy" "OccupancyPercent" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
     i=$((i+1))
-    timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $RAW/pmc_${w}_$i -o p -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $RAW/pmc_${w}_$i.log 2>&1
+    C25519_BENCH_PROBES=2 timeout 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $RAW/pmc_${w}_$i -o p -- python $R/bench.py --workload $w --steps 3 --warmup 1 --no-cpu-baseline > $RAW/pmc_${w}_$i.log 2>&1
   done
   python $R/tools/pmc_summary.py $RAW/pmc_${w}_* > $OUT/${TAG}_${w}_pmc.txt 2>&1
 done
