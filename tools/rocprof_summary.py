@@ -12,11 +12,13 @@ def main(path):
     rows = cur.execute(
         "select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3, "
         "max(vgpr_count), max(lds_size), max(grid_x), max(workgroup_x) from kernels group by name order by 3 desc").fetchall()
-    tot = sum(r[2] for r in rows) or 1.0
+    # the clock warm-up / roofline probes of bench.py (k_probe_*) are listed but kept out of the share column
+    tot = sum(r[2] for r in rows if "k_probe_" not in r[0]) or 1.0
     print("# %s" % path)
     print("%-72s %6s %12s %10s %10s %10s %6s %5s %7s %9s %5s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "share", "vgpr", "lds_B", "grid_x", "wg_x"))
     for r in rows:
-        print("%-72s %6d %12.1f %10.1f %10.1f %10.1f %5.1f%% %5d %7d %9d %5d" % (r[0][:72], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
+        share = "  probe" if "k_probe_" in r[0] else "%5.1f%%" % (100 * r[2] / tot)
+        print("%-72s %6d %12.1f %10.1f %10.1f %10.1f %s %5d %7d %9d %5d" % (r[0][:72], r[1], r[2], r[3], r[4], r[5], share, r[6] or 0, r[7] or 0, r[8] or 0, r[9] or 0))
 
 
 if __name__ == "__main__":
