@@ -1,0 +1,43 @@
+/* The C ABI from plain C (C11, gcc): proves include/c25519_hip.h is a C header and that the library can be driven
+ * without Python or C++.  RFC 7748 section 6.1 (Alice/Bob) through c25519_x25519_batch, 8 * B through
+ * c25519_mul_base_batch against the reference's BASE8 constant source (edwards.rs test module), and a 3-term MSM.
+ * Exit code 0 = all good.  Built and run by tests/test_gpu_abi_c.py. */
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/c25519_hip.h"
+
+static int hex2bin(const char *h, uint8_t *out, size_t n) {
+    for (size_t i = 0; i < n; i++) { unsigned v; if (sscanf(h + 2 * i, "%2x", &v) != 1) return -1; out[i] = (uint8_t)v; }
+    return 0;
+}
+
+int main(void) {
+    c25519_ctx *ctx = c25519_ctx_create(0, 0);
+    if (!ctx) { fprintf(stderr, "no context\n"); return 2; }
+    /* RFC 7748 6.1 */
+    uint8_t k[2][32], u[2][32], out[2][32], want[32];
+    hex2bin("77076d0a7318a57d3c16c17251b26645df4c2f87ebc0992ab177fba51db92c2a", k[0], 32);   /* Alice private */
+    hex2bin("5dab087e624a8a4b79e17f8b83800ee66f3bb1292618b6fd1c2f8b27ff88e0eb", k[1], 32);   /* Bob private   */
+    hex2bin("de9edb7d7b7dc1b4d35b61c2ece435373f8343c85b78674dadfc7e146f882b4f", u[0], 32);   /* Bob public    */
+    hex2bin("8520f0098930a754748b7ddcb43ef75a0dbf3a0d26381af4eba4a98eaa9b4e6a", u[1], 32);   /* Alice public  */
+    hex2bin("4a5d9d5ba4ce2de1728e3bf480350f25e07e21c947d19e3376f09b3c1e161742", want, 32);   /* shared secret */
+    if (c25519_x25519_batch(ctx, &k[0][0], &u[0][0], 2, &out[0][0]) != C25519_OK) { fprintf(stderr, "x25519: %s\n", c25519_last_error(ctx)); return 3; }
+    if (memcmp(out[0], want, 32) || memcmp(out[1], want, 32)) { fprintf(stderr, "x25519 mismatch\n"); return 4; }
+    /* fixed base: scalars 1 and 8; 1 * B must be the basepoint encoding 5866...66 */
+    uint8_t s[2][32] = {{1}, {8}}, enc[2][32], bp[32];
+    memset(bp, 0x66, 32); bp[0] = 0x58;
+    if (c25519_mul_base_batch(ctx, &s[0][0], 2, C25519_FMT_EDWARDS_Y, &enc[0][0]) != C25519_OK) return 5;
+    if (memcmp(enc[0], bp, 32)) { fprintf(stderr, "1*B mismatch\n"); return 6; }
+    /* MSM: 3*B + 5*B == 8*B, points given compressed */
+    uint8_t sc[2][32] = {{3}, {5}}, pts[2][32], sum[32];
+    memcpy(pts[0], bp, 32); memcpy(pts[1], bp, 32);
+    if (c25519_msm_vartime(ctx, &sc[0][0], &pts[0][0], 2, C25519_FMT_EDWARDS_Y, C25519_FMT_EDWARDS_Y, sum) != C25519_OK) return 7;
+    if (memcmp(sum, enc[1], 32)) { fprintf(stderr, "msm mismatch\n"); return 8; }
+    /* an encoding that is not on the curve -> NONE, like Option::None of optional_multiscalar_mul */
+    memset(pts[1], 0, 32); pts[1][0] = 2;
+    if (c25519_msm_vartime(ctx, &sc[0][0], &pts[0][0], 2, C25519_FMT_EDWARDS_Y, C25519_FMT_EDWARDS_Y, sum) != C25519_NONE) return 9;
+    c25519_ctx_destroy(ctx);
+    printf("abi_c_smoke ok\n");
+    return 0;
+}
