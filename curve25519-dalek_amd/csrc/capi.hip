@@ -255,17 +255,22 @@ EXPORT float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase) {
 // ---- fixed base --------------------------------------------------------------------------------
 EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
-    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_base: out_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RISTRETTO && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_base: out_fmt must be 0, 1 or 2"; return -(int32_t)hipErrorInvalidValue; }
     if (out_fmt == C25519_FMT_EDWARDS_Y) {
         int32_t r;
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     }
+    if (out_fmt == C25519_FMT_RISTRETTO) { int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256); if (r) return r; }
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     if (out_fmt == C25519_FMT_RAW160) {
         HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, nullptr, d_out, ctx->num_cus, ctx->stream));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    } else if (out_fmt == C25519_FMT_RISTRETTO) {         // RistrettoBasepointTable * scalar, then RistrettoPoint::compress (ristretto.rs:500-533)
+        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, nullptr, (uint8_t *)ctx->tmp_e.p, ctx->num_cus, ctx->stream));
+        HIPCHK(hipEventRecord(ring[1], ctx->stream));
+        HIPCHK(launch_compress_ristretto((const uint8_t *)ctx->tmp_e.p, n, d_out, ctx->stream));
     } else {
         HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));

@@ -160,6 +160,9 @@ def test_ristretto_vs_oracle(eng, orc, golden):
     got = eng.compress_batch(raw, out_fmt=1)
     for i in range(200):
         assert got[i].tobytes() == orc.ris_compress(orc.ed_mul_base(s[i].tobytes()))
+    # RistrettoBasepointTable * scalar in one call (out_fmt = 1): the sage table and the composed path
+    assert np.array_equal(eng.mul_base_batch(sc, out_fmt=1), encs)
+    assert np.array_equal(eng.mul_base_batch(s, out_fmt=1), got)
 
 
 def test_to_montgomery_batch_vs_oracle(eng, orc):
