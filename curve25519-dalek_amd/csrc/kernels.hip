@@ -289,6 +289,23 @@ __global__ void __launch_bounds__(256) k_decompress_ristretto(const uint8_t *__r
     if (!good) atomicOr(any_bad, 1u);
 }
 // ================================================================================================
+// MSM / verify_batch input preparation for compressed points (msm.hip prep_points)
+// ================================================================================================
+// compressed (Edwards y / Ristretto) -> packed affine Niels at pts[dst0 + i]; bad encodings counted
+template <int FMT>
+__global__ void __launch_bounds__(256) k_prep_compressed(const uint8_t *__restrict__ in, u64 stride_items, u64 n, u32 *__restrict__ pts,
+                                                         u64 dst0, u32 *__restrict__ bad_count) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 w[8];
+    load8(in, i * stride_items, w);     // stride 1 for point arrays, 2 to pick R out of 64-byte signatures
+    ge_p3 P;
+    bool ok = (FMT == 0) ? ge_decompress(P, w) : ris_decompress(P, w);
+    pts_store(pts, dst0 + i, P.X, P.Y);
+    if (!ok) atomicAdd(bad_count, 1u);
+}
+
+// ================================================================================================
 // Integer-multiplier roofline probes (c25519_microbench)
 // ================================================================================================
 __global__ void __launch_bounds__(256) k_probe_mad(u32 *out, int iters, u32 seed) {
@@ -507,6 +524,13 @@ hipError_t launch_decompress_ristretto(const uint8_t *in, u64 n, uint8_t *out_ra
 }
 
 
+
+hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (fmt == 0) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up(n, 256)), dim3(256), 0, st, in, stride_items, n, pts, dst0, bad_count);
+    else hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up(n, 256)), dim3(256), 0, st, in, stride_items, n, pts, dst0, bad_count);
+    return hipGetLastError();
+}
 
 hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipStream_t st) {
     switch (which) {

@@ -43,19 +43,8 @@ namespace c25519 {
 // ================================================================================================
 // prep kernels
 // ================================================================================================
-// compressed (Edwards y / Ristretto) -> packed affine Niels at pts[dst0 + i]; bad encodings counted
-template <int FMT>
-__global__ void __launch_bounds__(256) k_prep_compressed(const uint8_t *__restrict__ in, u64 stride_items, u64 n, u32 *__restrict__ pts,
-                                                         u64 dst0, u32 *__restrict__ bad_count) {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    u32 w[8];
-    load8(in, i * stride_items, w);     // stride 1 for point arrays, 2 to pick R out of 64-byte signatures
-    ge_p3 P;
-    bool ok = (FMT == 0) ? ge_decompress(P, w) : ris_decompress(P, w);
-    pts_store(pts, dst0 + i, P.X, P.Y);
-    if (!ok) atomicAdd(bad_count, 1u);
-}
+// (compressed inputs: k_prep_compressed lives in kernels.hip -- a 252-squaring chain per lane at full occupancy wants
+// the chained-carry field arithmetic of that translation unit; launch_prep_compressed)
 // raw 160-byte points: Montgomery-trick normalisation, CH points per lane (cf. k_compress_p32)
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
@@ -1109,8 +1098,8 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
     hipStream_t st = ctx->stream;
     if (n == 0) return C25519_OK;
-    if (in_fmt == C25519_FMT_EDWARDS_Y) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up64(n, 256)), dim3(256), 0, st, d_points, (uint64_t)1, n, d_pts, dst0, d_badcount);
-    else if (in_fmt == C25519_FMT_RISTRETTO) hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up64(n, 256)), dim3(256), 0, st, d_points, (uint64_t)1, n, d_pts, dst0, d_badcount);
+    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, st));
+    else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, st));
     else if (in_fmt == C25519_FMT_RAW160) {
         int32_t r = ctx_reserve(ctx, ctx->prefix, n * 48);
         if (r) return r;
@@ -1237,8 +1226,8 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
     if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 0))) return r; }
-    else hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_pks, (uint64_t)1, n, d_pts, n + 1, d_cnt + 0);
-    hipLaunchKernelGGL(k_prep_compressed<0>, dim3(nblk), dim3(256), 0, st, d_sigs, (uint64_t)2, n, d_pts, (uint64_t)1, d_cnt + 1);
+    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 0, st));
+    HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 1, st));                 // R_i = the first half of every 64-byte signature
     // (A)
     hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, d_sigs, d_pks, n, hram, d_cnt + 2);
     HIPCHK(hipGetLastError());
