@@ -189,3 +189,26 @@ def test_verify_batch_with_cached_key_points(eng, orc):
     print("verify_batch 2^20 with cached key points: %.3f ms" % eng.last_kernel_ms())
     ds2 = ds.clone(); ds2[99, 7] ^= 1
     assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts) == VERIFY
+
+
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4097, 16385, 16400])
+def test_verify_batch_tree_boundaries(eng, orc, n):
+    """Batch sizes around the shapes of the z-derivation tree (16 signatures per first-level node, 4-ary upper levels,
+    <= 1024 nodes handled by the single-block tail) and of the block-wise scalar sums: honest batch Ok, one flipped bit
+    anywhere Err, in both z modes."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    lens = [(7 * i) % 61 for i in range(n)]                         # ragged messages, some empty, mostly unaligned
+    off = np.zeros(n + 1, dtype=np.int64); off[1:] = np.cumsum(lens)
+    dm = torch.randint(0, 256, (max(int(off[-1]), 1),), dtype=torch.uint8, device="cuda", generator=g)
+    doff = torch.from_numpy(off).cuda()
+    dp, ds = eng.sign_batch_t(seeds, dm, doff)
+    i = n // 2
+    m = dm[int(off[i]):int(off[i + 1])].cpu().numpy().tobytes()
+    assert orc.ed25519_verify(dp[i].cpu().numpy().tobytes(), m, ds[i].cpu().numpy().tobytes()) == 0
+    for z_mode in (1, 0):
+        assert eng.verify_batch_t(dm, doff, ds, dp, z_mode) == OK
+        for j in sorted({0, i, n - 1}):
+            bad = ds.clone(); bad[j, 9] ^= 0x10
+            assert eng.verify_batch_t(dm, doff, bad, dp, z_mode) == VERIFY
