@@ -218,3 +218,16 @@ def test_msm_maximally_skewed_digits(eng, orc, log2n):
     want2 = orc.ed_compress(orc.ed_mul(dP[0].cpu().numpy().tobytes(), i2b(s_int * n % L)))
     st, got = eng.msm_vartime_t(ds, same, in_fmt=2, out_fmt=0)
     assert st == 0 and got == want2
+
+
+@pytest.mark.parametrize("n", [65535, 65536, 65537, (1 << 17) + 3, (1 << 18) + 5, (1 << 19) - 3, (1 << 20) - 1, (3 << 20), (3 << 20) + 1])
+def test_msm_window_and_path_boundaries(eng, orc, n):
+    """Sizes at which the window width, the sort path (one-pass below 2^16 terms or c < 13, two-pass partition sort
+    above) and the pass splitting (above 3 * 2^20) change: sum-of-squares identity on device-generated points."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(77 + n)
+    dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dx[:, 31] &= 0x0F
+    draw = eng.mul_base_batch_t(dx, out_fmt=2)
+    st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
