@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
 }
 
 // ================================================================================================
-// K2c fixed-base batch, signed multi-table comb (the default): 31 mixed additions + 4 doublings per
+// K2c fixed-base batch, signed multi-table comb (context flags = 9; bootstraps the wide tables): 31 mixed additions + 4 doublings per
 //     scalar instead of 43 additions.
 //     With s' = s | 1 and c = (s' + 2^270 - 1)/2 = (s >> 1) + 2^269, s' = sum_{i<270} (2 c_i - 1) 2^i
 //     (every digit is +-1).  Bits are arranged in T = 9 teeth x D = 30 columns (bit i = tooth*30 + col);

@@ -5,17 +5,24 @@
 // buckets, running-sum bucket reduction, Horner fold over the digit columns).  The GPU version keeps
 // the algorithm and re-derives its schedule for a machine with 256 CUs and no cheap scatter-add:
 //
-//   prep      every point -> affine Niels (y+x, y-x, 2dxy), 96 B packed, so bucket accumulation is the
-//             7 M mixed addition (curve_models.rs:455) instead of the reference's 8 M re-addition
-//   digits    s' = s + sum_k HALF*2^(ck)  makes the signed digit of every window independent:
-//             d_k = window_k(s') - HALF (top window left unsigned, scalar.rs:1136-1147)
-//   sort      per window, counting sort of the term indices by bucket with LDS histograms
-//             (the scatter-add "buckets[b] += P" of pippenger.rs:122-136 becomes gather lists)
-//   accumulate one lane per (window, bucket): sequential mixed additions over its gather list
-//   reduce    sum_b (b+1) B_b by an 8-ary hierarchy of running sums (pippenger.rs:146-151 per segment)
-//   fold      total.mul_by_pow_2(w) + column (pippenger.rs:159) over <= 43 window sums: on the host,
-//             through the same ge26.h formulas (a serial chain of ~250 doublings is a latency-bound
-//             tail that a single CPU core finishes faster than a single GPU lane)
+//   prep      every point -> affine Niels (y+x, y-x, 2dxy) as a 128-byte limb record (one cache line per gather, nothing to
+//             unpack), so bucket accumulation is the 7 M mixed addition (curve_models.rs:455) instead of the reference's
+//             8 M re-addition; the sign of a digit is an operand swap in ge_madd_signed_p3
+//   digits    s' = s + sum_k HALF_k*2^(pos_k)  makes the signed digit of every window independent:
+//             d_k = window_k(s') - HALF_k; the 253 bits of a reduced scalar are shared out evenly over the windows
+//             (msm_geom), the top content window is unsigned, bits 253..255 get an (empty) window of their own
+//   sort      per window, counting sort of the term indices by bucket (the scatter-add "buckets[b] += P" of
+//             pippenger.rs:122-136 becomes gather lists): two-pass partition sort through LDS for wide windows,
+//             one-pass LDS histogram + sliced scatter for small inputs
+//   order     buckets sorted by list length, so that the lanes of a wave walk lists of equal length
+//   accumulate one lane per (window, bucket): sequential mixed additions over its gather list, next point and the
+//             index after it in flight; lists longer than LONG_CAP go to a wave-cooperative path on the second stream
+//   reduce    sum_b (b+1) B_b by an 8-ary hierarchy of running sums (pippenger.rs:146-151 per segment); the narrow
+//             upper levels use eight lanes per segment
+//   fold      total.mul_by_pow_2(w_k) + column (pippenger.rs:159) over the window sums: on the host, through the
+//             same ge26.h formulas (a serial chain of ~250 doublings is a latency-bound tail that a single CPU core
+//             finishes faster than a single GPU lane)
+//   passes    inputs beyond 3 * 2^20 terms are cut into passes of ~2^21 terms (the multi-GPU decomposition, in time)
 //
 // Window width c is chosen per call from n (reference: w = 6/7/8, pippenger.rs:81-87).
 #include <hip/hip_runtime.h>
