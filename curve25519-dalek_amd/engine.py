@@ -127,6 +127,8 @@ class Engine:
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible to PyTorch-ROCm: the engine has no CPU fallback")
         self.device = torch.device("cuda", device)
+        if window == 0:                       # test knob: run any caller against another fixed-base algorithm
+            window = int(os.environ.get("C25519_DEFAULT_WINDOW", "0"))
         self.ctx = self.lib.c25519_ctx_create(device, window & 0x1f)
         if not self.ctx:
             raise EngineError("c25519_ctx_create(%d) failed" % device)
