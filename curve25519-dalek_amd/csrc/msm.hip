@@ -910,6 +910,35 @@ static int pick_window(uint64_t n) {
     return c;
 }
 
+// window layout for n terms (see msm_geom): signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit
+// window, then bits 253..255
+static void msm_layout(uint64_t n, msm_geom &g) {
+    g.c = pick_window(n);
+    g.half = 1 << (g.c - 1);
+    const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
+    uint32_t a[9] = {0};
+    int bit = 0;
+    for (int k = 0; k < nsig; k++) {
+        g.pos[k] = (unsigned char)bit; g.wid[k] = (unsigned char)(wbase + (k < wrem ? 1 : 0));
+        bit += g.wid[k];
+        a[(bit - 1) >> 5] |= 1u << ((bit - 1) & 31);
+    }
+    g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 1);          // bit == 253 - (c-1)
+    g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
+    g.nwin = nsig + 2;
+    for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
+    for (int i = 0; i < 8; i++) g.addk[i] = a[i];
+}
+// diagnostics (host only, no GPU needed): the layout msm_core would use for n terms
+EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_t *pos, uint8_t *wid, uint32_t *addk) {
+    msm_geom g;
+    msm_layout(n, g);
+    *c = g.c; *nwin = g.nwin;
+    for (int k = 0; k < g.nwin; k++) { pos[k] = g.pos[k]; wid[k] = g.wid[k]; }
+    for (int i = 0; i < 8; i++) addk[i] = g.addk[i];
+    return C25519_OK;
+}
+
 // Sum over `nterms` (scalars at d_scalars, packed affine Niels points at d_pts) -> R.
 // sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are enqueued
 // (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
@@ -917,23 +946,7 @@ static int pick_window(uint64_t n) {
 int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream,
                  void *extra_dst, const void *extra_src, size_t extra_bytes) {
     msm_geom g;
-    g.c = pick_window(n);
-    g.half = 1 << (g.c - 1);
-    {   // see msm_geom: signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit window, then bits 253..255
-        const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
-        uint32_t a[9] = {0};
-        int bit = 0;
-        for (int k = 0; k < nsig; k++) {
-            g.pos[k] = (unsigned char)bit; g.wid[k] = (unsigned char)(wbase + (k < wrem ? 1 : 0));
-            bit += g.wid[k];
-            a[(bit - 1) >> 5] |= 1u << ((bit - 1) & 31);
-        }
-        g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 1);          // bit == 253 - (c-1)
-        g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
-        g.nwin = nsig + 2;
-        for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
-        for (int i = 0; i < 8; i++) g.addk[i] = a[i];
-    }
+    msm_layout(n, g);
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
     if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)

@@ -85,6 +85,7 @@ def load_library():
         "c25519_double_and_compress_batch": (i32, [vp, vp, u64, vp]),
         "c25519_scalar_invert_batch": (i32, [vp, vp, u64, vp]),
         "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
+        "c25519_msm_geometry": (i32, [u64, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(lib, name)  # AttributeError here = the library does not export the ABI
@@ -98,7 +99,7 @@ ABI_SYMBOLS = [
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_mul_base_batch_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
-    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench",
+    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",

@@ -213,6 +213,11 @@ int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t n, uin
  * engine), 2 fe_sq, 3 fe_mul written on 5 x u64 limbs with unsigned __int128 products (the
  * reference's literal layout, for the A/B in DESIGN.md), 4 v_add_u32, 5 v_mul_lo_u32. */
 double c25519_microbench(c25519_ctx *ctx, int which, int iters);
+/* The window layout the MSM uses for n terms (host arithmetic, no GPU needed): window k covers bits
+ * [pos[k], pos[k] + wid[k]) of s' = s + addk (addk as 8 little-endian 32-bit words); all windows but the last two are
+ * signed (digit = slice - 2^(wid-1)).  pos / wid need room for 56 entries.  Used by the CPU tests to check that the
+ * digits always recompose the scalar. */
+int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_t *pos, uint8_t *wid, uint32_t *addk);
 
 #ifdef __cplusplus
 }

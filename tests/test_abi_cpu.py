@@ -37,3 +37,45 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(base, f)).read()
                 assert "oracle" not in src.replace("SURVEY", ""), f
+
+
+def test_msm_window_layout_recomposes_every_scalar():
+    """c25519_msm_geometry (host arithmetic of msm.hip, no GPU): for every window width the MSM can pick, the bit
+    slices of s' = s + addk, read as signed digits (all windows but the top two) or unsigned ones (the top two),
+    recompose s -- for reduced scalars, for the 2^255 - 1 edge, and with every digit inside its bucket range."""
+    import ctypes as C
+    import random
+    import curve25519_dalek_amd as pkg
+    lib = pkg.load_library()
+    L = 2**252 + 27742317777372353535851937790883648493
+    rng = random.Random(7)
+    seen_c = set()
+    for lg in range(0, 41):
+        n = 1 << lg
+        c = C.c_int32(); nwin = C.c_int32()
+        pos = (C.c_uint8 * 56)(); wid = (C.c_uint8 * 56)(); addk = (C.c_uint32 * 8)()
+        assert lib.c25519_msm_geometry(n, C.byref(c), C.byref(nwin), pos, wid, addk) == 0
+        if c.value in seen_c:
+            continue
+        seen_c.add(c.value)
+        nw, half = nwin.value, 1 << (c.value - 1)
+        assert 5 <= c.value <= 16 and nw <= 56
+        assert pos[0] == 0 and all(pos[k] + wid[k] == pos[k + 1] for k in range(nw - 1)) and pos[nw - 1] + wid[nw - 1] == 256
+        assert pos[nw - 1] == 253 and wid[nw - 2] == c.value - 1 and max(wid[:nw]) == c.value
+        add = sum(int(addk[i]) << (32 * i) for i in range(8))
+        assert add == sum(1 << (pos[k] + wid[k] - 1) for k in range(nw - 2))
+        samples = [0, 1, L - 1, 2**252 - 1, 2**253 - 1, 2**255 - 1, 2**255 - 19, (1 << 254) + 12345] + [rng.randrange(L) for _ in range(300)]
+        samples += [rng.randrange(2**255) for _ in range(100)]
+        for s in samples:
+            sp = s + add
+            assert sp < 2**256
+            total = 0
+            for k in range(nw):
+                v = (sp >> pos[k]) & ((1 << wid[k]) - 1)
+                d = v if k >= nw - 2 else v - (1 << (wid[k] - 1))
+                assert abs(d) <= half                      # bucket index |d| - 1 < half
+                if s < 2**253 and k == nw - 1:
+                    assert d <= 1                          # the overflow window only ever sees the carry of a reduced scalar
+                total += d << pos[k]
+            assert total == s
+    assert seen_c == set(range(5, 17))
