@@ -23,6 +23,7 @@ struct ge_cached { feL YpX, YmX; feT Z; feL T2d; };  // ProjectiveNielsPoint, cu
 C25519_HD feT fe_const(const u32 (&c)[10]) { feT r; for (int i = 0; i < 10; i++) r.v[i] = c[i]; return r; }
 C25519_HD feT fe_d() { const u32 c[10] = C25519_EDWARDS_D_26; return fe_const(c); }
 C25519_HD feT fe_d2() { const u32 c[10] = C25519_EDWARDS_D2_26; return fe_const(c); }
+C25519_HD feT fe_d_inv() { const u32 c[10] = C25519_EDWARDS_D_INV_26; return fe_const(c); }
 C25519_HD feT fe_sqrtm1() { const u32 c[10] = C25519_SQRT_M1_26; return fe_const(c); }
 C25519_HD feT fe_invsqrt_a_minus_d() { const u32 c[10] = C25519_INVSQRT_A_MINUS_D_26; return fe_const(c); }
 
@@ -120,6 +121,23 @@ C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) 
     r.Y = fe_mul(fy, Y);
     r.Z = fe_mul(zm, zp);
     r.T = fe_mul(X, Y);
+    return r;
+}
+
+// (neg ? -Q : Q) as an extended point, for the FIRST addition of a chain (identity + Q): with (y+x, y-x, 2dxy) at hand,
+// (X : Y : Z : T) = (2x : 2y : 2 : 2xy) is (y+x) - (y-x), (y+x) + (y-x), 2 and 2dxy / d -- one multiplication by the
+// constant 1/d instead of the 7 M of a mixed addition onto the identity.  -Q swaps the first two entries, which negates X,
+// and negates T.
+C25519_HD ge_p3 ge_from_aniels_signed(const ge_aniels &q, bool neg) {
+    feT qa, qb;
+    for (int i = 0; i < 10; i++) { qa.v[i] = neg ? q.ymx.v[i] : q.ypx.v[i]; qb.v[i] = neg ? q.ypx.v[i] : q.ymx.v[i]; }
+    feT t = fe_mul(q.xy2d, fe_d_inv());
+    feT tn = fe_carry(fe_neg(t));
+    ge_p3 r;
+    r.X = fe_carry(fe_sub(qa, qb));
+    r.Y = fe_carry(fe_add(qa, qb));
+    r.Z = fe_small(2);
+    for (int i = 0; i < 10; i++) r.T.v[i] = neg ? tn.v[i] : t.v[i];
     return r;
 }
 

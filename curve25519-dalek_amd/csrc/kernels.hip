@@ -209,7 +209,8 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
         ge_aniels A;                                                // the table holds limbs: no unpacking
 #pragma unroll
         for (int i = 0; i < 10; i++) { A.ypx.v[i] = tw[i]; A.ymx.v[i] = tw[10 + i]; A.xy2d.v[i] = tw[20 + i]; }
-        P = ge_madd_signed_p3(P, A, cur_neg);
+        if (j == 0) P = ge_from_aniels_signed(A, cur_neg);         // identity + Q: 1 M instead of 7 M (ge26.h)
+        else P = ge_madd_signed_p3(P, A, cur_neg);
         ge_pin(P);
     }
 #undef C25519_STAGE_ENTRY

@@ -59,6 +59,13 @@ void h_ge_madd_signed(const uint8_t *a, const uint8_t *q, int neg, uint8_t *o) {
     A.ypx = fe_carry(fe_add(Q.Y, Q.X)); A.ymx = fe_carry(fe_sub(Q.Y, Q.X)); A.xy2d = fe_mul(Q.T, fe_d2());
     pstore(o, ge_madd_signed_p3(pload(a), A, neg != 0));
 }
+// +/- q as an extended point straight from its affine Niels form (first addition of a chain)
+void h_ge_from_aniels_signed(const uint8_t *q, int neg, uint8_t *o) {
+    ge_p3 Q = pload(q);
+    ge_aniels A;
+    A.ypx = fe_carry(fe_add(Q.Y, Q.X)); A.ymx = fe_carry(fe_sub(Q.Y, Q.X)); A.xy2d = fe_mul(Q.T, fe_d2());
+    pstore(o, ge_from_aniels_signed(A, neg != 0));
+}
 // p +/- q through the cached (ProjectiveNiels) path with the per-lane conditional negation
 void h_ge_add_cached_signed(const uint8_t *a, const uint8_t *q, int neg, uint8_t *o) {
     pstore(o, ge_p1p1_to_p3(ge_add_cached(pload(a), ge_cached_cneg(ge_p3_to_cached(pload(q)), neg != 0))));

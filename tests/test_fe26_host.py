@@ -158,6 +158,12 @@ def test_point_formulas_vs_oracle(host, orc):
         assert call(host, "h_ge_compress", call(host, "h_ge_madd", ah, qh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, q))
         assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", ah, qh, C.c_int(0), out=128)) == orc.ed_compress(orc.ed_add(ao, q))
         assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", ah, qh, C.c_int(1), out=128)) == orc.ed_compress(orc.ed_sub(ao, q))
+        # the first addition of a chain: +/- q straight from the affine Niels form, then used as an accumulator
+        for neg in (0, 1):
+            first = call(host, "h_ge_from_aniels_signed", qh, C.c_int(neg), out=128)
+            assert call(host, "h_ge_compress", first, out=32) == orc.ed_compress(orc.ed_neg(q) if neg else q)
+            nxt = call(host, "h_ge_madd_signed", first, to_host(orc.ed_decompress(orc.ed_compress(pts[3][0]))), C.c_int(0), out=128)
+            assert call(host, "h_ge_compress", nxt, out=32) == orc.ed_compress(orc.ed_add(orc.ed_neg(q) if neg else q, pts[3][0]))
         # chained: the output of the signed form feeds the next addition (bounds of the next fe_mul operands)
         acc = ah
         for i in range(20):
@@ -171,6 +177,7 @@ def test_point_formulas_vs_oracle(host, orc):
     for neg in (0, 1):
         assert call(host, "h_ge_compress", call(host, "h_ge_madd", pts[0][1], ident, C.c_int(neg), out=128)) == orc.ed_compress(pts[0][0])
         assert call(host, "h_ge_compress", call(host, "h_ge_madd_signed", pts[0][1], ident, C.c_int(neg), out=128)) == orc.ed_compress(pts[0][0])
+        assert host.h_ge_is_identity(call(host, "h_ge_from_aniels_signed", ident, C.c_int(neg), out=128))
     # a long chain (the reference's overflow hunt, edwards.rs:2254-2261): 300 chained doublings+adds
     acc_h, acc_o = pts[0][1], pts[0][0]
     for i in range(300):

@@ -182,6 +182,7 @@ def main():
         ("BASEPOINT_X", BX, "Ed25519 basepoint x (even)"),
         ("BASEPOINT_Y", BY, "Ed25519 basepoint y = 4/5"),
         ("BASEPOINT_T", BX * BY % P, "x*y of the basepoint"),
+        ("EDWARDS_D_INV", inv(D), "1/d: 2xy from the affine Niels coordinate 2dxy (first window of k_mul_base_wide)"),
     ]
     out = ["/* GENERATED by tools/gen_constants.py -- do not edit. Test infrastructure. */",
            "#ifndef ORC_CONSTANTS_H", "#define ORC_CONSTANTS_H", "#include <stdint.h>", ""]
