@@ -311,6 +311,32 @@ EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, ui
 }
 
 // ---- X25519 --------------------------------------------------------------------------------------
+// X25519 public keys: u([clamp(k)] B) through the fixed-base tables and the birational map, not through the ladder
+EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, uint64_t n, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48)) || (r = ctx_reserve(ctx, ctx->tmp_e, n * 32 + 256))) return r;
+    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    HIPCHK(launch_clamp(d_k, n, (uint8_t *)ctx->tmp_e.p, ctx->stream));
+    HIPCHK(launch_mul_base(ctx->w, (const uint8_t *)ctx->tmp_e.p, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
+    HIPCHK(hipEventRecord(ring[1], ctx->stream));
+    HIPCHK(launch_ratio_p32(1, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // (Z+Y)/(Z-Y)
+    HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // secret-derived intermediates: wipe
+    HIPCHK(hipMemsetAsync(ctx->tmp_e.p, 0, n * 32, ctx->stream));
+    HIPCHK(hipEventRecord(ring[2], ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint64_t n, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    staged in(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
+    int32_t r;
+    if ((r = in.up(k, n * 32)) || (r = o.alloc(n * 32))) return r;
+    if ((r = c25519_x25519_base_batch_dev(ctx, in.p, n, o.p))) return r;
+    return o.down(out, n * 32);
+}
 EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;

@@ -8,6 +8,7 @@ namespace c25519 {
 hipError_t launch_mul_base(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *scratch,
                            uint8_t *out_raw, int num_cus, hipStream_t st);
 hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, hipStream_t st);
+hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st);
 hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st);
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);

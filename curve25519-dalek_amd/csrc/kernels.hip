@@ -533,6 +533,21 @@ hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_it
     return hipGetLastError();
 }
 
+// clamp_integer (scalar.rs:1407) over a batch: the X25519 secret -> the integer the basepoint is multiplied by
+__global__ void __launch_bounds__(256) k_clamp(const uint8_t *__restrict__ in, u64 n, uint8_t *__restrict__ out) {
+    const u64 idx = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    u32 s[8];
+    load8(in, idx, s);
+    s[0] &= 0xfffffff8u; s[7] &= 0x7fffffffu; s[7] |= 0x40000000u;
+    store8(out, idx, s);
+}
+hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_clamp, dim3(div_up(n, 256)), dim3(256), 0, st, in, n, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipStream_t st) {
     switch (which) {
     case 0: hipLaunchKernelGGL(k_probe_mad, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;

@@ -145,6 +145,14 @@ def verify_batch(messages, signatures, verifying_keys, engine=None, z_mode=_e.Z_
                           _e.NONE: "PointDecompression"}[st])
 
 
+def x25519_public_keys(secrets, engine=None):
+    """PublicKey::from(&StaticSecret | &EphemeralSecret) (x25519-dalek/src/x25519.rs:105-109, :255-259), batched:
+    EdwardsPoint::mul_base_clamped(secret).to_montgomery() through the fixed-base tables, not the ladder."""
+    eng = engine or default_engine()
+    out = eng.x25519_base_batch(_cat(secrets, 32))
+    return [out[i].tobytes() for i in range(out.shape[0])]
+
+
 def verify_each(messages, signatures, verifying_keys, strict=False, engine=None):
     """Per-signature VerifyingKey::verify (verifying.rs:565) or verify_strict (:359): a list with None for
     Ok(()) and a SignatureError for every failing signature."""

@@ -53,6 +53,8 @@ def load_library():
         "c25519_mul_base_batch": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_x25519_batch_dev": (i32, [vp, vp, vp, u64, vp]),
         "c25519_x25519_batch": (i32, [vp, vp, vp, u64, vp]),
+        "c25519_x25519_base_batch_dev": (i32, [vp, vp, u64, vp]),
+        "c25519_x25519_base_batch": (i32, [vp, vp, u64, vp]),
         "c25519_decompress_batch_dev": (i32, [vp, vp, u64, C.c_int, vp, vp]),
         "c25519_decompress_batch": (i32, [vp, vp, u64, C.c_int, vp, vp]),
         "c25519_compress_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
@@ -97,7 +99,7 @@ def load_library():
 ABI_SYMBOLS = [
     "c25519_ctx_create", "c25519_ctx_destroy", "c25519_ctx_set_stream", "c25519_ctx_synchronize", "c25519_last_error",
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_mul_base_batch_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
-    "c25519_x25519_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
+    "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
@@ -185,6 +187,14 @@ class Engine:
             out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
         self._bind_stream()
         self._chk(self.lib.c25519_mul_base_batch_dev(self.ctx, scalars.data_ptr(), n, out_fmt, out.data_ptr()))
+        return out
+
+    def x25519_base_batch_t(self, k, out=None):
+        n = self._t(k, 32)
+        if out is None:
+            out = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_x25519_base_batch_dev(self.ctx, k.data_ptr(), n, out.data_ptr()))
         return out
 
     def x25519_batch_t(self, k, u, out=None):
@@ -296,6 +306,14 @@ class Engine:
         out = np.empty((n, _PT[out_fmt]), dtype=np.uint8)
         self._bind_stream()
         self._chk(self.lib.c25519_mul_base_batch(self.ctx, s.ctypes.data, n, out_fmt, out.ctypes.data))
+        return out
+
+    def x25519_base_batch(self, k):
+        """X25519 public keys x25519(k_i, 9) through the fixed-base path (x25519.rs:105-109)."""
+        k = _np8(k, 32); n = k.shape[0]
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_x25519_base_batch(self.ctx, k.ctypes.data, n, out.ctypes.data))
         return out
 
     def x25519_batch(self, k, u):

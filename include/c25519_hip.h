@@ -90,6 +90,11 @@ int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t 
  * :183-211): k is clamped inside, bit 255 of u ignored, u >= p reduced, low-order u -> all-zero. */
 int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out);
 int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out);
+/* X25519 public keys: out[i] = x25519(k[i], 9), computed the way x25519-dalek does it -- PublicKey::from(&secret) =
+ * EdwardsPoint::mul_base_clamped(secret).to_montgomery() (x25519.rs:105-109, :255-259; edwards.rs:948, :574-590) --
+ * i.e. through the fixed-base tables and the birational map (Z+Y)/(Z-Y), 12x cheaper than the ladder. */
+int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, uint64_t n, uint8_t *d_out);
+int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint64_t n, uint8_t *out);
 
 /* ---- (de)compression ------------------------------------------------------------------------------
  * decompress: CompressedEdwardsY::decompress (edwards.rs:211-258, ZIP-215 rules) for in_fmt 0,

@@ -110,6 +110,29 @@ def test_x25519_full_size_2p20_diffie_hellman(eng, orc, torch):
     assert np.array_equal(sab[idx].cpu().numpy(), want)
 
 
+def test_x25519_public_keys_through_the_fixed_base_path(eng, orc, golden, torch):
+    """x25519-dalek derives public keys as EdwardsPoint::mul_base_clamped(secret).to_montgomery() (x25519.rs:105-109):
+    c25519_x25519_base_batch must equal the ladder on u = 9 -- RFC 7748 6.1 keys, edge secrets, 2^16 random ones
+    against the engine's own ladder and a slice against the oracle."""
+    f = "x25519_tests.rs"
+    ks = [golden.bytes(f, "ALICE_PRIVATE_KEY"), golden.bytes(f, "BOB_PRIVATE_KEY")]
+    want = [golden.bytes(f, "ALICE_PUBLIC_KEY"), golden.bytes(f, "BOB_PUBLIC_KEY")]
+    got = eng.x25519_base_batch(np.frombuffer(b"".join(ks), np.uint8).reshape(-1, 32))
+    assert [got[i].tobytes() for i in range(2)] == want
+    edge = np.zeros((4, 32), np.uint8); edge[1] = 0xFF; edge[2, 0] = 7; edge[3, 31] = 0x80      # clamping decides all of these
+    nine = np.zeros((4, 32), np.uint8); nine[:, 0] = 9
+    assert np.array_equal(eng.x25519_base_batch(edge), orc.x25519_batch(edge, nine, threads=2))
+    n = 1 << 16
+    g = torch.Generator(device="cuda"); g.manual_seed(90125)
+    dk = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    d9 = torch.zeros((n, 32), dtype=torch.uint8, device="cuda"); d9[:, 0] = 9
+    pub = eng.x25519_base_batch_t(dk)
+    assert torch.equal(pub, eng.x25519_batch_t(dk, d9))
+    idx = torch.arange(0, n, 97, device="cuda")
+    assert np.array_equal(pub[idx].cpu().numpy(), orc.x25519_batch(dk[idx].cpu().numpy(), d9[idx].cpu().numpy(), threads=8))
+    assert eng.x25519_base_batch(np.zeros((0, 32), np.uint8)).shape == (0, 32)
+
+
 def test_decompress_compress_vs_oracle(eng, orc):
     n = 4000
     enc = util.rand_bytes(41, n)
