@@ -33,7 +33,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # Field work per unit as implemented, counted from the kernels: M = fe_mul = 100 MACs, S = fe_sq = 55 MACs;
 # "ref" = the reference algorithm's count from SURVEY.md 8d (M = 100, S = 60 in its 5x51 schoolbook terms).
 VALU = {
-    "fixed_base": {"M": 118, "S": 16, "ref": 47100, "what": "16 madd x 7M (radix-2^16 tables in HBM) + 5M compress + 1/16 inversion"},
+    "fixed_base": {"M": 112, "S": 16, "ref": 47100, "what": "1M (first window) + 15 madd x 7M (radix-2^16 tables in HBM) + 5M compress + 1/16 inversion"},
     "fixed_base_comb": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) (LDS comb) + 5M compress + 1/16 inversion"},
     "x25519": {"M": 1303, "S": 1036, "ref": 231000, "what": "255 x (5M + 4S + 10-product a24 mul) + 3M + 1/16 inversion"},
     "msm": {"M": 121, "S": 0, "ref": 26500, "what": "16 windows x 7M bucket adds + 8M normalise + ~1M reduce (c = 16)"},
