@@ -153,6 +153,30 @@ static int32_t build_wide_table(c25519_ctx *ctx, int C) {
     return C25519_OK;
 }
 
+// streams, events and pinned staging of a context (also of a peer context)
+static bool ctx_make_streams(c25519_ctx *ctx) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return false;
+    ctx->own_stream = true;
+    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
+    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) return false;
+    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
+    return hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) == hipSuccess;
+}
+EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
+c25519_ctx *ctx_peer(c25519_ctx *ctx) {
+    if (ctx->peer) return ctx->peer;
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    c25519_ctx *p = new c25519_ctx();
+    p->device = ctx->device; p->flags = ctx->flags; p->num_cus = ctx->num_cus; p->w = ctx->w;
+    p->d_table = ctx->d_table; p->owns_table = false;
+    if (!ctx_make_streams(p) || hipMalloc(&p->d_flag, 256) != hipSuccess) { c25519_ctx_destroy(p); return nullptr; }
+    ctx->peer = p;
+    return p;
+}
+
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
 EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     int ndev = 0;
@@ -169,15 +193,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     ctx->num_cus = prop.multiProcessorCount;
     if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         fprintf(stderr, "c25519_ctx_create: warning: device arch %s, kernels are built for gfx950 only\n", prop.gcnArchName);
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
-    ctx->own_stream = true;
-    hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
-    hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
-    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
-    if (hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) != hipSuccess) { c25519_ctx_destroy(ctx); return nullptr; }
+    if (!ctx_make_streams(ctx)) { c25519_ctx_destroy(ctx); return nullptr; }
     int w = (int)(flags & 0x1f);
     const int wide = (w >= 10 && w <= 20) ? w : (w == 0 ? 16 : 0);   // default: radix 2^16 (measured best table size / speed point)
     ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position LDS window tables; 9: signed comb (also bootstraps the wide table)
@@ -204,7 +220,8 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
-    if (ctx->d_table) hipFree(ctx->d_table);
+    if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
+    if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
     if (ctx->d_flag) hipFree(ctx->d_flag);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);

@@ -24,6 +24,11 @@ struct c25519_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_sort = nullptr;
     void *h_pinned = nullptr; size_t h_pinned_cap = 0;   // pinned host staging for small read-backs
     void *h_msm = nullptr;                               // 20 KB pinned: window totals + flags of msm_core
+    // a second set of streams / workspaces on the same device (shares the fixed-base table): multi-pass MSM and
+    // verify_batch run alternate passes on it from a second host thread, so that the low-VALU phases of one pass
+    // (normalise, sort, reduce, read-back) overlap the accumulation of the other.  Created on first use.
+    c25519_ctx *peer = nullptr;
+    bool owns_table = true;
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
     devbuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
     std::string err;
@@ -31,3 +36,4 @@ struct c25519_ctx {
 
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);
 int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
+c25519_ctx *ctx_peer(c25519_ctx *ctx);      // nullptr if it cannot be created

@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include "../../include/c25519_hip.h"
 #include "devio.h"
@@ -1155,6 +1156,20 @@ static int32_t msm_partial_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const
 // multi-GPU path uses across ranks -- whose partial sums are added on the host.  This also bounds
 // the workspace (~0.5 GB) for any n.
 static const uint64_t MSM_PASS_MAX = 3ull << 20, MSM_PASS = 1ull << 21;
+static int pass_lanes() { static const int v = [] { const char *e = getenv("C25519_PASS_LANES"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob
+// run(c, first, step) on `lanes` contexts: the caller's and up to three peers (each the peer of the previous one)
+template <class F>
+static void run_on_lanes(c25519_ctx *ctx, uint64_t passes, F run) {
+    c25519_ctx *cs[4] = {ctx, nullptr, nullptr, nullptr};
+    int lanes = 1;
+    const int want = (int)std::min<uint64_t>(passes, (uint64_t)pass_lanes());
+    while (lanes < want) { c25519_ctx *p = ctx_peer(cs[lanes - 1]); if (!p) break; cs[lanes++] = p; }
+    if (lanes > 1) hipStreamSynchronize(ctx->stream);               // the inputs are complete before other streams read them
+    std::vector<std::thread> ts;
+    for (int l = 1; l < lanes; l++) ts.emplace_back(run, cs[l], (uint64_t)l, (uint64_t)lanes);
+    run(ctx, 0, (uint64_t)lanes);
+    for (auto &t : ts) t.join();
+}
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     HIPCHK(hipSetDevice(ctx->device));
     R = ge_identity();
@@ -1163,14 +1178,25 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const uint64_t passes = n <= MSM_PASS_MAX ? 1 : (n + MSM_PASS - 1) / MSM_PASS, per = (n + passes - 1) / passes;
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    // Passes are independent.  With several of them they are dealt round-robin to the caller's context and its peer
+    // contexts (own streams and workspaces, same device), one host thread each: two thirds of a pass is low-VALU work
+    // (normalise, sort, reduce, read-back) that now overlaps the accumulation of a neighbouring pass.
+    std::vector<ge_p3> part(passes, ge_identity());
+    std::vector<int32_t> st(passes, C25519_OK);
+    auto run = [&](c25519_ctx *c, uint64_t first, uint64_t step) {
+        hipSetDevice(c->device);
+        for (uint64_t i = first; i < passes; i += step) {
+            const uint64_t lo = i * per, cnt = std::min(per, n - lo);
+            st[i] = msm_partial_pass(c, d_scalars + lo * 32, d_points + lo * psz, cnt, in_fmt, part[i]);
+            if (st[i] < 0) break;
+        }
+    };
+    run_on_lanes(ctx, passes, run);
     bool none = false;
-    for (uint64_t lo = 0; lo < n; lo += per) {
-        const uint64_t cnt = std::min(per, n - lo);
-        ge_p3 part;
-        int32_t r = msm_partial_pass(ctx, d_scalars + lo * 32, d_points + lo * psz, cnt, in_fmt, part);
-        if (r < 0) return r;
-        if (r == C25519_NONE) none = true;             // keep going: the status must not depend on the split
-        else R = passes == 1 ? part : ge_add(R, part);
+    for (uint64_t i = 0; i < passes; i++) {
+        if (st[i] < 0) { if (ctx->err.empty()) ctx->err = "msm: a pass failed on a peer context"; return st[i]; }
+        if (st[i] == C25519_NONE) none = true;          // the status must not depend on the split
+        else R = passes == 1 ? part[i] : ge_add(R, part[i]);
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return none ? C25519_NONE : C25519_OK;
@@ -1310,12 +1336,21 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
     if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
-    bool seen[5] = {false, false, false, false, false};
-    for (uint64_t lo = 0; lo < n; lo += per) {
-        int32_t r = verify_batch_pass(ctx, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr,
+    std::vector<int32_t> st(passes, C25519_OK);
+    auto run = [&](c25519_ctx *c, uint64_t first, uint64_t step) {              // see msm_partial_impl
+        hipSetDevice(c->device);
+        for (uint64_t i = first; i < passes; i += step) {
+            const uint64_t lo = i * per;
+            st[i] = verify_batch_pass(c, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr,
                                       std::min(per, n - lo), z_mode);
-        if (r < 0) return r;
-        seen[r] = true;
+            if (st[i] < 0) break;
+        }
+    };
+    run_on_lanes(ctx, passes, run);
+    bool seen[5] = {false, false, false, false, false};
+    for (uint64_t i = 0; i < passes; i++) {
+        if (st[i] < 0) { if (ctx->err.empty()) ctx->err = "verify_batch: a pass failed on a peer context"; return st[i]; }
+        seen[st[i]] = true;
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
