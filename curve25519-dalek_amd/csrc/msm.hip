@@ -1155,7 +1155,8 @@ static int32_t msm_partial_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const
 // bucket only get longer: larger inputs are cut into passes of about 2^21 terms -- the same decomposition the
 // multi-GPU path uses across ranks -- whose partial sums are added on the host.  This also bounds
 // the workspace (~0.5 GB) for any n.
-static const uint64_t MSM_PASS_MAX = 3ull << 20, MSM_PASS = 1ull << 21;
+static const int MSM_PASS_LOG2 = [] { const char *e = getenv("C25519_MSM_PASS_LOG2"); int v = e ? atoi(e) : 21; return v < 16 ? 16 : (v > 21 ? 21 : v); }();   // A/B knob
+static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
 static int pass_lanes() { static const int v = [] { const char *e = getenv("C25519_PASS_LANES"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob
 // run(c, first, step) on `lanes` contexts: the caller's and up to three peers (each the peer of the previous one)
 template <class F>
@@ -1326,7 +1327,8 @@ static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const u
 // 2^20 signatures each (same reason as MSM_PASS_MAX; every pass derives its own z_i).  All passes run even after
 // a failure so that the reference's precedence -- key decoding, then ScalarFormat for ANY non-canonical s
 // (batch.rs:208-211), then Verify -- does not depend on where the batch was cut.
-static const uint64_t VERIFY_PASS_MAX = 3ull << 19, VERIFY_PASS = 1ull << 20;
+static const int VERIFY_PASS_LOG2 = [] { const char *e = getenv("C25519_VERIFY_PASS_LOG2"); int v = e ? atoi(e) : 20; return v < 15 ? 15 : (v > 20 ? 20 : v); }();   // A/B knob
+static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
 EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                              const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
     (void)msgs_len;
