@@ -1,19 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- one JSON line per run (driver contract).
 
-A "step" is one pass of the hot path over one batch of synthetic input that is already resident in
-HBM when the timed region starts.  Default workload = BASELINE.json configs[1]:
-    2^20 fixed-base scalar multiplications (EdwardsBasepointTable . scalar) -> CompressedEdwardsY
-Other configs are selectable with --workload (x25519 | msm | verify) for DESIGN.md's tables; they are
-parity-test cases, not the driver's bench line.
+Headline (the top-level `value`): BASELINE.json's metric, MSM scalar-mults/s, on the configuration it is quoted on --
+configs[3], a 2^24-term variable-base Pippenger MSM -- as ONE c25519_msm_vartime call per step with scalars and raw
+points already resident in HBM.  At N = 1 the 2^24 terms run on one GPU; at N > 1 (`--gpus N`) the same 2^24 terms are
+sharded over N ranks, one process per GPU, with the ONE exchange step of the path per step (all_gather of a 160-byte
+partial sum per rank over RCCL, then the fold): strong scaling, as configs[3] and north_star state it
+(`--scaling weak` keeps 2^24 terms per GPU instead).
 
-N > 1: one process per GPU (torchrun), units sharded across ranks with no data-path collective for
-the replicated workloads ("weak" scaling: per-GPU work is fixed); the MSM workload exchanges one
-160-byte partial point per rank (all_gather over RCCL) and folds.
+`--gpus N` with N > 1 and no RANK in the environment re-executes itself through torch.distributed.run (one rank per
+GPU); under a launcher (RANK / WORLD_SIZE set, the driver's way) it just joins.  On a box with fewer than N GPUs it
+fails loudly.
+
+At N = 1 the same line carries, as `sub`, the other BASELINE configurations timed the same way (K steps after W warmup
+steps each, their own HIP-event kernel timings): configs[2] verify_batch of 2^20 signatures (VerifyingKey mode, device
+z-mode; plus the strict-transcript z-mode at 2^14 and 2^20), configs[1] 2^20 fixed-base multiplications (radix-2^16
+tables and the constant-time scan), configs[4] 2^20 X25519 ladders -- each with its own `roofline`, `valu` and
+`cpu_baseline` objects.  `--workload X` makes X the headline and drops `sub`.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -21,25 +31,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# algorithmic bytes and integer multiply-accumulates per unit
-ALGO = {
-    "fixed_base": {"bytes": 64, "unit": "scalar-mults/s", "metric": "fixed-base scalar mults/sec (2^20 EdwardsBasepointTable*scalar, compressed out)"},
-    "x25519": {"bytes": 96, "unit": "ladders/s", "metric": "X25519 key agreements/sec (2^20 Montgomery ladders)"},
-    "msm": {"bytes": 192, "unit": "terms/s", "metric": "MSM terms/sec (variable-base Pippenger)"},
-    "verify": {"bytes": 128, "unit": "verifies/s", "metric": "Ed25519 batch verifies/sec (verify_batch)"},
-}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-# The roof that actually binds: 32x32->64 multiply-accumulate issue (v_mad_u64_u32).
-# Field work per unit as implemented, counted from the kernels: M = fe_mul = 100 MACs, S = fe_sq = 55 MACs;
-# "ref" = the reference algorithm's count from SURVEY.md 8d (M = 100, S = 60 in its 5x51 schoolbook terms).
-VALU = {
-    "fixed_base": {"M": 112, "S": 16, "ref": 47100, "what": "1M (first window) + 15 madd x 7M (radix-2^16 tables in HBM) + 5M compress + 1/16 inversion"},
-    "fixed_base_comb": {"M": 239, "S": 32, "ref": 47100, "what": "31 madd x 7M + 4 dbl x (4S+4M) (LDS comb) + 5M compress + 1/16 inversion"},
-    "x25519": {"M": 1303, "S": 1036, "ref": 231000, "what": "255 x (5M + 4S + 10-product a24 mul) + 3M + 1/16 inversion"},
-    "msm": {"M": 121, "S": 0, "ref": 26500, "what": "16 windows x 7M bucket adds + 8M normalise + ~1M reduce (c = 16)"},
-    "verify": {"M": 197, "S": 255, "ref": 57000, "what": "decompress R (255S + 21M) + normalise A (8M) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
-    "verify_bytes": {"M": 210, "S": 510, "ref": 74400, "what": "decompress R and A (2 x (255S + 21M)) + (16 + 8) windows x 7M; SHA-512 and scalar muls not counted"},
+L_ORDER = 2**252 + 27742317777372353535851937790883648493
+
+# algorithmic bytes per unit and the kernel whose launches the roofline object describes
+ALGO = {
+    "msm": {"bytes": 192, "unit": "terms/s", "metric": "MSM scalar-mults/sec (variable-base Pippenger MSM)", "kernel": "k_accumulate",
+            "bytes_what": "32-byte scalar + 160-byte raw point per term"},
+    "verify": {"bytes": 128, "unit": "verifies/s", "metric": "Ed25519 batch verifies/sec (verify_batch)", "kernel": "k_prep_compressed",
+               "bytes_what": "64-byte signature + 32-byte key + 32-byte message per signature"},
+    "fixed_base": {"bytes": 64, "unit": "scalar-mults/s", "metric": "fixed-base scalar mults/sec (EdwardsBasepointTable*scalar, compressed out)", "kernel": "k_mul_base",
+                   "bytes_what": "32-byte scalar in + 32-byte CompressedEdwardsY out"},
+    "x25519": {"bytes": 96, "unit": "ladders/s", "metric": "X25519 key agreements/sec (Montgomery ladders)", "kernel": "k_x25519",
+               "bytes_what": "32-byte scalar + 32-byte u in, 32-byte u out"},
 }
+DEFAULT_LOG2N = {"msm": 24, "verify": 20, "fixed_base": 20, "x25519": 20}
 
 
 def host_cores():
@@ -57,20 +63,351 @@ def host_cores():
     return c
 
 
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of `kernel` from the newest committed PMC profile of this workload (rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes, tools/profile_all.sh; FETCH_SIZE doubled per the gfx950 correction in MI355X_MICROARCH.md)."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.txt" % workload)), reverse=True):
+        fetch = write = None
+        cur = None
+        for line in open(f):
+            if not line.startswith(" "):
+                cur = line.strip()
+            elif cur and kernel in cur:
+                parts = line.split()
+                if parts[0] == "FETCH_SIZE":
+                    fetch = float(parts[1])
+                if parts[0] == "WRITE_SIZE":
+                    write = float(parts[1])
+        if fetch is not None and write is not None:
+            return (2.0 * fetch + write) * 1024.0, os.path.relpath(f, ROOT)
+    return None, None
+
+
+class Workload:
+    """One BASELINE configuration: synthetic inputs resident in HBM, run() = one step, checks, kernel timings."""
+
+    def __init__(self, name, eng, pkg, torch, dev, log2n, rank=0, world=1, args=None):
+        self.name, self.eng, self.pkg, self.torch, self.dev = name, eng, pkg, torch, dev
+        self.rank, self.world, self.args = rank, world, args
+        self.log2n, self.n = log2n, 1 << log2n
+        self.variant = ""
+        self.result = {}
+        gen = torch.Generator(device=dev)
+        gen.manual_seed(0xC25519 + 1000 * rank + {"msm": 1, "verify": 2, "fixed_base": 3, "x25519": 4}[name])
+        self.gen = gen
+        getattr(self, "_setup_" + name)()
+
+    def rnd(self, rows, width=32):
+        return self.torch.randint(0, 256, (rows, width), dtype=self.torch.uint8, device=self.dev, generator=self.gen)
+
+    # -- setups -------------------------------------------------------------------------------------------------
+    def _setup_msm(self):
+        # config 4 shape: P_i = y_i * B generated on the device (the host never materialises the points)
+        E = self.pkg.engine
+        n = self.n
+        self.xs, ys = self.rnd(n), self.rnd(n)
+        self.xs[:, 31] &= 0x0F; ys[:, 31] &= 0x0F
+        self.ys = ys
+        self.pts = self.torch.empty((n, 160), dtype=self.torch.uint8, device=self.dev)
+        step = 1 << 21
+        for lo in range(0, n, step):
+            self.eng.mul_base_batch_vartime_t(ys[lo:lo + step], E.FMT_RAW160, self.pts[lo:lo + step])
+
+        def run():
+            # this rank's partial sum, then the one exchange step (160 B per rank over RCCL) + fold
+            st, out = self.pkg.multi.msm_vartime_sharded(self.eng, self.xs, self.pts, E.FMT_RAW160, E.FMT_EDWARDS_Y)
+            assert st == 0
+            self.result["out"] = out
+        self.run = run
+
+    def _setup_verify(self):
+        # 2^k independent keypairs and 32-byte messages, signed by the engine's own batched signer (byte-exact against the
+        # reference's TESTVECTORS in tests/test_gpu_single.py; not on the measured path)
+        E = self.pkg.engine
+        n = self.n
+        seeds, self.d_msgs = self.rnd(n), self.rnd(n).reshape(-1)
+        self.d_off = self.torch.arange(0, 32 * (n + 1), 32, dtype=self.torch.int64, device=self.dev)
+        self.d_pks, self.d_sigs = self.eng.sign_batch_t(seeds, self.d_msgs, self.d_off)
+        self.d_pk_points = None
+        self.keys_as_bytes = bool(self.args and self.args.keys_as_bytes)
+        if not self.keys_as_bytes:
+            _, self.d_pk_points, ok = self.eng.decompress_batch_t(self.d_pks)       # VerifyingKey::from_bytes, done once per key
+            assert bool(ok.all())
+        self.z_mode = E.Z_TRANSCRIPT if (self.args and self.args.z_mode == "transcript") else E.Z_DEVICE
+
+        def run():
+            self.result["st"] = self.eng.verify_batch_t(self.d_msgs, self.d_off, self.d_sigs, self.d_pks, self.z_mode, pk_points=self.d_pk_points)
+        self.run = run
+
+    def _setup_fixed_base(self):
+        E = self.pkg.engine
+        self.scalars = self.rnd(self.n)
+        self.scalars[:, 31] &= 0x0F                     # uniform in [0, 2^252): reduced scalars
+        self.out = self.torch.empty((self.n, 32), dtype=self.torch.uint8, device=self.dev)
+
+        def run():
+            self.eng.mul_base_batch_t(self.scalars, E.FMT_EDWARDS_Y, self.out)
+        self.run = run
+
+    def _setup_x25519(self):
+        self.ks, self.us = self.rnd(self.n), self.rnd(self.n)
+        self.out = self.torch.empty((self.n, 32), dtype=self.torch.uint8, device=self.dev)
+
+        def run():
+            self.eng.x25519_batch_t(self.ks, self.us, self.out)
+        self.run = run
+
+    # -- product-only sanity outside the timed region (the CPU restatement is used ONLY in cpu_baseline()) -------------
+    def self_check(self):
+        torch, eng, E = self.torch, self.eng, self.pkg.engine
+        self.run()
+        torch.cuda.synchronize(self.dev)
+        if self.name == "verify" and self.result["st"] != 0:
+            raise SystemExit("SELF-CHECK FAILURE: valid batch rejected (status %d)" % self.result["st"])
+        if self.name == "msm":
+            # (sum x_i y_i mod l) * B through the fixed-base kernel must equal this rank's partial MSM over P_i = y_i * B
+            def limbs(t):
+                return (t.view(torch.int16).to(torch.int64) & 0xFFFF)
+            acc = 0
+            step = 1 << 21
+            for lo in range(0, self.n, step):
+                ax, ay = limbs(self.xs[lo:lo + step]), limbs(self.ys[lo:lo + step])
+                for j in range(16):
+                    col = (ax[:, j:j + 1] * ay).sum(0).cpu().tolist()           # exact: each entry < 2^21 * 2^32
+                    for k in range(16):
+                        acc += int(col[k]) << (16 * (j + k))
+            import numpy as np
+            want = eng.mul_base_batch(np.frombuffer((acc % L_ORDER).to_bytes(32, "little"), np.uint8).reshape(1, 32))[0].tobytes()
+            st, part = eng.msm_partial_t(self.xs, self.pts, E.FMT_RAW160)
+            got = self.pkg.multi.fold_partials([part], E.FMT_EDWARDS_Y)
+            if st != 0 or got != want:
+                raise SystemExit("SELF-CHECK FAILURE: MSM result differs from (sum x_i y_i) B")
+            del self.ys
+
+    # -- kernel timings from the HIP events the library records on the launch streams -----------------------------------
+    def kernel_times(self, steps):
+        """-> dict: dominant kernel ms per LAUNCH (averaged over the timed steps), launches per step, other figures"""
+        eng = self.eng
+        if self.name in ("msm", "verify"):
+            # the latest call's passes (the timed steps are identical; the ring keeps per-pass events)
+            acc_ms, passes = eng.last_call_phase_ms(0)
+            tail_ms, _ = eng.last_call_phase_ms(1)
+            pass_ms, _ = eng.last_call_phase_ms(2)
+            out = {"passes_per_step": passes, "k_accumulate_ms_per_launch": acc_ms / passes, "reduce_tail_ms_per_pass": tail_ms / passes,
+                   "pass_span_ms": pass_ms / passes}
+            if self.name == "verify":
+                dec_ms, _ = eng.last_call_phase_ms(3)
+                out["k_prep_compressed_R_ms_per_launch"] = dec_ms / passes
+                out["dominant_ms"] = max(dec_ms, acc_ms) / passes
+                out["dominant_kernel"] = "k_prep_compressed<0> (decompression of R_i)" if dec_ms >= acc_ms else "k_accumulate<3>"
+            else:
+                out["dominant_ms"] = acc_ms / passes
+                out["dominant_kernel"] = "k_accumulate<3>"
+            return out
+        k = min(steps, 64)
+        dom = sum(eng.phase_ms(b, 0) for b in range(k)) / k
+        rest = sum(eng.phase_ms(b, 1) for b in range(k)) / k
+        return {"passes_per_step": 1, "dominant_ms": dom, "other_kernels_ms": rest,
+                "dominant_kernel": {"fixed_base": "k_mul_base_*", "x25519": "k_x25519"}[self.name]}
+
+    def units_per_launch(self, kt):
+        return float(self.n) / kt["passes_per_step"]
+
+    def cost(self):
+        from curve25519_dalek_amd import costs
+        import ctypes as C
+        if self.name == "fixed_base":
+            return costs.fixed_base_ct() if self.variant == "ct" else (costs.fixed_base_comb() if self.variant == "comb" else costs.fixed_base_wide(16)), costs.reference_mac["fixed_base"]
+        if self.name == "x25519":
+            return costs.x25519(), costs.reference_mac["x25519"]
+        lib = self.pkg.load_library()
+        c = C.c_int32(); nwin = C.c_int32()
+        pos = (C.c_uint8 * 56)(); wid = (C.c_uint8 * 56)(); addk = (C.c_uint32 * 8)()
+        passes = max(1, self.kt["passes_per_step"]) if hasattr(self, "kt") else 1
+        per = -(-self.n // passes)
+        terms = per if self.name == "msm" else 2 * per + 1
+        lib.c25519_msm_geometry(terms, C.byref(c), C.byref(nwin), pos, wid, addk)
+        half = 1 << (c.value - 1)
+        self._nwin = nwin.value
+        if self.name == "msm":
+            return costs.msm(per, nwin.value, half), costs.reference_mac["msm"]
+        return costs.verify(per, nwin.value, half, self.keys_as_bytes), costs.reference_mac["verify_bytes" if self.keys_as_bytes else "verify"]
+
+    # -- CPU baseline: the C restatement of the reference's serial_u64 path (test infrastructure), bounded sample --------
+    def cpu_baseline(self, budget_s):
+        import numpy as np
+        from oracle import orc
+        torch, eng, E, n = self.torch, self.eng, self.pkg.engine, self.n
+        cores = host_cores()
+        name = self.name
+        if name in ("fixed_base", "x25519"):
+            idx = torch.randperm(n, device=self.dev, generator=self.gen)[:1024].cpu().numpy()
+            if name == "fixed_base":
+                want = orc.mul_base_compress_batch(self.scalars[idx].cpu().numpy(), threads=cores)
+            else:
+                want = orc.x25519_batch(self.ks[idx].cpu().numpy(), self.us[idx].cpu().numpy(), threads=cores)
+            if not np.array_equal(self.out[idx].cpu().numpy(), want):
+                raise SystemExit("PARITY FAILURE: GPU output differs from the CPU restatement (%s)" % name)
+            probe = min(n, 1024 * cores)
+            if name == "fixed_base":
+                a = self.scalars[:probe].cpu().numpy()
+                f = lambda m: orc.mul_base_compress_batch(np.resize(a, (m, 32)), threads=cores)
+            else:
+                a, b = self.ks[:probe].cpu().numpy(), self.us[:probe].cpu().numpy()
+                f = lambda m: orc.x25519_batch(np.resize(a, (m, 32)), np.resize(b, (m, 32)), threads=cores)
+            used, cap = cores, 16 * n
+        elif name == "msm":
+            m0 = 2048
+            xa = self.xs[:1 << 17].cpu().numpy(); pa = self.pts[:1 << 17].cpu().numpy()
+            want = orc.ed_compress(orc.ed_msm([xa[i].tobytes() for i in range(m0)], [pa[i].tobytes() for i in range(m0)]))
+            st, got = eng.msm_vartime_t(self.xs[:m0].contiguous(), self.pts[:m0].contiguous(), E.FMT_RAW160, E.FMT_EDWARDS_Y)
+            if st != 0 or got != want:
+                raise SystemExit("PARITY FAILURE: MSM result differs from the CPU restatement's")
+            # the reference's MSM is one single-threaded call (Pippenger, w = 8): time it as such
+            probe = 4096
+            f = lambda m: orc.ed_msm([xa[i].tobytes() for i in range(m)], [pa[i].tobytes() for i in range(m)])
+            used, cap = 1, 1 << 17
+        else:
+            mh = self.d_msgs.reshape(n, 32).cpu().numpy(); sig_h = self.d_sigs.cpu().numpy(); pk_h = self.d_pks.cpu().numpy()
+            for i in range(0, n, max(1, n // 64)):
+                if orc.ed25519_verify(pk_h[i].tobytes(), mh[i].tobytes(), sig_h[i].tobytes()) != 0:
+                    raise SystemExit("PARITY FAILURE: the CPU restatement rejects a signature the engine accepts")
+            probe = 2048
+            f = lambda m: orc.ed25519_verify_batch([mh[i].tobytes() for i in range(m)], [sig_h[i].tobytes() for i in range(m)], [pk_h[i].tobytes() for i in range(m)])
+            used, cap = 1, n
+        f(min(probe, 256))                                              # warm caches / tables
+        c0 = time.perf_counter(); f(probe); c1 = time.perf_counter() - c0
+        m = int(max(probe, min(cap, probe * budget_s / max(c1, 1e-4))))
+        c0 = time.perf_counter(); f(m); c1 = time.perf_counter() - c0
+        return {"value": m / c1, "unit": ALGO[name]["unit"], "cores": used, "kind": "port",
+                "sample": "%d units of the same workload through the C restatement of the reference serial_u64 path, %d thread(s), %.1f s; host exposes %d usable cores"
+                          % (m, used, c1, cores)}
+
+
+def time_steps(run, steps, warmup, barrier):
+    for _ in range(warmup):
+        run()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling):
+    """The JSON object of one workload."""
+    name = w.name
+    kt = w.kernel_times(steps)
+    w.kt = kt
+    cost, ref_mac = w.cost()
+    from curve25519_dalek_amd import costs
+    mac_impl = costs.mac(cost)
+    total_units = float(w.total_terms) if (name == "msm" and scaling == "strong") else float(w.n) * world
+    units = total_units * steps
+    upl = w.units_per_launch(kt)
+    algo_bytes = ALGO[name]["bytes"] * upl
+    dom_ms = kt["dominant_ms"]
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
+    # PMC traffic of the kernel the roofline object describes
+    pk = {"msm": "k_accumulate", "verify": "k_prep_compressed" if "prep" in kt.get("dominant_kernel", "") else "k_accumulate",
+          "fixed_base": "k_mul_base_comb" if w.variant == "comb" else ("k_mul_base<" if w.variant == "ct" else "k_mul_base_wide"), "x25519": "k_x25519"}[name]
+    traffic, traffic_src = pmc_traffic(name if not w.variant else name + "_" + w.variant, pk)
+    per_gpu = units / dt / world
+    res = {
+        "metric": ALGO[name]["metric"], "value": units / dt, "unit": ALGO[name]["unit"],
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
+        "config": {"workload": w.describe(), "units_per_gpu": w.n, "units_per_step": int(total_units),
+                   "parallelism": (("%d-term MSM sharded over %d rank(s), all_gather of 160-B partials + fold" % (int(total_units), world)) if name == "msm" else "replicas x%d" % world)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms) else None,
+                     "kernel": kt["dominant_kernel"], "kernel_ms_per_launch": dom_ms, "launches_per_step": kt["passes_per_step"],
+                     "units_per_launch": upl, "algorithmic_bytes_per_unit": ALGO[name]["bytes"], "algorithmic_bytes_what": ALGO[name]["bytes_what"],
+                     "algorithmic_bytes": algo_bytes, "timings_ms": {k: v for k, v in kt.items() if isinstance(v, float)},
+                     "note": "`frac` prices the ALGORITHMIC bytes (what the caller hands over) against HBM: small, because the kernel is bound by "
+                             "v_mad_u64_u32 issue (see `valu`).  `traffic` is what the kernel actually moves per launch (PMC; table / point "
+                             "gathers): `traffic_frac` of HBM peak is the second roof these kernels sit under"},
+        "valu": {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": ref_mac,
+                 "field_ops_per_unit": "%.1f M + %.1f S: %s" % (cost["M"], cost["S"], cost["what"]),
+                 "achieved": per_gpu * mac_impl / 1e12, "peak": mac_peak / 1e12, "unit": "TMAC/s (per GPU)",
+                 "frac": per_gpu * mac_impl / mac_peak, "peak_source": "c25519_microbench(0) on this GPU, this run",
+                 "dominant_kernel_frac": (upl * costs.mac(w.kernel_cost(cost)) / (dom_ms * 1e-3) / mac_peak) if dom_ms else None},
+        "cpu_baseline": cpu_baseline,
+    }
+    return res
+
+
+def _describe(self):
+    n = "2^%d" % self.log2n
+    if self.name == "msm":
+        tot = getattr(self, "total_terms", self.n)
+        return "msm: %d-term variable-base MSM (raw 160-byte points, reduced scalars) in one call per step; this rank holds %s terms; inputs resident in HBM; CompressedEdwardsY out" % (tot, n)
+    if self.name == "verify":
+        return "verify: verify_batch of %s signatures (32-byte messages, distinct keys) per step, z_mode %s, %s; inputs resident in HBM" % (
+            n, "transcript (reference-exact, host-sequential)" if self.z_mode == 0 else "device",
+            "keys as 32 bytes (decompressed inside)" if self.keys_as_bytes else "keys = VerifyingKey (bytes + cached point), as in the reference")
+    if self.name == "fixed_base":
+        return "fixed_base: %s scalar*B -> CompressedEdwardsY per step, %s; inputs resident in HBM" % (
+            n, {"": "radix-2^16 tables in HBM (public scalars)", "comb": "LDS comb", "ct": "constant-time full-window scan (secret scalars)"}[self.variant])
+    return "x25519: %s Montgomery ladders (constant-time cswap) per step; inputs resident in HBM" % n
+
+
+def _kernel_cost(self, cost):
+    """field work of the dominant kernel alone, per unit"""
+    from curve25519_dalek_amd import costs
+    nwin = getattr(self, "_nwin", 17)
+    if self.name == "msm":
+        return {"M": 7 * (nwin - 1), "S": 0}
+    if self.name == "verify":
+        return {"M": 23, "S": 255} if "prep" in self.kt.get("dominant_kernel", "") else {"M": 7 * (8 + nwin - 1), "S": 0}
+    if self.name == "fixed_base":
+        c = costs.compress_batch()
+        return {"M": cost["M"] - c["M"], "S": cost["S"] - c["S"]}
+    return {"M": 255 * 5.1, "S": 255 * 4}
+
+
+Workload.describe = _describe
+Workload.kernel_cost = _kernel_cost
+
+
+def respawn(args):
+    """--gpus N without a launcher: re-execute through torch.distributed.run, one rank per GPU."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py: --gpus %d requested but this box has %d GPU(s): refusing to report a number for a run that did not happen" % (args.gpus, have))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="fixed_base", choices=sorted(ALGO))
-    ap.add_argument("--log2n", type=int, default=None, help="units per GPU = 2^log2n (default: the BASELINE size)")
+    ap.add_argument("--workload", default=None, choices=sorted(ALGO), help="make this the headline and report it alone (default: msm + the others as `sub`)")
+    ap.add_argument("--log2n", type=int, default=None, help="units = 2^log2n (default: the BASELINE size; msm: TOTAL terms under --scaling strong)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"], help="N > 1, msm: 2^24 terms in total (strong, configs[3]) or per GPU (weak)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sub", action="store_true", help="headline only")
+    ap.add_argument("--z-mode", default="device", choices=["device", "transcript"], help="verify headline: z derivation")
+    ap.add_argument("--fixed-base-variant", default="ct", choices=["ct", "vartime"], help="fixed_base headline: ct = constant-time scan (the reference's mul_base semantics), vartime = radix-2^16 tables (public scalars)")
     ap.add_argument("--keys-as-bytes", action="store_true",
                     help="verify: pass only the 32-byte keys (A_i is decompressed inside the call); default: the keys' points "
                          "are cached like the reference's VerifyingKey (verifying.rs:64-71, batch.rs:236)")
     args = ap.parse_args()
 
-    import numpy as np
+    if args.gpus > 1 and "RANK" not in os.environ:
+        respawn(args)
+
     import torch
     import curve25519_dalek_amd as pkg
 
@@ -78,221 +415,146 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = "RANK" in os.environ and "MASTER_ADDR" in os.environ      # launched by torch.distributed.run
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (device_count %d)" % (rank, torch.cuda.device_count() if torch.cuda.is_available() else 0))
     torch.cuda.set_device(local_rank)
+    dist = None
     if use_dist:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     dev = torch.device("cuda", local_rank)
     eng = pkg.Engine(local_rank, window=int(os.environ.get("C25519_WINDOW", "0")))
+    E = pkg.engine
 
-    wl = args.workload
-    log2n = args.log2n if args.log2n is not None else {"fixed_base": 20, "x25519": 20, "msm": 21, "verify": 20}[wl]
-    n = 1 << log2n
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(0xC25519 + rank)
-
-    def rnd(rows, width=32):
-        return torch.randint(0, 256, (rows, width), dtype=torch.uint8, device=dev, generator=gen)
-
-    run = None
-    if wl == "fixed_base":
-        scalars = rnd(n)
-        scalars[:, 31] &= 0x0F                     # uniform in [0, 2^252): reduced scalars
-        out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-
-        def run():
-            eng.mul_base_batch_t(scalars, pkg.engine.FMT_EDWARDS_Y, out)
-    elif wl == "x25519":
-        ks, us = rnd(n), rnd(n)
-        out = torch.empty((n, 32), dtype=torch.uint8, device=dev)
-
-        def run():
-            eng.x25519_batch_t(ks, us, out)
-    elif wl == "msm":
-        # config 4 shape: P_i = y_i * B generated on the device (the host never materialises the points)
-        xs, ys = rnd(n), rnd(n)
-        xs[:, 31] &= int(os.environ.get("C25519_BENCH_TOPMASK", "0x0F"), 16); ys[:, 31] &= 0x0F
-        pts = eng.mul_base_batch_t(ys, pkg.engine.FMT_RAW160)
-        result = {}
-
-        def run():
-            # partial sum on this GPU, then the one exchange step (160 B per rank over RCCL) + fold
-            st, out = pkg.multi.msm_vartime_sharded(eng, xs, pts, pkg.engine.FMT_RAW160, pkg.engine.FMT_EDWARDS_Y)
-            assert st == 0
-            result["out"] = out
-    elif wl == "verify":
-        # inputs: 2^k independent keypairs and 32-byte messages, signed by the engine's own batched signer
-        # (byte-exact against the reference's TESTVECTORS in tests/test_gpu_single.py; not on the measured path)
-        seeds, d_msgs = rnd(n), rnd(n).reshape(-1)
-        d_off = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
-        d_pks, d_sigs = eng.sign_batch_t(seeds, d_msgs, d_off)
-        d_pk_points = None
-        if not args.keys_as_bytes:
-            _, d_pk_points, ok = eng.decompress_batch_t(d_pks)       # VerifyingKey::from_bytes, done once per key
-            assert bool(ok.all())
-        result = {}
-
-        def run():
-            result["st"] = eng.verify_batch_t(d_msgs, d_off, d_sigs, d_pks, pkg.engine.Z_DEVICE, pk_points=d_pk_points)
+    head = args.workload or "msm"
+    scaling = args.scaling if head == "msm" else "weak"
+    log2n = args.log2n if args.log2n is not None else DEFAULT_LOG2N[head]
+    if head == "msm" and scaling == "strong":
+        total = 1 << log2n
+        lo, hi = pkg.multi.shard_range(total, rank, world)
+        w = Workload.__new__(Workload)
+        # shard sizes are equal powers of two for world in {1, 2, 4, 8}; otherwise round the shard to its own size
+        per = hi - lo
+        Workload.__init__(w, "msm", eng, pkg, torch, dev, max(0, per.bit_length() - 1), rank, world, args)
+        if w.n != per:
+            raise SystemExit("bench.py: --scaling strong needs a power-of-two world size")
+        w.total_terms = total
+    else:
+        w = Workload(head, eng, pkg, torch, dev, log2n, rank, world, args)
+        w.total_terms = w.n * world
+    if head == "fixed_base":
+        w.variant = "ct"
+        if args.fixed_base_variant == "vartime":
+            w.variant = ""
+            w.run = lambda: eng.mul_base_batch_vartime_t(w.scalars, E.FMT_EDWARDS_Y, w.out)
 
     def barrier():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- sanity outside the timed region.  The oracle (test infrastructure) is used ONLY in the cpu_baseline leg:
-    # there its outputs on the sample are also compared with the GPU's.  Here: product-only checks. -------------
-    cpu_baseline = None
-    use_oracle = (rank == 0 and world == 1 and not args.no_cpu_baseline)
-    run()
-    torch.cuda.synchronize(dev)
-    if wl == "verify" and result["st"] != 0:
-        raise SystemExit("SELF-CHECK FAILURE: valid batch rejected (status %d)" % result["st"])
-    if wl == "msm" and world == 1:
-        # (sum x_i y_i mod l) * B through the engine's fixed-base kernel must equal the MSM over P_i = y_i * B
-        L = 2**252 + 27742317777372353535851937790883648493
-        def limbs(t):
-            return (t.view(torch.int16).to(torch.int64) & 0xFFFF)
-        ax, ay = limbs(xs), limbs(ys)
-        acc = 0
-        for j in range(16):
-            col = (ax[:, j:j + 1] * ay).sum(0).cpu().tolist()           # exact: each entry < 2^21 * 2^32
-            for k in range(16):
-                acc += int(col[k]) << (16 * (j + k))
-        want = eng.mul_base_batch(np.frombuffer((acc % L).to_bytes(32, "little"), np.uint8).reshape(1, 32))[0].tobytes()
-        if result["out"] != want:
-            raise SystemExit("SELF-CHECK FAILURE: MSM result differs from (sum x_i y_i) B")
-
+    w.self_check()
     # live peak of the binding unit on THIS box (box-to-box spread is ~6 %): v_mad_u64_u32 issue rate, measured right
-    # before the warmup steps by the library's own probe kernel (c25519_microbench, kernels.hip), best of 100 runs.
+    # before the timed steps by the library's own probe kernel (c25519_microbench, kernels.hip), best of 100 runs.
     # The ~60 ms of full-rate integer work also bring the GPU from its idle clock to the sustained one (measured: the
-    # probe reads 27 T/s cold and 33 T/s after ~50 ms; a 0.8 ms step is 15 % slower on a cold clock), so a short
-    # --steps measures steady-state throughput, not the ramp, and `valu.peak` is taken in the same clock state.
-    mac_peak = max(eng.microbench(0, 4000) for _ in range(int(os.environ.get("C25519_BENCH_PROBES", "100")))) * 1e9
-    for _ in range(args.warmup):
-        run()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    barrier()
-    dt = time.perf_counter() - t0
+    # probe reads 27 T/s cold and 33 T/s after ~50 ms), so a short --steps measures steady-state throughput, not the ramp.
+    probes = int(os.environ.get("C25519_BENCH_PROBES", "100"))
+    mac_peak = max(eng.microbench(0, 4000) for _ in range(probes)) * 1e9
+
+    dt = time_steps(w.run, args.steps, args.warmup, barrier)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    rccl_ranks = dist.get_world_size() if use_dist else 1
 
-    # dominant-kernel duration: HIP events recorded inside the library on the launch stream,
-    # averaged over the timed steps (ring of the last 64 calls)
-    k = min(args.steps, 64)
-    dom_ms = sum(eng.phase_ms(b, 0) for b in range(k)) / k
-    rest_ms = sum(eng.phase_ms(b, 1) for b in range(k)) / k
-
-    if use_oracle:
-        from oracle import orc
-        cores = host_cores()
-        # parity of the GPU outputs against the oracle on the sample it is about to be timed on
-        if wl in ("fixed_base", "x25519"):
-            idx = torch.randperm(n, device=dev, generator=gen)[:1024].cpu().numpy()
-            if wl == "fixed_base":
-                want = orc.mul_base_compress_batch(scalars[idx].cpu().numpy(), threads=cores)
-            else:
-                want = orc.x25519_batch(ks[idx].cpu().numpy(), us[idx].cpu().numpy(), threads=cores)
-            if not np.array_equal(out[idx].cpu().numpy(), want):
-                raise SystemExit("PARITY FAILURE: GPU output differs from the oracle")
-        elif wl == "msm":
-            m = 2048
-            want = orc.ed_compress(orc.ed_msm([xs[i].cpu().numpy().tobytes() for i in range(m)], [pts[i].cpu().numpy().tobytes() for i in range(m)]))
-            st, got = eng.msm_vartime_t(xs[:m].contiguous(), pts[:m].contiguous(), pkg.engine.FMT_RAW160, pkg.engine.FMT_EDWARDS_Y)
-            if st != 0 or got != want:
-                raise SystemExit("PARITY FAILURE: MSM result differs from the oracle's")
-        else:
-            mh = d_msgs.reshape(n, 32).cpu().numpy(); sig_h = d_sigs.cpu().numpy(); pk_h = d_pks.cpu().numpy()
-            for i in range(0, n, n // 64):
-                if orc.ed25519_verify(pk_h[i].tobytes(), mh[i].tobytes(), sig_h[i].tobytes()) != 0:
-                    raise SystemExit("PARITY FAILURE: the oracle rejects a signature the engine accepts")
-        if wl in ("fixed_base", "x25519"):
-            # embarrassingly parallel in the reference too: one slice per host core
-            probe = min(n, 1024 * cores)
-            if wl == "fixed_base":
-                a = scalars[:probe].cpu().numpy()
-                f = lambda m: orc.mul_base_compress_batch(np.resize(a, (m, 32)), threads=cores)
-            else:
-                a, b = ks[:probe].cpu().numpy(), us[:probe].cpu().numpy()
-                f = lambda m: orc.x25519_batch(np.resize(a, (m, 32)), np.resize(b, (m, 32)), threads=cores)
-            used = cores
-        elif wl == "msm":
-            # the reference's MSM is one single-threaded call (Pippenger, w = 8): time it as such
-            probe = 4096
-            xa = xs[:1 << 17].cpu().numpy(); pa = pts[:1 << 17].cpu().numpy()
-            f = lambda m: orc.ed_msm([xa[i].tobytes() for i in range(m)], [pa[i].tobytes() for i in range(m)])
-            used = 1
-        else:
-            probe = 2048
-            f = lambda m: orc.ed25519_verify_batch([mh[i].tobytes() for i in range(m)], [sig_h[i].tobytes() for i in range(m)], [pk_h[i].tobytes() for i in range(m)])
-            used = 1
-        f(min(probe, 256))                                              # warm caches / tables
-        c0 = time.perf_counter(); f(probe); c1 = time.perf_counter() - c0
-        cap = (16 * n) if wl in ("fixed_base", "x25519") else (n if wl == "verify" else (1 << 17))
-        m = int(max(probe, min(cap, probe * 10.0 / max(c1, 1e-4))))     # ~10 s of work
-        c0 = time.perf_counter(); f(m); c1 = time.perf_counter() - c0
-        cpu_baseline = {"value": m / c1, "unit": ALGO[wl]["unit"], "cores": used, "kind": "port",
-                        "sample": "%d units of the same workload through the C restatement of the reference serial_u64 path (oracle/), %d thread(s), %.1f s; host exposes %d usable cores" % (m, used, c1, cores)}
-
-    traffic = None
-    traffic_src = None
+    want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
+    budget = float(os.environ.get("C25519_BENCH_CPU_S", "6"))
+    res = None
     if rank == 0:
-        # HBM bytes per launch of the dominant kernel from the committed PMC profile of this workload
-        # (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, tools/profile_all.sh; FETCH_SIZE doubled per the
-        # gfx950 correction in MI355X_MICROARCH.md).  null if no profile has been committed yet.
-        dom_kernel = {"fixed_base": "k_mul_base_comb" if os.environ.get("C25519_WINDOW", "0") == "9" else "k_mul_base_wide", "x25519": "k_x25519", "msm": "k_accumulate", "verify": "k_accumulate"}[wl]
-        import glob
-        for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc.txt" % wl)), reverse=True):
-            fetch = write = None
-            cur = None
-            for line in open(f):
-                if not line.startswith(" "):
-                    cur = line.strip()
-                elif cur and dom_kernel in cur:
-                    parts = line.split()
-                    if parts[0] == "FETCH_SIZE":
-                        fetch = float(parts[1])
-                    if parts[0] == "WRITE_SIZE":
-                        write = float(parts[1])
-            if fetch is not None and write is not None:
-                traffic = (2.0 * fetch + write) * 1024.0
-                traffic_src = os.path.relpath(f, ROOT)
-                break
+        res = record(w, dt, args.steps, args.warmup, world, mac_peak, w.cpu_baseline(budget) if want_cpu else None, scaling)
+        res["ranks_seen_by_rccl"] = rccl_ranks
+    if use_dist:
+        dist.barrier()
+
+    # ---- the other BASELINE configurations, N = 1 only ----------------------------------------------------------------
+    if rank == 0 and world == 1 and args.workload is None and not args.no_sub:
+        del w
+        torch.cuda.empty_cache()
+        sub = {}
+
+        def run_sub(key, ww, steps=args.steps, warmup=args.warmup, cpu=True):
+            ww.self_check()
+            max(eng.microbench(0, 4000) for _ in range(10))             # keep the clock up between workloads
+            d = time_steps(ww.run, steps, warmup, barrier)
+            r = record(ww, d, steps, warmup, 1, mac_peak, ww.cpu_baseline(budget) if (cpu and want_cpu) else None, "weak")
+            for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus"):
+                r.pop(k, None)
+            sub[key] = r
+
+        wv = Workload("verify", eng, pkg, torch, dev, 20, 0, 1, args)
+        run_sub("verify_batch_2p20", wv)
+        # the strict-transcript z-mode (what the INTEGRATION.md shim passes): host-sequential STROBE, reported at 2^14 and 2^20
+        strict = {}
+        for lg, st_steps in ((14, 10), (20, 3)):
+            if lg == 20:
+                ws_ = wv
+            else:
+                ws_ = Workload("verify", eng, pkg, torch, dev, lg, 0, 1, args)
+            ws_.z_mode = E.Z_TRANSCRIPT
+            ws_.self_check()
+            d = time_steps(ws_.run, st_steps, 1, barrier)
+            strict["2^%d" % lg] = {"verifies_per_s": (1 << lg) * st_steps / d, "ms_per_batch": d / st_steps * 1e3}
+        sub["verify_batch_2p20"]["strict_transcript_z_mode"] = strict
+        sub["verify_batch_2p20"]["strict_transcript_z_mode"]["note"] = "z_mode 0: byte-for-byte the reference's Merlin transcript, one host core absorbs 96 bytes per signature; the curve work stays on the GPU"
+        del wv, ws_
+        torch.cuda.empty_cache()
+        # configs[1] as the reference defines it (mul_base is constant-time: the context's default) ...
+        wf = Workload("fixed_base", eng, pkg, torch, dev, 20, 0, 1, args)
+        wf.variant = "ct"
+        run_sub("fixed_base_2p20", wf)
+        # ... and with the fast tables, for callers whose scalars are public
+        wf.variant = ""
+        wf.run = lambda: eng.mul_base_batch_vartime_t(wf.scalars, E.FMT_EDWARDS_Y, wf.out)
+        run_sub("fixed_base_2p20_vartime_tables", wf, cpu=False)
+        del wf
+        wx = Workload("x25519", eng, pkg, torch, dev, 20, 0, 1, args)
+        run_sub("x25519_2p20", wx, steps=min(args.steps, 5))
+        del wx
+        res["sub"] = sub
+        res["side"] = side_numbers(pkg, eng, torch, dev)
+
     if rank == 0:
-        units = float(n) * world * args.steps
-        algo_bytes = ALGO[wl]["bytes"] * n
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else None
-        res = {
-            "metric": ALGO[wl]["metric"], "value": units / dt, "unit": ALGO[wl]["unit"],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
-            "config": {"workload": "%s: 2^%d units per GPU, inputs resident in HBM, canonical 32-byte outputs%s" % (
-                wl, log2n, "" if wl != "verify" else (", keys as 32 bytes (decompressed inside)" if args.keys_as_bytes else ", keys = VerifyingKey (bytes + cached point), as in the reference")),
-                       "units_per_gpu": n, "parallelism": ("sharded terms, all_gather of 160-B partials x%d" if wl == "msm" else "replicas x%d") % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes": algo_bytes,
-                         "dominant_kernel_ms": dom_ms, "other_kernels_ms": rest_ms,
-                         "note": "integer (VALU v_mad_u64_u32) bound kernel: HBM fraction is tiny by construction; see DESIGN.md"},
-            "cpu_baseline": cpu_baseline,
-        }
-        v = VALU["fixed_base_comb" if (wl == "fixed_base" and os.environ.get("C25519_WINDOW", "0") == "9") else
-                 "verify_bytes" if (wl == "verify" and args.keys_as_bytes) else wl]
-        mac_impl = 100 * v["M"] + 55 * v["S"]
-        per_gpu = units / dt / world
-        res["valu"] = {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": v["ref"],
-                       "field_ops_per_unit": "%d M + %d S: %s" % (v["M"], v["S"], v["what"]),
-                       "achieved": per_gpu * mac_impl / 1e12, "peak": mac_peak / 1e12, "unit": "TMAC/s (per GPU)",
-                       "frac": per_gpu * mac_impl / mac_peak, "peak_source": "c25519_microbench(0) on this GPU, this run"}
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
+
+
+def side_numbers(pkg, eng, torch, dev):
+    """PCIe-inclusive and first-call figures (never `value`): host-pointer entry points, context creation."""
+    import numpy as np
+    E = pkg.engine
+    out = {}
+    t0 = time.perf_counter(); e2 = pkg.Engine(dev.index); torch.cuda.synchronize(dev); out["ctx_create_default_ms"] = (time.perf_counter() - t0) * 1e3
+    rng = np.random.default_rng(5)
+    n = 1 << 20
+    s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); s[:, 31] &= 0x0F
+    t0 = time.perf_counter(); e2.mul_base_batch(s); out["first_call_mul_base_2p20_host_ms"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); e2.mul_base_batch(s); out["mul_base_2p20_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
+    out["mul_base_2p20_host_pointers_per_s"] = n / (out["mul_base_2p20_host_pointers_ms"] * 1e-3)
+    k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); u = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    e2.x25519_batch(k[:1024], u[:1024])
+    t0 = time.perf_counter(); e2.x25519_batch(k, u); out["x25519_2p20_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
+    m = 1 << 21
+    x = rng.integers(0, 256, size=(m, 32), dtype=np.uint8); x[:, 31] &= 0x0F
+    pts = e2.mul_base_batch(x, out_fmt=E.FMT_RAW160)
+    e2.msm_vartime(x[:4096], pts[:4096])
+    t0 = time.perf_counter(); e2.msm_vartime(x, pts); out["msm_2p21_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
+    out["note"] = "wall-clock including pageable-host H2D/D2H copies (PCIe); ctx_create builds the fixed-base tables on the device"
+    e2.close()
+    return out
 
 
 if __name__ == "__main__":

@@ -161,9 +161,11 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) return false;
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_fork2, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming);
-    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) hipEventCreate(&ctx->ring[i][j]);
-    return hipHostMalloc(&ctx->h_msm, 20 * 1024, hipHostMallocDefault) == hipSuccess;
+    hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
+    if (hipMalloc((void **)&ctx->d_slots, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4) != hipSuccess) return false;
+    return hipHostMalloc(&ctx->h_msm, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
 }
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
 c25519_ctx *ctx_peer(c25519_ctx *ctx) {
@@ -171,7 +173,7 @@ c25519_ctx *ctx_peer(c25519_ctx *ctx) {
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
     c25519_ctx *p = new c25519_ctx();
     p->device = ctx->device; p->flags = ctx->flags; p->num_cus = ctx->num_cus; p->w = ctx->w;
-    p->d_table = ctx->d_table; p->owns_table = false;
+    p->d_table = ctx->d_table; p->d_table_ct = ctx->d_table_ct; p->owns_table = false;
     if (!ctx_make_streams(p) || hipMalloc(&p->d_flag, 256) != hipSuccess) { c25519_ctx_destroy(p); return nullptr; }
     ctx->peer = p;
     return p;
@@ -206,6 +208,15 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
         c25519_ctx_destroy(ctx);
         return nullptr;
     }
+    {   // constant-time path: radix-2^5 window tables (52 x 17 entries x 96 B)
+        std::vector<uint32_t> tct;
+        build_basepoint_table(C25519_CT_W, tct);
+        if (hipMalloc(&ctx->d_table_ct, tct.size() * 4) != hipSuccess || hipMemcpy(ctx->d_table_ct, tct.data(), tct.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
+            c25519_ctx_destroy(ctx);
+            return nullptr;
+        }
+    }
     if (wide && build_wide_table(ctx, wide) != C25519_OK) {
         fprintf(stderr, "c25519_ctx_create: building the radix-2^%d fixed-base table failed: %s\n", wide, ctx->err.c_str());
         c25519_ctx_destroy(ctx);
@@ -218,10 +229,11 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
     if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
+    if (ctx->d_table_ct && ctx->owns_table) hipFree(ctx->d_table_ct);
     if (ctx->d_flag) hipFree(ctx->d_flag);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -229,18 +241,25 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_sort) hipEventDestroy(ctx->ev_sort);
-    if (ctx->ev_fork2) hipEventDestroy(ctx->ev_fork2);
-    if (ctx->ev_join2) hipEventDestroy(ctx->ev_join2);
-    if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
+    if (ctx->ev_z) hipEventDestroy(ctx->ev_z);
+    if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
-    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < 3; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);
+    if (ctx->d_slots) hipFree(ctx->d_slots);
+    for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 EXPORT int32_t c25519_ctx_set_stream(c25519_ctx *ctx, void *hip_stream) {
-    hipSetDevice(ctx->device);
+    HIPCHK(hipSetDevice(ctx->device));
+    if ((hipStream_t)hip_stream == ctx->stream) return C25519_OK;
+    // the context's workspaces may still be in use by work enqueued on the old stream: the new stream starts after it
     if (ctx->own_stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
+    else {
+        HIPCHK(hipEventRecord(ctx->ev_rebind, ctx->stream));
+        HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_rebind, 0));
+    }
     ctx->stream = (hipStream_t)hip_stream;
     return C25519_OK;
 }
@@ -258,19 +277,39 @@ EXPORT float c25519_last_kernel_ms(c25519_ctx *ctx) {
     return ms;
 }
 
-// phase p (0: dominant kernel, 1: the rest) of the call made `back` calls ago (0 = latest)
-EXPORT float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase) {
-    if (back >= ctx->ncalls || back >= (uint32_t)c25519_ctx::RING || phase < 0 || phase > 1) return -1.f;
-    hipSetDevice(ctx->device);
-    hipEvent_t *ev = ctx->ring[(ctx->ncalls - 1 - back) % c25519_ctx::RING];
+// phase of one ring entry: 0 = events 0 -> 1 (the dominant kernel), 1 = 1 -> 2 (what follows it), 2 = 3 -> 2 (a whole
+// MSM / verify_batch pass), 3 = 4 -> 5 (decompression of R inside a verify_batch pass)
+static float ring_phase_ms(hipEvent_t *ev, int phase) {
+    static const int from[4] = {0, 1, 3, 4}, to[4] = {1, 2, 2, 5};
+    if (phase < 0 || phase > 3) return -1.f;
     float ms = -1.f;
     if (hipEventSynchronize(ev[2]) != hipSuccess) return -1.f;
-    if (hipEventElapsedTime(&ms, ev[phase], ev[phase + 1]) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, ev[from[phase]], ev[to[phase]]) != hipSuccess) return -1.f;
     return ms;
+}
+// phase of the call (pass, for MSM / verify_batch) made `back` calls ago on THIS context (0 = latest)
+EXPORT float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase) {
+    if (back >= ctx->ncalls || back >= (uint32_t)c25519_ctx::RING) return -1.f;
+    hipSetDevice(ctx->device);
+    return ring_phase_ms(ctx->ring[(ctx->ncalls - 1 - back) % c25519_ctx::RING], phase);
+}
+// the same summed over every pass of the most recent MSM / verify_batch call (passes alternate between the context
+// and its peer); *passes (may be NULL) receives their number.  -1 if the call had more passes than the ring holds.
+EXPORT float c25519_last_call_phase_ms(c25519_ctx *ctx, int phase, uint32_t *passes) {
+    if (passes) *passes = (uint32_t)ctx->last_passes.size();
+    if (ctx->last_passes.empty() || ctx->last_passes.size() > (size_t)c25519_ctx::RING) return -1.f;
+    hipSetDevice(ctx->device);
+    float sum = 0.f;
+    for (auto &pr : ctx->last_passes) {
+        float ms = ring_phase_ms(pr.first->ring[pr.second], phase);
+        if (ms < 0) return -1.f;
+        sum += ms;
+    }
+    return sum;
 }
 
 // ---- fixed base --------------------------------------------------------------------------------
-EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
+int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret) {
     HIPCHK(hipSetDevice(ctx->device));
     if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RISTRETTO && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_base: out_fmt must be 0, 1 or 2"; return -(int32_t)hipErrorInvalidValue; }
     if (out_fmt == C25519_FMT_EDWARDS_Y) {
@@ -281,21 +320,37 @@ EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scala
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    auto mul = [&](uint32_t *scratch, uint8_t *out_raw) -> hipError_t {
+        return secret ? launch_mul_base_ct(d_scalars, n, ctx->d_table_ct, scratch, out_raw, ctx->num_cus, ctx->stream)
+                      : launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, scratch, out_raw, ctx->num_cus, ctx->stream);
+    };
     if (out_fmt == C25519_FMT_RAW160) {
-        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, nullptr, d_out, ctx->num_cus, ctx->stream));
+        HIPCHK(mul(nullptr, d_out));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
     } else if (out_fmt == C25519_FMT_RISTRETTO) {         // RistrettoBasepointTable * scalar, then RistrettoPoint::compress (ristretto.rs:500-533)
-        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, nullptr, (uint8_t *)ctx->tmp_e.p, ctx->num_cus, ctx->stream));
+        HIPCHK(mul(nullptr, (uint8_t *)ctx->tmp_e.p));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
         HIPCHK(launch_compress_ristretto((const uint8_t *)ctx->tmp_e.p, n, d_out, ctx->stream));
+        if (secret) HIPCHK(hipMemsetAsync(ctx->tmp_e.p, 0, n * 160, ctx->stream));
     } else {
-        HIPCHK(launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
+        HIPCHK(mul((uint32_t *)ctx->scratch.p, nullptr));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
         HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+        if (secret) {           // the projective scratch records and prefix products are secret-derived: wipe
+            HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
+        }
     }
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
+}
+EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
+    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, ctx_secret_default(ctx));
+}
+// the same for scalars the caller declares PUBLIC: always the fast tables (addresses depend on the scalar)
+EXPORT int32_t c25519_mul_base_batch_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
+    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, false);
 }
 
 // host-pointer wrapper helper
@@ -324,7 +379,9 @@ EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, ui
     int32_t r;
     if ((r = in.up(scalars, n * 32)) || (r = o.alloc(n * osz))) return r;
     if ((r = c25519_mul_base_batch_dev(ctx, in.p, n, out_fmt, o.p))) return r;
-    return o.down(out, n * osz);
+    r = o.down(out, n * osz);
+    if (ctx_secret_default(ctx) && n) hipMemsetAsync(in.p, 0, n * 32, ctx->stream);      // the staged scalars
+    return r;
 }
 
 // ---- X25519 --------------------------------------------------------------------------------------
@@ -337,10 +394,12 @@ EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k,
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     HIPCHK(launch_clamp(d_k, n, (uint8_t *)ctx->tmp_e.p, ctx->stream));
-    HIPCHK(launch_mul_base(ctx->w, (const uint8_t *)ctx->tmp_e.p, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
+    if (ctx_secret_default(ctx)) HIPCHK(launch_mul_base_ct((const uint8_t *)ctx->tmp_e.p, n, ctx->d_table_ct, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
+    else HIPCHK(launch_mul_base(ctx->w, (const uint8_t *)ctx->tmp_e.p, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     HIPCHK(launch_ratio_p32(1, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // (Z+Y)/(Z-Y)
     HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // secret-derived intermediates: wipe
+    HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
     HIPCHK(hipMemsetAsync(ctx->tmp_e.p, 0, n * 32, ctx->stream));
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -352,7 +411,9 @@ EXPORT int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint6
     int32_t r;
     if ((r = in.up(k, n * 32)) || (r = o.alloc(n * 32))) return r;
     if ((r = c25519_x25519_base_batch_dev(ctx, in.p, n, o.p))) return r;
-    return o.down(out, n * 32);
+    r = o.down(out, n * 32);
+    if (n) hipMemsetAsync(in.p, 0, n * 32, ctx->stream);      // the staged secrets
+    return r;
 }
 EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -365,6 +426,7 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     HIPCHK(launch_ratio_p32(0, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // U / W, 0 -> 0
     HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // the projective result is secret-derived: wipe
+    HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
@@ -375,7 +437,9 @@ EXPORT int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint
     int32_t r;
     if ((r = a.up(k, n * 32)) || (r = b.up(u, n * 32)) || (r = o.alloc(n * 32))) return r;
     if ((r = c25519_x25519_batch_dev(ctx, a.p, b.p, n, o.p))) return r;
-    return o.down(out, n * 32);
+    r = o.down(out, n * 32);
+    if (n) hipMemsetAsync(a.p, 0, n * 32, ctx->stream);      // the staged secret scalars
+    return r;
 }
 
 // ---- (de)compression -------------------------------------------------------------------------------

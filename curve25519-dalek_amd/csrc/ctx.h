@@ -3,8 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <utility>
+#include <vector>
 
 struct devbuf { void *p = nullptr; size_t cap = 0; };
+
+// result slot of one MSM / verify_batch pass (msm.hip): 56 column sums of 40 u32 + 16 u32 of flags and counters
+constexpr int C25519_SLOT_U32 = 56 * 40 + 16, C25519_MAX_SLOTS = 16;
 
 struct c25519_ctx {
     int device = 0;
@@ -14,26 +19,35 @@ struct c25519_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;   // bracket of the most recent entry point
-    // ring of per-call phase events: slot k = {start, after dominant kernel, end} of call (ncalls-1-k)
-    static const int RING = 64;
-    hipEvent_t ring[RING][3] = {};
+    // ring of per-call (per-pass) phase events.  Fixed base / X25519: {start, after the dominant kernel, end}.
+    // MSM / verify_batch pass: {before k_accumulate, after it, end of the pass, start of the pass, before / after the
+    // decompression of R}
+    static const int RING = 64, RING_EV = 6;
+    hipEvent_t ring[RING][RING_EV] = {};
     uint64_t ncalls = 0;
-    uint32_t *d_table = nullptr;   // fixed-base table, [NWIN][HALF+1][24] u32
+    std::vector<std::pair<c25519_ctx *, int>> last_passes;   // (context, ring index) of every pass of the latest MSM / verify_batch call
+    uint32_t *d_table = nullptr;   // fixed-base table of algorithm `w` (LDS window / comb tables: canonical words; radix-2^C: limb records)
+    uint32_t *d_table_ct = nullptr;   // radix-2^5 LDS window tables for the constant-time (full-scan) fixed-base kernel
     void *d_flag = nullptr;        // 256 bytes of device flags / small results
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_fork2 = nullptr, ev_join2 = nullptr, ev_sort = nullptr;
-    void *h_pinned = nullptr; size_t h_pinned_cap = 0;   // pinned host staging for small read-backs
-    void *h_msm = nullptr;                               // 20 KB pinned: window totals + flags of msm_core
-    // a second set of streams / workspaces on the same device (shares the fixed-base table): multi-pass MSM and
-    // verify_batch run alternate passes on it from a second host thread, so that the low-VALU phases of one pass
-    // (normalise, sort, reduce, read-back) overlap the accumulation of the other.  Created on first use.
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr;
+    void *h_msm = nullptr;                               // pinned: C25519_MAX_SLOTS result slots
+    uint32_t *d_slots = nullptr;                         // device: C25519_MAX_SLOTS result slots (written by this context and its peer)
+    // a second set of streams / workspaces on the same device (shares the fixed-base tables): multi-pass MSM and
+    // verify_batch enqueue alternate passes on it, so that the low-VALU phases of one pass (normalise, sort, reduce)
+    // overlap the accumulation of the other.  Created on first use.
     c25519_ctx *peer = nullptr;
     bool owns_table = true;
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
-    devbuf tmp_a, tmp_b, tmp_c, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
+    devbuf tmp_a, tmp_b, tmp_c, tmp_c2, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
     std::string err;
 };
 
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);
 int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
 c25519_ctx *ctx_peer(c25519_ctx *ctx);      // nullptr if it cannot be created
+// out[i] = scalars[i] * B.  secret: constant-time table scan (k_mul_base<5, CT>) and wiped scratch; otherwise the context's
+// fast tables (the radix-2^16 HBM tables by default), whose addresses depend on the scalar.
+int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret);
+int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok, bool ct);
+inline bool ctx_secret_default(const c25519_ctx *ctx) { return !(ctx->flags & 0x100u); }   // !C25519_FLAG_VARTIME_TABLES

@@ -215,7 +215,7 @@ EXPORT int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp 
     HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (hb) return C25519_NONE;
-    if ((r = msm_core(ctx, d_sc, m, d_pts, R, nullptr))) return r;
+    if ((r = msm_core(ctx, d_sc, m, d_pts, R))) return r;
     host_encode(R, out_fmt, out);
     return C25519_OK;
 }
@@ -233,7 +233,10 @@ EXPORT int32_t c25519_msm_consttime(c25519_ctx *ctx, const uint8_t *scalars, con
     HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, scalars, n * 32, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, st));
     uint8_t *d_raw = (uint8_t *)ctx->tmp_c.p, *d_ok = d_raw + n * 160;
-    if ((r = c25519_mul_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, C25519_FMT_RAW160, d_raw, d_ok))) return r;
+    // always the constant-address table scan, whatever the context's flags: that is what this entry point is for
+    r = mul_batch_impl(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, C25519_FMT_RAW160, d_raw, d_ok, true);
+    hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, st);          // the staged secret scalars, on every path
+    if (r) return r;
     // c25519_mul_batch_dev left the products as P40 records in tmp_e: fold them
     const int K = 4;
     uint32_t *cur = (uint32_t *)ctx->tmp_e.p;

@@ -7,10 +7,13 @@ namespace c25519 {
 
 hipError_t launch_mul_base(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *scratch,
                            uint8_t *out_raw, int num_cus, hipStream_t st);
+constexpr int C25519_CT_W = 5;     // window width of the constant-time fixed-base tables (52 windows x 17 entries, 85 KB of LDS)
+hipError_t launch_mul_base_ct(const uint8_t *scalars, uint64_t n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40 = false);
 hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, hipStream_t st);
 hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st);
-hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st);
+// flags[0] += signatures with a non-canonical s; flags[1] |= 1 if the message offsets are not monotone / run past msgs_len
+hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st);
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, uint64_t n, uint32_t *scratch, hipStream_t st);
 hipError_t launch_ratio_p32(int mode, const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);

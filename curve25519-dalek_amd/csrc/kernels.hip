@@ -17,8 +17,12 @@ namespace c25519 {
 //     Table layout (global and LDS): [NWIN][HALF+1] entries x 6 uint4; entry j of window i is
 //     j * 2^(W*i) * B as canonical (y+x, y-x, 2dxy) 3 x 32 bytes; entry 0 is the identity.
 // ================================================================================================
+//     CT = true is the constant-time form for SECRET scalars: the reference's LookupTable::select (window.rs:54-76)
+//     -- every entry of the window's table is read (one LDS address for the whole wave: a broadcast) and the wanted one is
+//     kept with v_cndmask, so neither an address nor a branch depends on the scalar; the recoding and the conditional
+//     negation are already branch-free.  Cost: (2^(W-1) + 1) x 24 selects per window beside the 7 M addition.
 // OUT: 0 = P32 scratch record (X,Y,Z) for the batched compressor, 1 = raw 160-byte point, 2 = P40 (tight limbs)
-template <int W, int BS, int OUT>
+template <int W, int BS, int OUT, bool CT>
 __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ scalars, u64 n,
                                                  const uint4 *__restrict__ gtab, u32 *__restrict__ scratch,
                                                  uint8_t *__restrict__ out_raw) {
@@ -42,10 +46,29 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
             bool neg = (win != NWIN - 1) && (d >= (u32)HALF);
             u32 mag = neg ? 2u * HALF - d : d;
             carry = neg ? 1u : 0u;
-            const uint4 *e = wtab + mag * 6;
-            uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
-            u32 tw[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
-                          q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+            u32 tw[24];
+            if (CT) {
+#pragma unroll
+                for (int i = 0; i < 24; i++) tw[i] = 0;
+#pragma unroll 1
+                for (int ent = 0; ent < ENT; ent++) {
+                    const uint4 *e = wtab + ent * 6;                    // wave-uniform address
+                    const bool hit = (u32)ent == mag;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) {
+                        const uint4 v = e[i];
+                        tw[4 * i] = hit ? v.x : tw[4 * i]; tw[4 * i + 1] = hit ? v.y : tw[4 * i + 1];
+                        tw[4 * i + 2] = hit ? v.z : tw[4 * i + 2]; tw[4 * i + 3] = hit ? v.w : tw[4 * i + 3];
+                    }
+                }
+            } else {
+                const uint4 *e = wtab + mag * 6;
+                uint4 q0 = e[0], q1 = e[1], q2 = e[2], q3 = e[3], q4 = e[4], q5 = e[5];
+                u32 t2[24] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w,
+                              q4.x, q4.y, q4.z, q4.w, q5.x, q5.y, q5.z, q5.w};
+#pragma unroll
+                for (int i = 0; i < 24; i++) tw[i] = t2[i];
+            }
             aniels_words_cneg(tw, neg);
             P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
             wtab += ENT * 6;
@@ -415,7 +438,7 @@ __global__ void __launch_bounds__(256) k_probe_femul51(u32 *out, int iters, u32 
 // ================================================================================================
 static inline unsigned div_up(u64 a, u64 b) { return (unsigned)((a + b - 1) / b); }
 
-template <int W, int BS>
+template <int W, int BS, bool CT = false>
 static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw,
                                     int num_cus, hipStream_t st, bool p40 = false) {
     constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
@@ -424,17 +447,17 @@ static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_
     unsigned maxgrid = (unsigned)num_cus * (lds_bytes > 80 * 1024 ? 1u : 2u);
     if (grid > maxgrid) grid = maxgrid;
     if (p40) {
-        auto kfn = k_mul_base<W, BS, 2>;
+        auto kfn = k_mul_base<W, BS, 2, CT>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
     } else if (out_raw) {
-        auto kfn = k_mul_base<W, BS, 1>;
+        auto kfn = k_mul_base<W, BS, 1, CT>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
     } else {
-        auto kfn = k_mul_base<W, BS, 0>;
+        auto kfn = k_mul_base<W, BS, 0, CT>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab), scratch, out_raw);
@@ -486,6 +509,13 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t 
         return hipGetLastError();
     }
     return hipErrorInvalidValue;
+}
+
+// constant-time fixed base (secret scalars): radix-2^5 LDS tables with the full-window scan.  out_raw / scratch as launch_mul_base;
+// p40: write P40 records to scratch instead
+hipError_t launch_mul_base_ct(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
+    if (n == 0) return hipSuccess;
+    return launch_mul_base_w<C25519_CT_W, 1024, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
 }
 
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st) {

@@ -17,19 +17,19 @@
 //   order     buckets sorted by list length, so that the lanes of a wave walk lists of equal length
 //   accumulate one lane per (window, bucket): sequential mixed additions over its gather list, next point and the
 //             index after it in flight; lists longer than LONG_CAP go to a wave-cooperative path on the second stream
-//   reduce    sum_b (b+1) B_b by an 8-ary hierarchy of running sums (pippenger.rs:146-151 per segment); the narrow
-//             upper levels use eight lanes per segment
+//   reduce    sum_b (b+1) B_b in two launches: serial running sums over 8 buckets per lane (pippenger.rs:146-151), then
+//             wave-wide weighted sums through shuffles (one wave per 512 buckets, then one wave per window)
 //   fold      total.mul_by_pow_2(w_k) + column (pippenger.rs:159) over the window sums: on the host, through the
 //             same ge26.h formulas (a serial chain of ~250 doublings is a latency-bound tail that a single CPU core
-//             finishes faster than a single GPU lane)
-//   passes    inputs beyond 3 * 2^20 terms are cut into passes of ~2^21 terms (the multi-GPU decomposition, in time)
+//             finishes faster than a single GPU lane), ONCE per call: passes leave their column sums in device slots
+//   passes    inputs beyond 3 * 2^20 terms are cut into passes of ~2^21 terms (the multi-GPU decomposition, in time),
+//             enqueued back to back on two stream sets by one host thread; no pass waits for the host
 //
 // Window width c is chosen per call from n (reference: w = 6/7/8, pippenger.rs:81-87).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
-#include <thread>
 #include <vector>
 #include "../../include/c25519_hip.h"
 #include "devio.h"
@@ -58,34 +58,40 @@ template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
+    // two waves per SIMD at n = 2^21: nothing else hides the load latency, so every record is fetched one step ahead
+    // of the multiplication that consumes it (as k_compress_p32 does)
     feT acc = fe_one();
     bool affine = true;                 // every Z of this lane is literally 1 (points straight from a decompression,
                                         // e.g. VerifyingKey.point): the shared inversion is skipped
+    int cnt = 0;
+    feT Zc = raw160_fe(in, t, 2);
+    bool onec = raw160_z_is_one(in, t);
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
-        u64 idx = t + (u64)j * T;
+        const u64 idx = t + (u64)j * T;
         if (idx >= n) break;
-        affine = affine && raw160_z_is_one(in, idx);
-        uint4 *q = reinterpret_cast<uint4 *>(prefix) + 3 * idx;
-        q[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]); q[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
-        q[2] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
-        acc = fe_mul(acc, raw160_fe(in, idx, 2));
+        cnt = j + 1;
+        const u64 nxt = idx + T;
+        const bool more = (j + 1 < CH) && nxt < n;
+        feT Zn = more ? raw160_fe(in, nxt, 2) : Zc;
+        const bool onen = more ? raw160_z_is_one(in, nxt) : true;
+        affine = affine && onec;
+        fe48_store(prefix, idx, acc);
+        acc = fe_mul(acc, Zc);
+        Zc = Zn; onec = onen;
     }
     feT inv = fe_one();
     if (!affine) inv = fe_invert(acc);
+    u64 idx = t + (u64)(cnt - 1) * T;
+    feT Z = raw160_fe(in, idx, 2), X = raw160_fe(in, idx, 0), Y = raw160_fe(in, idx, 1), pre = fe48_load(prefix, idx);
 #pragma unroll 1
-    for (int j = CH - 1; j >= 0; j--) {
-        u64 idx = t + (u64)j * T;
-        if (idx >= n) continue;
-        const uint4 *q = reinterpret_cast<const uint4 *>(prefix) + 3 * idx;
-        uint4 a = q[0], b = q[1], c = q[2];
-        feT pre;
-        pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
-        pre.v[8] = c.x; pre.v[9] = c.y;
-        feT Z = raw160_fe(in, idx, 2);
+    for (int j = cnt - 1; j >= 0; j--) {
+        const u64 cur = t + (u64)j * T, prv = j > 0 ? cur - T : cur;
+        feT Zp = raw160_fe(in, prv, 2), Xp = raw160_fe(in, prv, 0), Yp = raw160_fe(in, prv, 1), prep = fe48_load(prefix, prv);
         feT zi = fe_mul(inv, pre);
         inv = fe_mul(inv, Z);
-        pts_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
+        pts_store(pts, dst0 + cur, fe_mul(X, zi), fe_mul(Y, zi));
+        Z = Zp; X = Xp; Y = Yp; pre = prep;
     }
 }
 __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
@@ -102,8 +108,7 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 // fill all `half` buckets and it produces no carry), and below it signed windows of c or c-1 bits.
 //   digit k = bits [pos[k], pos[k] + wid[k]) of s' = s + addk, minus 2^(wid[k]-1) for the signed windows,
 //   addk = sum over signed windows of 2^(pos[k] + wid[k] - 1).
-constexpr int MSM_MAX_WIN = 56;
-struct msm_geom { int c, nwin, half; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+// (struct msm_geom: msm_internal.h)
 
 // D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
 __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
@@ -418,12 +423,39 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const uint16_t *__restr
 // Counting sort of the (window, bucket) ids by list length (clamped to 255), longest first, so that a
 // wave's 64 lanes finish together (Poisson-distributed lengths otherwise cost ~25 % idle lanes) and the
 // long lists start first.  ord_hist: 256 global bins; perm: bucket ids in processing order.
-__global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ totals, u64 nb, u32 *__restrict__ ord_hist) {
+struct long_item { u32 gid, lo, hi, first; };
+constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
+constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
+// The same sweep over the bucket totals also emits the work list of the wave-cooperative long-bucket path (one item per
+// segment of LONG_SEG entries of a bucket longer than LONG_CAP), so the list exists before accumulation starts
+// (round 1 had a separate k_find_long on the second stream: a 16-VGPR scan that took 0.6 ms starved beside k_accumulate).
+__global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ totals, const u32 *__restrict__ base, msm_geom g, u64 gid_off, u64 nb,
+                                                    u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items,
+                                                    u32 *__restrict__ counters /* [0]=#items [1]=#long buckets */, u32 *__restrict__ long_gids,
+                                                    u32 *__restrict__ long_first) {
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < nb) { u32 c = totals[gid]; atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u); }
+    if (gid < nb) {
+        const u32 c = totals[gid_off + gid];
+        atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u);
+        if (c > LONG_CAP) {
+            const u64 G = gid + gid_off;
+            const int k = (int)(G / g.half), b = (int)(G % g.half);
+            const u32 lo = base[(u64)k * (g.half + 1) + b], hi = lo + c;
+            const u32 nseg = (c + LONG_SEG - 1) / LONG_SEG;
+            const u32 first = atomicAdd(&counters[0], nseg);
+            const u32 lb = atomicAdd(&counters[1], 1u);
+            long_gids[lb] = (u32)G;
+            long_first[lb] = first;
+            // number of segments of this bucket is recomputed by the combiner from base[]
+            for (u32 sg = 0; sg < nseg && first + sg < max_items; sg++) {
+                long_item it; it.gid = (u32)G; it.lo = lo + sg * LONG_SEG; it.hi = (it.lo + LONG_SEG < hi) ? it.lo + LONG_SEG : hi; it.first = first;
+                items[first + sg] = it;
+            }
+        }
+    }
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ord_hist[threadIdx.x], h[threadIdx.x]);
 }
@@ -454,10 +486,8 @@ __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ t
 }
 
 // Buckets longer than LONG_CAP are left to the wave-cooperative path below, so that no lane ever walks a
-// long list alone (skewed inputs: e.g. the +1 carry digit of every 128-bit z_i in verify_batch lands
+// long list alone (skewed inputs: e.g. the +1 carry digit of every unsigned 128-bit z_i in verify_batch lands
 // ~n/2 terms in ONE bucket; identical scalars do the same in every window).
-constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
-constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
                                                     const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
@@ -513,30 +543,16 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
     p40_store(buckets, gid, acc);
 }
 
-// ---- long buckets -------------------------------------------------------------------------------------
-// work list: one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
-struct long_item { u32 gid, lo, hi, first; };
-__global__ void __launch_bounds__(256) k_find_long(const u32 *__restrict__ base, msm_geom g, u64 gid_off, u64 count, u32 max_items, long_item *__restrict__ items,
-                                                   u32 *__restrict__ counters /* [0]=#items [1]=#long buckets */, u32 *__restrict__ long_gids,
-                                                   u32 *__restrict__ long_first) {
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= count) return;
-    gid += gid_off;
-    int k = (int)(gid / g.half), b = (int)(gid % g.half);
-    u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
-    u32 cnt = hi - lo;
-    if (cnt <= LONG_CAP) return;
-    u32 nseg = (cnt + LONG_SEG - 1) / LONG_SEG;
-    u32 first = atomicAdd(&counters[0], nseg);
-    u32 lb = atomicAdd(&counters[1], 1u);
-    long_gids[lb] = (u32)gid;
-    long_first[lb] = first;
-    // number of segments of this bucket is recomputed by the combiner from base[]
-    for (u32 s = 0; s < nseg && first + s < max_items; s++) {
-        long_item it; it.gid = (u32)gid; it.lo = lo + s * LONG_SEG; it.hi = (it.lo + LONG_SEG < hi) ? it.lo + LONG_SEG : hi; it.first = first;
-        items[first + s] = it;
-    }
+static void launch_accumulate(int pipe, const u32 *pts, const u32 *sorted, const u32 *base, const u32 *perm, u64 count, u64 n, const msm_geom &g, u32 *buckets, hipStream_t st) {
+    const dim3 grid((unsigned)((count + 255) / 256)), blk(256);
+    if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 3) hipLaunchKernelGGL(k_accumulate<3>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else hipLaunchKernelGGL(k_accumulate<2>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
 }
+
+// ---- long buckets -------------------------------------------------------------------------------------
+// work list (made by k_order_hist): one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
 // sum across the 64 lanes of a wave (complete additions; lane 0 ends with the total)
 __device__ __forceinline__ ge_p3 wave_sum(ge_p3 acc) {
 #pragma unroll 1
@@ -593,49 +609,24 @@ __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ bas
 }
 
 // ================================================================================================
-// bucket reduction: one level of the 8-ary running-sum hierarchy   [pippenger.rs:146-151 per segment]
-//   S_out[seg] = sum_j S_in[seg*L + j]
-//   P_out[seg] = 2^shift * sum_j j * S_in[seg*L + j]  +  sum_j P_in[seg*L + j]
+// bucket reduction: col_k = sum_b (b+1) * B_b   [pippenger.rs:146-151]
+//
+// Round 1 ran an 8-ary hierarchy of running sums: one serial level and four wave-starved "cooperative" levels with
+// 3..12 doublings each -- five launches and a dependent chain of ~62 additions + 30 doublings (0.33 ms at c = 16).
+// Now two launches.  Level A: one WAVE per segment of 512 buckets; every lane folds 8 consecutive buckets serially
+// (S = sum B_j, W = sum j B_j: 13 additions, the work-efficient part), then the 64 lanes combine through shuffles:
+//     T_l = sum_{i >= l} S_i (6-step suffix scan),  V_l = 8 * [l >= 1] T_l + W_l,  W_seg = sum_l V_l (6-step butterfly)
+// because sum_l l*S_l = sum_{l >= 1} T_l.  Level B: one wave per window does the same over the <= 64 segment pairs with
+// weight 512 and adds S once more (bucket b holds digit magnitude b+1).  Chain: 26 additions + 3 doublings, then
+// 14 additions + 9 doublings.
 // ================================================================================================
-__global__ void __launch_bounds__(128) k_reduce_level(const u32 *__restrict__ S_in, const u32 *__restrict__ P_in, int m_in, int L, int shift,
-                                                      int nwin, u32 *__restrict__ S_out, u32 *__restrict__ P_out) {
-    int m_out = m_in / L;
-    u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (u64)nwin * m_out) return;
-    int k = (int)(gid / m_out), seg = (int)(gid % m_out);
-    u64 in0 = (u64)k * m_in + (u64)seg * L;
-    ge_p3 run = p40_load(S_in, in0 + L - 1);
-    ge_p3 acc = run;                      // weight of entry L-1 so far: 1
-#pragma unroll 1
-    for (int j = L - 2; j >= 1; j--) {
-        run = ge_add(run, p40_load(S_in, in0 + j));
-        acc = ge_add(acc, run);
-    }
-    if (L > 1) {
-        run = ge_add(run, p40_load(S_in, in0));
-    } else {
-        acc = ge_identity();              // L == 1: weight 0
-    }
-    if (shift > 0) acc = ge_mul_by_pow_2(acc, shift);
-    if (P_in) {
-#pragma unroll 1
-        for (int j = 0; j < L; j++) acc = ge_add(acc, p40_load(P_in, in0 + j));
-    }
-    p40_store(S_out, gid, run);
-    p40_store(P_out, gid, acc);
-}
-
-// The same level computed by EIGHT lanes per segment (lane j holds entry j): a 3-step suffix scan gives the running
-// sums, two 3-step butterflies give sum_j j*S_j and sum_j P_j -- 10 dependent additions instead of 22.  The upper
-// levels have so few segments that they are pure latency (one wave per SIMD or less), so the 8x lane count is free
-// there; the first level keeps k_reduce_level (its 8x lanes would be real work).
-__device__ __forceinline__ ge_p3 p3_shfl_down8(const ge_p3 &a, int d, int j) {
+__device__ __forceinline__ ge_p3 p3_shfl_down64(const ge_p3 &a, int d, int lane) {
     ge_p3 o;
     for (int i = 0; i < 10; i++) {
-        o.X.v[i] = __shfl_down(a.X.v[i], d, 8); o.Y.v[i] = __shfl_down(a.Y.v[i], d, 8);
-        o.Z.v[i] = __shfl_down(a.Z.v[i], d, 8); o.T.v[i] = __shfl_down(a.T.v[i], d, 8);
+        o.X.v[i] = __shfl_down(a.X.v[i], d, 64); o.Y.v[i] = __shfl_down(a.Y.v[i], d, 64);
+        o.Z.v[i] = __shfl_down(a.Z.v[i], d, 64); o.T.v[i] = __shfl_down(a.T.v[i], d, 64);
     }
-    const bool in = j + d < 8;
+    const bool in = lane + d < 64;
     const ge_p3 id = ge_identity();
     for (int i = 0; i < 10; i++) {
         o.X.v[i] = in ? o.X.v[i] : id.X.v[i]; o.Y.v[i] = in ? o.Y.v[i] : id.Y.v[i];
@@ -643,57 +634,88 @@ __device__ __forceinline__ ge_p3 p3_shfl_down8(const ge_p3 &a, int d, int j) {
     }
     return o;
 }
-__device__ __forceinline__ ge_p3 p3_sum8(ge_p3 a) {          // every lane of the group ends with the group total
-#pragma unroll 1
-    for (int d = 4; d > 0; d >>= 1) {
-        ge_p3 o;
-        for (int i = 0; i < 10; i++) {
-            o.X.v[i] = __shfl_xor(a.X.v[i], d, 8); o.Y.v[i] = __shfl_xor(a.Y.v[i], d, 8);
-            o.Z.v[i] = __shfl_xor(a.Z.v[i], d, 8); o.T.v[i] = __shfl_xor(a.T.v[i], d, 8);
-        }
-        a = ge_add(a, o);
+__device__ __forceinline__ ge_p3 p3_shfl_xor64(const ge_p3 &a, int d) {
+    ge_p3 o;
+    for (int i = 0; i < 10; i++) {
+        o.X.v[i] = __shfl_xor(a.X.v[i], d, 64); o.Y.v[i] = __shfl_xor(a.Y.v[i], d, 64);
+        o.Z.v[i] = __shfl_xor(a.Z.v[i], d, 64); o.T.v[i] = __shfl_xor(a.T.v[i], d, 64);
     }
-    return a;
+    return o;
 }
-__global__ void __launch_bounds__(128) k_reduce_level_coop(const u32 *__restrict__ S_in, const u32 *__restrict__ P_in, int m_in, int L, int shift,
-                                                           int nwin, u32 *__restrict__ S_out, u32 *__restrict__ P_out) {
-    const int m_out = m_in / L;
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x, gid = t >> 3;
-    const int j = (int)(t & 7);
-    const bool active = gid < (u64)nwin * m_out;              // whole 8-lane groups are active or not; nobody returns early
-    const int k = active ? (int)(gid / m_out) : 0, seg = active ? (int)(gid % m_out) : 0;
-    const u64 in0 = (u64)k * m_in + (u64)seg * L;
-    const bool have = active && j < L;
-    ge_p3 run = have ? p40_load(S_in, in0 + j) : ge_identity();
-    ge_p3 psum = (have && P_in) ? p40_load(P_in, in0 + j) : ge_identity();
+// in: lane l holds (S_l, W_l).  out (every lane): S = sum_l S_l is in lane 0's S; W = sum_l W_l + 2^shift * sum_l l*S_l in every lane
+__device__ __forceinline__ void wave_weighted_sum(ge_p3 &S, ge_p3 &W, int shift, int lane) {
 #pragma unroll 1
-    for (int d = 1; d < 8; d <<= 1) run = ge_add(run, p3_shfl_down8(run, d, j));      // run_j = sum_{i >= j} S_i
-    ge_p3 acc = p3_sum8(j >= 1 ? run : ge_identity());                                  // sum_{j >= 1} run_j = sum_i i * S_i
-    if (shift > 0) acc = ge_mul_by_pow_2(acc, shift);
-    if (P_in) acc = ge_add(acc, p3_sum8(psum));
-    if (active && j == 0) { p40_store(S_out, gid, run); p40_store(P_out, gid, acc); }
+    for (int d = 1; d < 64; d <<= 1) S = ge_add(S, p3_shfl_down64(S, d, lane));      // S_l <- sum_{i >= l} S_i
+    ge_p3 V = S;
+    {
+        const ge_p3 id = ge_identity();
+        const bool keep = lane >= 1;
+        for (int i = 0; i < 10; i++) {
+            V.X.v[i] = keep ? V.X.v[i] : id.X.v[i]; V.Y.v[i] = keep ? V.Y.v[i] : id.Y.v[i];
+            V.Z.v[i] = keep ? V.Z.v[i] : id.Z.v[i]; V.T.v[i] = keep ? V.T.v[i] : id.T.v[i];
+        }
+    }
+    V = ge_mul_by_pow_2(V, shift);
+    V = ge_add(V, W);
+#pragma unroll 1
+    for (int d = 32; d > 0; d >>= 1) V = ge_add(V, p3_shfl_xor64(V, d));
+    W = V;
+}
+constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A
+// level A: block (one wave) = segment `seg` of window k.  direct: the window has a single segment, write col_k itself.
+__global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct) {
+    const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg, lane = threadIdx.x;
+    const int b0 = seg * RED_SEG + lane * RED_LB;
+    const u32 *B = buckets + (u64)k * half * 40;
+    const ge_p3 id = ge_identity();
+    ge_p3 run = (b0 + RED_LB - 1 < half) ? p40_load(B, b0 + RED_LB - 1) : id;
+    ge_p3 acc = run;
+#pragma unroll 1
+    for (int j = RED_LB - 2; j >= 1; j--) {
+        run = ge_add(run, (b0 + j < half) ? p40_load(B, b0 + j) : id);
+        acc = ge_add(acc, run);
+    }
+    run = ge_add(run, (b0 < half) ? p40_load(B, b0) : id);
+    wave_weighted_sum(run, acc, 3, lane);                // run (lane 0) = S_seg, acc = W_seg = sum (b - seg base) B_b
+    if (lane == 0) {
+        if (direct) p40_store(cols, k, ge_add(acc, run));
+        else { p40_store(SW, 2 * (u64)blockIdx.x, run); p40_store(SW, 2 * (u64)blockIdx.x + 1, acc); }
+    }
+}
+// level B: one wave per window over its nseg <= 64 segment pairs
+__global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int nseg, u32 *__restrict__ cols) {
+    const int k = blockIdx.x, lane = threadIdx.x;
+    const ge_p3 id = ge_identity();
+    ge_p3 S = lane < nseg ? p40_load(SW, 2 * ((u64)k * nseg + lane)) : id;
+    ge_p3 W = lane < nseg ? p40_load(SW, 2 * ((u64)k * nseg + lane) + 1) : id;
+    wave_weighted_sum(S, W, 9, lane);                    // 512 = RED_SEG buckets per segment
+    if (lane == 0) p40_store(cols, k, ge_add(W, S));
 }
 
 // ================================================================================================
 // verify_batch kernels
 // ================================================================================================
-// hram_i = SHA-512(R_i || A_i || M_i) (batch.rs:179-191): 64-byte digest out + canonical-s flag
-__global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, const uint8_t *__restrict__ sigs,
-                                              const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ bad_s) {
+// hram_i = SHA-512(R_i || A_i || M_i) (batch.rs:179-191): 64-byte digest out; flags[0] += non-canonical s,
+// flags[1] |= 1 if the message offsets are not monotone or run past msgs_len (that message is hashed as empty)
+__global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len, const uint8_t *__restrict__ sigs,
+                                              const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 r[8], a[8], s[8];
     load8(sigs, 2 * i, r);
     load8(sigs, 2 * i + 1, s);
     load8(pks, i, a);
-    if (!sc_is_canonical(s)) atomicAdd(bad_s, 1u);     // signature.rs:89-94 check_scalar
+    if (!sc_is_canonical(s)) atomicAdd(&flags[0], 1u);     // signature.rs:89-94 check_scalar
     sha512_stream st;
     st.init();
     for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)r[2 * j] | ((u64)r[2 * j + 1] << 32));       // R || A fills the
     for (int j = 0; j < 4; j++) st.w[4 + j] = bswap64((u64)a[2 * j] | ((u64)a[2 * j + 1] << 32));   // first 64 bytes
     st.fill = 64; st.total = 64;
-    const uint8_t *m = msgs + msg_off[i];
-    u64 len = msg_off[i + 1] - msg_off[i];
+    const u64 o0 = msg_off[i], o1 = msg_off[i + 1];
+    const bool okoff = o0 <= o1 && o1 <= msgs_len;
+    if (!okoff) atomicOr(&flags[1], 1u);
+    const uint8_t *m = msgs + o0;
+    const u64 len = okoff ? o1 - o0 : 0;
     for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
     st.finish();
     u32 w[16];
@@ -701,45 +723,54 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
     for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
 }
-// device z-mode.  The z_i must depend on every input bit of the batch (a per-signature or per-subtree derivation
-// allows a 2^64 meet-in-the-middle forgery), so they are derived from the root of a hash tree over the batch.  The tree
-// is built from the SHA-512 COMPRESSION FUNCTION on fixed-size inputs -- no length padding, hence no extra padding
-// block per node -- with the node's level and the level's node count folded into the chaining value (domain separation
-// and shape binding); nodes are the first 32 bytes of the output (128-bit collision resistance, the level of the z_i).
-// A tree of fixed shape over a collision-resistant compression function is binding, which is all that is needed.
-//   level 0: node_j = F_0(hram_16j[0..32] || s_16j || ... || hram_16j+15[0..32] || s_16j+15): 8 chained blocks per 16
-//            signatures; hram_i = H(R_i || A_i || M_i) already commits to (R_i, A_i, M_i).  Throughput-bound.
-//   level l: node_j = F_l(four children): ONE compression per node.  These levels are pure latency (one dependent
-//            SHA-512 compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
-__device__ __forceinline__ void ztree_iv(u64 hs[8], u32 level, u64 count) {
-    sha512_init(hs);
-    hs[0] ^= 0x7a5f747265650000ull | level;           // "z_tree" || level
-    hs[1] ^= count;                                    // number of nodes of the level being consumed
-}
-__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, uint8_t *__restrict__ out) {
+
+// device z-mode (C25519_Z_DEVICE; NOT the reference's derivation -- see include/c25519_hip.h).  The z_i must depend on
+// every input bit of the batch (a per-signature or per-subtree derivation allows a 2^64 meet-in-the-middle forgery), so
+// they are derived from the root of a hash tree over exactly the byte strings the reference's transcript absorbs
+// (batch.rs:191-199): the 64-byte hram_i = H(R_i || A_i || M_i) and the 32-byte s_i of every signature.
+//   node = first 32 bytes of the SHA-512 chaining value after absorbing  TAG(level, inputs, n) || data , where TAG is one
+//   128-byte block (domain separation and shape binding: level, number of inputs of the level, batch size) whose
+//   compression is done once on the host (the per-level IVs below), and `data` has a fixed length per level, so no
+//   length padding is needed: a Merkle-Damgard chain over fixed-length inputs is collision resistant if the compression
+//   function is; 32-byte nodes give the 128-bit level of the z_i.
+//   level 0: data = hram_16j || s_16j || ... || hram_16j+15 || s_16j+15 (absent = zero bytes): 12 blocks per 16 signatures.
+//   level l: data = four children: ONE compression per node.  These levels are pure latency (one dependent SHA-512
+//            compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
+constexpr int ZTREE_MAX_LEVELS = 16;
+struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
+__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (n + 15) / 16;
     if (j >= m_out) return;
-    u64 hs[8], w[16];
-    ztree_iv(hs, 0u, n);
+    u64 hs[8];
+    for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
 #pragma unroll 1
-    for (int blk = 0; blk < 8; blk++) {                   // 2 signatures x 64 B per block (absent = zero bytes)
+    for (int grp = 0; grp < 4; grp++) {                   // 4 records of 96 bytes = 3 blocks
+        u64 rec[48];
 #pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const u64 c = 16 * j + 2 * blk + half;
+        for (int r = 0; r < 4; r++) {
+            const u64 c = 16 * j + 4 * grp + r;
             const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
 #pragma unroll
-            for (int q = 0; q < 4; q++) { w[8 * half + q] = c < n ? bswap64(h[q]) : 0ull; w[8 * half + 4 + q] = c < n ? bswap64(sg[q]) : 0ull; }
+            for (int q = 0; q < 8; q++) rec[12 * r + q] = c < n ? bswap64(h[q]) : 0ull;
+#pragma unroll
+            for (int q = 0; q < 4; q++) rec[12 * r + 8 + q] = c < n ? bswap64(sg[q]) : 0ull;
         }
-        sha512_compress(hs, w);
+#pragma unroll
+        for (int blk = 0; blk < 3; blk++) {
+            u64 w[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) w[q] = rec[16 * blk + q];
+            sha512_compress(hs, w);
+        }
     }
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
     for (int q = 0; q < 4; q++) o[q] = hs[q];
 }
 // one 4-ary level: out[j] = F_level(in[4j] || in[4j+1] || in[4j+2] || in[4j+3])[0..32]
-__device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, u32 level, u64 *out4) {
+__device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, const u64 iv[8], u64 *out4) {
     u64 hs[8], w[16];
-    ztree_iv(hs, level, m_in);
+    for (int q = 0; q < 8; q++) hs[q] = iv[q];
 #pragma unroll
     for (int ch = 0; ch < 4; ch++) {
         const u64 c = 4 * j + ch;
@@ -749,16 +780,16 @@ __device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, u32 
     sha512_compress(hs, w);
     for (int q = 0; q < 4; q++) out4[q] = hs[q];
 }
-__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, uint8_t *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out) {
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (m_in + 3) / 4) return;
     u64 r[4];
-    ztree_node4(reinterpret_cast<const u64 *>(in), m_in, j, level, r);
+    ztree_node4(reinterpret_cast<const u64 *>(in), m_in, j, ivs.iv[level], r);
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
     for (int q = 0; q < 4; q++) o[q] = r[q];
 }
 // the last levels (m_in <= 1024 nodes) in ONE block: no launch gaps between levels that hold a handful of nodes
-__global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, uint8_t *__restrict__ root) {
+__global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ root) {
     __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
     for (u64 i = threadIdx.x; i < m_in * 4; i += 256) buf0[i] = reinterpret_cast<const u64 *>(in)[i];
     __syncthreads();
@@ -768,7 +799,7 @@ __global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ 
         const u64 mo = (m + 3) / 4;                                  // <= 256 = blockDim
         if (threadIdx.x < mo) {
             u64 r[4];
-            ztree_node4(cur, m, threadIdx.x, level, r);
+            ztree_node4(cur, m, threadIdx.x, ivs.iv[level], r);
             for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = r[q];
         }
         __syncthreads();
@@ -777,29 +808,44 @@ __global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ 
     }
     if (threadIdx.x < 4) reinterpret_cast<u64 *>(root)[threadIdx.x] = cur[threadIdx.x];
 }
-// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)); n4 = ceil(n/4) lanes,
-// z16 has room for 4*n4 entries
+// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)) (standard, padded); n4 = ceil(n/4)
+// lanes, z16 has room for 4*n4 entries.  A quarter is read as SIGN-MAGNITUDE: bit 127 = sign, bits 0..126 = |z_i|, i.e.
+// z_i is uniform on {-(2^127-1) .. 2^127-1} (2^128 - 1 values; a forged batch passes with probability <= 2^-127.99
+// against the reference's 2^-128).  Why signed: the MSM recodes scalars into signed windows, and a magnitude below 2^127
+// never carries out of its eighth 16-bit window, so the R_i terms stay out of windows 8..15; an unsigned 128-bit z_i
+// (C25519_Z_TRANSCRIPT) puts the carry digit +1 of about half of all R_i into ONE bucket of window 8 (the long-bucket
+// path takes it).  The sign is applied to the stored point (k_apply_sign), the MSM scalar is |z_i|.
 __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n4, uint8_t *__restrict__ z16) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
     u64 hs[8], w[16];   // 40-byte message: one block
     sha512_init(hs);
-    for (int q = 0; q < 4; q++) w[q] = bswap64(h[q]);
+    for (int q = 0; q < 4; q++) w[q] = h[q];           // the root is kept as big-endian words of the chaining value
     w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
     for (int q = 6; q < 15; q++) w[q] = 0;
     w[15] = 40 * 8;
     sha512_compress(hs, w);
-    // z_i < 2^127: with the signed recoding s' = s + sum HALF 2^(ck) a 127-bit value never carries out of its eighth
-    // 16-bit window, so the R_i terms leave windows 8..15 empty; a full 128-bit z_i would put about half of all R_i
-    // into ONE bucket of window 8 (carry digit +1).  A forged batch then passes with probability 2^-127 instead of 2^-128.
     u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]) & ((q & 1) ? 0x7fffffffffffffffull : ~0ull);
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
 }
-// scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = z_i, [1+n+i] = z_i*h_i;
-// per-block partial sums of z_i*s_i (mod l) to `partial`
+// R_i <- -R_i where z_i is negative (device z-mode): swap y+x / y-x, negate 2dxy of the stored affine Niels record
+__global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 dst0, const uint8_t *__restrict__ z16, u64 n) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!(reinterpret_cast<const u32 *>(z16)[4 * i + 3] >> 31)) return;
+    ge_aniels A = pts_load(pts, dst0 + i);
+    feT t = fe_carry(fe_neg(A.xy2d));
+    u32 w[32];
+    for (int q = 0; q < 10; q++) { w[q] = A.ymx.v[q]; w[10 + q] = A.ypx.v[q]; w[20 + q] = t.v[q]; }
+    w[30] = 0; w[31] = 0;
+    uint4 *q4 = reinterpret_cast<uint4 *>(pts) + PTS_Q * (dst0 + i);
+    for (int q = 0; q < PTS_Q; q++) q4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+// scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = |z_i|, [1+n+i] = z_i*h_i;
+// per-block partial sums of z_i*s_i (mod l) to `partial`.  signed_z: z16 is sign-magnitude (device z-mode).
 __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ z16,
-                                                       u64 n, uint8_t *__restrict__ msm_scalars, u64 *__restrict__ partial) {
+                                                       u64 n, int signed_z, uint8_t *__restrict__ msm_scalars, u64 *__restrict__ partial) {
     __shared__ u64 red[256][5];
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     sc52 zs = sc_zero();
@@ -808,10 +854,12 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
         u32 h16[16];
         for (int j = 0; j < 16; j++) h16[j] = hw[j];
         const u32 *zw = reinterpret_cast<const u32 *>(z16) + 4 * i;
-        u32 zwords[8] = {zw[0], zw[1], zw[2], zw[3], 0, 0, 0, 0};
+        const bool neg = signed_z && (zw[3] >> 31);
+        u32 zwords[8] = {zw[0], zw[1], zw[2], signed_z ? (zw[3] & 0x7fffffffu) : zw[3], 0, 0, 0, 0};
         u32 s[8];
         load8(sigs, 2 * i + 1, s);
         sc52 z = sc_from_words(zwords), h = sc_from_wide(h16), sv = sc_from_words(s);
+        if (neg) z = sc_neg(z);
         zs = sc_mul(z, sv);
         u32 out[8];
         sc_to_words(sc_mul(h, z), out);
@@ -861,9 +909,9 @@ __global__ void __launch_bounds__(256) k_bsum_finish(const u64 *__restrict__ par
     }
 }
 
-hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *bad_s, hipStream_t st) {
+hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_hram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msgs, msg_off, sigs, pks, n, hram, bad_s);
+    hipLaunchKernelGGL(k_hram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msgs, msg_off, msgs_len, sigs, pks, n, hram, flags);
     return hipGetLastError();
 }
 
@@ -873,6 +921,7 @@ hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, const uint8
 // host orchestration
 // ================================================================================================
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+static int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 
 static ge_p3 host_p40(const uint32_t *t) {
     ge_p3 p;
@@ -913,7 +962,7 @@ static int pick_window(uint64_t n) {
 
 // window layout for n terms (see msm_geom): signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit
 // window, then bits 253..255
-static void msm_layout(uint64_t n, msm_geom &g) {
+void msm_layout(uint64_t n, msm_geom &g) {
     g.c = pick_window(n);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
@@ -930,7 +979,7 @@ static void msm_layout(uint64_t n, msm_geom &g) {
     for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
     for (int i = 0; i < 8; i++) g.addk[i] = a[i];
 }
-// diagnostics (host only, no GPU needed): the layout msm_core would use for n terms
+// diagnostics (host only, no GPU needed): the layout the MSM would use for n terms
 EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_t *pos, uint8_t *wid, uint32_t *addk) {
     msm_geom g;
     msm_layout(n, g);
@@ -940,30 +989,36 @@ EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_
     return C25519_OK;
 }
 
-// Sum over `nterms` (scalars at d_scalars, packed affine Niels points at d_pts) -> R.
-// sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are enqueued
-// (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
-// second stream while the main stream still prepares the points; msm_core joins the two itself.
-int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream,
-                 void *extra_dst, const void *extra_src, size_t extra_bytes) {
-    msm_geom g;
-    msm_layout(n, g);
+// ---- result slots ------------------------------------------------------------------------------------------
+// Nothing in a pass waits for the host any more.  A pass leaves its nwin column sums (col_k = sum_b (b+1) B_kb, 160 bytes
+// each) and its flags / counters in a SLOT of a small device buffer; the caller enqueues all passes of a call, reads the
+// slots back with ONE copy and one synchronisation, and does the O(windows) Horner fold (pippenger.rs:159) on the host
+// through the same ge26.h formulas (a serial chain of ~250 doublings is a latency-bound tail that one CPU core
+// finishes faster than one GPU lane).
+//   slot flags: [0] a scalar has bit 255 set  [1] points that do not decode (prep)  [2] bad A  [3] bad R  [4] non-canonical s
+//               [5] bad message offsets
+static_assert(C25519_SLOT_U32 == MSM_MAX_WIN * 40 + 16, "slot layout");
+static inline uint32_t *slot_flags(uint32_t *slot) { return slot + MSM_MAX_WIN * 40; }
+
+// Enqueue sum_i scalars[i] * pts[i] (packed affine Niels points already on the device) with window layout g; the column
+// sums go to d_slot.  sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are
+// enqueued (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
+// second stream while the main stream still prepares the points; the two are joined here.
+// ring (may be null): [0] / [1] bracket k_accumulate, [2] = end of the pass.
+int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
+                    hipStream_t sort_stream) {
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
     if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
     uint64_t chunk = (n + nchunk - 1) / nchunk;
     const uint64_t nb = (uint64_t)g.nwin * g.half;
-    // level plan for the reduction
-    struct lvl { int m_in, L, shift; };
-    std::vector<lvl> plan;
-    { int m = g.half, sh = 0; while (m > 1) { int L = m >= 8 ? 8 : m; plan.push_back({m, L, sh}); int l2 = 0; while ((1 << l2) < L) l2++; sh += l2; m /= L; } }
-    // workspace carve-up (tmp_d): D | counts | base | sorted | buckets | S/P ping-pong | flags
+    const int nseg = (g.half + RED_SEG - 1) / RED_SEG;
+    // workspace carve-up (tmp_d): D | counts | base | sorted | buckets | segment pairs | flags | perm | long-bucket lists
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oD = carve((size_t)g.nwin * n * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
     size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oT = carve(nb * 4);
-    size_t lvl_pts = plan.empty() ? (size_t)g.nwin : (size_t)g.nwin * (plan[0].m_in / plan[0].L);
-    size_t oR0 = carve(lvl_pts * 160 * 2), oR1 = carve(lvl_pts * 160 * 2), oF = carve(256 + 2048), oPerm = carve(nb * 4);
+    size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(256 + 1024), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * n;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / LONG_CAP + 1);
@@ -971,7 +1026,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     size_t oLS = carve((size_t)max_items * 160);
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
-    static const int sort2 = [] { const char *e = getenv("C25519_SORT2"); return e ? atoi(e) : 1; }();
+    static const int sort2 = env_int("C25519_SORT2", 1);
     const bool use_part = sort2 && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
     const int SL = g.half / PART_BPS, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
@@ -982,15 +1037,16 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
-    static const bool overlap = [] { const char *e = getenv("C25519_SORT_OVERLAP"); return e && atoi(e) != 0; }();   // measured: no gain (MSM 3.15 -> 3.35 ms, verify neutral) -- every kernel already fills the chip
-    if (!overlap && sort_stream && sort_stream != ctx->stream) {    // A/B knob: serialise (main waits for the scalars, sorts itself)
+    uint32_t *SW = (uint32_t *)(ws + oSW);
+    static const bool overlap = env_int("C25519_SORT_OVERLAP", 1) != 0;   // A/B knob: 0 = the main stream waits for the scalars and sorts itself
+    if (!overlap && sort_stream && sort_stream != ctx->stream) {
         HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
         sort_stream = nullptr;
     }
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;      // sort phase
-    HIPCHK(hipMemsetAsync(flags, 0, 256 + 2048, st));
-    hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, flags);
+    HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
+    hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
     if (use_part) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
         const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS + PART_CAP) * 4;
@@ -1001,121 +1057,88 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
         hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, cc, P1);
         hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted);
     } else {
-    size_t lds = (size_t)g.half * 4;
-    static int xswap = -1;   // tuning knob: C25519_XCD_SWAP = 0 | 1
-    if (xswap < 0) { const char *e = getenv("C25519_XCD_SWAP"); xswap = e ? atoi(e) : 1; }
-    if (lds > 48 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        size_t lds = (size_t)g.half * 4;
+        static const int xswap = env_int("C25519_XCD_SWAP", 1);
+        if (lds > 48 * 1024) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (xswap) hipLaunchKernelGGL(k_hist<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts);
+        else hipLaunchKernelGGL(k_hist<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
+        hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
+        hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
+        static const int sparts = [] { int v = env_int("C25519_SCATTER_PARTS", 8); return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }();
+        const size_t lds_sliced = (size_t)g.half / sparts * 4 + (size_t)chunk * 2;
+        if (sparts > 1 && g.half >= 1024 * sparts && lds_sliced <= 160 * 1024) {
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced));
+            hipLaunchKernelGGL(k_scatter_sliced, dim3(g.nwin, nchunk), dim3(1024), lds_sliced, st, D, n, g, chunk, sparts, counts, base, sorted);
+        } else if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+        else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     }
-    if (xswap) hipLaunchKernelGGL(k_hist<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts);
-    else hipLaunchKernelGGL(k_hist<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
-    hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
-    static const int sparts = [] { const char *e = getenv("C25519_SCATTER_PARTS"); int v = e ? atoi(e) : 8; return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }();
-    const size_t lds_sliced = (size_t)g.half / sparts * 4 + (size_t)chunk * 2;
-    if (sparts > 1 && g.half >= 1024 * sparts && lds_sliced <= 160 * 1024) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced));
-        hipLaunchKernelGGL(k_scatter_sliced, dim3(g.nwin, nchunk), dim3(1024), lds_sliced, st, D, n, g, chunk, sparts, counts, base, sorted);
-    } else if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
-    else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
-    }
+    // bucket order (longest lists first) and the long-bucket work list: still on the sort stream -- they only need the lists
+    long_item *items = (long_item *)(ws + oLI);
+    uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
+    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, items, counters, lgids, lfirst);
+    hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
+    hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, 0u, ord_hist, perm);
+    HIPCHK(hipGetLastError());
     if (sort_stream && sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
         HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
     }
     st = ctx->stream;
-    // Window groups: while group g+1 accumulates (VALU-bound, the whole chip), the latency-bound reduction
-    // levels of group g (a few thousand lanes) run on the second stream.
-    static int groups = -1;   // tuning knob: C25519_MSM_GROUPS = 1 | 2
-    if (groups < 0) { const char *e = getenv("C25519_MSM_GROUPS"); groups = e ? atoi(e) : 1; if (groups != 2) groups = 1; }   // measured: 2 groups cost more (two kernel tails) than the overlap returns
-    const int G = (groups == 2 && g.nwin >= 8 && n >= 65536) ? 2 : 1;
-    static int pipe = -1;   // tuning knob (A/B on hardware): C25519_ACC_PIPE = 0 | 1 | 2 | 3 (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
-    if (pipe < 0) { const char *e = getenv("C25519_ACC_PIPE"); pipe = e ? atoi(e) : 3; if (pipe < 0 || pipe > 3) pipe = 3; }
-    long_item *items = (long_item *)(ws + oLI);
-    uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS);
-    uint32_t *bufs[2] = {(uint32_t *)(ws + oR0), (uint32_t *)(ws + oR1)};
-    const uint32_t *S_fin[2] = {nullptr, nullptr}, *P_fin[2] = {nullptr, nullptr};
-    int k_lo[3] = {0, G == 2 ? g.nwin / 2 : g.nwin, g.nwin};
+    static const int pipe = [] { int v = env_int("C25519_ACC_PIPE", 3); return (v < 0 || v > 3) ? 3 : v; }();   // A/B knob (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
+    // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, sorted, n, g, items, counters, max_items, segs);
+    hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 1024u)), dim3(64), 0, ctx->aux, base, g, counters, max_items, lgids, lfirst, segs, buckets);
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    for (int grp = 0; grp < G; grp++) {
-        const int k0 = k_lo[grp], k1 = k_lo[grp + 1], nw = k1 - k0;
-        const uint64_t goff = (uint64_t)k0 * g.half, cnt = (uint64_t)nw * g.half;
-        uint32_t *oh = ord_hist + 256 * grp, *pg = perm + goff, *counters = flags + 8 + 4 * grp;
-        hipLaunchKernelGGL(k_order_hist, dim3(div_up64(cnt, 256)), dim3(256), 0, st, totals + goff, cnt, oh);
-        hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, oh);
-        hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(cnt, 256)), dim3(256), 0, st, totals + goff, cnt, (uint32_t)goff, oh, pg);
-        // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
-        HIPCHK(hipEventRecord(ctx->ev_fork, st));
-        HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-        hipLaunchKernelGGL(k_find_long, dim3(div_up64(cnt, 256)), dim3(256), 0, ctx->aux, base, g, goff, cnt, max_items, items, counters, lgids, lfirst);
-        hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, sorted, n, g, items, counters, max_items, segs);
-        hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 1024u)), dim3(64), 0, ctx->aux, base, g, counters, max_items, lgids, lfirst, segs, buckets);
-        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
-        if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
-        else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
-        else if (pipe == 3) hipLaunchKernelGGL(k_accumulate<3>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
-        else hipLaunchKernelGGL(k_accumulate<2>, dim3(div_up64(cnt, 256)), dim3(256), 0, st, d_pts, sorted, base, pg, cnt, n, g, buckets);
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
-        if (grp == G - 1 && ring) HIPCHK(hipEventRecord(ring[1], st));
-        // reduction levels of this group: on the aux stream unless it is the last group
-        hipStream_t rs = st;
-        if (grp < G - 1) {
-            rs = ctx->aux;
-            HIPCHK(hipEventRecord(ctx->ev_fork2, st));
-            HIPCHK(hipStreamWaitEvent(rs, ctx->ev_fork2, 0));
-        }
-        const uint32_t *S_in = buckets + goff * 40, *P_in = nullptr;
-        const size_t gl = (size_t)nw * (plan.empty() ? 1 : plan[0].m_in / plan[0].L);       // points per level buffer of this group
-        uint32_t *gb[2] = {bufs[0] + (size_t)k0 * (lvl_pts / g.nwin) * 80, bufs[1] + (size_t)k0 * (lvl_pts / g.nwin) * 80};
-        int which = 0;
-        for (size_t li = 0; li < plan.size(); li++) {
-            int m_out = plan[li].m_in / plan[li].L;
-            uint32_t *S_out = gb[which], *P_out = gb[which] + gl * 40;
-            static const int coop = [] { const char *e = getenv("C25519_REDUCE_COOP"); return e ? atoi(e) : 1; }();
-            if (coop && (uint64_t)nw * m_out * 8 <= (1u << 17))     // <= 2 waves per SIMD even with 8 lanes per segment: latency-bound
-                hipLaunchKernelGGL(k_reduce_level_coop, dim3(div_up64((uint64_t)nw * m_out * 8, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in,
-                                   plan[li].L, plan[li].shift, nw, S_out, P_out);
-            else
-                hipLaunchKernelGGL(k_reduce_level, dim3(div_up64((uint64_t)nw * m_out, 128)), dim3(128), 0, rs, S_in, P_in, plan[li].m_in, plan[li].L,
-                                   plan[li].shift, nw, S_out, P_out);
-            S_in = S_out; P_in = P_out; which ^= 1;
-        }
-        S_fin[grp] = S_in; P_fin[grp] = P_in;
-        if (grp < G - 1) HIPCHK(hipEventRecord(ctx->ev_join2, rs));
-    }
+    launch_accumulate(pipe, d_pts, sorted, base, perm, nb, n, g, buckets, st);
+    if (ring) HIPCHK(hipEventRecord(ring[1], st));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
+    hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * nseg)), dim3(64), 0, st, buckets, g.half, nseg, SW, d_slot, nseg == 1 ? 1 : 0);
+    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, st, SW, nseg, d_slot);
     HIPCHK(hipGetLastError());
-    if (G == 2) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join2, 0));
-    // window totals -> host, Horner fold (pippenger.rs:159)
-    // (pinned staging: three small copies queue back to back instead of three staged pageable copies)
-    static_assert((size_t)MSM_MAX_WIN * 160 * 2 + 64 <= 20 * 1024, "h_msm too small");
-    uint32_t *hS = (uint32_t *)ctx->h_msm, *hP = hS + (size_t)MSM_MAX_WIN * 40, *hflags = hP + (size_t)MSM_MAX_WIN * 40;
-    hflags[0] = hflags[1] = 0;
-    const bool haveP = !plan.empty();
-    for (int grp = 0; grp < G; grp++) {
-        const int k0 = k_lo[grp], nw = k_lo[grp + 1] - k0;
-        HIPCHK(hipMemcpyAsync(hS + (size_t)k0 * 40, S_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
-        if (haveP) HIPCHK(hipMemcpyAsync(hP + (size_t)k0 * 40, P_fin[grp], (size_t)nw * 160, hipMemcpyDeviceToHost, st));
-    }
-    HIPCHK(hipMemcpyAsync(hflags, flags, 8, hipMemcpyDeviceToHost, st));
-    if (extra_bytes) HIPCHK(hipMemcpyAsync(extra_dst, extra_src, extra_bytes, hipMemcpyDeviceToHost, st));
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (hflags[0]) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
-    ge_p3 total = ge_identity();
-    for (int k = g.nwin - 1; k >= 0; k--) {
-        ge_p3 col = host_p40(&hS[(size_t)k * 40]);                    // sum_b B_b
-        if (haveP) col = ge_add(col, host_p40(&hP[(size_t)k * 40]));  // + sum_b b*B_b
-        if (k != g.nwin - 1) total = ge_mul_by_pow_2(total, g.pos[k + 1] - g.pos[k]);
-        total = ge_add(total, col);
-    }
-    R = total;
     return C25519_OK;
 }
 
-// points in any format -> packed affine Niels at d_pts[dst0..]; returns C25519_NONE if some point is invalid
+// total = sum_k 2^pos_k col_k by Horner (pippenger.rs:159), host arithmetic over <= 56 points
+static ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
+    ge_p3 total = ge_identity();
+    for (int k = g.nwin - 1; k >= 0; k--) {
+        if (k != g.nwin - 1) total = ge_mul_by_pow_2(total, g.pos[k + 1] - g.pos[k]);
+        total = ge_add(total, host_p40(&cols[(size_t)k * 40]));
+    }
+    return total;
+}
+// read slots [0, count) back (one copy, one synchronisation of the context's main stream)
+static int32_t slots_collect(c25519_ctx *ctx, int count) {
+    HIPCHK(hipMemcpyAsync(ctx->h_msm, ctx->d_slots, (size_t)count * C25519_SLOT_U32 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+static inline uint32_t *dslot(c25519_ctx *ctx, int i) { return ctx->d_slots + (size_t)i * C25519_SLOT_U32; }
+static inline const uint32_t *hslot(c25519_ctx *ctx, int i) { return (const uint32_t *)ctx->h_msm + (size_t)i * C25519_SLOT_U32; }
+
+// one-shot MSM over prepared points (extra.hip: precomputed tables): enqueue, collect, fold
+int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R) {
+    msm_geom g;
+    msm_layout(n, g);
+    HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
+    int32_t r = msm_enqueue(ctx, d_scalars, n, d_pts, g, dslot(ctx, 0), nullptr, nullptr);
+    if (r) return r;
+    if ((r = slots_collect(ctx, 1))) return r;
+    if (slot_flags((uint32_t *)hslot(ctx, 0))[0]) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
+    R = msm_horner(hslot(ctx, 0), g);
+    return C25519_OK;
+}
+
+// points in any format -> packed affine Niels at d_pts[dst0..]; *d_badcount counts the encodings that do not decode
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
     hipStream_t st = ctx->stream;
     if (n == 0) return C25519_OK;
@@ -1131,45 +1154,57 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
     return C25519_OK;
 }
 
-// One bucket-method pass over at most MSM_PASS_MAX terms.
-static int32_t msm_partial_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
-    R = ge_identity();
+// ---- passes -------------------------------------------------------------------------------------------------------
+// The window width stops at c = 16 (the two-pass sort keeps a (window, slice) bin in LDS), so beyond ~2^22 terms the
+// lists per bucket only get longer: larger inputs are cut into passes of about 2^21 terms -- the same decomposition the
+// multi-GPU path uses across ranks.  This also bounds the workspace (~0.5 GB per stream set) for any n.
+// Passes are independent and nothing in them waits for the host, so ONE host thread deals them alternately to the
+// caller's context and a peer context (own streams and workspaces on the same GPU): the low-VALU two thirds of a pass
+// (normalise, sort, reduce) overlap the accumulation of its neighbour.  (Round 1 used a host thread per stream set and
+// a stream synchronisation + host fold per pass.)
+static const int MSM_PASS_LOG2 = [] { int v = env_int("C25519_MSM_PASS_LOG2", 21); return v < 16 ? 16 : (v > 21 ? 21 : v); }();   // A/B knob
+static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
+static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 2 ? 2 : x); }(); return v; }   // A/B knob
+
+struct pass_set { c25519_ctx *c[2]; int lanes; };
+// the peer's streams start after everything already enqueued on the caller's stream (the inputs are complete)
+static int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps) {
+    ps.c[0] = ctx; ps.c[1] = nullptr; ps.lanes = 1;
+    ctx->last_passes.clear();
+    if (passes > 1 && pass_lanes() > 1) { c25519_ctx *p = ctx_peer(ctx); if (p) { ps.c[1] = p; ps.lanes = 2; } }
+    if (ps.lanes > 1) {
+        HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
+        HIPCHK(hipStreamWaitEvent(ps.c[1]->stream, ctx->ev_in, 0));
+    }
+    return C25519_OK;
+}
+// the caller's stream continues after the peer's passes
+static int32_t passes_join(c25519_ctx *ctx, pass_set &ps) {
+    if (ps.lanes > 1) {
+        HIPCHK(hipEventRecord(ps.c[1]->ev_in, ps.c[1]->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ps.c[1]->ev_in, 0));
+    }
+    return C25519_OK;
+}
+static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
+    const int idx = (int)(c->ncalls++ % c25519_ctx::RING);
+    owner->last_passes.push_back({c, idx});
+    return c->ring[idx];
+}
+
+// One bucket-method pass over at most MSM_PASS_MAX terms, enqueued on context c (ctx or its peer); results to d_slot.
+static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot) {
     int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256);
     if (r) return r;
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
-    uint32_t *d_bad = (uint32_t *)ctx->d_flag;
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
-    HIPCHK(hipMemsetAsync(d_bad, 0, 16, ctx->stream));
+    hipEvent_t *ring = pass_ring(owner, ctx);
+    HIPCHK(hipEventRecord(ring[3], ctx->stream));
+    HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, ctx->stream));
     // points are normalised on the main stream while the scalars are recoded and sorted on the second one
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, d_bad))) return r;
-    r = msm_core(ctx, d_scalars, n, d_pts, R, ring, ctx->aux);
-    if (r != C25519_OK) return r;
-    uint32_t bad = 0;                                  // msm_core has synchronised: prep's counter is final
-    HIPCHK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return bad ? C25519_NONE : C25519_OK;
-}
-// The window width stops at c = 16 (the per-window histogram lives in LDS), so beyond ~2^22 terms the lists per
-// bucket only get longer: larger inputs are cut into passes of about 2^21 terms -- the same decomposition the
-// multi-GPU path uses across ranks -- whose partial sums are added on the host.  This also bounds
-// the workspace (~0.5 GB) for any n.
-static const int MSM_PASS_LOG2 = [] { const char *e = getenv("C25519_MSM_PASS_LOG2"); int v = e ? atoi(e) : 21; return v < 16 ? 16 : (v > 21 ? 21 : v); }();   // A/B knob
-static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
-static int pass_lanes() { static const int v = [] { const char *e = getenv("C25519_PASS_LANES"); int x = e ? atoi(e) : 2; return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob
-// run(c, first, step) on `lanes` contexts: the caller's and up to three peers (each the peer of the previous one)
-template <class F>
-static void run_on_lanes(c25519_ctx *ctx, uint64_t passes, F run) {
-    c25519_ctx *cs[4] = {ctx, nullptr, nullptr, nullptr};
-    int lanes = 1;
-    const int want = (int)std::min<uint64_t>(passes, (uint64_t)pass_lanes());
-    while (lanes < want) { c25519_ctx *p = ctx_peer(cs[lanes - 1]); if (!p) break; cs[lanes++] = p; }
-    if (lanes > 1) hipStreamSynchronize(ctx->stream);               // the inputs are complete before other streams read them
-    std::vector<std::thread> ts;
-    for (int l = 1; l < lanes; l++) ts.emplace_back(run, cs[l], (uint64_t)l, (uint64_t)lanes);
-    run(ctx, 0, (uint64_t)lanes);
-    for (auto &t : ts) t.join();
+    if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r;
+    return msm_enqueue(ctx, d_scalars, n, d_pts, g, d_slot, ring, ctx->aux);
 }
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1179,28 +1214,39 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const uint64_t passes = n <= MSM_PASS_MAX ? 1 : (n + MSM_PASS - 1) / MSM_PASS, per = (n + passes - 1) / passes;
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
-    // Passes are independent.  With several of them they are dealt round-robin to the caller's context and its peer
-    // contexts (own streams and workspaces, same device), one host thread each: two thirds of a pass is low-VALU work
-    // (normalise, sort, reduce, read-back) that now overlaps the accumulation of a neighbouring pass.
-    std::vector<ge_p3> part(passes, ge_identity());
-    std::vector<int32_t> st(passes, C25519_OK);
-    auto run = [&](c25519_ctx *c, uint64_t first, uint64_t step) {
-        hipSetDevice(c->device);
-        for (uint64_t i = first; i < passes; i += step) {
-            const uint64_t lo = i * per, cnt = std::min(per, n - lo);
-            st[i] = msm_partial_pass(c, d_scalars + lo * 32, d_points + lo * psz, cnt, in_fmt, part[i]);
-            if (st[i] < 0) break;
+    msm_geom g;
+    msm_layout(per, g);                                   // one layout for every pass: their column sums add up window by window
+    pass_set ps;
+    int32_t r;
+    if ((r = passes_begin(ctx, passes, ps))) return r;
+    std::vector<ge_p3> cols(g.nwin, ge_identity());
+    bool none = false, bad_scalar = false;
+    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
+        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        for (int i = 0; i < cnt; i++) {
+            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
+            if ((r = msm_pass_enqueue(ctx, ps.c[(p0 + i) % ps.lanes], d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i)))) {
+                if (ctx->err.empty()) ctx->err = ps.c[(p0 + i) % ps.lanes]->err;
+                return r;
+            }
         }
-    };
-    run_on_lanes(ctx, passes, run);
-    bool none = false;
-    for (uint64_t i = 0; i < passes; i++) {
-        if (st[i] < 0) { if (ctx->err.empty()) ctx->err = "msm: a pass failed on a peer context"; return st[i]; }
-        if (st[i] == C25519_NONE) none = true;          // the status must not depend on the split
-        else R = passes == 1 ? part[i] : ge_add(R, part[i]);
+        if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
+            if (f[0]) bad_scalar = true;
+            if (f[1]) none = true;                         // the status must not depend on the split
+            for (int k = 0; k < g.nwin; k++) cols[k] = (passes == 1) ? host_p40(s + (size_t)k * 40) : ge_add(cols[k], host_p40(s + (size_t)k * 40));
+        }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    return none ? C25519_NONE : C25519_OK;
+    if (bad_scalar) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
+    if (none) return C25519_NONE;
+    std::vector<uint32_t> flat((size_t)g.nwin * 40);
+    for (int k = 0; k < g.nwin; k++) for (int i = 0; i < 10; i++) {
+        flat[(size_t)k * 40 + i] = cols[k].X.v[i]; flat[(size_t)k * 40 + 10 + i] = cols[k].Y.v[i]; flat[(size_t)k * 40 + 20 + i] = cols[k].Z.v[i]; flat[(size_t)k * 40 + 30 + i] = cols[k].T.v[i];
+    }
+    R = msm_horner(flat.data(), g);
+    return C25519_OK;
 }
 
 EXPORT int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160) {
@@ -1242,119 +1288,165 @@ EXPORT int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160,
 // ---- verify_batch ---------------------------------------------------------------------------------------
 #include "transcript_host.h"
 
-// One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms).
+// IVs of the z tree: iv[l] = SHA-512 chaining value after the one-block tag of level l (see k_ztree_first)
+static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
+    uint64_t count = n;                                  // inputs of level 0: signatures
+    for (int l = 0; l < ZTREE_MAX_LEVELS; l++) {
+        u64 w[16] = {0};
+        const char tag[] = "c25519-hip/verify_batch/z-tree/v2";
+        static_assert(sizeof(tag) - 1 <= 64, "tag fits the first half of the block");
+        uint8_t blk[128] = {0};
+        memcpy(blk, tag, sizeof(tag) - 1);
+        for (int q = 0; q < 16; q++) { u64 v = 0; for (int b = 0; b < 8; b++) v = (v << 8) | blk[8 * q + b]; w[q] = v; }
+        w[13] = (u64)l; w[14] = count; w[15] = n;        // level, number of inputs of this level, batch size
+        sha512_init(ivs.iv[l]);
+        sha512_compress(ivs.iv[l], w);
+        count = l == 0 ? (count + 15) / 16 : (count + 3) / 4;
+    }
+}
+// the z_i of one pass (n signatures) by the device derivation; z16: room for 4 * ceil(n/4) entries.  t0 / t1: tree scratch
+// ((n/16 + 1) * 32 bytes each).  Enqueued on `sa`.
+static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hram, const uint8_t *d_sigs, uint64_t n, uint8_t *t0, uint8_t *t1, uint8_t *z16) {
+    ztree_ivs ivs;
+    ztree_make_ivs(n, ivs);
+    uint64_t mm = (n + 15) / 16; uint8_t *a = t0, *b = t1;
+    uint32_t level = 1;
+    hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, ivs, a);
+    while (mm > 1024) {
+        uint64_t mo = (mm + 3) / 4;
+        hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, ivs, b);
+        mm = mo; level++; std::swap(a, b);
+    }
+    hipLaunchKernelGGL(k_ztree_tail, dim3(1), dim3(256), 0, sa, a, mm, level, ivs, b);      // leaves the 32-byte root at b
+    hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, b, (n + 3) / 4, z16);
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+
+// One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms), enqueued on
+// context ctx (the caller's or its peer); column sums and counters go to d_slot, nothing waits for the host.
 // d_pk_points (may be NULL): the keys' decompressed points, n x 160 raw -- what VerifyingKey carries beside its bytes
 // (verifying.rs:64-71), so that, like the reference (batch.rs:236), the batch does not decompress A_i again.
-static int32_t verify_batch_pass(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off,
-                                 const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
+// d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
+static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                   const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
-    // tmp_f: hram (64n) | z16 (16n) | msm scalars (32m) | leaf/tree (64n + 64n/16 + ..) | partial sums
+    // tmp_f: hram (64n) | z16 (16n) | msm scalars (32m) | tree scratch | partial sums
     const unsigned nblk = div_up64(n, 256);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve(n * 64), oT1 = carve((n / 16 + 1) * 64), oP = carve((size_t)nblk * 40);
+    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 16 + 2) * 32), oT1 = carve((n / 16 + 2) * 32), oP = carve((size_t)nblk * 40);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1;
     uint64_t *partial = (uint64_t *)(ws + oP);
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
-    uint32_t *d_cnt = (uint32_t *)ctx->d_flag;      // [0] bad A, [1] bad R, [2] bad s
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
-    HIPCHK(hipMemsetAsync(d_cnt, 0, 16, st));
-    // Two independent chains: (S) decompress A_i and R_i -- VALU-bound, ~30 % of the call; (A) hash,
-    // derive z_i, batch scalars -- partly latency-bound (the Merkle levels).  They run on two streams
-    // and join before the MSM.
+    uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
+    hipEvent_t *ring = pass_ring(owner, ctx);
+    HIPCHK(hipEventRecord(ring[3], st));
+    HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, st));
+    // Two independent chains: (S) decompress A_i and R_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
+    // partly latency-bound (the tree levels).  They run on two streams and join before the accumulation.
     hipStream_t sa = ctx->aux;
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
-    if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 0))) return r; }
-    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 0, st));
-    HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 1, st));                 // R_i = the first half of every 64-byte signature
+    if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2))) return r; }
+    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, st));
+    HIPCHK(hipEventRecord(ring[4], st));
+    HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 3, st));                 // R_i = the first half of every 64-byte signature
+    HIPCHK(hipEventRecord(ring[5], st));
     // (A)
-    hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, d_sigs, d_pks, n, hram, d_cnt + 2);
+    const uint8_t *hr = d_hram_pre;
+    if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4); hr = hram; }
     HIPCHK(hipGetLastError());
-    if (z_mode == C25519_Z_TRANSCRIPT) {
-        // the reference's sequential Merlin transcript (batch.rs:168-222), on the host
-        std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
-        HIPCHK(hipMemcpyAsync(hh.data(), hram, n * 64, hipMemcpyDeviceToHost, sa));
-        HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, sa));
-        HIPCHK(hipStreamSynchronize(sa));
-        c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
-        HIPCHK(hipMemcpyAsync(z16, hz.data(), n * 16, hipMemcpyHostToDevice, sa));
-        HIPCHK(hipStreamSynchronize(sa));
-    } else {
-        uint64_t mm = (n + 15) / 16; uint8_t *a = t0, *b = t1;
-        uint32_t level = 1;
-        hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, a);
-        while (mm > 1024) {
-            uint64_t mo = (mm + 3) / 4;
-            hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, b);
-            mm = mo; level++; std::swap(a, b);
-        }
-        hipLaunchKernelGGL(k_ztree_tail, dim3(1), dim3(256), 0, sa, a, mm, level, b);      // leaves the 32-byte root at b
-        std::swap(a, b);
-        hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, a, (n + 3) / 4, z16);
-        HIPCHK(hipGetLastError());
+    const uint8_t *zz = d_z_pre;
+    if (!zz) {
+        if ((r = zchain_enqueue(ctx, sa, hr, d_sigs, n, t0, t1, z16))) return r;
+        zz = z16;
+        // the sign of z_i goes onto the stored R_i (main stream, beside the sort on the second one)
+        HIPCHK(hipEventRecord(ctx->ev_z, sa));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_z, 0));
+        hipLaunchKernelGGL(k_apply_sign, dim3(nblk), dim3(256), 0, st, d_pts, (uint64_t)1, zz, n);
     }
-    hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hram, d_sigs, z16, n, msc, partial);
-    HIPCHK(hipGetLastError());
-    // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block on
-    // the device, so the host does not have to wait for chain (A) before it can enqueue the MSM
+    hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hr, d_sigs, zz, n, z_mode == C25519_Z_DEVICE ? 1 : 0, msc, partial);
+    // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block
     hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
     HIPCHK(hipGetLastError());
-    if (ctx->h_pinned_cap < 64) {
-        if (ctx->h_pinned) HIPCHK(hipHostFree(ctx->h_pinned));
-        ctx->h_pinned = nullptr; ctx->h_pinned_cap = 0;
-        HIPCHK(hipHostMalloc(&ctx->h_pinned, 4096, hipHostMallocDefault));
-        ctx->h_pinned_cap = 4096;
-    }
-    uint32_t *cnt = (uint32_t *)ctx->h_pinned;          // pinned staging of the three counters
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
-    ge_p3 R;
-    r = msm_core(ctx, msc, m, d_pts, R, ring, sa, cnt, d_cnt, 16);      // the decode / canonical-s counters ride along with the last copy
-    if (r != C25519_OK) return r;
-    if (cnt[0]) return C25519_NONE;                     // a key that VerifyingKey::from_bytes rejects
-    if (cnt[2]) return C25519_SCALAR_FORMAT;            // batch.rs:208-211
-    if (cnt[1]) return C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
-    return ge_is_identity(R) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa);
 }
 // Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
-// 2^20 signatures each (same reason as MSM_PASS_MAX; every pass derives its own z_i).  All passes run even after
-// a failure so that the reference's precedence -- key decoding, then ScalarFormat for ANY non-canonical s
-// (batch.rs:208-211), then Verify -- does not depend on where the batch was cut.
-static const int VERIFY_PASS_LOG2 = [] { const char *e = getenv("C25519_VERIFY_PASS_LOG2"); int v = e ? atoi(e) : 20; return v < 15 ? 15 : (v > 20 ? 20 : v); }();   // A/B knob
+// 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
+// tree; in the transcript z-mode the z_i come from ONE transcript over the whole batch, exactly the reference's).  Every
+// pass keeps its own identity check.  All passes run even after a failure so that the reference's precedence -- key
+// decoding, then ScalarFormat for ANY non-canonical s (batch.rs:208-211), then Verify -- does not depend on where the
+// batch was cut.
+static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 20 ? 20 : v); }();   // A/B knob
 static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
 EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                              const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
-    (void)msgs_len;
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
     if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
-    std::vector<int32_t> st(passes, C25519_OK);
-    auto run = [&](c25519_ctx *c, uint64_t first, uint64_t step) {              // see msm_partial_impl
-        hipSetDevice(c->device);
-        for (uint64_t i = first; i < passes; i += step) {
-            const uint64_t lo = i * per;
-            st[i] = verify_batch_pass(c, d_msgs, d_msg_off + lo, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr,
-                                      std::min(per, n - lo), z_mode);
-            if (st[i] < 0) break;
+    msm_geom g;
+    msm_layout(2 * per + 1, g);
+    int32_t r;
+    uint32_t pre_flags[4] = {0, 0, 0, 0};               // transcript mode: [0] non-canonical s, [1] bad offsets over the whole batch
+    uint8_t *d_hram_all = nullptr, *d_z_all = nullptr;
+    if (z_mode == C25519_Z_TRANSCRIPT) {
+        // the reference's sequential Merlin transcript (batch.rs:168-222) over the WHOLE batch, on one host core
+        if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 64))) return r;
+        d_hram_all = (uint8_t *)ctx->tmp_c2.p; d_z_all = d_hram_all + n * 64;
+        uint32_t *fl = (uint32_t *)ctx->d_flag;
+        HIPCHK(hipMemsetAsync(fl, 0, 16, ctx->stream));
+        HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all, fl, ctx->stream));
+        std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
+        HIPCHK(hipMemcpyAsync(hh.data(), d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(pre_flags, fl, 16, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
+        HIPCHK(hipMemcpyAsync(d_z_all, hz.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));      // hz is a local buffer
+    }
+    pass_set ps;
+    if ((r = passes_begin(ctx, passes, ps))) return r;
+    bool seen[5] = {false, false, false, false, false}, bad_off = pre_flags[1] != 0, bad_scalar = false;
+    if (pre_flags[0]) seen[C25519_SCALAR_FORMAT] = true;
+    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
+        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        for (int i = 0; i < cnt; i++) {
+            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
+            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
+                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i));
+            if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
         }
-    };
-    run_on_lanes(ctx, passes, run);
-    bool seen[5] = {false, false, false, false, false};
-    for (uint64_t i = 0; i < passes; i++) {
-        if (st[i] < 0) { if (ctx->err.empty()) ctx->err = "verify_batch: a pass failed on a peer context"; return st[i]; }
-        seen[st[i]] = true;
+        if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
+            if (f[0]) bad_scalar = true;
+            if (f[5]) bad_off = true;
+            int32_t v;
+            if (f[2]) v = C25519_NONE;                          // a key that VerifyingKey::from_bytes rejects
+            else if (f[4]) v = C25519_SCALAR_FORMAT;            // batch.rs:208-211
+            else if (f[3]) v = C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
+            else v = ge_is_identity(msm_horner(s, g)) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
+            seen[v] = true;
+        }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (bad_off) { ctx->err = "verify_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
+    if (bad_scalar) { ctx->err = "verify_batch: internal error (batch scalar with bit 255 set)"; return -(int32_t)hipErrorInvalidValue; }
     return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
 }
 
@@ -1362,10 +1454,16 @@ EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, 
                                         const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
     return ed25519_verify_batch_keys_dev(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, nullptr, n, z_mode);
 }
+// host-side check of the offsets array (the _dev entry points check on the device, inside k_hram)
+static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) return false;
+    return true;
+}
 EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                          const uint8_t *pk_points, uint64_t n, uint32_t z_mode) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
+    if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
     uint64_t mlen = msg_off[n];
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||
@@ -1383,4 +1481,38 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
 EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                     uint64_t n, uint32_t z_mode) {
     return ed25519_verify_batch_keys(ctx, msgs, msg_off, sigs, pks, nullptr, n, z_mode);
+}
+
+// diagnostics: the z_i a batch of n <= VERIFY_PASS_MAX signatures gets (16 bytes each to the HOST buffer out_z16;
+// device z-mode: sign-magnitude, see k_zderive).  For the tests that pin the derivation's dependence on every input.
+EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n,
+                                     uint32_t z_mode, uint8_t *out_z16) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    if (n > VERIFY_PASS_MAX || z_mode > 1 || !offsets_ok(msg_off, n)) { ctx->err = "debug_batch_zs: bad arguments"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t mlen = msg_off[n];
+    int32_t r;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oM = carve(mlen + 64), oO = carve((n + 1) * 8), oS = carve(n * 64), oK = carve(n * 32), oH = carve(n * 64), oZ = carve((n + 4) * 16), oT0 = carve((n / 16 + 2) * 32), oT1 = carve((n / 16 + 2) * 32);
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
+    hipStream_t st = ctx->stream;
+    if (mlen) HIPCHK(hipMemcpyAsync(ws + oM, msgs, mlen, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oO, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oS, sigs, n * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oK, pks, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
+    HIPCHK(launch_hram(ws + oM, (const uint64_t *)(ws + oO), mlen, ws + oS, ws + oK, n, ws + oH, (uint32_t *)ctx->d_flag, st));
+    if (z_mode == C25519_Z_DEVICE) {
+        if ((r = zchain_enqueue(ctx, st, ws + oH, ws + oS, n, ws + oT0, ws + oT1, ws + oZ))) return r;
+        HIPCHK(hipMemcpyAsync(out_z16, ws + oZ, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        std::vector<uint8_t> hh(n * 64);
+        HIPCHK(hipMemcpyAsync(hh.data(), ws + oH, n * 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        c25519_transcript_zs(hh.data(), sigs, n, out_z16);
+    }
+    return C25519_OK;
 }

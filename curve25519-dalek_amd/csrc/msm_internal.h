@@ -5,9 +5,15 @@
 #include "ge26.h"
 #include "ctx.h"
 
-// sum_i scalars[i] * pts[i] over packed affine Niels points already on the device
-int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, c25519::ge_p3 &R, hipEvent_t *ring, hipStream_t sort_stream = nullptr,
-                 void *extra_dst = nullptr, const void *extra_src = nullptr, size_t extra_bytes = 0);   // one more small D2H before the final sync
+namespace c25519 {
+// Window layout of the bucket method.  Scalars are reduced mod l (< 2^253, scalar.rs:193-205) in every MSM the reference
+// performs, so the 253 bits are shared out EVENLY (msm_layout); see msm.hip "digits".
+constexpr int MSM_MAX_WIN = 56;
+struct msm_geom { int c, nwin, half; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+}
+void msm_layout(uint64_t n, c25519::msm_geom &g);
+// sum_i scalars[i] * pts[i] over packed affine Niels points already on the device (enqueue, one read-back, host fold)
+int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, c25519::ge_p3 &R);
 // any point format -> packed affine Niels at d_pts[dst0 ..]; *d_badcount counts encodings that do not decode
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount);
 void host_encode(const c25519::ge_p3 &R, int out_fmt, uint8_t *out);

@@ -53,7 +53,9 @@ __device__ __forceinline__ ge_cached tab_load(const uint4 *tab, u64 stride, u64 
 //   IN_FMT 0: CompressedEdwardsY, 2: raw 160-byte;  NEGATE: multiply -P (verify: [k](-A))
 //   ok[i] = 0 if the point does not decompress (result unspecified)
 // ================================================================================================
-template <int IN_FMT, bool NEGATE>
+//   CT: constant-time table access for secret scalars -- all nine entries of the lane's table are read and the wanted
+//   one kept with selects (LookupTable::select, window.rs:54-76), so no address depends on the scalar
+template <int IN_FMT, bool NEGATE, bool CT>
 __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points, u64 n,
                                                   uint4 *__restrict__ tab, u32 *__restrict__ out40, uint8_t *__restrict__ ok) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -97,7 +99,19 @@ __global__ void __launch_bounds__(256) k_var_base(const uint8_t *__restrict__ sc
         if (i != 63) acc = ge_mul_by_pow_2(acc, 4);
         bool neg = d < 0;
         u32 mag = (u32)(neg ? -d : d);
-        ge_cached c = tab_load(tab, stride, idx, mag);
+        ge_cached c;
+        if (CT) {
+            c = tab_load(tab, stride, idx, 0);
+#pragma unroll 1
+            for (u32 ent = 1; ent <= 8; ent++) {
+                const ge_cached t = tab_load(tab, stride, idx, ent);
+                const bool hit = ent == mag;
+                c.YpX = fe_select(c.YpX, t.YpX, hit); c.YmX = fe_select(c.YmX, t.YmX, hit);
+                c.Z = fe_select(c.Z, t.Z, hit); c.T2d = fe_select(c.T2d, t.T2d, hit);
+            }
+        } else {
+            c = tab_load(tab, stride, idx, mag);
+        }
         acc = ge_p1p1_to_p3(ge_add_cached(acc, ge_cached_cneg(c, neg)));
     }
     p40_store(out40, idx, acc);
@@ -201,7 +215,7 @@ __global__ void __launch_bounds__(256) k_expand_seed(const uint8_t *__restrict__
     store8(prefix, i, d + 8);
 }
 // r_i = SHA-512(prefix_i || M_i) mod l
-__global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ prefix, const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 n,
+__global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ prefix, const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len, u64 n,
                                                     uint8_t *__restrict__ rscal) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -211,8 +225,9 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     st.init();
     for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)p[2 * j] | ((u64)p[2 * j + 1] << 32));
     st.fill = 32; st.total = 32;
-    const uint8_t *m = msgs + msg_off[i];
-    u64 len = msg_off[i + 1] - msg_off[i];
+    const u64 o0 = msg_off[i], o1 = msg_off[i + 1];
+    const u64 len = (o0 <= o1 && o1 <= msgs_len) ? o1 - o0 : 0;        // bad offsets: flagged by k_hram, nothing read out of bounds
+    const uint8_t *m = msgs + o0;
     for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
     st.finish();
     u32 d[16], r[8];
@@ -249,25 +264,29 @@ __global__ void __launch_bounds__(256) k_place_R(const uint8_t *__restrict__ Ren
 static inline unsigned dup(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
 // ---- variable base ------------------------------------------------------------------------------------
-static int32_t var_base_launch(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, bool negate, uint32_t *out40, uint8_t *d_ok) {
+// ct: the scalars are secret (constant-address table scan); false for public scalars (per-signature verification)
+static int32_t var_base_launch(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, bool negate, bool ct, uint32_t *out40, uint8_t *d_ok) {
     const unsigned grid = dup(n, 256);
     const uint64_t stride = (uint64_t)grid * 256;
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, stride * 9 * 160);
     if (r) return r;
     uint4 *tab = (uint4 *)ctx->tmp_d.p;
     hipStream_t st = ctx->stream;
+#define VB(F, N, C) hipLaunchKernelGGL((k_var_base<F, N, C>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok)
     if (in_fmt == C25519_FMT_EDWARDS_Y) {
-        if (negate) hipLaunchKernelGGL((k_var_base<0, true>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
-        else hipLaunchKernelGGL((k_var_base<0, false>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+        if (negate) { if (ct) VB(0, true, true); else VB(0, true, false); }
+        else { if (ct) VB(0, false, true); else VB(0, false, false); }
     } else if (in_fmt == C25519_FMT_RAW160) {
-        if (negate) hipLaunchKernelGGL((k_var_base<2, true>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
-        else hipLaunchKernelGGL((k_var_base<2, false>), dim3(grid), dim3(256), 0, st, d_scalars, d_points, n, tab, out40, d_ok);
+        if (negate) { if (ct) VB(2, true, true); else VB(2, true, false); }
+        else { if (ct) VB(2, false, true); else VB(2, false, false); }
     } else { ctx->err = "mul_batch: in_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+#undef VB
     HIPCHK(hipGetLastError());
+    if (ct) HIPCHK(hipMemsetAsync(tab, 0, stride * 9 * 160, st));     // the per-lane tables are multiples of a possibly secret point path: wipe
     return C25519_OK;
 }
 
-EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
+int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok, bool ct) {
     HIPCHK(hipSetDevice(ctx->device));
     if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_batch: out_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
     if (n == 0) return C25519_OK;
@@ -278,7 +297,7 @@ EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, c
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
-    if ((r = var_base_launch(ctx, d_scalars, d_points, n, in_fmt, false, p40, okbuf))) return r;
+    if ((r = var_base_launch(ctx, d_scalars, d_points, n, in_fmt, false, ct, p40, okbuf))) return r;
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     if (out_fmt == C25519_FMT_RAW160) {
         hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, d_out);
@@ -286,11 +305,15 @@ EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, c
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
         hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, (uint32_t *)ctx->scratch.p);
         HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
+        if (ct) { HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream)); }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
+}
+EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
+    return mul_batch_impl(ctx, d_scalars, d_points, n, in_fmt, out_fmt, d_out, d_ok, !(ctx->flags & C25519_FLAG_VARTIME_TABLES));
 }
 EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -305,6 +328,7 @@ EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const u
     HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
     if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!(ctx->flags & C25519_FLAG_VARTIME_TABLES)) HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // staged secret scalars
     return C25519_OK;
 }
 
@@ -322,9 +346,9 @@ EXPORT int32_t c25519_double_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_a,
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipEventRecord(ring[0], st));
-    if ((r = var_base_launch(ctx, d_a, d_A, n, in_fmt, false, P40, okbuf))) return r;                 // a * A
+    if ((r = var_base_launch(ctx, d_a, d_A, n, in_fmt, false, false, P40, okbuf))) return r;          // a * A (vartime by contract)
     HIPCHK(hipEventRecord(ring[1], st));
-    HIPCHK(launch_mul_base_p40(ctx->w, d_b, n, ctx->d_table, Q40, ctx->num_cus, st));                 // b * B
+    HIPCHK(launch_mul_base_p40(ctx->w, d_b, n, ctx->d_table, Q40, ctx->num_cus, st));                 // b * B (public)
     if (out_fmt == C25519_FMT_RAW160) {
         hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, st, P40, Q40, n, d_out);
     } else {
@@ -359,7 +383,6 @@ EXPORT int32_t c25519_double_base_batch(c25519_ctx *ctx, const uint8_t *a, const
 // ---- per-signature verify ---------------------------------------------------------------------------------
 EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status) {
-    (void)msgs_len;
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
     hipStream_t st = ctx->stream;
@@ -375,10 +398,10 @@ EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, c
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
-    HIPCHK(launch_hram(d_msgs, d_msg_off, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
     hipLaunchKernelGGL(k_hram_reduce, dim3(dup(n, 256)), dim3(256), 0, st, hram, d_sigs, n, kscal, sscal, s_ok);
     HIPCHK(hipEventRecord(ring[0], st));
-    if ((r = var_base_launch(ctx, kscal, d_pks, n, C25519_FMT_EDWARDS_Y, true, P40, a_ok))) return r;    // [k](-A)
+    if ((r = var_base_launch(ctx, kscal, d_pks, n, C25519_FMT_EDWARDS_Y, true, false, P40, a_ok))) return r;    // [k](-A), k public
     HIPCHK(hipEventRecord(ring[1], st));
     HIPCHK(launch_mul_base_p40(ctx->w, sscal, n, ctx->d_table, Q40, ctx->num_cus, st));                      // [s]B
     hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, st, P40, Q40, n, (uint32_t *)ctx->scratch.p);
@@ -416,34 +439,47 @@ EXPORT int32_t ed25519_keygen_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds,
     if ((r = ctx_reserve(ctx, ctx->tmp_f, n * 64 + 256))) return r;
     uint8_t *a = (uint8_t *)ctx->tmp_f.p, *prefix = a + n * 32;
     hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, d_seeds, n, a, prefix);
+    r = mul_base_impl(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks, ctx_secret_default(ctx));       // secret scalar: constant-time tables
+    hipError_t e = hipMemsetAsync(a, 0, n * 64, ctx->stream);   // wipe the expanded secrets, on every path
+    if (r) return r;
+    HIPCHK(e);
     HIPCHK(hipGetLastError());
-    if ((r = c25519_mul_base_batch_dev(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks))) return r;
-    HIPCHK(hipMemsetAsync(a, 0, n * 64, ctx->stream));   // wipe the expanded secrets
+    return C25519_OK;
+}
+static int32_t sign_body(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, uint64_t n,
+                         uint8_t *d_pks, uint8_t *d_sigs, uint8_t *a, uint8_t *prefix, uint8_t *rscal, uint8_t *Renc, uint8_t *hram) {
+    hipStream_t st = ctx->stream;
+    const bool secret = ctx_secret_default(ctx);
+    int32_t r;
+    hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, st, d_seeds, n, a, prefix);
+    if ((r = mul_base_impl(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks, secret))) return r;              // A = a*B
+    hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, msgs_len, n, rscal);
+    if ((r = mul_base_impl(ctx, rscal, n, C25519_FMT_EDWARDS_Y, Renc, secret))) return r;           // R = r*B (the nonce is as secret as the key)
+    hipLaunchKernelGGL(k_place_R, dim3(dup(n, 256)), dim3(256), 0, st, Renc, n, d_sigs);
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
+    hipLaunchKernelGGL(k_sign_finish, dim3(dup(n, 256)), dim3(256), 0, st, hram, a, rscal, Renc, n, d_sigs);
+    HIPCHK(hipGetLastError());
     return C25519_OK;
 }
 EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                       uint64_t n, uint8_t *d_pks, uint8_t *d_sigs) {
-    (void)msgs_len;
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
-    hipStream_t st = ctx->stream;
     int32_t r;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oA = carve(n * 32), oPre = carve(n * 32), oR = carve(n * 32), oRe = carve(n * 32), oH = carve(n * 64);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
-    uint8_t *a = ws + oA, *prefix = ws + oPre, *rscal = ws + oR, *Renc = ws + oRe, *hram = ws + oH;
-    hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, st, d_seeds, n, a, prefix);
-    if ((r = c25519_mul_base_batch_dev(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks))) return r;              // A = a*B
-    hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, n, rscal);
-    if ((r = c25519_mul_base_batch_dev(ctx, rscal, n, C25519_FMT_EDWARDS_Y, Renc))) return r;           // R = r*B
-    hipLaunchKernelGGL(k_place_R, dim3(dup(n, 256)), dim3(256), 0, st, Renc, n, d_sigs);
-    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
-    HIPCHK(launch_hram(d_msgs, d_msg_off, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
-    hipLaunchKernelGGL(k_sign_finish, dim3(dup(n, 256)), dim3(256), 0, st, hram, a, rscal, Renc, n, d_sigs);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(ws, 0, oRe, st));     // wipe secret scalars / prefixes / nonces (zeroize discipline)
+    r = sign_body(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, ws + oA, ws + oPre, ws + oR, ws + oRe, ws + oH);
+    hipError_t e = hipMemsetAsync(ws, 0, oRe, ctx->stream);     // wipe secret scalars / prefixes / nonces on EVERY exit path
+    if (r) return r;
+    HIPCHK(e);
+    uint32_t fl[4] = {0, 0, 0, 0};                              // bad message offsets (k_hram) -> error, like verify_batch
+    HIPCHK(hipMemcpyAsync(fl, ctx->d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (fl[1]) { ctx->err = "sign_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
     return C25519_OK;
 }
 EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs) {
@@ -456,7 +492,10 @@ EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const u
     if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipMemcpyAsync(dseed, seeds, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((r = ed25519_sign_batch_dev(ctx, dseed, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, n, dpk, dsig))) return r;
+    if ((r = ed25519_sign_batch_dev(ctx, dseed, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, n, dpk, dsig))) {
+        hipMemsetAsync(dseed, 0, n * 32, ctx->stream);
+        return r;
+    }
     HIPCHK(hipMemcpyAsync(pks, dpk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipMemcpyAsync(sigs, dsig, n * 64, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -107,8 +107,13 @@ class VerifyingKey:
     """ed25519-dalek/src/verifying.rs:64-71: the 32 key bytes together with the decompressed point, so that
     verify_batch does not decompress A_i again (batch.rs:236)."""
     __slots__ = ("compressed", "point")
+    _from_bytes_token = object()
 
-    def __init__(self, compressed, point):
+    def __init__(self, compressed, point, _token=None):
+        # the type invariant of the reference (point == decompress(compressed)) is what verify_batch relies on when it
+        # hashes the bytes and multiplies the point: only from_bytes, which computes the point itself, may build one
+        if _token is not VerifyingKey._from_bytes_token:
+            raise TypeError("VerifyingKey objects are built by VerifyingKey.from_bytes (verifying.rs:167-175)")
         self.compressed, self.point = bytes(compressed), bytes(point)
 
     @staticmethod
@@ -119,7 +124,7 @@ class VerifyingKey:
         _, pts, ok = eng.decompress_batch(_cat(keys, 32), _e.FMT_EDWARDS_Y)
         if len(keys) and not ok.all():
             raise SignatureError("PointDecompression")
-        return [VerifyingKey(keys[i], pts[i].tobytes()) for i in range(len(keys))]
+        return [VerifyingKey(keys[i], pts[i].tobytes(), VerifyingKey._from_bytes_token) for i in range(len(keys))]
 
     def as_bytes(self):
         return self.compressed

@@ -12,6 +12,7 @@ import numpy as np
 OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH = 0, 1, 2, 3, 4
 FMT_EDWARDS_Y, FMT_RISTRETTO, FMT_RAW160 = 0, 1, 2
 Z_TRANSCRIPT, Z_DEVICE = 0, 1
+FLAG_VARTIME_TABLES = 0x100      # c25519_ctx_create: fast secret-indexed tables for mul_base / mul_batch / sign / keygen (public scalars only)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
@@ -49,8 +50,11 @@ def load_library():
         "c25519_last_error": (C.c_char_p, [vp]),
         "c25519_last_kernel_ms": (C.c_float, [vp]),
         "c25519_phase_ms": (C.c_float, [vp, C.c_uint32, C.c_int]),
+        "c25519_last_call_phase_ms": (C.c_float, [vp, C.c_int, vp]),
+        "c25519_debug_batch_zs": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32, vp]),
         "c25519_mul_base_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_mul_base_batch": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_mul_base_batch_vartime_dev": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_x25519_batch_dev": (i32, [vp, vp, vp, u64, vp]),
         "c25519_x25519_batch": (i32, [vp, vp, vp, u64, vp]),
         "c25519_x25519_base_batch_dev": (i32, [vp, vp, u64, vp]),
@@ -98,7 +102,7 @@ def load_library():
 
 ABI_SYMBOLS = [
     "c25519_ctx_create", "c25519_ctx_destroy", "c25519_ctx_set_stream", "c25519_ctx_synchronize", "c25519_last_error",
-    "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_mul_base_batch_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
+    "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_msm_geometry",
@@ -123,7 +127,8 @@ class Engine:
     uint8 CUDA tensors already resident in HBM; the plain methods take/return numpy arrays / bytes
     and go through the host-pointer entry points (PCIe copies included)."""
 
-    def __init__(self, device=0, window=0):
+    def __init__(self, device=0, window=0, flags=0):
+        """window: fixed-base table algorithm (c25519_ctx_create flags & 0x1f); flags: FLAG_VARTIME_TABLES or 0"""
         import torch
         self.torch = torch
         self.lib = load_library()
@@ -132,7 +137,9 @@ class Engine:
         self.device = torch.device("cuda", device)
         if window == 0:                       # test knob: run any caller against another fixed-base algorithm
             window = int(os.environ.get("C25519_DEFAULT_WINDOW", "0"))
-        self.ctx = self.lib.c25519_ctx_create(device, window & 0x1f)
+        if flags == 0 and os.environ.get("C25519_DEFAULT_VARTIME_TABLES", "0") == "1":    # test knob
+            flags = FLAG_VARTIME_TABLES
+        self.ctx = self.lib.c25519_ctx_create(device, (window & 0x1f) | flags)
         if not self.ctx:
             raise EngineError("c25519_ctx_create(%d) failed" % device)
         self._bind_stream()
@@ -176,6 +183,12 @@ class Engine:
     def phase_ms(self, back=0, phase=0):
         return float(self.lib.c25519_phase_ms(self.ctx, back, phase))
 
+    def last_call_phase_ms(self, phase=0):
+        """-> (ms summed over the passes of the latest MSM / verify_batch call, number of passes)"""
+        passes = C.c_uint32(0)
+        ms = float(self.lib.c25519_last_call_phase_ms(self.ctx, phase, C.byref(passes)))
+        return ms, int(passes.value)
+
     def microbench(self, which, iters=2000):
         self._bind_stream()
         return float(self.lib.c25519_microbench(self.ctx, which, iters))
@@ -187,6 +200,15 @@ class Engine:
             out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
         self._bind_stream()
         self._chk(self.lib.c25519_mul_base_batch_dev(self.ctx, scalars.data_ptr(), n, out_fmt, out.data_ptr()))
+        return out
+
+    def mul_base_batch_vartime_t(self, scalars, out_fmt=FMT_EDWARDS_Y, out=None):
+        """scalars declared PUBLIC: the fast tables whatever the context's flags"""
+        n = self._t(scalars, 32)
+        if out is None:
+            out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_base_batch_vartime_dev(self.ctx, scalars.data_ptr(), n, out_fmt, out.data_ptr()))
         return out
 
     def x25519_base_batch_t(self, k, out=None):
@@ -244,7 +266,7 @@ class Engine:
         self._chk(self.lib.c25519_fold_partials(self.ctx, blob, len(partials), out_fmt, out))
         return out.raw
 
-    def verify_batch_t(self, msgs, msg_off, sigs, pks, z_mode=Z_DEVICE, pk_points=None):
+    def verify_batch_t(self, msgs, msg_off, sigs, pks, z_mode=Z_TRANSCRIPT, pk_points=None):
         """msgs: uint8 CUDA tensor of the concatenated messages; msg_off: int64/uint64 CUDA tensor (n+1);
         pk_points: optional (n, 160) raw points of the keys (VerifyingKey.point), skips their decompression."""
         n = self._t(sigs, 64)
@@ -352,6 +374,7 @@ class Engine:
         if not (len(msgs) == len(sigs) == len(pks)):
             return ARRAY_LENGTH  # batch.rs:152-165
         n = len(msgs)
+        self._check_items(sigs, 64, "signature"); self._check_items(pks, 32, "public key")
         off = np.zeros(n + 1, dtype=np.uint64)
         for i, m in enumerate(msgs):
             off[i + 1] = off[i] + len(m)
@@ -366,6 +389,20 @@ class Engine:
         return self._chk(self.lib.ed25519_verify_batch_keys(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data,
                                                             pp.ctypes.data if pp is not None else None, n, z_mode),
                          (OK, NONE, SCALAR_FORMAT, VERIFY))
+
+    def debug_batch_zs(self, msgs, sigs, pks, z_mode=Z_DEVICE):
+        """The z_i of a batch as an (n, 16) uint8 array (diagnostics, see c25519_debug_batch_zs)."""
+        n = len(msgs)
+        assert len(sigs) == n and len(pks) == n
+        self._check_items(sigs, 64, "signature"); self._check_items(pks, 32, "public key")
+        out = np.zeros((n, 16), dtype=np.uint8)
+        if n == 0:
+            return out
+        blob, off = self._pack(list(msgs))
+        s = _np8(b"".join(sigs), 64); p = _np8(b"".join(pks), 32)
+        self._bind_stream()
+        self._chk(self.lib.c25519_debug_batch_zs(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, z_mode, out.ctypes.data))
+        return out
 
     def mul_batch(self, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
         s = _np8(scalars, 32); p = _np8(points, _PT[in_fmt]); n = s.shape[0]
@@ -385,6 +422,12 @@ class Engine:
         return out, ok
 
     @staticmethod
+    def _check_items(items, width, what):
+        for i, it in enumerate(items):
+            if len(it) != width:
+                raise ValueError("%s %d has %d bytes, expected %d" % (what, i, len(it), width))
+
+    @staticmethod
     def _pack(msgs):
         n = len(msgs)
         off = np.zeros(n + 1, dtype=np.uint64)
@@ -399,6 +442,7 @@ class Engine:
         status = np.empty((n,), dtype=np.uint8)
         if n == 0:
             return status
+        self._check_items(sigs, 64, "signature"); self._check_items(pks, 32, "public key")
         blob, off = self._pack(list(msgs))
         s = _np8(b"".join(sigs), 64); p = _np8(b"".join(pks), 32)
         self._bind_stream()
@@ -412,6 +456,7 @@ class Engine:
         pks = np.empty((n, 32), dtype=np.uint8); sigs = np.empty((n, 64), dtype=np.uint8)
         if n == 0:
             return pks, sigs
+        self._check_items(seeds, 32, "seed")
         blob, off = self._pack(list(msgs))
         sd = _np8(b"".join(seeds), 32)
         self._bind_stream()

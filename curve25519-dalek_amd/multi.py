@@ -87,7 +87,7 @@ def combine_verdicts(status, group=None, device=None):
     return _RANK_VERDICT[int(t.item())]
 
 
-def verify_batch_sharded(eng, msgs_t, msg_off_t, sigs_t, pks_t, z_mode=_e.Z_DEVICE, pk_points=None, group=None):
+def verify_batch_sharded(eng, msgs_t, msg_off_t, sigs_t, pks_t, z_mode=_e.Z_TRANSCRIPT, pk_points=None, group=None):
     """THIS rank's shard of the batch (device tensors, as Engine.verify_batch_t) -> the verdict of the whole batch."""
     st = eng.verify_batch_t(msgs_t, msg_off_t, sigs_t, pks_t, z_mode, pk_points=pk_points)
     return combine_verdicts(st, group, sigs_t.device)

@@ -46,9 +46,34 @@ extern "C" {
 #define C25519_FMT_RISTRETTO 1
 #define C25519_FMT_RAW160 2
 
-/* ed25519_verify_batch z_mode: how the 128-bit batch coefficients z_i are derived */
-#define C25519_Z_TRANSCRIPT 0 /* byte-for-byte the reference's Merlin/STROBE transcript (batch.rs:168-222), host-sequential */
-#define C25519_Z_DEVICE 1     /* 127-bit z_i = SHA-512(root || counter) on the device, root = hash tree over every (H(R||A||M), s) of the batch */
+/* ed25519_verify_batch z_mode: how the 128-bit batch coefficients z_i are derived.
+ * C25519_Z_TRANSCRIPT (0, the default of every host-language wrapper): byte for byte the reference's derivation --
+ *   ONE Merlin/STROBE-128 transcript over the whole batch (batch.rs:168-222, batch/transcript.rs), whatever n is.  It is
+ *   a sequential sponge (about 1.7 Keccak-f per signature), so it runs on one host core and bounds the call near
+ *   2-3 x 10^6 signatures/s; the curve arithmetic still runs on the GPU.
+ * C25519_Z_DEVICE (1, explicit opt-in, NOT the reference's derivation and not a reviewed standard construction):
+ *   z_i = a 16-byte quarter of SHA-512(root || LE64(i / 4)), read as sign-magnitude (uniform on the 2^128 - 1 integers
+ *   -(2^127 - 1) .. 2^127 - 1), where root is the root of a hash tree over exactly what the reference's transcript
+ *   absorbs: the 64-byte H(R_i || A_i || M_i) and the 32-byte s_i of every signature (level 0: 16 signatures per
+ *   node; upper levels 4-ary; node = first 32 bytes of the SHA-512 chaining value after a one-block domain tag
+ *   (level, inputs of the level, batch size) and the fixed-length data).  Every z_i depends on every bit of the batch;
+ *   honest batches give the same verdict in both modes; a batch containing an invalid signature passes with
+ *   probability <= 2^-127.99 (reference: 2^-128) under the usual assumption that SHA-512's compression function is
+ *   collision resistant and its output unpredictable.  Batches beyond ~1.5 x 2^20 signatures are checked as
+ *   independent sub-batches (own tree, own z_i, own identity check).  The z_i VALUES differ from the reference's. */
+#define C25519_Z_TRANSCRIPT 0
+#define C25519_Z_DEVICE 1
+
+/* c25519_ctx_create flags, bit 8: VARTIME_TABLES.  By default every entry point that replaces a CONSTANT-TIME function
+ * of the reference -- mul_base (edwards.rs:918, :1192-1209), `&EdwardsPoint * &Scalar` (variable_base.rs), sign / keygen,
+ * X25519 public keys -- reads its tables the way the reference's LookupTable::select does (window.rs:54-76): every
+ * entry of the window is read and the wanted one kept by selects, so no address and no branch depends on the scalar
+ * (fixed base: radix-2^5 tables in LDS, 52 additions; variable base: the 8-entry table of variable_base.rs).
+ * With this flag those entry points use the fast tables instead -- fixed base: the radix-2^16 tables in HBM, 16
+ * additions, 4x faster -- whose ADDRESSES depend on the scalar: set it only when every scalar handed to this context
+ * is public (or call the *_vartime entry points).  The X25519 ladder is constant-time in either mode; MSM /
+ * verify_batch / double_base are variable-time by definition, as in the reference. */
+#define C25519_FLAG_VARTIME_TABLES 0x100u
 
 typedef struct c25519_ctx c25519_ctx;
 
@@ -59,8 +84,8 @@ typedef struct c25519_ctx c25519_ctx;
  * 9: signed 9-tooth x 6-table comb in LDS (31 additions + 4 doublings per scalar, 147 KB);
  * 10 .. 20: the EdwardsBasepointTable structure with radix 2^w and the table in HBM, served by L2 / MALL:
  * ceil(256/w) additions with one 128-byte gather each, no doublings (table 1.7 MB at w = 10, 71 MB at w = 16);
- * 0 (default) = 16.  The table is computed on the device when the context is created.  Returns NULL
- * if there is no usable GPU: there is NO CPU fallback. */
+ * 0 (default) = 16.  The table is computed on the device when the context is created.
+ * flags & C25519_FLAG_VARTIME_TABLES: see above.  Returns NULL if there is no usable GPU: there is NO CPU fallback. */
 c25519_ctx *c25519_ctx_create(int device, uint32_t flags);
 void c25519_ctx_destroy(c25519_ctx *ctx);
 /* Use an existing hipStream_t (e.g. PyTorch's current stream) instead of the context's own. */
@@ -71,12 +96,15 @@ const char *c25519_last_error(const c25519_ctx *ctx);
 /* milliseconds the device spent in the most recent entry point's kernels (hipEvent pair on the
  * context's stream); valid after the call returned / the stream was synchronised. */
 float c25519_last_kernel_ms(c25519_ctx *ctx);
-/* Per-call phase timing from a ring of hipEvents recorded on the context's stream (the last 64
- * calls): phase 0 = the dominant kernel of the call made `back` calls ago (0 = most recent),
- * phase 1 = the kernels after it (e.g. batched compression).  Synchronises that call's last event.
- * Recorded by c25519_mul_base_batch_dev, c25519_x25519_batch_dev, c25519_msm_*_dev and
- * ed25519_verify_batch_dev.  Returns -1 if unavailable. */
+/* Per-call phase timing from a ring of hipEvents recorded on the launch streams (the last 64 calls of this context):
+ * phase 0 = the dominant kernel of the call made `back` calls ago (0 = most recent) -- k_mul_base_*, k_x25519,
+ * k_var_base, or k_accumulate for an MSM / verify_batch pass; phase 1 = the kernels after it (batched compression;
+ * bucket reduction); for MSM / verify_batch passes also phase 2 = the whole pass and phase 3 = the decompression of
+ * R_i (verify_batch).  Synchronises that call's last event.  Returns -1 if unavailable. */
 float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase);
+/* The same, summed over every pass of the most recent c25519_msm_* / ed25519_verify_batch* call (large inputs run as
+ * several passes that alternate between two stream sets); *passes (may be NULL) receives the number of passes. */
+float c25519_last_call_phase_ms(c25519_ctx *ctx, int phase, uint32_t *passes);
 
 /* ---- fixed base: out[i] = scalars[i] * B ------------------------------------------------------
  * replaces EdwardsBasepointTable::mul_base / EdwardsPoint::mul_base (edwards.rs:918, :1192-1209),
@@ -84,6 +112,8 @@ float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase);
  * scalars: n x 32;  out: n x 32 (fmt 0/1) or n x 160 (fmt 2). */
 int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out);
 int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out);
+/* the same for scalars the caller declares PUBLIC: always the context's fast tables (variable-time table access). */
+int32_t c25519_mul_base_batch_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out);
 
 /* ---- X25519: out[i] = x25519(k[i], u[i]) -------------------------------------------------------
  * replaces x25519-dalek/src/x25519.rs:390 = MontgomeryPoint(u).mul_clamped(k) (montgomery.rs:150,
@@ -134,7 +164,9 @@ int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64
  * Error precedence as in the reference: a public key that does not decompress -> C25519_NONE (the
  * reference fails earlier, at VerifyingKey::from_bytes, verifying.rs:167); any non-canonical s ->
  * SCALAR_FORMAT; any R that does not decompress, or a non-identity result -> VERIFY.
- * (ARRAY_LENGTH is raised by the host-language wrapper, which owns the three lengths.) */
+ * (ARRAY_LENGTH is raised by the host-language wrapper, which owns the three lengths.)
+ * msg_off must be non-decreasing with msg_off[n] <= msgs_len (the bytes readable at msgs); otherwise the call returns
+ * -(hipErrorInvalidValue) and no byte outside [msgs, msgs + msgs_len) is read. */
 int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                  const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
@@ -142,11 +174,21 @@ int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_
 /* The same check for callers that hold VerifyingKey values: the reference's VerifyingKey keeps the decompressed
  * point beside the 32 key bytes (verifying.rs:64-71, built once by from_bytes :167-175), so its verify_batch
  * never decompresses A_i (batch.rs:236 uses pk.point directly).  pk_points: n x 160 raw
- * EdwardsPoints matching pks (e.g. from c25519_decompress_batch), or NULL = decompress the key bytes here. */
+ * EdwardsPoints matching pks (e.g. from c25519_decompress_batch), or NULL = decompress the key bytes here.
+ * CONTRACT (the reference's VerifyingKey type invariant, verifying.rs:64-71): pk_points[i] MUST be the decompression of
+ * pks[i].  The hash uses the bytes and the group equation the point; a mismatched pair verifies against a key that
+ * was not hashed.  The library does not re-check it (that would be the decompression this entry point exists to skip);
+ * host-language wrappers must only build the pair through from_bytes (dalek.VerifyingKey does). */
 int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                       const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                                   const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_points, uint64_t n, uint32_t z_mode);
+
+/* diagnostics for the tests that pin the z derivation: the z_i a batch of n <= 1.5 x 2^20 signatures gets, 16 bytes each
+ * to the HOST buffer out_z16 (HOST pointers throughout).  z_mode 0: little-endian u128, the reference's values;
+ * z_mode 1: bit 127 = sign, bits 0..126 = magnitude. */
+int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n,
+                              uint32_t z_mode, uint8_t *out_z16);
 
 /* ---- variable base: out[i] = scalars[i] * points[i] ------------------------------------------------
  * replaces backend::variable_base_mul (backend.rs:253 -> scalar_mul/variable_base.rs:11-47;
@@ -198,8 +240,9 @@ int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp *p, con
 
 /* ---- regular-schedule multiscalar multiplication: MultiscalarMul::multiscalar_mul ------------------------
  * replaces backend::straus_multiscalar_mul (backend.rs:196 -> scalar_mul/straus.rs:103-144;
- * edwards.rs:966-1000).  One radix-16 fixed-window ladder per term (the schedule of variable_base.rs,
- * identical instruction stream for every input) and a tree sum; HOST pointers; fmt as c25519_mul_batch. */
+ * edwards.rs:966-1000).  One radix-16 fixed-window ladder per term (the schedule of variable_base.rs: identical
+ * instruction stream for every input, every table lookup a full scan with selects, whatever the context's flags) and a
+ * tree sum; staged scalars and per-lane tables are wiped.  HOST pointers; fmt as c25519_mul_batch. */
 int32_t c25519_msm_consttime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
 
 /* ---- RistrettoPoint::double_and_compress_batch (ristretto.rs:564-648): out[i] = compress(2 * P_i) with one

@@ -85,7 +85,7 @@ def test_verify_batch_validation_vectors_consistency(eng, orc):
     with open(os.path.join(ROOT, "tests", "golden", "ed25519_validation.json")) as fh:
         vv = json.load(fh)
     mism = 0
-    for v in vv[::3]:
+    for v in vv:
         pk, sig, msg = bytes.fromhex(v["key"]), bytes.fromhex(v["sig"]), v["msg"].encode()
         want = orc.ed25519_verify_batch([msg], [sig], [pk])
         got = eng.verify_batch([msg], [sig], [pk], 0)
@@ -142,6 +142,8 @@ def test_verify_batch_multi_pass_precedence(eng, orc):
     for z_mode in (1, 0):
         assert eng.verify_batch_t(dm, doff, ds, dp, z_mode) == OK
     first, last = 1000, n - 1000                              # in the first and in the last pass
+    bad = ds.clone(); bad[last, 3] ^= 1                       # transcript z-mode: one transcript over the whole batch, passes only cut the MSM
+    assert eng.verify_batch_t(dm, doff, bad, dp, 0) == VERIFY
     bad = ds.clone(); bad[first, 3] ^= 1
     assert eng.verify_batch_t(dm, doff, bad, dp, 1) == VERIFY
     bad = ds.clone(); bad[last, 3] ^= 1
@@ -174,7 +176,9 @@ def test_verify_batch_with_cached_key_points(eng, orc):
     with pytest.raises(dalek.SignatureError, match="PointDecompression"):
         dalek.VerifyingKey.from_bytes(P[:5] + [(2).to_bytes(32, "little")], engine=eng)
     # a key whose cached point is another key's: the batch equation must fail (the points are really used)
-    swapped = list(vks); swapped[10] = dalek.VerifyingKey(P[10], vks[11].point)
+    with pytest.raises(TypeError):
+        dalek.VerifyingKey(P[10], vks[11].point)                         # the invariant is not constructible from outside
+    swapped = list(vks); swapped[10] = dalek.VerifyingKey(P[10], vks[11].point, dalek.VerifyingKey._from_bytes_token)   # broken on purpose
     with pytest.raises(dalek.SignatureError, match="Verify"):
         dalek.verify_batch(M, S, swapped, engine=eng, z_mode=1)
     # device-resident, full size, with timing
@@ -212,3 +216,114 @@ def test_verify_batch_tree_boundaries(eng, orc, n):
         for j in sorted({0, i, n - 1}):
             bad = ds.clone(); bad[j, 9] ^= 0x10
             assert eng.verify_batch_t(dm, doff, bad, dp, z_mode) == VERIFY
+
+
+def _forged_pair(orc, seed_byte, t_scalar):
+    """Two signatures under ONE key that are individually invalid but cancel in the batch equation iff z_1 == z_2:
+    R'_1 = R_1 + T, R'_2 = R_2 - T with s_i = r_i + H(R'_i || A || M_i) a, so that
+    sum z_i (R'_i + h_i A - s_i B) = (z_1 - z_2) T."""
+    import hashlib
+    seed = bytes([seed_byte]) * 32
+    h = hashlib.sha512(seed).digest()
+    a = int.from_bytes(orc.sc_clamp(h[:32]), "little")
+    A = orc.ed25519_pubkey(seed)
+    T = orc.ed_mul_base(i2b(t_scalar))
+    out = []
+    for j, sign in enumerate((+1, -1)):
+        r = int.from_bytes(hashlib.sha512(b"nonce" + bytes([seed_byte, j])).digest(), "little") % L
+        R = orc.ed_mul_base(i2b(r))
+        Rp = orc.ed_compress(orc.ed_add(R, T) if sign > 0 else orc.ed_sub(R, T))
+        msg = b"forged message %d" % j
+        hh = int.from_bytes(hashlib.sha512(Rp + A + msg).digest(), "little") % L
+        out.append((msg, Rp + i2b((r + hh * a) % L), A))
+    return out
+
+
+@pytest.mark.parametrize("z_mode", [0, 1])
+def test_verify_batch_rejects_cancellation_forgery(eng, orc, z_mode):
+    """Soundness of the z derivation: a pair (R_1 + T, R_2 - T) passes the batch equation exactly when z_1 == z_2 (shown
+    with the oracle, which accepts injected z's); the engine must reject it alone, in any order, and buried in a large
+    honest batch -- i.e. its z_i are not equal across indices."""
+    pair = _forged_pair(orc, 7, 0x1234567890abcdef1234567)
+    M, S, P = [p[0] for p in pair], [p[1] for p in pair], [p[2] for p in pair]
+    z = (0x0123456789abcdef0123456789abcdef).to_bytes(16, "little")
+    assert orc.ed25519_verify_batch(M, S, P, zs=[z, z]) == OK                  # the construction works: equal z's cancel
+    assert orc.ed25519_verify_batch(M, S, P, zs=[z, (5).to_bytes(16, "little")]) == VERIFY
+    assert orc.ed25519_verify(P[0], M[0], S[0]) != 0 and orc.ed25519_verify(P[1], M[1], S[1]) != 0
+    assert eng.verify_batch(M, S, P, z_mode) == VERIFY
+    assert eng.verify_batch(M[::-1], S[::-1], P[::-1], z_mode) == VERIFY
+    # ... at every distance up to 70 inside an honest batch (same 16-signature tree leaf, same 4-signature z block, across them)
+    n = 300
+    seeds = util.rand_bytes(77, n); msgs = util.rand_bytes(78, n, 33)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    M0 = [msgs[i].tobytes() for i in range(n)]; S0 = [sigs[i].tobytes() for i in range(n)]; P0 = [pks[i].tobytes() for i in range(n)]
+    assert eng.verify_batch(M0, S0, P0, z_mode) == OK
+    for i, j in [(0, 1), (0, 2), (0, 3), (1, 2), (4, 7), (3, 4), (15, 16), (0, 16), (0, 64), (100, 170), (5, 299)]:
+        Mx, Sx, Px = list(M0), list(S0), list(P0)
+        Mx[i], Sx[i], Px[i] = pair[0]; Mx[j], Sx[j], Px[j] = pair[1]
+        assert eng.verify_batch(Mx, Sx, Px, z_mode) == VERIFY, (i, j)
+
+
+def test_z_derivation_depends_on_every_input(eng, orc):
+    """c25519_debug_batch_zs: (a) transcript z-mode reproduces the oracle's restatement of the reference's Merlin
+    transcript byte for byte; (b) device z-mode: all z_i of a batch are distinct, and flipping ONE bit of any message,
+    any signature half or any key changes (practically) every z_i of the batch; the batch size is bound too."""
+    import hashlib
+    n = 1000
+    seeds = util.rand_bytes(601, n); msgs = util.rand_bytes(602, n, 21)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+    M = [msgs[i].tobytes() for i in range(n)]; S = [sigs[i].tobytes() for i in range(n)]; P = [pks[i].tobytes() for i in range(n)]
+    hr = [hashlib.sha512(S[i][:32] + P[i] + M[i]).digest() for i in range(n)]
+    z0 = eng.debug_batch_zs(M, S, P, 0)
+    assert [z0[i].tobytes() for i in range(n)] == orc.batch_transcript_zs(hr, [s[32:] for s in S])
+    z1 = eng.debug_batch_zs(M, S, P, 1)
+    assert len({z1[i].tobytes() for i in range(n)}) == n
+    assert np.array_equal(z1, eng.debug_batch_zs(M, S, P, 1))                   # deterministic
+    def changed(za, zb):
+        return int((za != zb).any(axis=1).sum())
+    for what in ("msg", "R", "s", "key", "last-msg"):
+        M2, S2, P2 = list(M), list(S), list(P)
+        if what == "msg":
+            M2[500] = bytes([M[500][0] ^ 1]) + M[500][1:]
+        elif what == "last-msg":
+            M2[n - 1] = M[n - 1][:-1] + bytes([M[n - 1][-1] ^ 0x80])
+        elif what == "R":
+            S2[3] = bytes([S[3][0] ^ 2]) + S[3][1:]
+        elif what == "s":
+            S2[998] = S[998][:40] + bytes([S[998][40] ^ 4]) + S[998][41:]
+        else:
+            P2[0] = P[0][:31] + bytes([P[0][31] ^ 0x40])
+        for zm in (0, 1):
+            assert changed(eng.debug_batch_zs(M, S, P, zm), eng.debug_batch_zs(M2, S2, P2, zm)) == n, (what, zm)
+    # a prefix of the batch is a different batch: its z_i are unrelated to the first z_i of the full one
+    assert changed(z1[:n - 1], eng.debug_batch_zs(M[:-1], S[:-1], P[:-1], 1)) == n - 1
+    # sign-magnitude: both signs occur, magnitudes below 2^127 by construction
+    signs = (z1[:, 15] >> 7)
+    assert 0.35 * n < int(signs.sum()) < 0.65 * n
+
+
+def test_verify_batch_rejects_bad_offsets(eng, orc):
+    """msg_off must be monotone and stay inside msgs: the entry points fail (negative status -> EngineError) instead of
+    reading out of bounds."""
+    import torch
+    import curve25519_dalek_amd as pkg
+    n = 64
+    g = torch.Generator(device="cuda"); g.manual_seed(31337)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dm = torch.randint(0, 256, (n * 20,), dtype=torch.uint8, device="cuda", generator=g)
+    doff = torch.arange(0, 20 * (n + 1), 20, dtype=torch.int64).cuda()
+    dp, ds = eng.sign_batch_t(seeds, dm, doff)
+    assert eng.verify_batch_t(dm, doff, ds, dp, 1) == OK
+    for z_mode in (0, 1):
+        bad = doff.clone(); bad[10] = bad[12]                                   # not monotone
+        with pytest.raises(pkg.EngineError, match="msg_off"):
+            eng.verify_batch_t(dm, bad, ds, dp, z_mode)
+        bad = doff.clone(); bad[n] = 20 * n + 4096                              # runs past the end of msgs
+        with pytest.raises(pkg.EngineError, match="msg_off"):
+            eng.verify_batch_t(dm, bad, ds, dp, z_mode)
+    bad = doff.clone(); bad[n] = 1 << 40
+    with pytest.raises(pkg.EngineError, match="msg_off"):
+        eng.sign_batch_t(seeds, dm, bad)
+    assert eng.verify_batch_t(dm, doff, ds, dp, 1) == OK                        # the context is still usable
+    with pytest.raises(ValueError):
+        eng.verify_batch([b"m"], [b"\0" * 63], [b"\0" * 32], 1)                # a 63-byte signature must not silently misalign the batch
