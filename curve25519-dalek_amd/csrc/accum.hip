@@ -1,0 +1,79 @@
+// Bucket accumulation of the Pippenger MSM (pippenger.rs:122-136 as gather lists): one lane per (window, bucket).
+// Its own translation unit because it is built twice, once per carry form of the field arithmetic (fe26.h C25519_CHAIN):
+// the kernel runs at 6 waves per SIMD and 87 % VALU-busy, so the chained form (carry of column k rides in as the addend of
+// the first multiply of column k+1: nine 64-bit adds less per product) is an A/B arm here (C25519_ACC_CHAIN).
+//   hipcc -DC25519_CHAIN=0 -DACCUM_LAUNCH=launch_accumulate_c0 ...   /   -DC25519_CHAIN=1 -DACCUM_LAUNCH=launch_accumulate_c1
+#include <hip/hip_runtime.h>
+#include "devio.h"
+#include "msm_internal.h"
+
+namespace c25519 {
+namespace ACCUM_NS {
+
+template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
+__global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
+                                                    const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
+    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= count) return;
+    const u64 gid = perm[tid];
+    int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
+    if (hi - lo > LONG_CAP) return;
+    const u32 *list = sorted + (u64)k * n;
+    ge_p3 acc = ge_identity();
+    if (PIPE == 0) {
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            u32 e = list[i];
+            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
+        }
+    } else if (PIPE == 1) {
+        u32 e_next = lo < hi ? list[lo] : 0u;
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            u32 e = e_next;
+            if (i + 1 < hi) e_next = list[i + 1];
+            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
+        }
+    } else if (PIPE == 3) {
+        // point i+1 AND index i+2 in flight during addition i: the gather of the next point never waits for its index
+        uint4 q[PTS_Q];
+        u32 e = 0, e1 = 0;
+        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+        if (lo + 1 < hi) e1 = list[lo + 1];
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            const ge_aniels A = pts_from_q(q);
+            const bool neg = (e >> 31) != 0;
+            e = e1;
+            if (i + 1 < hi) { const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+            if (i + 2 < hi) e1 = list[i + 2];
+            acc = ge_madd_signed_p3(acc, A, neg);
+        }
+    } else {
+        uint4 q[PTS_Q];
+        u32 e = 0;
+        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+#pragma unroll 1
+        for (u32 i = lo; i < hi; i++) {
+            const ge_aniels A = pts_from_q(q);
+            const bool neg = (e >> 31) != 0;
+            if (i + 1 < hi) { e = list[i + 1]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
+            acc = ge_madd_signed_p3(acc, A, neg);
+        }
+    }
+    p40_store(buckets, gid, acc);
+}
+
+}  // namespace ACCUM_NS
+}  // namespace c25519
+
+void ACCUM_LAUNCH(int pipe, const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, hipStream_t st) {
+    using namespace c25519;
+    const dim3 grid((unsigned)((count + 255) / 256)), blk(256);
+    if (pipe == 0) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<0>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 1) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<1>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 3) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<3>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<2>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+}
+

@@ -4,6 +4,7 @@
 // generation and the O(windows) tail of an MSM, both through the very same fe26/ge26 headers.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -158,11 +159,17 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) return false;
     ctx->own_stream = true;
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
-    if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) return false;
+    // The second stream carries the latency-bound chains (hash tree, sort) that the VALU-bound kernels of the main stream
+    // would otherwise starve (older waves win the issue arbiter): it is created with the highest priority.
+    static const int aux_prio = [] { const char *e = getenv("C25519_AUX_PRIO"); return e ? atoi(e) : 1; }();   // A/B knob
+    int plo = 0, phi = 0;
+    if (aux_prio && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo) {
+        if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, phi) != hipSuccess) return false;
+    } else if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) return false;
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming);
-    hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
     if (hipMalloc((void **)&ctx->d_slots, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4) != hipSuccess) return false;
     return hipHostMalloc(&ctx->h_msm, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
@@ -244,6 +251,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_in) hipEventDestroy(ctx->ev_in);
     if (ctx->ev_z) hipEventDestroy(ctx->ev_z);
     if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
+    if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
     if (ctx->d_slots) hipFree(ctx->d_slots);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);

@@ -40,7 +40,7 @@ C25519_HD ge_p3 ge_basepoint() {
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void fe_pin(feT &a) { for (int i = 0; i < 10; i++) asm("" : "+v"(a.v[i])); }
 #else
-inline void fe_pin(feT &) {}
+C25519_HD void fe_pin(feT &) {}
 #endif
 C25519_HD void ge_pin(ge_p3 &p) { fe_pin(p.X); fe_pin(p.Y); fe_pin(p.Z); fe_pin(p.T); }
 

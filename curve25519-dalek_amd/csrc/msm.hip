@@ -54,44 +54,43 @@ namespace c25519 {
 // (compressed inputs: k_prep_compressed lives in kernels.hip -- a 252-squaring chain per lane at full occupancy wants
 // the chained-carry field arithmetic of that translation unit; launch_prep_compressed)
 // raw 160-byte points: Montgomery-trick normalisation, CH points per lane (cf. k_compress_p32)
+// raw 160-byte points: Montgomery-trick normalisation, CH points per lane (cf. k_compress_p32).  The kernel moves 1.1 GB per
+// 2^21 points (Z, then X, Y, Z again, 48-byte prefix products out and back, 128-byte records out): 0.30 ms against a
+// memory floor of ~0.27 ms.  Tried in round 2 and dropped: one inversion per BLOCK through an LDS tree (-45 % field
+// operations, but one wave inverts while three wait: 0.35 ms; 0.40 ms when LLVM moved the wave-uniform inversion to the
+// scalar unit), CH = 32 / 8, and fetching every record one step ahead (+12 VGPRs, 0.34 ms).
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    // two waves per SIMD at n = 2^21: nothing else hides the load latency, so every record is fetched one step ahead
-    // of the multiplication that consumes it (as k_compress_p32 does)
     feT acc = fe_one();
     bool affine = true;                 // every Z of this lane is literally 1 (points straight from a decompression,
                                         // e.g. VerifyingKey.point): the shared inversion is skipped
-    int cnt = 0;
-    feT Zc = raw160_fe(in, t, 2);
-    bool onec = raw160_z_is_one(in, t);
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
-        const u64 idx = t + (u64)j * T;
+        u64 idx = t + (u64)j * T;
         if (idx >= n) break;
-        cnt = j + 1;
-        const u64 nxt = idx + T;
-        const bool more = (j + 1 < CH) && nxt < n;
-        feT Zn = more ? raw160_fe(in, nxt, 2) : Zc;
-        const bool onen = more ? raw160_z_is_one(in, nxt) : true;
-        affine = affine && onec;
-        fe48_store(prefix, idx, acc);
-        acc = fe_mul(acc, Zc);
-        Zc = Zn; onec = onen;
+        affine = affine && raw160_z_is_one(in, idx);
+        uint4 *q = reinterpret_cast<uint4 *>(prefix) + 3 * idx;
+        q[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]); q[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+        q[2] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
+        acc = fe_mul(acc, raw160_fe(in, idx, 2));
     }
     feT inv = fe_one();
     if (!affine) inv = fe_invert(acc);
-    u64 idx = t + (u64)(cnt - 1) * T;
-    feT Z = raw160_fe(in, idx, 2), X = raw160_fe(in, idx, 0), Y = raw160_fe(in, idx, 1), pre = fe48_load(prefix, idx);
 #pragma unroll 1
-    for (int j = cnt - 1; j >= 0; j--) {
-        const u64 cur = t + (u64)j * T, prv = j > 0 ? cur - T : cur;
-        feT Zp = raw160_fe(in, prv, 2), Xp = raw160_fe(in, prv, 0), Yp = raw160_fe(in, prv, 1), prep = fe48_load(prefix, prv);
+    for (int j = CH - 1; j >= 0; j--) {
+        u64 idx = t + (u64)j * T;
+        if (idx >= n) continue;
+        const uint4 *q = reinterpret_cast<const uint4 *>(prefix) + 3 * idx;
+        uint4 a = q[0], b = q[1], c = q[2];
+        feT pre;
+        pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
+        pre.v[8] = c.x; pre.v[9] = c.y;
+        feT Z = raw160_fe(in, idx, 2);
         feT zi = fe_mul(inv, pre);
         inv = fe_mul(inv, Z);
-        pts_store(pts, dst0 + cur, fe_mul(X, zi), fe_mul(Y, zi));
-        Z = Zp; X = Xp; Y = Yp; pre = prep;
+        pts_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
     }
 }
 __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
@@ -424,8 +423,6 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const uint16_t *__restr
 // wave's 64 lanes finish together (Poisson-distributed lengths otherwise cost ~25 % idle lanes) and the
 // long lists start first.  ord_hist: 256 global bins; perm: bucket ids in processing order.
 struct long_item { u32 gid, lo, hi, first; };
-constexpr u32 LONG_CAP = 192;      // > mean + 8 sigma of a balanced bucket (mean <= 96)
-constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 // The same sweep over the bucket totals also emits the work list of the wave-cooperative long-bucket path (one item per
 // segment of LONG_SEG entries of a bucket longer than LONG_CAP), so the list exists before accumulation starts
 // (round 1 had a separate k_find_long on the second stream: a 16-VGPR scan that took 0.6 ms starved beside k_accumulate).
@@ -488,69 +485,7 @@ __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ t
 // Buckets longer than LONG_CAP are left to the wave-cooperative path below, so that no lane ever walks a
 // long list alone (skewed inputs: e.g. the +1 carry digit of every unsigned 128-bit z_i in verify_batch lands
 // ~n/2 terms in ONE bucket; identical scalars do the same in every window).
-template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
-__global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
-                                                    const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
-    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= count) return;
-    const u64 gid = perm[tid];
-    int k = (int)(gid / g.half), b = (int)(gid % g.half);
-    u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
-    if (hi - lo > LONG_CAP) return;
-    const u32 *list = sorted + (u64)k * n;
-    ge_p3 acc = ge_identity();
-    if (PIPE == 0) {
-#pragma unroll 1
-        for (u32 i = lo; i < hi; i++) {
-            u32 e = list[i];
-            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
-        }
-    } else if (PIPE == 1) {
-        u32 e_next = lo < hi ? list[lo] : 0u;
-#pragma unroll 1
-        for (u32 i = lo; i < hi; i++) {
-            u32 e = e_next;
-            if (i + 1 < hi) e_next = list[i + 1];
-            acc = ge_madd_signed_p3(acc, pts_load(pts, e & 0x7fffffffu), (e >> 31) != 0);
-        }
-    } else if (PIPE == 3) {
-        // point i+1 AND index i+2 in flight during addition i: the gather of the next point never waits for its index
-        uint4 q[PTS_Q];
-        u32 e = 0, e1 = 0;
-        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
-        if (lo + 1 < hi) e1 = list[lo + 1];
-#pragma unroll 1
-        for (u32 i = lo; i < hi; i++) {
-            const ge_aniels A = pts_from_q(q);
-            const bool neg = (e >> 31) != 0;
-            e = e1;
-            if (i + 1 < hi) { const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
-            if (i + 2 < hi) e1 = list[i + 2];
-            acc = ge_madd_signed_p3(acc, A, neg);
-        }
-    } else {
-        uint4 q[PTS_Q];
-        u32 e = 0;
-        if (lo < hi) { e = list[lo]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
-#pragma unroll 1
-        for (u32 i = lo; i < hi; i++) {
-            const ge_aniels A = pts_from_q(q);
-            const bool neg = (e >> 31) != 0;
-            if (i + 1 < hi) { e = list[i + 1]; const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)(e & 0x7fffffffu); for (int j = 0; j < PTS_Q; j++) q[j] = src[j]; }
-            acc = ge_madd_signed_p3(acc, A, neg);
-        }
-    }
-    p40_store(buckets, gid, acc);
-}
-
-static void launch_accumulate(int pipe, const u32 *pts, const u32 *sorted, const u32 *base, const u32 *perm, u64 count, u64 n, const msm_geom &g, u32 *buckets, hipStream_t st) {
-    const dim3 grid((unsigned)((count + 255) / 256)), blk(256);
-    if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else if (pipe == 3) hipLaunchKernelGGL(k_accumulate<3>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else hipLaunchKernelGGL(k_accumulate<2>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-}
-
+// (k_accumulate lives in accum.hip, built once per carry form of fe_mul: launch_accumulate_c0 / _c1)
 // ---- long buckets -------------------------------------------------------------------------------------
 // work list (made by k_order_hist): one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
 // sum across the 64 lanes of a wave (complete additions; lane 0 ends with the total)
@@ -1000,13 +935,20 @@ EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_
 static_assert(C25519_SLOT_U32 == MSM_MAX_WIN * 40 + 16, "slot layout");
 static inline uint32_t *slot_flags(uint32_t *slot) { return slot + MSM_MAX_WIN * 40; }
 
-// Enqueue sum_i scalars[i] * pts[i] (packed affine Niels points already on the device) with window layout g; the column
-// sums go to d_slot.  sort_stream: stream on which the scalars become ready and on which the digit/sort kernels are
-// enqueued (nullptr = the context's main stream).  Sorting depends only on the scalars, so a caller can run it on the
-// second stream while the main stream still prepares the points; the two are joined here.
-// ring (may be null): [0] / [1] bracket k_accumulate, [2] = end of the pass.
-int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream) {
+// An MSM is enqueued in two halves so that a caller can put other work between them:
+//   msm_enqueue_sort  digits, counting sort, bucket order and the long-bucket work list -- needs only the SCALARS; runs on
+//                     sort_stream (nullptr = the context's main stream).  Memory-bound.
+//   msm_enqueue_acc   joins sort_stream into the main stream, then accumulation (+ the long-bucket path on the second
+//                     stream) and bucket reduction -- needs the POINTS (packed affine Niels records).  VALU-bound.
+// The column sums go to d_slot.  ring (may be null): [0] / [1] bracket k_accumulate, [2] = end of the pass.
+// wait_acc (may be null): an event the accumulation waits for -- the previous pass's accumulation on the other stream
+// set: two accumulations side by side only share the multipliers, while a sort beside an accumulation is free.
+struct msm_plan {
+    msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
+    uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs; long_item *items;
+    hipStream_t sort_stream;
+};
+int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl) {
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
     if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
@@ -1037,14 +979,17 @@ int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
-    uint32_t *SW = (uint32_t *)(ws + oSW);
+    pl.g = g; pl.n = n; pl.nb = nb; pl.nseg = nseg; pl.max_items = max_items; pl.max_long = max_long;
+    pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8;
+    pl.items = (long_item *)(ws + oLI); pl.lgids = (uint32_t *)(ws + oLG); pl.lfirst = (uint32_t *)(ws + oLF); pl.segs = (uint32_t *)(ws + oLS);
     static const bool overlap = env_int("C25519_SORT_OVERLAP", 1) != 0;   // A/B knob: 0 = the main stream waits for the scalars and sorts itself
     if (!overlap && sort_stream && sort_stream != ctx->stream) {
         HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
         sort_stream = nullptr;
     }
-    hipStream_t st = sort_stream ? sort_stream : ctx->stream;      // sort phase
+    pl.sort_stream = sort_stream;
+    hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
     hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
     if (use_part) {
@@ -1078,33 +1023,47 @@ int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const
         else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     }
     // bucket order (longest lists first) and the long-bucket work list: still on the sort stream -- they only need the lists
-    long_item *items = (long_item *)(ws + oLI);
-    uint32_t *lgids = (uint32_t *)(ws + oLG), *lfirst = (uint32_t *)(ws + oLF), *segs = (uint32_t *)(ws + oLS), *counters = flags + 8;
-    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, items, counters, lgids, lfirst);
+    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
     hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, 0u, ord_hist, perm);
     HIPCHK(hipGetLastError());
-    if (sort_stream && sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
-        HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
+    return C25519_OK;
+}
+int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc) {
+    const msm_geom &g = pl.g;
+    if (pl.sort_stream && pl.sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
+        HIPCHK(hipEventRecord(ctx->ev_sort, pl.sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
     }
-    st = ctx->stream;
+    hipStream_t st = ctx->stream;
     static const int pipe = [] { int v = env_int("C25519_ACC_PIPE", 3); return (v < 0 || v > 3) ? 3 : v; }();   // A/B knob (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
+    static const int acc_serial = env_int("C25519_ACC_SERIAL", 1);                                              // A/B knob
+    if (wait_acc && acc_serial) HIPCHK(hipStreamWaitEvent(st, wait_acc, 0));
     // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, sorted, n, g, items, counters, max_items, segs);
-    hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(max_long, 1024u)), dim3(64), 0, ctx->aux, base, g, counters, max_items, lgids, lfirst, segs, buckets);
+    hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(pl.max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, pl.sorted, pl.n, g, pl.items, pl.counters, pl.max_items, pl.segs);
+    hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(pl.max_long, 1024u)), dim3(64), 0, ctx->aux, pl.base, g, pl.counters, pl.max_items, pl.lgids, pl.lfirst, pl.segs, pl.buckets);
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    launch_accumulate(pipe, d_pts, sorted, base, perm, nb, n, g, buckets, st);
+    static const int acc_chain = env_int("C25519_ACC_CHAIN", 0);                                              // A/B knob: carry form of the field arithmetic in k_accumulate
+    if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    else launch_accumulate_c0(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
-    hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * nseg)), dim3(64), 0, st, buckets, g.half, nseg, SW, d_slot, nseg == 1 ? 1 : 0);
-    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, st, SW, nseg, d_slot);
+    hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, st, pl.buckets, g.half, pl.nseg, pl.SW, d_slot, pl.nseg == 1 ? 1 : 0);
+    if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, st, pl.SW, pl.nseg, d_slot);
     HIPCHK(hipGetLastError());
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     return C25519_OK;
+}
+int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr) {
+    msm_plan pl;
+    int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
+    if (r) return r;
+    return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
 
 // total = sum_k 2^pos_k col_k by Horner (pippenger.rs:159), host arithmetic over <= 56 points
@@ -1193,18 +1152,25 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
 }
 
 // One bucket-method pass over at most MSM_PASS_MAX terms, enqueued on context c (ctx or its peer); results to d_slot.
-static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot) {
+// Normalisation on the main stream, sort on the second one.  They do not really overlap: both are within 10 % of their
+// memory floor (1.1 GB and 0.7 GB per 2^21 terms), and whichever starts second is starved by the older waves.
+static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot,
+                                hipEvent_t wait_acc) {
     int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256);
     if (r) return r;
+    if (in_fmt == C25519_FMT_RAW160 && (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     hipEvent_t *ring = pass_ring(owner, ctx);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
     HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, ctx->stream));
-    // points are normalised on the main stream while the scalars are recoded and sorted on the second one
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    msm_plan pl;
+    static const int sort_first = env_int("C25519_SORT_FIRST", 0);      // A/B knob: measured 2.26 (prep first) vs 2.34 ms (sort first) at 2^21 terms
+    if (sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
     if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r;
-    return msm_enqueue(ctx, d_scalars, n, d_pts, g, d_slot, ring, ctx->aux);
+    if (!sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
+    return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1221,14 +1187,17 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     if ((r = passes_begin(ctx, passes, ps))) return r;
     std::vector<ge_p3> cols(g.nwin, ge_identity());
     bool none = false, bad_scalar = false;
+    hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
-            if ((r = msm_pass_enqueue(ctx, ps.c[(p0 + i) % ps.lanes], d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i)))) {
-                if (ctx->err.empty()) ctx->err = ps.c[(p0 + i) % ps.lanes]->err;
+            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc))) {
+                if (ctx->err.empty()) ctx->err = c->err;
                 return r;
             }
+            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
         if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
         for (int i = 0; i < cnt; i++) {
@@ -1330,7 +1299,7 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
 // d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
-                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot) {
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot, hipEvent_t wait_acc) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -1379,7 +1348,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
     HIPCHK(hipGetLastError());
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
-    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa);
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
 }
 // Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
 // 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
@@ -1421,6 +1390,7 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
     bool seen[5] = {false, false, false, false, false}, bad_off = pre_flags[1] != 0, bad_scalar = false;
+    hipEvent_t prev_acc = nullptr;
     if (pre_flags[0]) seen[C25519_SCALAR_FORMAT] = true;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
@@ -1428,8 +1398,9 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
-                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i));
+                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i), prev_acc);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
+            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
         if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
         for (int i = 0; i < cnt; i++) {
