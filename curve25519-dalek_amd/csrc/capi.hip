@@ -530,6 +530,7 @@ EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     if (ctx_reserve(ctx, ctx->tmp_a, 4096)) return -1.0;
     hipMemsetAsync(ctx->tmp_a.p, 0x5a, 4096, ctx->stream);
     unsigned grid = (unsigned)ctx->num_cus * 8;   // 8 blocks x 4 waves per CU = 8 waves per SIMD
+    if (which >= 100) { which -= 100; grid = (unsigned)ctx->num_cus; }   // which + 100: ONE wave per SIMD (latency, not throughput)
     if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, 16, grid, ctx->stream) != hipSuccess) return -1.0;  // warm-up
     hipEventRecord(ctx->ev0, ctx->stream);
     if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, iters, grid, ctx->stream) != hipSuccess) return -1.0;

@@ -403,6 +403,104 @@ __global__ void __launch_bounds__(256) k_probe_fesq(u32 *out, int iters, u32 see
     for (int i = 0; i < 10; i++) r ^= x.v[i] ^ y.v[i];
     if (r == 0x12345678u) out[0] = r;
 }
+// ---- instruction-rate probes (which = 10 ..): ITER x 8 independent chains of ONE instruction, written in asm so that
+//      the compiler cannot fuse, reorder or drop them.  They price the non-multiplier half of fe_mul.
+#define C25519_PROBE32(NAME, ASM)                                                                       \
+    __global__ void __launch_bounds__(256) NAME(u32 *out, int iters, u32 seed) {                        \
+        u32 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        u32 b = seed | 1u;                                                                              \
+        for (int i = 0; i < iters; i++) {                                                               \
+            asm volatile(ASM : "+v"(a0) : "v"(b)); asm volatile(ASM : "+v"(a1) : "v"(b));               \
+            asm volatile(ASM : "+v"(a2) : "v"(b)); asm volatile(ASM : "+v"(a3) : "v"(b));               \
+            asm volatile(ASM : "+v"(a4) : "v"(b)); asm volatile(ASM : "+v"(a5) : "v"(b));               \
+            asm volatile(ASM : "+v"(a6) : "v"(b)); asm volatile(ASM : "+v"(a7) : "v"(b));               \
+        }                                                                                               \
+        u32 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                                  \
+        if (r == 0x12345678u) out[0] = r;                                                               \
+    }
+#define C25519_PROBE64(NAME, ASM)                                                                       \
+    __global__ void __launch_bounds__(256) NAME(u32 *out, int iters, u32 seed) {                        \
+        u64 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        u64 b = ((u64)seed << 20) | 1u;                                                                 \
+        for (int i = 0; i < iters; i++) {                                                               \
+            asm volatile(ASM : "+v"(a0) : "v"(b)); asm volatile(ASM : "+v"(a1) : "v"(b));               \
+            asm volatile(ASM : "+v"(a2) : "v"(b)); asm volatile(ASM : "+v"(a3) : "v"(b));               \
+            asm volatile(ASM : "+v"(a4) : "v"(b)); asm volatile(ASM : "+v"(a5) : "v"(b));               \
+            asm volatile(ASM : "+v"(a6) : "v"(b)); asm volatile(ASM : "+v"(a7) : "v"(b));               \
+        }                                                                                               \
+        u64 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;                                                  \
+        if ((u32)r == 0x12345678u) out[0] = (u32)(r >> 32);                                             \
+    }
+C25519_PROBE64(k_probe_lshr64, "v_lshrrev_b64 %0, 26, %0")
+C25519_PROBE64(k_probe_lshladd64, "v_lshl_add_u64 %0, %0, 0, %1")
+C25519_PROBE32(k_probe_alignbit, "v_alignbit_b32 %0, %1, %0, 26")
+C25519_PROBE32(k_probe_and, "v_and_b32_e32 %0, %1, %0")
+C25519_PROBE32(k_probe_lshl, "v_lshlrev_b32_e32 %0, 1, %0")
+C25519_PROBE32(k_probe_andor, "v_and_or_b32 %0, %0, %1, %1")
+C25519_PROBE32(k_probe_mul24, "v_mul_u32_u24_e32 %0, %1, %0")
+C25519_PROBE32(k_probe_mad24, "v_mad_u32_u24 %0, %0, %1, %1")
+C25519_PROBE32(k_probe_mulhi, "v_mul_hi_u32 %0, %0, %1")
+C25519_PROBE32(k_probe_add3, "v_add3_u32 %0, %0, %1, %1")
+C25519_PROBE32(k_probe_bfe, "v_bfe_u32 %0, %0, 3, 26")
+C25519_PROBE32(k_probe_lshladd32, "v_lshl_add_u32 %0, %0, 1, %1")
+C25519_PROBE32(k_probe_lshr, "v_lshrrev_b32_e32 %0, 3, %0")
+C25519_PROBE32(k_probe_sub, "v_sub_u32_e32 %0, %1, %0")
+C25519_PROBE32(k_probe_or, "v_or_b32_e32 %0, %1, %0")
+C25519_PROBE32(k_probe_xor, "v_xor_b32_e32 %0, %1, %0")
+C25519_PROBE32(k_probe_cndmask, "v_cndmask_b32_e32 %0, %1, %0, vcc")
+C25519_PROBE32(k_probe_mov, "v_mov_b32_e32 %0, %1")
+C25519_PROBE32(k_probe_perm, "v_perm_b32 %0, %0, %1, %1")
+C25519_PROBE32(k_probe_add_sdwa, "v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1")
+C25519_PROBE32(k_probe_lshlor, "v_lshl_or_b32 %0, %0, 6, %1")
+// a 64-bit add as a carry pair on 32-bit halves (8 independent pairs per iteration; one pair counts as one operation)
+__global__ void __launch_bounds__(256) k_probe_addco(u32 *out, int iters, u32 seed) {
+    u32 lo[8], hi[8], b = seed | 1u;
+    for (int j = 0; j < 8; j++) { lo[j] = threadIdx.x * (2 * j + 3) + seed; hi[j] = out[j] + threadIdx.x; }
+    for (int i = 0; i < iters; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            asm volatile("v_add_co_u32_e32 %0, vcc, %2, %0\n\tv_addc_co_u32_e32 %1, vcc, %2, %1, vcc" : "+v"(lo[j]), "+v"(hi[j]) : "v"(b) : "vcc");
+    }
+    u32 r = 0;
+    for (int j = 0; j < 8; j++) r ^= lo[j] ^ hi[j];
+    if (r == 0x12345678u) out[0] = r;
+}
+// R full-rate adds issued beside every v_mad_u64_u32: does the adder run while the multiplier is busy?
+template <int R>
+__global__ void __launch_bounds__(256) k_probe_mix_add(u32 *out, int iters, u32 seed) {
+    u32 b = seed | 1u;
+    u64 a0 = threadIdx.x + 1, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    u32 c[8];
+    for (int j = 0; j < 8; j++) c[j] = threadIdx.x * (2 * j + 3) + out[j & 7];
+    for (int i = 0; i < iters; i++) {
+#define C25519_MIXSTEP(A, C)                                                                                   \
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %1, %0" : "+v"(A) : "v"(b) : "s6", "s7");                   \
+        for (int r = 0; r < R; r++) asm volatile("v_add_u32_e32 %0, %1, %0" : "+v"(C) : "v"(b));
+        C25519_MIXSTEP(a0, c[0]) C25519_MIXSTEP(a1, c[1]) C25519_MIXSTEP(a2, c[2]) C25519_MIXSTEP(a3, c[3])
+        C25519_MIXSTEP(a4, c[4]) C25519_MIXSTEP(a5, c[5]) C25519_MIXSTEP(a6, c[6]) C25519_MIXSTEP(a7, c[7])
+#undef C25519_MIXSTEP
+    }
+    u64 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    u32 q = 0;
+    for (int j = 0; j < 8; j++) q ^= c[j];
+    if ((u32)r == 0x12345678u && q == 0x9abcdef0u) out[0] = (u32)(r >> 32);
+}
+// one DEPENDENT chain of v_mad_u64_u32 per lane (the accumulator feeds the next multiply-add): its latency
+__global__ void __launch_bounds__(256) k_probe_mad_dep(u32 *out, int iters, u32 seed) {
+    u64 a = threadIdx.x + seed;
+    u32 b = seed | 1u, c = threadIdx.x | 3u;
+    for (int i = 0; i < iters; i++) {
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+        asm volatile("v_mad_u64_u32 %0, s[6:7], %1, %2, %0" : "+v"(a) : "v"(b), "v"(c) : "s6", "s7");
+    }
+    if ((u32)a == 0x12345678u) out[0] = (u32)(a >> 32);
+}
 // The reference's literal layout: 5 x u64 limbs, u128 products (u64/field.rs:111-214) -- the A/B arm.
 struct fe51 { u64 v[5]; };
 __device__ __forceinline__ fe51 fe51_mul(const fe51 &x, const fe51 &y) {
@@ -589,6 +687,32 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 8: hipLaunchKernelGGL(k_probe_add2, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 6: hipLaunchKernelGGL(k_probe_mix<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 7: hipLaunchKernelGGL(k_probe_mix<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 10: hipLaunchKernelGGL(k_probe_lshr64, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 11: hipLaunchKernelGGL(k_probe_lshladd64, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 12: hipLaunchKernelGGL(k_probe_alignbit, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 13: hipLaunchKernelGGL(k_probe_and, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 14: hipLaunchKernelGGL(k_probe_lshl, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 15: hipLaunchKernelGGL(k_probe_andor, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 16: hipLaunchKernelGGL(k_probe_mul24, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 17: hipLaunchKernelGGL(k_probe_mad24, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 18: hipLaunchKernelGGL(k_probe_mulhi, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 19: hipLaunchKernelGGL(k_probe_add3, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 20: hipLaunchKernelGGL(k_probe_bfe, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 21: hipLaunchKernelGGL(k_probe_lshladd32, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 22: hipLaunchKernelGGL(k_probe_mad_dep, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 23: hipLaunchKernelGGL(k_probe_lshr, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 24: hipLaunchKernelGGL(k_probe_sub, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 25: hipLaunchKernelGGL(k_probe_or, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 26: hipLaunchKernelGGL(k_probe_xor, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 27: hipLaunchKernelGGL(k_probe_cndmask, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 28: hipLaunchKernelGGL(k_probe_mov, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 29: hipLaunchKernelGGL(k_probe_perm, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 30: hipLaunchKernelGGL(k_probe_add_sdwa, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 31: hipLaunchKernelGGL(k_probe_lshlor, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 32: hipLaunchKernelGGL(k_probe_addco, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 33: hipLaunchKernelGGL(k_probe_mix_add<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 34: hipLaunchKernelGGL(k_probe_mix_add<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 35: hipLaunchKernelGGL(k_probe_mix_add<3>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

@@ -1123,25 +1123,26 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 // a stream synchronisation + host fold per pass.)
 static const int MSM_PASS_LOG2 = [] { int v = env_int("C25519_MSM_PASS_LOG2", 21); return v < 16 ? 16 : (v > 21 ? 21 : v); }();   // A/B knob
 static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
-static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 2 ? 2 : x); }(); return v; }   // A/B knob
+static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
 
-struct pass_set { c25519_ctx *c[2]; int lanes; };
-// the peer's streams start after everything already enqueued on the caller's stream (the inputs are complete)
+struct pass_set { c25519_ctx *c[4]; int lanes; };
+// the peers' streams start after everything already enqueued on the caller's stream (the inputs are complete)
 static int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps) {
-    ps.c[0] = ctx; ps.c[1] = nullptr; ps.lanes = 1;
+    ps.c[0] = ctx; ps.lanes = 1;
     ctx->last_passes.clear();
-    if (passes > 1 && pass_lanes() > 1) { c25519_ctx *p = ctx_peer(ctx); if (p) { ps.c[1] = p; ps.lanes = 2; } }
+    const int want = (int)std::min<uint64_t>(passes, (uint64_t)pass_lanes());
+    while (ps.lanes < want) { c25519_ctx *p = ctx_peer(ps.c[ps.lanes - 1]); if (!p) break; ps.c[ps.lanes++] = p; }   // each the peer of the previous one
     if (ps.lanes > 1) {
         HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
-        HIPCHK(hipStreamWaitEvent(ps.c[1]->stream, ctx->ev_in, 0));
+        for (int l = 1; l < ps.lanes; l++) HIPCHK(hipStreamWaitEvent(ps.c[l]->stream, ctx->ev_in, 0));
     }
     return C25519_OK;
 }
-// the caller's stream continues after the peer's passes
+// the caller's stream continues after the peers' passes
 static int32_t passes_join(c25519_ctx *ctx, pass_set &ps) {
-    if (ps.lanes > 1) {
-        HIPCHK(hipEventRecord(ps.c[1]->ev_in, ps.c[1]->stream));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ps.c[1]->ev_in, 0));
+    for (int l = 1; l < ps.lanes; l++) {
+        HIPCHK(hipEventRecord(ps.c[l]->ev_in, ps.c[l]->stream));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ps.c[l]->ev_in, 0));
     }
     return C25519_OK;
 }

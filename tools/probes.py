@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Instruction-rate probes of the integer vector unit (c25519_microbench): giga-instructions per second for the whole chip
+at 8 waves per SIMD, and at ONE wave per SIMD (which + 100: how much a lone wave can issue -- the latency-bound kernels).
+    python tools/probes.py > profiles/rNN_instruction_rates.txt"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import curve25519_dalek_amd as pkg
+
+e = pkg.Engine(0)
+names = {0: "v_mad_u64_u32 (8 independent chains)", 22: "v_mad_u64_u32 (ONE dependent chain)", 5: "v_mul_lo_u32", 18: "v_mul_hi_u32", 16: "v_mul_u32_u24 (VOP2)",
+         17: "v_mad_u32_u24", 4: "v_xad_u32 / add+xor pair", 8: "v_add_u32 (VOP2)", 13: "v_and_b32 (VOP2)", 14: "v_lshlrev_b32 (VOP2)", 12: "v_alignbit_b32",
+         15: "v_and_or_b32", 19: "v_add3_u32", 20: "v_bfe_u32", 21: "v_lshl_add_u32", 10: "v_lshrrev_b64", 11: "v_lshl_add_u64",
+         23: "v_lshrrev_b32 (VOP2)", 24: "v_sub_u32 (VOP2)", 25: "v_or_b32 (VOP2)", 26: "v_xor_b32 (VOP2)", 27: "v_cndmask_b32 (VOP2)", 28: "v_mov_b32",
+         29: "v_perm_b32", 30: "v_add_u32_sdwa (src1 WORD_1)", 31: "v_lshl_or_b32", 32: "v_add_co_u32 + v_addc_co_u32 (pair = 1)",
+         6: "v_mad_u64_u32 with 1 v_xad_u32 beside each", 7: "v_mad_u64_u32 with 2 v_xad_u32 beside each",
+         33: "v_mad_u64_u32 with 1 v_add_u32 beside each", 34: "v_mad_u64_u32 with 2 v_add_u32 beside each", 35: "v_mad_u64_u32 with 3 v_add_u32 beside each",
+         1: "fe_mul (chained carries)", 2: "fe_sq (chained carries)"}
+for _ in range(60):
+    e.microbench(0, 4000)                      # bring the clock up
+cus = 256
+print("%-40s %12s %14s %12s %14s" % ("instruction", "Gop/s chip", "cycles/wave*", "1 wave/SIMD", "cycles/wave*"))
+for which, nm in names.items():
+    full = max(e.microbench(which, 4000) for _ in range(5))
+    lone = max(e.microbench(which + 100, 4000) for _ in range(5))
+    # cycles per wave-instruction on one SIMD at 2.4 GHz nominal: 1024 SIMDs x 64 lanes x f / rate
+    cyc = lambda r: 1024 * 64 * 2.4 / r
+    print("%-40s %12.1f %14.2f %12.1f %14.2f" % (nm, full, cyc(full), lone, cyc(lone)))
+print("* at a nominal 2.4 GHz; fe_mul / fe_sq rows count field operations, not instructions")
