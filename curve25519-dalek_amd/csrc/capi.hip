@@ -525,6 +525,23 @@ EXPORT int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, ui
 }
 
 // ---- diagnostics -------------------------------------------------------------------------------------
+// field self-test: raw limbs (n x 10 u32, HOST pointers; b may be NULL for the unary ops) -> n x 32 canonical bytes
+EXPORT int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (op < 0 || op > 7 || (chain != 0 && chain != 1)) { ctx->err = "selftest_field: bad op / chain"; return -(int32_t)hipErrorInvalidValue; }
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 32))) return r;
+    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, a_limbs, n * 40, hipMemcpyHostToDevice, ctx->stream));
+    if (b_limbs) HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, b_limbs, n * 40, hipMemcpyHostToDevice, ctx->stream));
+    const uint32_t *db = b_limbs ? (const uint32_t *)ctx->tmp_b.p : nullptr;
+    if (chain) HIPCHK(launch_selftest_c1(op, (const uint32_t *)ctx->tmp_a.p, db, n, (uint8_t *)ctx->tmp_c.p, ctx->stream));
+    else HIPCHK(launch_selftest_c0(op, (const uint32_t *)ctx->tmp_a.p, db, n, (uint8_t *)ctx->tmp_c.p, ctx->stream));
+    HIPCHK(hipMemcpyAsync(out, ctx->tmp_c.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+
 EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     if (hipSetDevice(ctx->device) != hipSuccess) return -1.0;
     if (ctx_reserve(ctx, ctx->tmp_a, 4096)) return -1.0;

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include "devio.h"
 #include "kernels.h"
+#include "selftest.h"
 
 namespace c25519 {
 
@@ -123,6 +124,12 @@ __global__ void __launch_bounds__(256) k_raw_to_p32(const uint8_t *__restrict__ 
     p32_store(scratch, idx, P.X, P.Y, P.Z);
 }
 
+
+hipError_t launch_selftest_c0(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st) {   // ten-column unit
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_selftest_field<0>, dim3(div_up(n, 256)), dim3(256), 0, st, op, a, b, n, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, u64 n, uint8_t *out, hipStream_t st) {
     if (n == 0) return hipSuccess;

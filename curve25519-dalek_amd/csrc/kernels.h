@@ -22,6 +22,8 @@ hipError_t launch_decompress_ristretto(const uint8_t *in, uint64_t n, uint8_t *o
 hipError_t launch_compress_ristretto(const uint8_t *in_raw, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_compress_raw(const uint8_t *in_raw, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_raw_to_p32(const uint8_t *in_raw, uint64_t n, uint32_t *scratch, hipStream_t st);
+hipError_t launch_selftest_c0(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st);
+hipError_t launch_selftest_c1(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipStream_t st);
 
 }  // namespace c25519

@@ -5,6 +5,7 @@
 #define C25519_CHAIN 1   // chained-carry fe_mul / fe_sq (fe26.h): +4 % on the comb and the ladder
 #include "devio.h"
 #include "kernels.h"
+#include "selftest.h"
 
 namespace c25519 {
 
@@ -673,6 +674,12 @@ __global__ void __launch_bounds__(256) k_clamp(const uint8_t *__restrict__ in, u
 hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_clamp, dim3(div_up(n, 256)), dim3(256), 0, st, in, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_selftest_c1(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st) {   // chained-carry unit
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_selftest_field<1>, dim3(div_up(n, 256)), dim3(256), 0, st, op, a, b, n, out);
     return hipGetLastError();
 }
 

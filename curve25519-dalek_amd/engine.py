@@ -91,6 +91,7 @@ def load_library():
         "c25519_double_and_compress_batch": (i32, [vp, vp, u64, vp]),
         "c25519_scalar_invert_batch": (i32, [vp, vp, u64, vp]),
         "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
+        "c25519_selftest_field": (i32, [vp, C.c_int, C.c_int, vp, vp, u64, vp]),
         "c25519_msm_geometry": (i32, [u64, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -105,7 +106,7 @@ ABI_SYMBOLS = [
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
-    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_msm_geometry",
+    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
@@ -188,6 +189,16 @@ class Engine:
         passes = C.c_uint32(0)
         ms = float(self.lib.c25519_last_call_phase_ms(self.ctx, phase, C.byref(passes)))
         return ms, int(passes.value)
+
+    def selftest_field(self, op, a_limbs, b_limbs=None, chain=0):
+        """one field operation per row on the GPU: (n, 10) uint32 limbs in -> (n, 32) canonical bytes (c25519_selftest_field)"""
+        a = np.ascontiguousarray(a_limbs, dtype=np.uint32).reshape(-1, 10); n = a.shape[0]
+        b = None if b_limbs is None else np.ascontiguousarray(b_limbs, dtype=np.uint32).reshape(-1, 10)
+        assert b is None or b.shape[0] == n
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_selftest_field(self.ctx, op, chain, a.ctypes.data, b.ctypes.data if b is not None else None, n, out.ctypes.data))
+        return out
 
     def microbench(self, which, iters=2000):
         self._bind_stream()

@@ -261,6 +261,13 @@ int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t n, uin
  * engine), 2 fe_sq, 3 fe_mul written on 5 x u64 limbs with unsigned __int128 products (the
  * reference's literal layout, for the A/B in DESIGN.md), 4 v_add_u32, 5 v_mul_lo_u32. */
 double c25519_microbench(c25519_ctx *ctx, int which, int iters);
+/* Device field self-test: runs ONE field operation per element on the GPU, in the translation unit built with the
+ * chained-carry multiplication (chain = 1: kernels.hip) or the ten-column one (chain = 0), and returns canonical bytes
+ * (field.rs:368-450 to_bytes).  a_limbs / b_limbs: n x 10 u32 limbs at bit positions 0,26,51,...,230 (HOST pointers;
+ * any magnitudes the operation's bound class admits, csrc/fe26.h); out: n x 32.  op: 0 a*b (a wide, b loose), 1 a^2
+ * (loose), 2 1/a, 3 canonical encoding of a (wide), 4 a^((p-5)/8), 5 a-b (both loose), 6 weak reduction of a,
+ * 7 (a-b)*(a+b) (both tight).  Pins the device code generation against big integers (field.rs:552-642). */
+int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out);
 /* The window layout the MSM uses for n terms (host arithmetic, no GPU needed): window k covers bits
  * [pos[k], pos[k] + wid[k]) of s' = s + addk (addk as 8 little-endian 32-bit words); all windows but the last two are
  * signed (digit = slice - 2^(wid-1)).  pos / wid need room for 56 entries.  Used by the CPU tests to check that the
