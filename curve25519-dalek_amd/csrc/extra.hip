@@ -1,9 +1,10 @@
 // Callers and batch conversions either side of the MSM:
 //
 //   c25519_precomp_*        VartimePrecomputedStraus (backend.rs:100-192 ->
-//                           scalar_mul/precomputed_straus.rs:29-127; edwards.rs:1037-1076): the static
-//                           points are normalised once and stay resident in HBM as packed affine Niels
-//                           points; every call runs the bucket-method MSM over static + dynamic terms
+//                           scalar_mul/precomputed_straus.rs:29-127; edwards.rs:1037-1076): per static point the
+//                           multiples 2^(c k) P for every window k stay resident in HBM as affine Niels records, so a
+//                           call is ONE bucket accumulation + ONE bucket reduction over all digits of all scalars (no
+//                           point preparation, no Horner fold); dynamic terms go through the ordinary MSM and are added
 //   c25519_msm_consttime    MultiscalarMul::multiscalar_mul (straus.rs:103-144; edwards.rs:966-1000): a
 //                           regular (input-independent) schedule = one radix-16 variable-base ladder per
 //                           term (k_var_base) followed by a tree sum
@@ -29,7 +30,7 @@ using namespace c25519;
 
 static inline unsigned dup64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 
-struct c25519_precomp { uint32_t *d_pts; uint64_t n; };
+struct c25519_precomp { uint32_t *d_table; uint64_t n; c25519::msm_merged m; };
 
 namespace c25519 {
 
@@ -161,29 +162,31 @@ __global__ void __launch_bounds__(256) k_scalar_invert(uint8_t *__restrict__ io,
 }  // namespace c25519
 
 // ---- precomputed static MSM ------------------------------------------------------------------------------------
+// create: the per-window multiples 2^(c k) P_i of every static point, normalised, resident in HBM (msm_internal.h msm_merged)
 EXPORT c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *static_points, uint64_t n, int in_fmt) {
     if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    if (in_fmt < 0 || in_fmt > 2) { ctx->err = "precomp_create: bad in_fmt"; return nullptr; }
     size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
-    c25519_precomp *p = new c25519_precomp{nullptr, n};
-    if (hipMalloc(&p->d_pts, (n ? n : 1) * PTS_BYTES) != hipSuccess) { delete p; return nullptr; }
+    c25519_precomp *p = new c25519_precomp{nullptr, n, {}};
+    msm_merged_layout(n, p->m);
+    if (hipMalloc((void **)&p->d_table, (size_t)(n ? n : 1) * p->m.K * PTS_BYTES) != hipSuccess) { ctx->err = "precomp_create: hipMalloc failed"; delete p; return nullptr; }
     if (n == 0) return p;
-    if (ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) { hipFree(p->d_pts); delete p; return nullptr; }
     uint32_t *bad = (uint32_t *)ctx->d_flag;
-    uint32_t hb = 0;
-    if (hipMemsetAsync(bad, 0, 16, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(ctx->tmp_b.p, static_points, n * psz, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
-        prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, p->d_pts, 0, bad) != C25519_OK ||
-        hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess || hb != 0) {
-        ctx->err = "precomp_create: a static point does not decode, or a HIP call failed";
-        hipFree(p->d_pts); delete p; return nullptr;
-    }
+    uint32_t hb[2] = {0, 0};
+    bool ok = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16) == 0 && hipMemsetAsync(bad, 0, 16, ctx->stream) == hipSuccess &&
+              hipMemcpyAsync(ctx->tmp_b.p, static_points, n * psz, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+              msm_merged_build(ctx, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, p->m, p->d_table, bad) == C25519_OK &&
+              hipMemcpyAsync(hb, bad, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (ok && hb[0] != 0) { ctx->err = "precomp_create: a static point does not decode"; ok = false; }
+    else if (!ok && ctx->err.empty()) ctx->err = "precomp_create: a HIP call failed";
+    if (!ok) { hipFree(p->d_table); delete p; return nullptr; }
     return p;
 }
 EXPORT void c25519_precomp_destroy(c25519_ctx *ctx, c25519_precomp *p) {
     if (!p) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    hipFree(p->d_pts);
+    hipFree(p->d_table);
     delete p;
 }
 EXPORT uint64_t c25519_precomp_len(const c25519_precomp *p) { return p ? p->n : 0; }
@@ -192,30 +195,32 @@ EXPORT int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp 
     HIPCHK(hipSetDevice(ctx->device));
     if (out_fmt < 0 || out_fmt > 2) { ctx->err = "precomp_msm: bad out_fmt"; return -(int32_t)hipErrorInvalidValue; }
     if (n_static_scalars > p->n) { ctx->err = "precomp_msm: more static scalars than static points (precomputed_straus.rs:86)"; return -(int32_t)hipErrorInvalidValue; }
-    const uint64_t ns = n_static_scalars, m = ns + n_dyn;
+    const uint64_t ns = n_static_scalars;
     ge_p3 R = ge_identity();
-    if (m == 0) { host_encode(R, out_fmt, out); return C25519_OK; }
     size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
-    if ((r = ctx_reserve(ctx, ctx->tmp_a, m * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n_dyn * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
-    uint8_t *d_sc = (uint8_t *)ctx->tmp_a.p;
-    uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p, *bad = (uint32_t *)ctx->d_flag;
     hipStream_t st = ctx->stream;
-    HIPCHK(hipMemsetAsync(bad, 0, 16, st));
-    if (ns) {
-        HIPCHK(hipMemcpyAsync(d_sc, static_scalars, ns * 32, hipMemcpyHostToDevice, st));
-        HIPCHK(hipMemcpyAsync(d_pts, p->d_pts, ns * PTS_BYTES, hipMemcpyDeviceToDevice, st));
+    HIPCHK(hipEventRecord(ctx->ev0, st));
+    if (ns) {          // static part: every digit of every scalar is a term of ONE bucket problem over the resident table
+        if ((r = ctx_reserve(ctx, ctx->tmp_a, ns * 32 + 16))) return r;
+        HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, static_scalars, ns * 32, hipMemcpyHostToDevice, st));
+        if ((r = msm_merged_core(ctx, (const uint8_t *)ctx->tmp_a.p, ns, p->m, p->d_table, R))) return r;
     }
-    if (n_dyn) {
-        HIPCHK(hipMemcpyAsync(d_sc + ns * 32, dyn_scalars, n_dyn * 32, hipMemcpyHostToDevice, st));
+    if (n_dyn) {       // dynamic part: the ordinary pipeline (prepare, sort, accumulate, reduce, fold)
+        if ((r = ctx_reserve(ctx, ctx->tmp_a, n_dyn * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n_dyn * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_e, n_dyn * PTS_BYTES + 256))) return r;
+        uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p, *bad = (uint32_t *)ctx->d_flag;
+        HIPCHK(hipMemsetAsync(bad, 0, 16, st));
+        HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, dyn_scalars, n_dyn * 32, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, dyn_points, n_dyn * psz, hipMemcpyHostToDevice, st));
-        if ((r = prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n_dyn, in_fmt, d_pts, ns, bad))) return r;
+        if ((r = prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n_dyn, in_fmt, d_pts, 0, bad))) return r;
+        uint32_t hb = 0;
+        HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
+        ge_p3 Rd;
+        if ((r = msm_core(ctx, (const uint8_t *)ctx->tmp_a.p, n_dyn, d_pts, Rd))) return r;      // synchronises: hb is final
+        if (hb) return C25519_NONE;
+        R = ns ? ge_add(R, Rd) : Rd;
     }
-    uint32_t hb = 0;
-    HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (hb) return C25519_NONE;
-    if ((r = msm_core(ctx, d_sc, m, d_pts, R))) return r;
+    HIPCHK(hipEventRecord(ctx->ev1, st));
     host_encode(R, out_fmt, out);
     return C25519_OK;
 }

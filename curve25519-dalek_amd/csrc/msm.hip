@@ -126,11 +126,49 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
         D[(u64)k * n + t] = (uint16_t)v;
     }
 }
+// merged layout (precomputed static points): D[k * ns + t] = d + 2^(c-1), d = signed digit k of scalar t in [-2^(c-1), 2^(c-1))
+// (windows 0 .. K-2 signed through s' = s + sum_k 2^(c k + c - 1), window K-1 unsigned); t >= n: digit 0
+__global__ void __launch_bounds__(256) k_digits_merged(const uint8_t *__restrict__ scalars, u64 n, u64 ns, int c, int K, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= ns) return;
+    const u32 HALF = 1u << (c - 1);
+    if (t >= n) { for (int k = 0; k < K; k++) D[(u64)k * ns + t] = (uint16_t)HALF; return; }
+    u32 s[9];
+    load8(scalars, t, s);
+    s[8] = 0;
+    u32 carry = 0;
+    for (int k = 0; k < K; k++) {
+        const int bit = c * k, wi = bit >> 5, sh = bit & 31;
+        u32 v = 0;
+        if (wi < 8) {
+            u64 two = (u64)s[wi] | ((u64)s[wi + 1] << 32);
+            v = (u32)(two >> sh) & ((1u << c) - 1u);
+        }
+        v += carry;
+        const bool neg = (k != K - 1) && v >= HALF;              // d = v - 2^c in [-2^(c-1), 0), carry 1; else d = v in [0, 2^(c-1))
+        carry = neg ? 1u : 0u;
+        // stored value: d + HALF
+        const u32 st = neg ? (v + HALF - (1u << c)) : (v + HALF);
+        D[(u64)k * ns + t] = (uint16_t)st;
+        if (k == K - 1 && v > HALF) atomicOr(bad_scalar, 1u);    // cannot happen for scalars below 2^256 (layout: c (K-1) + c - 1 >= 256)
+    }
+}
+// table of the merged layout: lane i writes 2^(c k) P_i for k = 0 .. K-1 as raw 160-byte points [k][i] (normalised afterwards)
+__global__ void __launch_bounds__(256) k_merged_table(const uint8_t *__restrict__ in_raw, u64 ns, int c, int K, uint8_t *__restrict__ out_raw) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    ge_p3 P = raw160_load(in_raw, i);
+#pragma unroll 1
+    for (int k = 0; k < K; k++) {
+        raw160_store(out_raw, (u64)k * ns + i, P);
+        if (k + 1 < K) P = ge_mul_by_pow_2(P, c);
+    }
+}
 // signed digit of window k from the stored value
 // (a top digit above `half` can only come from a scalar with bit 255 set: k_digits has flagged it and the call fails;
 // it is dropped here so that no kernel indexes past its tables)
 __device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) {
-    return (k >= g.nwin - 2) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - (1 << (g.wid[k] - 1));     // the top two windows are unsigned
+    return (k >= g.first_unsigned) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - (1 << (g.wid[k] - 1));     // msm_layout: the top two windows are unsigned
 }
 
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
@@ -911,6 +949,7 @@ void msm_layout(uint64_t n, msm_geom &g) {
     g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 1);          // bit == 253 - (c-1)
     g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
     g.nwin = nsig + 2;
+    g.first_unsigned = nsig;
     for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
     for (int i = 0; i < 8; i++) g.addk[i] = a[i];
 }
@@ -948,7 +987,10 @@ struct msm_plan {
     uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs; long_item *items;
     hipStream_t sort_stream;
 };
-int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl) {
+// md (may be null): merged layout -- d_scalars holds n_scalars scalars, the sort runs over md->K * md->ns digit-terms
+int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
+                         const msm_merged *md = nullptr) {
+    const uint64_t n = md ? (uint64_t)md->K * md->ns : n_scalars;
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
     if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
@@ -991,7 +1033,8 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, 
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
-    hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
+    if (md) hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md->ns, 256)), dim3(256), 0, st, d_scalars, n_scalars, md->ns, md->c, md->K, D, slot_flags(d_slot));
+    else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
     if (use_part) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
         const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS + PART_CAP) * 4;
@@ -1094,6 +1137,49 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
     if ((r = slots_collect(ctx, 1))) return r;
     if (slot_flags((uint32_t *)hslot(ctx, 0))[0]) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
     R = msm_horner(hslot(ctx, 0), g);
+    return C25519_OK;
+}
+
+// ---- precomputed static points (VartimePrecomputedStraus, precomputed_straus.rs:57-127) --------------------------------
+// The reference keeps, per static point, a table of odd multiples for width-8 NAF and still shares ONE doubling chain
+// across all points.  The bucket method's analogue of "precompute so that the doublings disappear": keep 2^(c k) P_i for
+// every window k (msm_merged).  Then every digit of every scalar is a term of ONE bucket problem -- a single
+// accumulation over K * ns gather lists, a single bucket reduction, no Horner fold, no per-call point preparation.
+void msm_merged_layout(uint64_t ns, msm_merged &m) {
+    // window width from the number of digit-terms (as pick_window does for plain terms): c = clamp(log2(17 ns) - 4, 5, 16)
+    m.ns = ns;
+    m.c = pick_window(std::max<uint64_t>(1, ns) * 17);
+    m.K = (257 + m.c - 1) / m.c;                          // c (K - 1) + (c - 1) >= 256: the unsigned top window cannot overflow its buckets
+    while (m.c * (m.K - 1) + m.c - 1 < 256) m.K++;
+}
+int32_t msm_merged_build(c25519_ctx *ctx, const uint8_t *d_points, uint64_t ns, int in_fmt, const msm_merged &m, uint32_t *d_table, uint32_t *d_badcount) {
+    // points -> raw 160-byte (decompress if needed), multiples by repeated doubling, then the MSM's own normaliser
+    hipStream_t st = ctx->stream;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_c2, ns * 160 + ns + 64)) || (r = ctx_reserve(ctx, ctx->tmp_f, (size_t)m.K * ns * 160 + 64))) return r;
+    uint8_t *raw = (uint8_t *)ctx->tmp_c2.p, *ok = raw + ns * 160;
+    if (in_fmt == C25519_FMT_RAW160) HIPCHK(hipMemcpyAsync(raw, d_points, ns * 160, hipMemcpyDeviceToDevice, st));
+    else if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_decompress_edwards(d_points, ns, raw, ok, d_badcount, st));
+    else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_decompress_ristretto(d_points, ns, raw, ok, d_badcount, st));
+    else { ctx->err = "precomp: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
+    hipLaunchKernelGGL(k_merged_table, dim3(div_up64(ns, 256)), dim3(256), 0, st, raw, ns, m.c, m.K, (uint8_t *)ctx->tmp_f.p);
+    HIPCHK(hipGetLastError());
+    return prep_points(ctx, (const uint8_t *)ctx->tmp_f.p, (uint64_t)m.K * ns, C25519_FMT_RAW160, d_table, 0, d_badcount + 1);
+}
+int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const msm_merged &m, const uint32_t *d_table, ge_p3 &R) {
+    msm_geom g;
+    memset(&g, 0, sizeof g);
+    g.c = m.c; g.nwin = 1; g.half = 1 << (m.c - 1); g.first_unsigned = 1;
+    g.pos[0] = 0; g.wid[0] = (unsigned char)m.c;
+    for (int k = 1; k < MSM_MAX_WIN; k++) g.wid[k] = 1;
+    HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
+    msm_plan pl;
+    int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, dslot(ctx, 0), nullptr, pl, &m);
+    if (r) return r;
+    if ((r = msm_enqueue_acc(ctx, pl, d_table, dslot(ctx, 0), nullptr, nullptr))) return r;
+    if ((r = slots_collect(ctx, 1))) return r;
+    if (slot_flags((uint32_t *)hslot(ctx, 0))[0]) { ctx->err = "precomp_msm: internal error (top digit out of range)"; return -(int32_t)hipErrorInvalidValue; }
+    R = host_p40(hslot(ctx, 0));                          // one window at position 0: the column sum IS the result
     return C25519_OK;
 }
 

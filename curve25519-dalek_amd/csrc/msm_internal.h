@@ -9,7 +9,12 @@ namespace c25519 {
 // Window layout of the bucket method.  Scalars are reduced mod l (< 2^253, scalar.rs:193-205) in every MSM the reference
 // performs, so the 253 bits are shared out EVENLY (msm_layout); see msm.hip "digits".
 constexpr int MSM_MAX_WIN = 56;
-struct msm_geom { int c, nwin, half; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+// first_unsigned: windows k >= first_unsigned hold unsigned digits (msm_layout: the top two), the others signed ones
+struct msm_geom { int c, nwin, half, first_unsigned; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+// Precomputed-static MSM: ONE bucket set for all windows.  The table holds T[k][i] = 2^(c k) P_i for every window k, so
+// digit k of scalar i is a term of its own, (k, i) -> point k * ns + i, and all K * ns terms fall into the same 2^(c-1)
+// buckets: one accumulation, one bucket reduction, no Horner fold.
+struct msm_merged { int c, K; uint64_t ns; };
 constexpr u32 LONG_CAP = 192;      // buckets with more entries go to the wave-cooperative path: > mean + 8 sigma of a balanced bucket (mean <= 96)
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 }
@@ -19,6 +24,11 @@ void launch_accumulate_c1(int pipe, const uint32_t *pts, const uint32_t *sorted,
 void msm_layout(uint64_t n, c25519::msm_geom &g);
 // sum_i scalars[i] * pts[i] over packed affine Niels points already on the device (enqueue, one read-back, host fold)
 int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, c25519::ge_p3 &R);
+// window width / count of the merged layout for ns static points; sum_i s_i P_i over the table (first n scalars), result to R
+void msm_merged_layout(uint64_t ns, c25519::msm_merged &m);
+int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const c25519::msm_merged &m, const uint32_t *d_table, c25519::ge_p3 &R);
+// the table itself: d_table[(k * ns + i)] = affine Niels record of 2^(c k) * P_i, from packed affine Niels / raw points
+int32_t msm_merged_build(c25519_ctx *ctx, const uint8_t *d_points, uint64_t ns, int in_fmt, const c25519::msm_merged &m, uint32_t *d_table, uint32_t *d_badcount);
 // any point format -> packed affine Niels at d_pts[dst0 ..]; *d_badcount counts encodings that do not decode
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount);
 void host_encode(const c25519::ge_p3 &R, int out_fmt, uint8_t *out);

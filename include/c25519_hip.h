@@ -227,9 +227,13 @@ int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t 
 /* ---- precomputed static points: VartimePrecomputedMultiscalarMul (traits.rs:304-419) ---------------------
  * replaces backend::VartimePrecomputedStraus::{new, len, optional_mixed_multiscalar_mul}
  * (backend.rs:100-192 -> scalar_mul/precomputed_straus.rs:29-127; edwards.rs:1037-1076).
- * create: static points (HOST pointer; fmt 0/1/2) are normalised once and stay resident in HBM; returns
- * NULL if a point does not decode.  msm: sum static_scalars[i]*S_i (the first n_static_scalars static points;
- * more scalars than points is an error, precomputed_straus.rs:86) + sum dyn_scalars[j]*dyn_points[j].
+ * create: for static points S_i (HOST pointer; fmt 0/1/2) the multiples 2^(c k) S_i of every window k are computed
+ * once and stay resident in HBM as affine Niels records (17 x 128 bytes per point at c = 16): the bucket-method
+ * counterpart of the reference's per-point NAF tables.  A call then needs no point preparation, no per-window passes and
+ * no doubling chain -- one bucket accumulation and one bucket reduction over all digits of all scalars.  Returns NULL
+ * if a point does not decode.  msm: sum static_scalars[i]*S_i (the first n_static_scalars static points;
+ * more scalars than points is an error, precomputed_straus.rs:86) + sum dyn_scalars[j]*dyn_points[j] (the dynamic terms
+ * run through the ordinary MSM and are added).
  * All pointers of the msm call are HOST pointers; returns C25519_NONE iff a dynamic point does not decode. */
 typedef struct c25519_precomp c25519_precomp;
 c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *static_points, uint64_t n, int in_fmt);

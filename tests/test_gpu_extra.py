@@ -62,6 +62,33 @@ def test_precomputed_vs_nonprecomputed(eng, orc):
     eng.precomp_destroy(h)
 
 
+@pytest.mark.parametrize("ns", [1, 2, 17, 1000, 4096, 70000])
+def test_precomputed_tables_all_window_layouts(eng, orc, ns):
+    """precomputed_straus.rs:57-127 through the merged-window tables (2^(c k) P_i for every window k): the table layout
+    changes with the number of static points (c = 6 .. 16), every layout must give the oracle's result -- edge scalars
+    (0, 1, l - 1, unreduced up to 2^255 - 1: every digit pattern incl. the carry into the top window) and random ones,
+    Edwards and Ristretto encodings of the static points."""
+    e = util.edge_scalars()
+    ss = np.concatenate([e, util.rand_scalars(700 + ns, max(0, ns - e.shape[0]))])[:ns]
+    sp = eng.mul_base_batch(util.rand_scalars(701 + ns, ns), out_fmt=2)
+    total = orc.ed_msm(rows(ss), rows(sp))
+    e32, e160 = np.zeros((0, 32), np.uint8), np.zeros((0, 160), np.uint8)
+    for fmt, enc in ((2, sp), (0, eng.compress_batch(sp)), (1, eng.compress_batch(sp, out_fmt=1))):
+        h = eng.precomp_create(enc, in_fmt=fmt)
+        # a CompressedRistretto decodes to SOME representative of the coset: compare as Ristretto points (ristretto.rs:822-829)
+        out_fmt, want = (1, orc.ris_compress(total)) if fmt == 1 else (0, orc.ed_compress(total))
+        st, got = eng.precomp_msm_vartime(h, ss, e32, e160 if fmt == 2 else e32, in_fmt=fmt, out_fmt=out_fmt)
+        assert st == 0 and got == want, (ns, fmt)
+        if fmt == 2 and ns >= 17:
+            st, got = eng.precomp_msm_vartime(h, ss[:ns // 2], e32, e160, in_fmt=2)          # a prefix of the static points
+            assert st == 0 and got == orc.ed_compress(orc.ed_msm(rows(ss[:ns // 2]), rows(sp[:ns // 2])))
+        eng.precomp_destroy(h)
+    import curve25519_dalek_amd as pkg
+    bad = eng.compress_batch(sp); bad[ns // 2] = np.frombuffer(i2b(2), np.uint8)
+    with pytest.raises(pkg.EngineError):
+        eng.precomp_create(bad, in_fmt=0)                                                        # a static point that does not decode
+
+
 @pytest.mark.parametrize("n", [0, 1, 5, 64, 65, 300, 5000])
 def test_msm_consttime_vs_vartime(eng, orc, n):
     """edwards.rs:2276-2335: constant-time and variable-time multiscalar agree (and equal (sum x^2) B)"""
