@@ -12,6 +12,7 @@
 //   c25519_scalar_invert_batch         Scalar::invert_batch_alloc (scalar.rs:802-856)
 #include <hip/hip_runtime.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 #include "../../include/c25519_hip.h"
 #include "devio.h"
@@ -322,4 +323,64 @@ EXPORT int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t
     }
     if (prod_inv) { u32 w[8]; sc_to_words(prod, w); memcpy(prod_inv, w, 32); }
     return C25519_OK;
+}
+
+// ---- one process, several GPUs -------------------------------------------------------------------------------------------
+// The multi-GPU decomposition of SURVEY.md 8e for a host that drives all GPUs of a node from ONE process (a Rust
+// caller without torch / RCCL): the terms (signatures) are cut into contiguous shards, one per context -- contexts on
+// different devices, or several on one device -- every shard runs the full single-GPU path on its own context from its own
+// host thread, and the partial sums (verdicts) are folded on the host: the exchange step is nctx x 160 bytes (4 bytes)
+// over PCIe instead of an all_gather over xGMI.  Results are identical to the single-context calls by construction.
+EXPORT int32_t c25519_msm_vartime_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out) {
+    if (nctx < 1 || !ctxs || !ctxs[0]) return -(int32_t)hipErrorInvalidValue;
+    c25519_ctx *ctx = ctxs[0];
+    if (out_fmt < 0 || out_fmt > 2 || in_fmt < 0 || in_fmt > 2) { ctx->err = "msm_multi: bad format"; return -(int32_t)hipErrorInvalidValue; }
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    std::vector<std::vector<uint8_t>> part(nctx, std::vector<uint8_t>(160));
+    std::vector<int32_t> st(nctx, C25519_OK);
+    auto run = [&](int r) {
+        const uint64_t base = n / nctx, rem = n % nctx, lo = r * base + std::min<uint64_t>(r, rem), cnt = base + ((uint64_t)r < rem ? 1 : 0);
+        st[r] = c25519_msm_vartime(ctxs[r], scalars + lo * 32, points + lo * psz, cnt, in_fmt, C25519_FMT_RAW160, part[r].data());
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < nctx; r++) th.emplace_back(run, r);
+    run(0);
+    for (auto &t : th) t.join();
+    bool none = false;
+    for (int r = 0; r < nctx; r++) {
+        if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+        if (st[r] == C25519_NONE) none = true;
+    }
+    if (none) return C25519_NONE;
+    std::vector<uint8_t> all((size_t)nctx * 160);
+    for (int r = 0; r < nctx; r++) memcpy(&all[(size_t)r * 160], part[r].data(), 160);
+    return c25519_fold_partials(ctx, all.data(), (uint64_t)nctx, out_fmt, out);
+}
+EXPORT int32_t ed25519_verify_batch_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                          uint64_t n, uint32_t z_mode) {
+    if (nctx < 1 || !ctxs || !ctxs[0]) return -(int32_t)hipErrorInvalidValue;
+    c25519_ctx *ctx = ctxs[0];
+    if (n == 0) return C25519_OK;
+    for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) { ctx->err = "verify_batch_multi: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
+    std::vector<int32_t> st(nctx, C25519_OK);
+    auto run = [&](int r) {
+        const uint64_t base = n / nctx, rem = n % nctx, lo = r * base + std::min<uint64_t>(r, rem), cnt = base + ((uint64_t)r < rem ? 1 : 0);
+        if (cnt == 0) return;
+        // this shard's offsets, rebased to its first message
+        std::vector<uint64_t> off(cnt + 1);
+        for (uint64_t i = 0; i <= cnt; i++) off[i] = msg_off[lo + i] - msg_off[lo];
+        st[r] = ed25519_verify_batch(ctxs[r], msgs + msg_off[lo], off.data(), sigs + lo * 64, pks + lo * 32, cnt, z_mode);
+    };
+    std::vector<std::thread> th;
+    for (int r = 1; r < nctx; r++) th.emplace_back(run, r);
+    run(0);
+    for (auto &t : th) t.join();
+    // every shard is its own random linear combination; the batch verdict is the worst shard verdict in the reference's
+    // precedence (key decoding, then ScalarFormat, batch.rs:208-211, then Verify, :244-250)
+    bool seen[5] = {false, false, false, false, false};
+    for (int r = 0; r < nctx; r++) {
+        if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+        seen[st[r]] = true;
+    }
+    return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
 }

@@ -69,6 +69,8 @@ def load_library():
         "c25519_msm_vartime": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
         "c25519_msm_partial_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
         "c25519_fold_partials": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_msm_vartime_multi": (i32, [vp, i32, vp, vp, u64, C.c_int, C.c_int, vp]),
+        "ed25519_verify_batch_multi": (i32, [vp, i32, vp, vp, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch_keys_dev": (i32, [vp, vp, vp, u64, vp, vp, vp, u64, C.c_uint32]),
@@ -106,7 +108,7 @@ ABI_SYMBOLS = [
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
-    "c25519_fold_partials", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
+    "c25519_fold_partials", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
@@ -527,3 +529,28 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.c25519_scalar_invert_batch(self.ctx, s.ctypes.data, n, prod))
         return s, prod.raw
+
+
+def msm_vartime_multi(engines, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+    """c25519_msm_vartime_multi: one process, several contexts (GPUs); -> (status, bytes)"""
+    s = _np8(scalars, 32); p = _np8(points, _PT[in_fmt]); n = s.shape[0]
+    assert p.shape[0] == n and len(engines) >= 1
+    arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+    out = C.create_string_buffer(_PT[out_fmt])
+    st = engines[0]._chk(engines[0].lib.c25519_msm_vartime_multi(arr, len(engines), s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out), (OK, NONE))
+    return st, out.raw
+
+
+def verify_batch_multi(engines, msgs, sigs, pks, z_mode=Z_TRANSCRIPT):
+    """ed25519_verify_batch_multi: one process, several contexts (GPUs); -> status"""
+    if not (len(msgs) == len(sigs) == len(pks)):
+        return ARRAY_LENGTH
+    n = len(msgs)
+    if n == 0:
+        return OK
+    Engine._check_items(sigs, 64, "signature"); Engine._check_items(pks, 32, "public key")
+    blob, off = Engine._pack(list(msgs))
+    s = _np8(b"".join(sigs), 64); p = _np8(b"".join(pks), 32)
+    arr = (C.c_void_p * len(engines))(*[e.ctx for e in engines])
+    return engines[0]._chk(engines[0].lib.ed25519_verify_batch_multi(arr, len(engines), blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, z_mode),
+                           (OK, NONE, SCALAR_FORMAT, VERIFY))

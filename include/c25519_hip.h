@@ -159,6 +159,14 @@ int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_
 int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160);
 int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64_t count, int out_fmt, uint8_t *out);
 
+/* One process driving several GPUs (SURVEY.md 8e for a host without torch / RCCL, e.g. the Rust shim): the terms are cut
+ * into nctx contiguous shards, shard r runs the whole single-GPU path on ctxs[r] (contexts on different devices, or
+ * several on one) from its own host thread, and the nctx partial sums are folded on the host -- the one exchange step of
+ * the path, 160 bytes per context.  HOST pointers; the result is identical to c25519_msm_vartime on one context.
+ * (With one process PER GPU the same decomposition is c25519_msm_partial_dev + an all_gather of the partials over
+ * RCCL + c25519_fold_partials: curve25519-dalek_amd/multi.py.) */
+int32_t c25519_msm_vartime_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out);
+
 /* ---- ed25519_dalek::verify_batch (ed25519-dalek/src/batch.rs:146-251) ---------------------------
  * msgs: concatenated messages; msg_off: n+1 offsets into msgs (u64); sigs: n x 64; pks: n x 32.
  * Error precedence as in the reference: a public key that does not decompress -> C25519_NONE (the
@@ -171,6 +179,10 @@ int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const u
                                  const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                              const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint32_t z_mode);
+/* verify_batch over several contexts / GPUs from one process: contiguous shards of the signatures, each its own random
+ * linear combination on ctxs[r]; the verdict is the worst shard verdict in the reference's precedence. */
+int32_t ed25519_verify_batch_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                   uint64_t n, uint32_t z_mode);
 /* The same check for callers that hold VerifyingKey values: the reference's VerifyingKey keeps the decompressed
  * point beside the 32 key bytes (verifying.rs:64-71, built once by from_bytes :167-175), so its verify_batch
  * never decompresses A_i (batch.rs:236 uses pk.point directly).  pk_points: n x 160 raw

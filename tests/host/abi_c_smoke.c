@@ -1,6 +1,8 @@
 /* The C ABI from plain C (C11, gcc): proves include/c25519_hip.h is a C header and that the library can be driven
  * without Python or C++.  RFC 7748 section 6.1 (Alice/Bob) through c25519_x25519_batch, 8 * B through
- * c25519_mul_base_batch against the reference's BASE8 constant source (edwards.rs test module), and a 3-term MSM.
+ * c25519_mul_base_batch against the reference's BASE8 constant source (edwards.rs test module), a 3-term MSM,
+ * ed25519_verify_batch on RFC 8032 7.1 TEST 1 / TEST 2 (both z-modes, the three verdicts, bad offsets) and the
+ * one-process multi-context entry points.
  * Exit code 0 = all good.  Built and run by tests/test_gpu_abi_c.py. */
 #include <stdint.h>
 #include <stdio.h>
@@ -37,6 +39,33 @@ int main(void) {
     /* an encoding that is not on the curve -> NONE, like Option::None of optional_multiscalar_mul */
     memset(pts[1], 0, 32); pts[1][0] = 2;
     if (c25519_msm_vartime(ctx, &sc[0][0], &pts[0][0], 2, C25519_FMT_EDWARDS_Y, C25519_FMT_EDWARDS_Y, sum) != C25519_NONE) return 9;
+    /* ed25519_dalek::verify_batch: RFC 8032 7.1 TEST 1 (empty message) and TEST 2 (one byte) as one batch, both z-modes */
+    uint8_t vpk[2][32], vsig[2][64], vmsg[1] = {0x72};
+    uint64_t voff[3] = {0, 0, 1};
+    hex2bin("d75a980182b10ab7d54bfed3c964073a0ee172f3daa62325af021a68f707511a", vpk[0], 32);
+    hex2bin("3d4017c3e843895a92b70aa74d1b7ebc9c982ccf2ec4968cc0cd55f12af4660c", vpk[1], 32);
+    hex2bin("e5564300c360ac729086e2cc806e828a84877f1eb8e5d974d873e065224901555fb8821590a33bacc61e39701cf9b46bd25bf5f0595bbe24655141438e7a100b", vsig[0], 64);
+    hex2bin("92a009a9f0d4cab8720e820b5f642540a2b27b5416503f8fb3762223ebdb69da085ac1e43e15996e458f3613d0f11d8c387b2eaeb4302aeeb00d291612bb0c00", vsig[1], 64);
+    for (uint32_t z = 0; z < 2; z++) {
+        if (ed25519_verify_batch(ctx, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, z) != C25519_OK) { fprintf(stderr, "verify_batch (z_mode %u): %s\n", z, c25519_last_error(ctx)); return 10; }
+        vsig[1][7] ^= 1;                                                   /* a forged R */
+        if (ed25519_verify_batch(ctx, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, z) != C25519_VERIFY) return 11;
+        vsig[1][7] ^= 1;
+        vsig[0][63] |= 0x20;                                               /* s >= 2^253: non-canonical */
+        if (ed25519_verify_batch(ctx, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, z) != C25519_SCALAR_FORMAT) return 12;
+        vsig[0][63] &= (uint8_t)~0x20;
+    }
+    voff[1] = 5;                                                           /* offsets that are not monotone: refused, nothing read out of bounds */
+    if (ed25519_verify_batch(ctx, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, 1) >= 0) return 13;
+    /* the same batch over two contexts driven from this one process (c25519_msm_vartime_multi's sibling) */
+    voff[1] = 0;
+    c25519_ctx *ctx2 = c25519_ctx_create(0, 0);
+    if (!ctx2) return 14;
+    c25519_ctx *both[2] = {ctx, ctx2};
+    if (ed25519_verify_batch_multi(both, 2, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, 0) != C25519_OK) return 15;
+    memcpy(pts[1], bp, 32);
+    if (c25519_msm_vartime_multi(both, 2, &sc[0][0], &pts[0][0], 2, C25519_FMT_EDWARDS_Y, C25519_FMT_EDWARDS_Y, sum) != C25519_OK || memcmp(sum, enc[1], 32)) return 16;
+    c25519_ctx_destroy(ctx2);
     c25519_ctx_destroy(ctx);
     printf("abi_c_smoke ok\n");
     return 0;

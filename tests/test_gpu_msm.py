@@ -231,3 +231,35 @@ def test_msm_window_and_path_boundaries(eng, orc, n):
     draw = eng.mul_base_batch_t(dx, out_fmt=2)
     st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+
+
+def test_msm_and_verify_over_several_contexts_in_one_process(eng, orc):
+    """c25519_msm_vartime_multi / ed25519_verify_batch_multi (the C-ABI multi-GPU path for a host without torch / RCCL):
+    contexts on one device here; the results must equal the single-context calls for every shard count."""
+    import curve25519_dalek_amd as pkg
+    E = pkg.engine
+    engs = [eng, pkg.Engine(0), pkg.Engine(0)]
+    n = 70001
+    x = util.rand_scalars(4100, n)
+    pts = eng.mul_base_batch(x, out_fmt=2)
+    want = orc.ed_compress(orc.ed_mul_base(i2b(sumsq(x))))
+    for k in (1, 2, 3):
+        st, got = E.msm_vartime_multi(engs[:k], x, pts, E.FMT_RAW160, E.FMT_EDWARDS_Y)
+        assert st == 0 and got == want
+    st, got = E.msm_vartime_multi(engs, x[:2], pts[:2], E.FMT_RAW160, E.FMT_EDWARDS_Y)          # fewer terms than contexts
+    assert st == 0 and got == orc.ed_compress(orc.ed_msm(rows(x[:2]), rows(pts[:2])))
+    enc = eng.compress_batch(pts[:1000]); enc[777] = np.frombuffer(i2b(2), np.uint8)
+    st, _ = E.msm_vartime_multi(engs, x[:1000], enc, E.FMT_EDWARDS_Y, E.FMT_EDWARDS_Y)
+    assert st == E.NONE
+    m = 5000
+    seeds = util.rand_bytes(4200, m); msgs = util.rand_bytes(4201, m, 23)
+    pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=8)
+    M = [msgs[i].tobytes() for i in range(m)]; S = [sigs[i].tobytes() for i in range(m)]; P = [pks[i].tobytes() for i in range(m)]
+    for z in (0, 1):
+        assert E.verify_batch_multi(engs, M, S, P, z) == E.OK
+        bad = list(S); b = bytearray(bad[m - 3]); b[1] ^= 8; bad[m - 3] = bytes(b)
+        assert E.verify_batch_multi(engs, M, bad, P, z) == E.VERIFY
+        b = bytearray(bad[2]); b[63] |= 0x20; bad[2] = bytes(b)
+        assert E.verify_batch_multi(engs, M, bad, P, z) == E.SCALAR_FORMAT
+    for e in engs[1:]:
+        e.close()
