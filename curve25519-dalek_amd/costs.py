@@ -77,10 +77,12 @@ def x25519():
 
 
 def _reduce_per_bucket():
-    """msm.hip:k_reduce_a / k_reduce_b: per lane of level A 13 serial complete additions over 8 buckets, then 13 more
-    and 3 doublings in the wave-wide combine; level B is negligible (one wave per window)."""
-    adds, dbls = 26.0 / 8, 3.0 / 8
-    return {"M": adds * 9 + dbls * 4, "S": dbls * 4}
+    """Bucket reduction sum_b (b+1) B_b, priced at its ALGORITHMIC minimum -- the running-sum method of
+    pippenger.rs:146-151, two complete additions (9 M each) per bucket.  msm.hip:k_reduce_a / k_reduce_b issue more
+    (per 8 buckets: 13 serial additions, then 13 additions + 3 doublings of the wave-wide combine, i.e. 3.25 additions
+    + 0.375 doublings per bucket) to cut the dependent chain from 2 x 32768 additions to 40; the surplus is overhead,
+    not achieved work."""
+    return {"M": 2 * 9, "S": 0}
 
 
 def msm(n, nwin, half, raw_points=True, filled_windows=None):
