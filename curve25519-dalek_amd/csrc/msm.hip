@@ -58,7 +58,9 @@ namespace c25519 {
 // 2^21 points (Z, then X, Y, Z again, 48-byte prefix products out and back, 128-byte records out): 0.30 ms against a
 // memory floor of ~0.27 ms.  Tried in round 2 and dropped: one inversion per BLOCK through an LDS tree (-45 % field
 // operations, but one wave inverts while three wait: 0.35 ms; 0.40 ms when LLVM moved the wave-uniform inversion to the
-// scalar unit), CH = 32 / 8, and fetching every record one step ahead (+12 VGPRs, 0.34 ms).
+// scalar unit), CH = 32 / 8, fetching every record one step ahead (+12 VGPRs, 0.34 ms), and three launches (lane products,
+// ONE batched inversion over the lane totals, unwind: -68 % field operations, 0.083 + 0.107 + 0.192 ms -- the two
+// memory passes run at 3.6 - 5.2 TB/s and then contend with the sort on the second stream: no gain end to end).
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
