@@ -18,7 +18,7 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
     const u64 gid = perm[tid];
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
     u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
-    if (hi - lo > LONG_CAP) return;
+    if (hi - lo > g.long_cap) return;
     const u32 *list = sorted + (u64)k * n;
     ge_p3 acc = ge_identity();
     if (PIPE == 0) {

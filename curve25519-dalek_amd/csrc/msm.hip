@@ -249,20 +249,22 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
 // block that counting-sorts it by the low 8 bucket bits and writes the final list, the bucket totals and the bucket
 // offsets, all coalesced.  Intermediate entry: bucket_low8 << 24 | sign << 23 | term index (n <= 2^23).
 // ================================================================================================
-constexpr int PART_BPS = 256;            // buckets per slice
-constexpr int PART_CHUNK = 16384;        // terms per pass-1 block (64 KB of staging: two blocks per CU)
-constexpr int PART_CAP = 18432;          // bin capacity of the LDS path of pass 2 (mean 16384 at n = 2^21; larger bins take the global path)
+constexpr int PART_BPS_MAX = 256;        // buckets per slice: 2^g.bps_log2 <= this, chosen so that a bin holds ~16 K entries
+constexpr int PART_CAP = 18432;          // bin capacity of the LDS path of pass 2 (mean <= 16384; larger bins take the global path)
+// terms per pass-1 block: the staging buffer (4 bytes per term) plus 18 counters per slice must leave room for two blocks
+// per CU (2 x 80 KB of the 160 KB LDS)
+static inline int part_chunk(int SL) { return SL <= 128 ? 16384 : 15360; }
 
 __device__ __forceinline__ bool part_entry(u32 v, int k, const msm_geom &g, u32 t, u32 &slice, u32 &entry) {
     int d = digit_of(v, k, g);
     if (d == 0) return false;
     u32 b = (u32)((d > 0 ? d : -d) - 1);
-    slice = b / PART_BPS;
-    entry = ((b % PART_BPS) << 24) | (d < 0 ? (1u << 23) : 0u) | t;
+    slice = b >> g.bps_log2;
+    entry = ((b & ((1u << g.bps_log2) - 1u)) << 24) | (d < 0 ? (1u << 23) : 0u) | t;
     return true;
 }
 // cc[(k*SL + s)*nchunk + j] = number of non-zero digits of chunk j, window k, that fall into slice s
-__global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, u32 *__restrict__ cc) {
+__global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, int PART_CHUNK, u32 *__restrict__ cc) {
     extern __shared__ u32 sm[];                               // [4][SL]
     const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * SL; i += 256) sm[i] = 0;
@@ -315,7 +317,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL
     if (tid == 1023) { bin_base[(u64)k * (SL + 1) + SL] = part[1023]; base[(u64)k * (g.half + 1) + g.half] = part[1023]; }
 }
 // pass 1: chunk j of window k -> runs per slice in P1[k][..]
-__global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
+__global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, int PART_CHUNK, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
     extern __shared__ u32 sm[];
     u32 *cnt = sm;                         // [16][SL]: per-wave counts, then per-wave cursors
     u32 *ls = sm + 16 * SL;                // [SL + 1]: start of each slice in the staging buffer
@@ -357,7 +359,8 @@ constexpr int PART_R = PART_CAP / 1024;
 __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
                                                 u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted) {
     extern __shared__ u32 sm[];
-    u32 *cnt = sm, *cur = sm + PART_BPS, *out = sm + 2 * PART_BPS;
+    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *out = sm + 2 * PART_BPS_MAX;
+    const int PART_BPS = 1 << g.bps_log2;
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
     const u32 b0 = bin_base[(u64)k * (SL + 1) + sidx], m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0;
     const u32 *src = P1 + (u64)k * n + b0;
@@ -375,12 +378,14 @@ __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u
         for (u32 i = tid; i < m; i += 1024) atomicAdd(&cnt[src[i] >> 24], 1u);
     }
     __syncthreads();
-    if (tid < 64) {                                                    // exclusive scan of the 256 bucket counts by one wave
-        u32 c0 = cnt[4 * tid], c1 = cnt[4 * tid + 1], c2 = cnt[4 * tid + 2], c3 = cnt[4 * tid + 3];
-        u32 sum = c0 + c1 + c2 + c3, inc = sum;
+    if (tid < 64) {                                                    // exclusive scan of the bucket counts by one wave (4, 2 or 1 per lane)
+        const int per = PART_BPS >> 6;
+        u32 c4[4] = {0, 0, 0, 0}, sum = 0;
+        for (int q = 0; q < per; q++) { c4[q] = cnt[per * tid + q]; sum += c4[q]; }
+        u32 inc = sum;
         for (int off = 1; off < 64; off <<= 1) { u32 x = __shfl_up(inc, off, 64); if (tid >= off) inc += x; }
         u32 run = inc - sum;
-        cur[4 * tid] = run; cur[4 * tid + 1] = run + c0; cur[4 * tid + 2] = run + c0 + c1; cur[4 * tid + 3] = run + c0 + c1 + c2;
+        for (int q = 0; q < per; q++) { cur[per * tid + q] = run; run += c4[q]; }
     }
     __syncthreads();
     if (tid < PART_BPS) {
@@ -477,7 +482,7 @@ __global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ tota
     if (gid < nb) {
         const u32 c = totals[gid_off + gid];
         atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u);
-        if (c > LONG_CAP) {
+        if (c > g.long_cap) {
             const u64 G = gid + gid_off;
             const int k = (int)(G / g.half), b = (int)(G % g.half);
             const u32 lo = base[(u64)k * (g.half + 1) + b], hi = lo + c;
@@ -935,6 +940,15 @@ static int pick_window(uint64_t n) {
     return c;
 }
 
+// sort / long-bucket parameters that depend on the number of terms per window (n) and buckets per window (g.half)
+static void msm_sort_params(uint64_t n, msm_geom &g) {
+    // slices of 2^bps_log2 buckets such that a (window, slice) bin holds at most ~16 K entries (PART_CAP with 12 % headroom)
+    g.bps_log2 = 8;
+    while (g.bps_log2 > 6 && (n << g.bps_log2) / (uint64_t)g.half > 16500) g.bps_log2--;
+    if ((1 << g.bps_log2) > g.half) { g.bps_log2 = 0; while ((2 << g.bps_log2) <= g.half) g.bps_log2++; }
+    const uint64_t mean = n / (uint64_t)g.half + 1;
+    g.long_cap = (u32)std::max<uint64_t>(LONG_CAP_MIN, (mean * 5 + 1) / 2);
+}
 // window layout for n terms (see msm_geom): signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit
 // window, then bits 253..255
 void msm_layout(uint64_t n, msm_geom &g) {
@@ -952,6 +966,7 @@ void msm_layout(uint64_t n, msm_geom &g) {
     g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
     g.nwin = nsig + 2;
     g.first_unsigned = nsig;
+    msm_sort_params(n, g);
     for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
     for (int i = 0; i < 8; i++) g.addk[i] = a[i];
 }
@@ -1007,14 +1022,14 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(256 + 1024), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * n;
-    const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / LONG_CAP + 1);
+    const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
     const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
     size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     size_t oLS = carve((size_t)max_items * 160);
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
     static const int sort2 = env_int("C25519_SORT2", 1);
     const bool use_part = sort2 && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
-    const int SL = g.half / PART_BPS, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
+    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
     if (use_part) { oP1 = carve((size_t)g.nwin * n * 4); oCC = carve((size_t)g.nwin * SL * pchunks * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
@@ -1039,12 +1054,12 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
     if (use_part) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
-        const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS + PART_CAP) * 4;
+        const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS_MAX + PART_CAP) * 4;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, cc);
+        hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, PART_CHUNK, cc);
         hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(1024), 0, st, cc, SL, pchunks, g, bin_base, base);
-        hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, cc, P1);
+        hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, PART_CHUNK, cc, P1);
         hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted);
     } else {
         size_t lds = (size_t)g.half * 4;
@@ -1172,6 +1187,7 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     msm_geom g;
     memset(&g, 0, sizeof g);
     g.c = m.c; g.nwin = 1; g.half = 1 << (m.c - 1); g.first_unsigned = 1;
+    msm_sort_params((uint64_t)m.K * m.ns, g);
     g.pos[0] = 0; g.wid[0] = (unsigned char)m.c;
     for (int k = 1; k < MSM_MAX_WIN; k++) g.wid[k] = 1;
     HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
@@ -1209,7 +1225,7 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 // caller's context and a peer context (own streams and workspaces on the same GPU): the low-VALU two thirds of a pass
 // (normalise, sort, reduce) overlap the accumulation of its neighbour.  (Round 1 used a host thread per stream set and
 // a stream synchronisation + host fold per pass.)
-static const int MSM_PASS_LOG2 = [] { int v = env_int("C25519_MSM_PASS_LOG2", 21); return v < 16 ? 16 : (v > 21 ? 21 : v); }();   // A/B knob
+static const int MSM_PASS_LOG2 = [] { int v = env_int("C25519_MSM_PASS_LOG2", 21); return v < 16 ? 16 : (v > 22 ? 22 : v); }();   // A/B knob: 2^22-term passes measure 17.3 against 16.9 ms per 2^24 terms (the 537 MB point array of a pass is past the MALL: k_accumulate 2.76 ms per 2^22 terms against 2 x 1.22)
 static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
 static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
 
@@ -1445,7 +1461,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
 // pass keeps its own identity check.  All passes run even after a failure so that the reference's precedence -- key
 // decoding, then ScalarFormat for ANY non-canonical s (batch.rs:208-211), then Verify -- does not depend on where the
 // batch was cut.
-static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 20 ? 20 : v); }();   // A/B knob
+static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 21 ? 21 : v); }();   // A/B knob
 static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
 EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                              const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {

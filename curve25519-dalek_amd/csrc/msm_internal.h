@@ -10,12 +10,14 @@ namespace c25519 {
 // performs, so the 253 bits are shared out EVENLY (msm_layout); see msm.hip "digits".
 constexpr int MSM_MAX_WIN = 56;
 // first_unsigned: windows k >= first_unsigned hold unsigned digits (msm_layout: the top two), the others signed ones
-struct msm_geom { int c, nwin, half, first_unsigned; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+// bps_log2: log2 of the buckets per slice of the two-pass sort (a (window, slice) bin must fit the LDS of k_part2);
+// long_cap: bucket lists longer than this go to the wave-cooperative path (> mean + 8 sigma of a balanced bucket)
+struct msm_geom { int c, nwin, half, first_unsigned, bps_log2; u32 long_cap; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
 // Precomputed-static MSM: ONE bucket set for all windows.  The table holds T[k][i] = 2^(c k) P_i for every window k, so
 // digit k of scalar i is a term of its own, (k, i) -> point k * ns + i, and all K * ns terms fall into the same 2^(c-1)
 // buckets: one accumulation, one bucket reduction, no Horner fold.
 struct msm_merged { int c, K; uint64_t ns; };
-constexpr u32 LONG_CAP = 192;      // buckets with more entries go to the wave-cooperative path: > mean + 8 sigma of a balanced bucket (mean <= 96)
+constexpr u32 LONG_CAP_MIN = 192;  // msm_geom.long_cap = max(this, 2.5 x mean list length)
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 }
 // bucket accumulation (accum.hip), chained-carry (c1) and ten-column (c0) field arithmetic
