@@ -10,7 +10,12 @@
 namespace c25519 {
 namespace ACCUM_NS {
 
-template <int PIPE>   // 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched
+// Registers: 151 VGPRs, i.e. THREE waves per SIMD (rocprofv3 prints the count halved: 76) -- accumulator point 40, the
+// prefetched record 32, the ten 64-bit column sums 20, operands and pre-scaled limbs.  Measured in round 2 with
+// amdgpu_waves_per_eu budgets: 128 VGPRs (4 waves, 10 scratch accesses per addition) 1.73 ms, 96 (5 waves, 32) 3.6 ms,
+// 80 (6 waves, 105) 7.1 ms against 1.23 ms for this form -- at three waves the kernel already issues at 93 % of its
+// instruction bound, so occupancy has nothing to give and any spill costs more than it hides.
+template <int PIPE>   // PIPE 0: plain loop; 1: next index prefetched; 2: next index and next point prefetched; 3: point i+1 and index i+2
 __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
                                                     const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
     u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,10 +75,10 @@ __global__ void __launch_bounds__(256) k_accumulate(const u32 *__restrict__ pts,
 
 void ACCUM_LAUNCH(int pipe, const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, hipStream_t st) {
     using namespace c25519;
+    using namespace c25519::ACCUM_NS;
     const dim3 grid((unsigned)((count + 255) / 256)), blk(256);
-    if (pipe == 0) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<0>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else if (pipe == 1) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<1>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else if (pipe == 3) hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<3>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
-    else hipLaunchKernelGGL(c25519::ACCUM_NS::k_accumulate<2>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    if (pipe == 0) hipLaunchKernelGGL(k_accumulate<0>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 1) hipLaunchKernelGGL(k_accumulate<1>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else if (pipe == 3) hipLaunchKernelGGL(k_accumulate<3>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    else hipLaunchKernelGGL(k_accumulate<2>, grid, blk, 0, st, pts, sorted, base, perm, count, n, g, buckets);
 }
-

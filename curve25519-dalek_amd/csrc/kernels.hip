@@ -6,6 +6,9 @@
 #include "devio.h"
 #include "kernels.h"
 #include "selftest.h"
+#ifndef C25519_PREPC_ATTR
+#define C25519_PREPC_ATTR
+#endif
 
 namespace c25519 {
 
@@ -318,7 +321,7 @@ __global__ void __launch_bounds__(256) k_decompress_ristretto(const uint8_t *__r
 // ================================================================================================
 // compressed (Edwards y / Ristretto) -> packed affine Niels at pts[dst0 + i]; bad encodings counted
 template <int FMT>
-__global__ void __launch_bounds__(256) k_prep_compressed(const uint8_t *__restrict__ in, u64 stride_items, u64 n, u32 *__restrict__ pts,
+__global__ void __launch_bounds__(256) C25519_PREPC_ATTR k_prep_compressed(const uint8_t *__restrict__ in, u64 stride_items, u64 n, u32 *__restrict__ pts,
                                                          u64 dst0, u32 *__restrict__ bad_count) {
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
