@@ -54,18 +54,28 @@ def gather_fold(partial160, out_fmt=_e.FMT_EDWARDS_Y, group=None, device=None):
 
 def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None):
     """scalars_t / points_t: THIS rank's shard, already on its GPU.  -> (status, bytes).  status NONE if
-    any rank saw a point that does not decompress (agreed on with one tiny all_reduce)."""
+    any rank saw a point that does not decompress.  ONE collective per call: the all_gather carries the 160-byte partial
+    sum and the rank's status byte together (176 bytes per rank)."""
     import torch
     import torch.distributed as dist
     st, part = eng.msm_partial_t(scalars_t, points_t, in_fmt)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        flag = torch.tensor([1 if st == _e.NONE else 0], dtype=torch.int32, device=scalars_t.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
-        if int(flag.item()):
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if st == _e.NONE:
             return _e.NONE, None
-    elif st == _e.NONE:
+        return _e.OK, fold_partials([part], out_fmt)
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = scalars_t.device if backend == "nccl" else torch.device("cpu")
+    payload = bytearray(176)
+    payload[:160] = part if st == _e.OK else bytes(160)
+    payload[160] = 1 if st == _e.NONE else 0
+    mine = torch.frombuffer(payload, dtype=torch.uint8).to(dev)
+    allp = torch.empty((world * 176,), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allp, mine, group=group)
+    rows = allp.view(world, 176).cpu().numpy()
+    if rows[:, 160].any():
         return _e.NONE, None
-    return _e.OK, gather_fold(part, out_fmt, group, scalars_t.device)
+    return _e.OK, fold_partials([rows[i, :160].tobytes() for i in range(world)], out_fmt)
 
 
 # the reference's error precedence (batch.rs:208-211 before :244-250; a key that does not decode never reaches
