@@ -60,7 +60,9 @@ namespace c25519 {
 // operations, but one wave inverts while three wait: 0.35 ms; 0.40 ms when LLVM moved the wave-uniform inversion to the
 // scalar unit), CH = 32 / 8, fetching every record one step ahead (+12 VGPRs, 0.34 ms), and three launches (lane products,
 // ONE batched inversion over the lane totals, unwind: -68 % field operations, 0.083 + 0.107 + 0.192 ms -- the two
-// memory passes run at 3.6 - 5.2 TB/s and then contend with the sort on the second stream: no gain end to end).
+// memory passes run at 3.6 - 5.2 TB/s and then contend with the sort on the second stream: no gain end to end), and
+// wave-coalesced record I/O transposed through LDS (8x fewer cache-line requests per instruction, but 40 + 30 + 32 LDS
+// dword accesses and four barriers per point: 0.47 ms).
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
