@@ -34,6 +34,15 @@
 #ifdef C25519_CHECK_BOUNDS
 #include <stdio.h>
 #include <stdlib.h>
+// the counterpart of the reference's debug asserts on limb magnitudes (u64/field.rs:162-166).  Host: report and abort.
+// Device (make debug -> lib/libc25519hip_dbg.so): trap -- the kernel dies, the stream reports an error, the call fails.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define C25519_BOUND(limbs, even_max, odd_max, what)                                              \
+    do {                                                                                          \
+        for (int _i = 0; _i < 10; _i++)                                                           \
+            if ((uint64_t)(limbs)[_i] > ((_i & 1) ? (uint64_t)(odd_max) : (uint64_t)(even_max))) __builtin_trap(); \
+    } while (0)
+#else
 #define C25519_BOUND(limbs, even_max, odd_max, what)                                              \
     do {                                                                                          \
         for (int _i = 0; _i < 10; _i++)                                                           \
@@ -43,6 +52,7 @@
                 abort();                                                                          \
             }                                                                                     \
     } while (0)
+#endif
 #else
 #define C25519_BOUND(limbs, even_max, odd_max, what) do { } while (0)
 #endif

@@ -1005,7 +1005,6 @@ struct msm_plan {
     msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
     uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs; long_item *items;
     hipStream_t sort_stream;
-    bool multi;                 // part of a multi-pass call (other passes run beside this one)
 };
 // md (may be null): merged layout -- d_scalars holds n_scalars scalars, the sort runs over md->K * md->ns digit-terms
 int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
@@ -1051,7 +1050,6 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         sort_stream = nullptr;
     }
     pl.sort_stream = sort_stream;
-    pl.multi = false;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
     if (md) hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md->ns, 256)), dim3(256), 0, st, d_scalars, n_scalars, md->ns, md->c, md->K, D, slot_flags(d_slot));
@@ -1123,11 +1121,10 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     return C25519_OK;
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr, bool multi = false) {
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr) {
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
-    pl.multi = multi;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
 
@@ -1265,7 +1262,7 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
 // Normalisation on the main stream, sort on the second one.  They do not really overlap: both are within 10 % of their
 // memory floor (1.1 GB and 0.7 GB per 2^21 terms), and whichever starts second is starved by the older waves.
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot,
-                                hipEvent_t wait_acc, bool multi) {
+                                hipEvent_t wait_acc) {
     int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256);
     if (r) return r;
     if (in_fmt == C25519_FMT_RAW160 && (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
@@ -1280,7 +1277,6 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     if (sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
     if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r;
     if (!sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
-    pl.multi = multi;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
@@ -1304,7 +1300,7 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
-            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc, ps.lanes > 1))) {
+            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc))) {
                 if (ctx->err.empty()) ctx->err = c->err;
                 return r;
             }
@@ -1410,7 +1406,7 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
 // d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
-                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot, hipEvent_t wait_acc, bool multi) {
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot, hipEvent_t wait_acc) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -1466,7 +1462,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
     HIPCHK(hipGetLastError());
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
-    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc, multi);
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
 }
 // Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
 // 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
@@ -1516,7 +1512,7 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
-                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i), prev_acc, ps.lanes > 1);
+                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i), prev_acc);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
