@@ -547,7 +547,8 @@ EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     if (ctx_reserve(ctx, ctx->tmp_a, 4096)) return -1.0;
     hipMemsetAsync(ctx->tmp_a.p, 0x5a, 4096, ctx->stream);
     unsigned grid = (unsigned)ctx->num_cus * 8;   // 8 blocks x 4 waves per CU = 8 waves per SIMD
-    if (which >= 100) { which -= 100; grid = (unsigned)ctx->num_cus; }   // which + 100: ONE wave per SIMD (latency, not throughput)
+    if (which >= 200) { which -= 200; grid = (unsigned)ctx->num_cus * 3; }   // which + 200: THREE waves per SIMD (the occupancy of k_accumulate)
+    else if (which >= 100) { which -= 100; grid = (unsigned)ctx->num_cus; }   // which + 100: ONE wave per SIMD (latency, not throughput)
     if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, 16, grid, ctx->stream) != hipSuccess) return -1.0;  // warm-up
     hipEventRecord(ctx->ev0, ctx->stream);
     if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, iters, grid, ctx->stream) != hipSuccess) return -1.0;
@@ -556,7 +557,7 @@ EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     if (ms <= 0) return -1.0;
     // 6, 7: the mixed probes count their v_mad_u64_u32 only (8 per iteration), so the result reads as
     // "MAC rate with R simple integer ops issued beside every MAC"
-    double per_lane = (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
+    double per_lane = (which >= 40 && which <= 42) ? 3.0 * iters : (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
     double total = per_lane * 256.0 * grid;
     return total / (ms * 1e-3) / 1e9;
 }

@@ -86,10 +86,22 @@ C25519_HD feT fe_zero() { feT r; for (int i = 0; i < 10; i++) r.v[i] = 0; return
 C25519_HD feT fe_one() { feT r = fe_zero(); r.v[0] = 1; return r; }
 C25519_HD feT fe_small(u32 x) { feT r = fe_zero(); r.v[0] = x; return r; }  // x < 2^26
 
+// 2 x as an ADD: the shift LLVM makes of 2u * x (and of x + x) issues at a quarter of the rate of v_add_u32 on gfx950
+// (profiles/r02_instruction_rates.txt), and a product has five of them, a square eight
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ u32 fe_x2(u32 x) { u32 r; asm("v_add_u32_e32 %0, %1, %1" : "=v"(r) : "v"(x)); return r; }
+#else
+static inline u32 fe_x2(u32 x) { return 2u * x; }
+#endif
+
 // ---- additive ops (no carries) -------------------------------------------------------------
 // field.rs:58-73 (Add never reduces)
 C25519_HD feL fe_add(const feT &a, const feT &b) {
     feL r; for (int i = 0; i < 10; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+C25519_HD feL fe_twice(const feT &a) {
+    feL r; for (int i = 0; i < 10; i++) r.v[i] = fe_x2(a.v[i]);
     return r;
 }
 // (2 * tight) + tight stays loose: 3 * (2^26 + 2^19) < 1.52 * 2^27
@@ -205,7 +217,7 @@ C25519_HD feT fe_mul(const feW &f, const feL &g) {
     const u32 g5 = g.v[5], g6 = g.v[6], g7 = g.v[7], g8 = g.v[8], g9 = g.v[9];
     const u32 g1_19 = 19u * g1, g2_19 = 19u * g2, g3_19 = 19u * g3, g4_19 = 19u * g4, g5_19 = 19u * g5;
     const u32 g6_19 = 19u * g6, g7_19 = 19u * g7, g8_19 = 19u * g8, g9_19 = 19u * g9;
-    const u32 f1_2 = 2u * f1, f3_2 = 2u * f3, f5_2 = 2u * f5, f7_2 = 2u * f7, f9_2 = 2u * f9;
+    const u32 f1_2 = fe_x2(f1), f3_2 = fe_x2(f3), f5_2 = fe_x2(f5), f7_2 = fe_x2(f7), f9_2 = fe_x2(f9);
     u64 h[10];
     h[0] = (u64)f0 * g0;
     C25519_MAD(h[0], f1_2, g9_19); C25519_MAD(h[0], f2, g8_19); C25519_MAD(h[0], f3_2, g7_19);
@@ -255,8 +267,8 @@ C25519_HD feT fe_sq(const feL &f) {
     C25519_BOUND(f.v, L_EVEN, L_ODD, "fe_sq f");
     const u32 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];
     const u32 f5 = f.v[5], f6 = f.v[6], f7 = f.v[7], f8 = f.v[8], f9 = f.v[9];
-    const u32 f0_2 = 2u * f0, f1_2 = 2u * f1, f2_2 = 2u * f2, f3_2 = 2u * f3, f4_2 = 2u * f4;
-    const u32 f5_2 = 2u * f5, f6_2 = 2u * f6, f7_2 = 2u * f7;
+    const u32 f0_2 = fe_x2(f0), f1_2 = fe_x2(f1), f2_2 = fe_x2(f2), f3_2 = fe_x2(f3), f4_2 = fe_x2(f4);
+    const u32 f5_2 = fe_x2(f5), f6_2 = fe_x2(f6), f7_2 = fe_x2(f7);
     const u32 f5_38 = 38u * f5, f6_19 = 19u * f6, f7_38 = 38u * f7, f8_19 = 19u * f8, f9_38 = 38u * f9;
     u64 h[10];
     h[0] = (u64)f0 * f0;

@@ -65,7 +65,7 @@ C25519_HD ge_p2 ge_p1p1_to_p2(const ge_p1p1 &p) {
 // Doubling, curve_models.rs:381-397 (4 S).  Works on (X,Y,Z) of either a p2 or a p3.
 C25519_HD ge_p1p1 ge_dbl(const feT &X, const feT &Y, const feT &Z) {
     feT XX = fe_sq(X), YY = fe_sq(Y), ZZ = fe_sq(Z);
-    feL ZZ2 = fe_add(ZZ, ZZ);
+    feL ZZ2 = fe_twice(ZZ);
     feT S = fe_sq(fe_add(X, Y));
     feL YYpXX = fe_add(YY, XX), YYmXX = fe_sub(YY, XX);
     ge_p1p1 r;
@@ -91,7 +91,7 @@ C25519_HD ge_p1p1 ge_madd(const ge_p3 &p, const ge_aniels &q) {
     feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
     feT PP = fe_mul(YpX, q.ypx), MM = fe_mul(YmX, q.ymx);
     feT TT = fe_mul(p.T, q.xy2d);
-    feL Z2 = fe_add(p.Z, p.Z);
+    feL Z2 = fe_twice(p.Z);
     ge_p1p1 r;
     r.X = fe_sub(PP, MM);
     r.Y = fe_add(PP, MM);
@@ -110,7 +110,7 @@ C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) 
     feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
     feT PP = fe_mul(YpX, qa), MM = fe_mul(YmX, qb);
     feT TT = fe_mul(p.T, q.xy2d);
-    feL Z2 = fe_add(p.Z, p.Z);
+    feL Z2 = fe_twice(p.Z);
     feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
     feL zp = fe_add_lt(Z2, TT);            // Z of the completed point for +Q, T for -Q   (loose)
     feW zm = fe_sub_w(Z2, TT);             // T of the completed point for +Q, Z for -Q   (wide)
@@ -180,7 +180,7 @@ C25519_HD ge_p1p1 ge_add_cached(const ge_p3 &p, const ge_cached &q) {
     feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
     feT PP = fe_mul(YpX, q.YpX), MM = fe_mul(YmX, q.YmX);
     feT TT = fe_mul(p.T, q.T2d), ZZ = fe_mul(p.Z, q.Z);
-    feL ZZ2 = fe_add(ZZ, ZZ);
+    feL ZZ2 = fe_twice(ZZ);
     ge_p1p1 r;
     r.X = fe_sub(PP, MM);
     r.Y = fe_add(PP, MM);

@@ -6,6 +6,7 @@
 #include "devio.h"
 #include "kernels.h"
 #include "selftest.h"
+#include "fe26x.h"
 #ifndef C25519_PREPC_ATTR
 #define C25519_PREPC_ATTR
 #endif
@@ -505,6 +506,32 @@ __global__ void __launch_bounds__(256) k_probe_mad_dep(u32 *out, int iters, u32 
     }
     if ((u32)a == 0x12345678u) out[0] = (u32)(a >> 32);
 }
+// three independent products per iteration, both operands changing (19 g and 2 f are recomputed like in the point formulas):
+// MODE 0: three calls of this unit's fe_mul (chained); 1: fe_mul_chain_n<3> (the same chains in lockstep); 2: three ten-column products
+template <int MODE>
+__global__ void __launch_bounds__(256) k_probe_femul3(u32 *out, int iters, u32 seed) {
+    feT x[3], y[3];
+    _Pragma("unroll") for (int n = 0; n < 3; n++) for (int i = 0; i < 10; i++) { x[n].v[i] = (out[i] + seed + threadIdx.x + n) & M25; y[n].v[i] = (out[10 + i] + threadIdx.x * (n + 2)) & M25; }
+    for (int it = 0; it < iters; it++) {
+        feT r[3];
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (MODE == 1) {
+            feW f[3]; feL g[3];
+            _Pragma("unroll") for (int n = 0; n < 3; n++) { f[n] = x[n]; g[n] = y[n]; }
+            fe_mul_chain_n<3>(r, f, g);
+        } else if (MODE == 2) {
+            _Pragma("unroll") for (int n = 0; n < 3; n++) r[n] = fe_mul_cols_g(x[n], y[n]);
+        } else
+#endif
+        {
+            _Pragma("unroll") for (int n = 0; n < 3; n++) r[n] = fe_mul(x[n], y[n]);
+        }
+        _Pragma("unroll") for (int n = 0; n < 3; n++) { x[n] = y[n]; y[n] = r[n]; }
+    }
+    u32 q = 0;
+    _Pragma("unroll") for (int n = 0; n < 3; n++) for (int i = 0; i < 10; i++) q ^= x[n].v[i] ^ y[n].v[i];
+    if (q == 0x12345678u) out[0] = q;
+}
 // The reference's literal layout: 5 x u64 limbs, u128 products (u64/field.rs:111-214) -- the A/B arm.
 struct fe51 { u64 v[5]; };
 __device__ __forceinline__ fe51 fe51_mul(const fe51 &x, const fe51 &y) {
@@ -658,10 +685,16 @@ hipError_t launch_decompress_ristretto(const uint8_t *in, u64 n, uint8_t *out_ra
 
 
 
-hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, hipStream_t st) {
+// shared: the launch runs BESIDE a latency-bound chain on another stream (verify_batch: hash tree and sort while R is
+// decompressed).  The kernel fits three waves per SIMD (164 VGPRs), and three of them leave the SIMD's register file
+// no room for a wave of anything else: the chain then waits for the whole decompression (round 2: k_ztree_first 1025 us
+// instead of 380, verify_batch 3.38 against 3.08 ms).  A 64 KB LDS reservation caps it at two blocks per CU.
+hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, bool shared, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    if (fmt == 0) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up(n, 256)), dim3(256), 0, st, in, stride_items, n, pts, dst0, bad_count);
-    else hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up(n, 256)), dim3(256), 0, st, in, stride_items, n, pts, dst0, bad_count);
+    static const int cap = [] { const char *e = getenv("C25519_DEC_LDS"); return e ? atoi(e) : 65536; }();   // A/B knob
+    const unsigned lds = shared ? (unsigned)cap : 0u;
+    if (fmt == 0) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
+    else hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
     return hipGetLastError();
 }
 
@@ -720,6 +753,9 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 30: hipLaunchKernelGGL(k_probe_add_sdwa, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 31: hipLaunchKernelGGL(k_probe_lshlor, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 32: hipLaunchKernelGGL(k_probe_addco, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 40: hipLaunchKernelGGL(k_probe_femul3<0>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 41: hipLaunchKernelGGL(k_probe_femul3<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 42: hipLaunchKernelGGL(k_probe_femul3<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 33: hipLaunchKernelGGL(k_probe_mix_add<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 34: hipLaunchKernelGGL(k_probe_mix_add<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 35: hipLaunchKernelGGL(k_probe_mix_add<3>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;

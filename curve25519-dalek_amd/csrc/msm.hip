@@ -1108,8 +1108,11 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(pl.max_long, 1024u)), dim3(64), 0, ctx->aux, pl.base, g, pl.counters, pl.max_items, pl.lgids, pl.lfirst, pl.segs, pl.buckets);
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    static const int acc_chain = env_int("C25519_ACC_CHAIN", 0);                                              // A/B knob: carry form of the field arithmetic in k_accumulate
-    if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    static const int acc_chain = env_int("C25519_ACC_CHAIN", 2);                                              // A/B knob: carry form of the field arithmetic in k_accumulate
+    // (a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of the next pass -- measured
+    //  18.2 - 20.3 ms per 2^24 terms against 16.5 on the same box: the masked kernel loses more than the sort gains)
+    if (acc_chain == 2) launch_accumulate_c2(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    else if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     else launch_accumulate_c0(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
@@ -1207,8 +1210,8 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
     hipStream_t st = ctx->stream;
     if (n == 0) return C25519_OK;
-    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, st));
-    else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, st));
+    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
+    else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
     else if (in_fmt == C25519_FMT_RAW160) {
         int32_t r = ctx_reserve(ctx, ctx->prefix, n * 48);
         if (r) return r;
@@ -1433,7 +1436,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
     if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2))) return r; }
-    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, st));
+    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, true, st));
     HIPCHK(hipEventRecord(ring[4], st));
     {   // R_i = the first half of every 64-byte signature.  In slices: the hash chain on the second stream is the critical
         // path (hash -> tree -> z_i -> scalars -> sort), and against ONE long decompression kernel every kernel of that chain
@@ -1441,7 +1444,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         static const int chunks = std::max(1, env_int("C25519_DEC_CHUNKS", 1));
         const uint64_t per = ((n + chunks - 1) / chunks + 255) & ~(uint64_t)255;
         for (uint64_t lo = 0; lo < n; lo += per)
-            HIPCHK(launch_prep_compressed(0, d_sigs + lo * 64, 2, std::min(per, n - lo), d_pts, 1 + lo, d_cnt + 3, st));
+            HIPCHK(launch_prep_compressed(0, d_sigs + lo * 64, 2, std::min(per, n - lo), d_pts, 1 + lo, d_cnt + 3, true, st));
     }
     HIPCHK(hipEventRecord(ring[5], st));
     // (A)
