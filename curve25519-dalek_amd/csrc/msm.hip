@@ -46,6 +46,21 @@ using namespace c25519;
         if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
     } while (0)
 
+// Wave priorities (s_setprio): the issue arbiter of a SIMD takes the highest priority first and the oldest wave within it.
+// k_accumulate and the decompression run for a millisecond with every wave always ready to issue, and the short
+// latency-bound kernels of the NEXT pass (digits, sort, hash chain) that share the SIMDs with them are younger: at equal
+// priority they only get the issue slots the old waves leave.  They are the critical path, so they go first.
+#ifndef C25519_PRIO
+#define C25519_PRIO 1
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && C25519_PRIO
+#define C25519_PRIO_CHAIN() __builtin_amdgcn_s_setprio(3)
+#define C25519_PRIO_SIDE() __builtin_amdgcn_s_setprio(2)
+#else
+#define C25519_PRIO_CHAIN() do { } while (0)
+#define C25519_PRIO_SIDE() do { } while (0)
+#endif
+
 namespace c25519 {
 
 // ================================================================================================
@@ -65,6 +80,7 @@ namespace c25519 {
 // dword accesses and four barriers per point: 0.47 ms).
 template <int CH>
 __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
+    C25519_PRIO_SIDE();
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     feT acc = fe_one();
@@ -115,6 +131,7 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 
 // D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
 __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
+    C25519_PRIO_CHAIN();
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     u32 s[9];
@@ -133,6 +150,7 @@ __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scal
 // merged layout (precomputed static points): D[k * ns + t] = d + 2^(c-1), d = signed digit k of scalar t in [-2^(c-1), 2^(c-1))
 // (windows 0 .. K-2 signed through s' = s + sum_k 2^(c k + c - 1), window K-1 unsigned); t >= n: digit 0
 __global__ void __launch_bounds__(256) k_digits_merged(const uint8_t *__restrict__ scalars, u64 n, u64 ns, int c, int K, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
+    C25519_PRIO_CHAIN();
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ns) return;
     const u32 HALF = 1u << (c - 1);
@@ -178,6 +196,7 @@ __device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) {
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
 template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, u32 *__restrict__ counts) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 hist[];
     const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) hist[b] = 0;
@@ -194,6 +213,7 @@ __global__ void __launch_bounds__(1024) k_hist(const uint16_t *__restrict__ D, u
 // counting-sort offsets in two steps.
 // (1) one lane per (window, bucket): exclusive prefix over the chunks (in place) and the bucket total
 __global__ void __launch_bounds__(256) k_scan_chunks(u32 *__restrict__ counts, int nchunk, msm_geom g, u32 *__restrict__ totals) {
+    C25519_PRIO_CHAIN();
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (u64)g.nwin * g.half) return;
     int k = (int)(gid / g.half), b = (int)(gid % g.half);
@@ -206,6 +226,7 @@ __global__ void __launch_bounds__(256) k_scan_chunks(u32 *__restrict__ counts, i
 }
 // (2) one block per window: base[k][b] = exclusive scan of the bucket totals; base[k][half] = #entries
 __global__ void __launch_bounds__(1024) k_scan_buckets(const u32 *__restrict__ totals, msm_geom g, u32 *__restrict__ base) {
+    C25519_PRIO_CHAIN();
     __shared__ u32 part[1024];
     const int k = blockIdx.x, tid = threadIdx.x;
     const int per = (g.half + 1023) / 1024;
@@ -228,6 +249,7 @@ __global__ void __launch_bounds__(1024) k_scan_buckets(const u32 *__restrict__ t
 template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, const u32 *__restrict__ starts,
                                                   const u32 *__restrict__ base, u32 *__restrict__ sorted) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 cursor[];
     const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
     const u32 *st = starts + ((u64)k * nchunk + j) * g.half;
@@ -267,6 +289,7 @@ __device__ __forceinline__ bool part_entry(u32 v, int k, const msm_geom &g, u32 
 }
 // cc[(k*SL + s)*nchunk + j] = number of non-zero digits of chunk j, window k, that fall into slice s
 __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, int PART_CHUNK, u32 *__restrict__ cc) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];                               // [4][SL]
     const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < 4 * SL; i += 256) sm[i] = 0;
@@ -296,6 +319,7 @@ __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ 
 }
 // one block per window: exclusive scan of cc in (slice, chunk) order, in place; bin_base[k][s] (SL+1 entries); base[k][half]
 __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL, int nchunk, msm_geom g, u32 *__restrict__ bin_base, u32 *__restrict__ base) {
+    C25519_PRIO_CHAIN();
     __shared__ u32 part[1024];
     const int k = blockIdx.x, tid = threadIdx.x, M = SL * nchunk;
     u32 *v = cc + (u64)k * M;
@@ -320,6 +344,7 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL
 }
 // pass 1: chunk j of window k -> runs per slice in P1[k][..]
 __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, int PART_CHUNK, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     u32 *cnt = sm;                         // [16][SL]: per-wave counts, then per-wave cursors
     u32 *ls = sm + 16 * SL;                // [SL + 1]: start of each slice in the staging buffer
@@ -360,6 +385,7 @@ __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ 
 constexpr int PART_R = PART_CAP / 1024;
 __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
                                                 u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *out = sm + 2 * PART_BPS_MAX;
     const int PART_BPS = 1 << g.bps_log2;
@@ -435,6 +461,7 @@ __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u
 // together, so the region being written (4n/parts bytes) stays in that L2 until its lines are complete.
 __global__ void __launch_bounds__(1024) k_scatter_sliced(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, int parts,
                                                          const u32 *__restrict__ starts, const u32 *__restrict__ base, u32 *__restrict__ sorted) {
+    C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y;
     const int per = g.half / parts;
@@ -477,6 +504,7 @@ __global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ tota
                                                     u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items,
                                                     u32 *__restrict__ counters /* [0]=#items [1]=#long buckets */, u32 *__restrict__ long_gids,
                                                     u32 *__restrict__ long_first) {
+    C25519_PRIO_CHAIN();
     __shared__ u32 h[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -509,6 +537,7 @@ __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) 
     p[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
+    C25519_PRIO_CHAIN();
         u32 a = (int)threadIdx.x >= off ? p[threadIdx.x - off] : 0;
         __syncthreads();
         p[threadIdx.x] += a;
@@ -517,6 +546,7 @@ __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) 
     ord_hist[threadIdx.x] = p[threadIdx.x] - v;
 }
 __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ totals, u64 nb, u32 gid_off, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
+    C25519_PRIO_CHAIN();
     __shared__ u32 h[256], basep[256];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -552,6 +582,7 @@ __device__ __forceinline__ ge_p3 wave_sum(ge_p3 acc) {
 __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, u64 n, msm_geom g,
                                                       const long_item *__restrict__ items, const u32 *__restrict__ counters, u32 max_items,
                                                       u32 *__restrict__ seg_sums) {
+    C25519_PRIO_SIDE();
     const u32 nitems = counters[0] < max_items ? counters[0] : max_items;
 #pragma unroll 1
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -572,6 +603,7 @@ __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pt
 __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ base, msm_geom g, const u32 *__restrict__ counters, u32 max_items,
                                                      const u32 *__restrict__ long_gids, const u32 *__restrict__ long_first,
                                                      const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets) {
+    C25519_PRIO_SIDE();
 #pragma unroll 1
     for (u32 lb = blockIdx.x; lb < counters[1]; lb += gridDim.x) {
         u32 gid = long_gids[lb], first = long_first[lb];
@@ -646,6 +678,7 @@ __device__ __forceinline__ void wave_weighted_sum(ge_p3 &S, ge_p3 &W, int shift,
 constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A
 // level A: block (one wave) = segment `seg` of window k.  direct: the window has a single segment, write col_k itself.
 __global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct) {
+    C25519_PRIO_SIDE();
     const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg, lane = threadIdx.x;
     const int b0 = seg * RED_SEG + lane * RED_LB;
     const u32 *B = buckets + (u64)k * half * 40;
@@ -666,6 +699,7 @@ __global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets
 }
 // level B: one wave per window over its nseg <= 64 segment pairs
 __global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int nseg, u32 *__restrict__ cols) {
+    C25519_PRIO_SIDE();
     const int k = blockIdx.x, lane = threadIdx.x;
     const ge_p3 id = ge_identity();
     ge_p3 S = lane < nseg ? p40_load(SW, 2 * ((u64)k * nseg + lane)) : id;
@@ -681,6 +715,7 @@ __global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int
 // flags[1] |= 1 if the message offsets are not monotone or run past msgs_len (that message is hashed as empty)
 __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len, const uint8_t *__restrict__ sigs,
                                               const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags) {
+    C25519_PRIO_CHAIN();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     u32 r[8], a[8], s[8];
@@ -721,6 +756,7 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
 constexpr int ZTREE_MAX_LEVELS = 16;
 struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
+    C25519_PRIO_CHAIN();
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (n + 15) / 16;
     if (j >= m_out) return;
@@ -763,6 +799,7 @@ __device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, cons
     for (int q = 0; q < 4; q++) out4[q] = hs[q];
 }
 __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out) {
+    C25519_PRIO_CHAIN();
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= (m_in + 3) / 4) return;
     u64 r[4];
@@ -772,6 +809,7 @@ __global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u
 }
 // the last levels (m_in <= 1024 nodes) in ONE block: no launch gaps between levels that hold a handful of nodes
 __global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ root) {
+    C25519_PRIO_CHAIN();
     __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
     for (u64 i = threadIdx.x; i < m_in * 4; i += 256) buf0[i] = reinterpret_cast<const u64 *>(in)[i];
     __syncthreads();
@@ -798,6 +836,7 @@ __global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ 
 // (C25519_Z_TRANSCRIPT) puts the carry digit +1 of about half of all R_i into ONE bucket of window 8 (the long-bucket
 // path takes it).  The sign is applied to the stored point (k_apply_sign), the MSM scalar is |z_i|.
 __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n4, uint8_t *__restrict__ z16) {
+    C25519_PRIO_CHAIN();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
@@ -813,6 +852,7 @@ __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ roo
 }
 // R_i <- -R_i where z_i is negative (device z-mode): swap y+x / y-x, negate 2dxy of the stored affine Niels record
 __global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 dst0, const uint8_t *__restrict__ z16, u64 n) {
+    C25519_PRIO_CHAIN();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (!(reinterpret_cast<const u32 *>(z16)[4 * i + 3] >> 31)) return;
@@ -828,6 +868,7 @@ __global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 d
 // per-block partial sums of z_i*s_i (mod l) to `partial`.  signed_z: z16 is sign-magnitude (device z-mode).
 __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ z16,
                                                        u64 n, int signed_z, uint8_t *__restrict__ msm_scalars, u64 *__restrict__ partial) {
+    C25519_PRIO_CHAIN();
     __shared__ u64 red[256][5];
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     sc52 zs = sc_zero();
@@ -864,6 +905,7 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
 
 // msm_scalars[0] = -(sum of the per-block partial sums) mod l: one block, strided sums then a tree
 __global__ void __launch_bounds__(256) k_bsum_finish(const u64 *__restrict__ partial, u32 nblk, uint8_t *__restrict__ msm_scalars) {
+    C25519_PRIO_CHAIN();
     __shared__ u64 red[256][5];
     sc52 acc = sc_zero();
     for (u32 b = threadIdx.x; b < nblk; b += 256) {
@@ -1110,7 +1152,9 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
     static const int acc_chain = env_int("C25519_ACC_CHAIN", 2);                                              // A/B knob: carry form of the field arithmetic in k_accumulate
     // (a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of the next pass -- measured
-    //  18.2 - 20.3 ms per 2^24 terms against 16.5 on the same box: the masked kernel loses more than the sort gains)
+    //  18.2 - 20.3 ms per 2^24 terms against 16.5 on the same box: the masked kernel loses more than the sort gains;
+    //  512-thread blocks, i.e. two waves per SIMD with 176 registers and all of LDS left for the sort kernels: 16.9 - 17.0
+    //  against 16.6 - 16.9; an LDS reservation to the same effect: 16.2 against 15.9)
     if (acc_chain == 2) launch_accumulate_c2(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     else if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     else launch_accumulate_c0(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
