@@ -102,14 +102,14 @@ def msm(n, nwin, half, raw_points=True, filled_windows=None):
 
 
 def verify(n, nwin, half, keys_as_bytes=False, r_windows=8):
-    """One verify_batch pass: R decompressed (255 S + 23 M incl. record), A from the cached point (7 M, Z = 1: no
-    inversion) or decompressed, R-terms in `r_windows` windows (|z| < 2^127), A-terms in nwin - 1; SHA-512 and the scalar
+    """One verify_batch pass: R decompressed (255 S + 23 M incl. record), A from the cached point (Z = 1, as
+    VerifyingKey::from_bytes leaves it: 1 M prefix product + 2 M record, msm.hip:k_prep_raw's affine path) or decompressed, R-terms in `r_windows` windows (|z| < 2^127), A-terms in nwin - 1; SHA-512 and the scalar
     arithmetic mod l are integer work outside this count."""
-    a_prep = {"M": 23, "S": 255} if keys_as_bytes else {"M": 7, "S": 0}
+    a_prep = {"M": 23, "S": 255} if keys_as_bytes else {"M": 3, "S": 0}
     red = _scaled(_reduce_per_bucket(), float(nwin) * half / n)
     c = _add({"M": 23, "S": 255}, a_prep, {"M": 7 * (r_windows + nwin - 1), "S": 0}, red)
     c["what"] = "decompress R (255 S + 23 M) + %s + (%d + %d) windows x 7 M + bucket reduction; SHA-512 and scalar muls not counted" % (
-        "decompress A (255 S + 23 M)" if keys_as_bytes else "A from VerifyingKey.point (7 M)", r_windows, nwin - 1)
+        "decompress A (255 S + 23 M)" if keys_as_bytes else "A from VerifyingKey.point (Z = 1: 3 M)", r_windows, nwin - 1)
     return c
 
 

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
     if (t >= n) return;
     feT acc = fe_one();
     bool affine = true;                 // every Z of this lane is literally 1 (points straight from a decompression,
-                                        // e.g. VerifyingKey.point): the shared inversion is skipped
+                                        // e.g. VerifyingKey.point): the shared inversion and the unwinding are skipped
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
         u64 idx = t + (u64)j * T;
@@ -102,6 +102,7 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
     for (int j = CH - 1; j >= 0; j--) {
         u64 idx = t + (u64)j * T;
         if (idx >= n) continue;
+        if (affine) { pts_store(pts, dst0 + idx, raw160_fe(in, idx, 0), raw160_fe(in, idx, 1)); continue; }   // x = X, y = Y
         const uint4 *q = reinterpret_cast<const uint4 *>(prefix) + 3 * idx;
         uint4 a = q[0], b = q[1], c = q[2];
         feT pre;

@@ -181,6 +181,30 @@ def test_msm_config4_2p24_terms(eng, orc):
     print("MSM 2^24 single call: %.3f ms" % eng.last_kernel_ms())
 
 
+def test_msm_affine_and_projective_lanes_mixed(eng, orc):
+    """k_prep_raw takes a direct path for a lane whose sixteen points all have Z = 1 (points straight from a
+    decompression): lanes of both kinds in one launch, and lanes with both kinds of points, give the MSM of the
+    all-projective representation of the same points."""
+    n = 1 << 14                                             # 1024 lanes x 16 points, lane t owns t, t + 1024, ...
+    x = util.rand_scalars(91, n)
+    proj = eng.mul_base_batch(util.rand_scalars(92, n), out_fmt=2)
+    st, aff, ok = eng.decompress_batch(eng.compress_batch(proj))
+    assert st == 0 and ok.all()
+    one = np.zeros(40, np.uint8); one[0] = 1
+    assert all(aff[i, 80:120].tobytes() == one.tobytes() for i in (0, 777, n - 1))       # Z is literally 1
+    assert any(proj[i, 80:120].tobytes() != one.tobytes() for i in (0, 777, n - 1))
+    st, want = eng.msm_vartime(x, proj, in_fmt=2)
+    assert st == 0
+    idx = np.arange(n)
+    for mask in ((idx % 1024) < 512,                        # whole lanes affine, whole lanes projective
+                 idx < n // 2,                              # every lane: 8 affine then 8 projective points
+                 np.ones(n, bool),                          # everything affine
+                 (idx % 3) == 0):
+        pts = np.where(mask[:, None], aff, proj)
+        st, got = eng.msm_vartime(x, pts, in_fmt=2)
+        assert st == 0 and got == want
+
+
 def test_msm_two_passes_odd_size(eng, orc):
     """3*2^20 + 17 terms: two passes of unequal length (msm.hip MSM_PASS_MAX), partial sums added on the host."""
     import torch
