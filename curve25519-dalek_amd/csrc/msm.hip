@@ -56,7 +56,12 @@ using namespace c25519;
 #if defined(__HIP_DEVICE_COMPILE__) && C25519_PRIO
 #define C25519_PRIO_CHAIN() __builtin_amdgcn_s_setprio(3)
 #define C25519_PRIO_SIDE() __builtin_amdgcn_s_setprio(2)
+#ifndef C25519_PRIO_LONG_LEVEL
+#define C25519_PRIO_LONG_LEVEL 2
+#endif
+#define C25519_PRIO_LONG() __builtin_amdgcn_s_setprio(C25519_PRIO_LONG_LEVEL)
 #else
+#define C25519_PRIO_LONG() do { } while (0)
 #define C25519_PRIO_CHAIN() do { } while (0)
 #define C25519_PRIO_SIDE() do { } while (0)
 #endif
@@ -583,7 +588,7 @@ __device__ __forceinline__ ge_p3 wave_sum(ge_p3 acc) {
 __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, u64 n, msm_geom g,
                                                       const long_item *__restrict__ items, const u32 *__restrict__ counters, u32 max_items,
                                                       u32 *__restrict__ seg_sums) {
-    C25519_PRIO_SIDE();
+    C25519_PRIO_LONG();
     const u32 nitems = counters[0] < max_items ? counters[0] : max_items;
 #pragma unroll 1
     for (u32 item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -604,7 +609,7 @@ __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pt
 __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ base, msm_geom g, const u32 *__restrict__ counters, u32 max_items,
                                                      const u32 *__restrict__ long_gids, const u32 *__restrict__ long_first,
                                                      const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets) {
-    C25519_PRIO_SIDE();
+    C25519_PRIO_LONG();
 #pragma unroll 1
     for (u32 lb = blockIdx.x; lb < counters[1]; lb += gridDim.x) {
         u32 gid = long_gids[lb], first = long_first[lb];

@@ -167,6 +167,16 @@ def ed_msm(scalars, points, which=0):
     return o.raw
 
 
+def ed_msm_np(scalars, points, which=0):
+    """the same over contiguous numpy arrays (n x 32, n x 160 uint8): no per-item Python work in a timed region"""
+    import numpy as np
+    s = np.ascontiguousarray(scalars, dtype=np.uint8); p = np.ascontiguousarray(points, dtype=np.uint8)
+    assert s.ndim == 2 and s.shape[1] == 32 and p.shape == (s.shape[0], 160)
+    o = _pt()
+    lib().orc_ed_msm_vartime(s.ctypes.data_as(C.c_char_p), p.ctypes.data_as(C.c_char_p), C.c_size_t(s.shape[0]), C.c_int(which), o)
+    return o.raw
+
+
 # ---- Ristretto ----
 def ris_decompress(b):
     o = _pt()

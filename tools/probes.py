@@ -26,3 +26,10 @@ for which, nm in names.items():
     cyc = lambda r: 1024 * 64 * 2.4 / r
     print("%-40s %12.1f %14.2f %12.1f %14.2f" % (nm, full, cyc(full), lone, cyc(lone)))
 print("* at a nominal 2.4 GHz; fe_mul / fe_sq rows count field operations, not instructions")
+# three independent field products per iteration in three code shapes, at 8 / 3 / 1 waves per SIMD (G fe_mul/s, chip):
+# what k_accumulate (three waves) has to choose between
+print()
+print("%-44s %10s %10s %10s" % ("three independent products, shape", "8 waves", "3 waves", "1 wave"))
+for w, nm in {40: "3 x fe_mul, chained, one after another", 41: "fe_mul_chain_n<3>: chained, in lockstep", 42: "3 x ten-column fe_mul"}.items():
+    r = [max(e.microbench(w + o, 2000) for _ in range(5)) for o in (0, 200, 100)]
+    print("%-44s %10.1f %10.1f %10.1f" % (nm, *r))
