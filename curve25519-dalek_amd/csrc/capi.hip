@@ -528,7 +528,7 @@ EXPORT int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, ui
 // field self-test: raw limbs (n x 10 u32, HOST pointers; b may be NULL for the unary ops) -> n x 32 canonical bytes
 EXPORT int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out) {
     HIPCHK(hipSetDevice(ctx->device));
-    if (op < 0 || op > 7 || (chain != 0 && chain != 1)) { ctx->err = "selftest_field: bad op / chain"; return -(int32_t)hipErrorInvalidValue; }
+    if (op < 0 || op > 11 || (chain != 0 && chain != 1)) { ctx->err = "selftest_field: bad op / chain"; return -(int32_t)hipErrorInvalidValue; }
     if (n == 0) return C25519_OK;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 32))) return r;

@@ -282,7 +282,9 @@ double c25519_microbench(c25519_ctx *ctx, int which, int iters);
  * (field.rs:368-450 to_bytes).  a_limbs / b_limbs: n x 10 u32 limbs at bit positions 0,26,51,...,230 (HOST pointers;
  * any magnitudes the operation's bound class admits, csrc/fe26.h); out: n x 32.  op: 0 a*b (a wide, b loose), 1 a^2
  * (loose), 2 1/a, 3 canonical encoding of a (wide), 4 a^((p-5)/8), 5 a-b (both loose), 6 weak reduction of a,
- * 7 (a-b)*(a+b) (both tight).  Pins the device code generation against big integers (field.rs:552-642). */
+ * 7 (a-b)*(a+b) (both tight); 8-11 the lockstep multiplier of the bucket accumulation (csrc/fe26x.h; a wide, b loose):
+ * 8 a*b and 9 b^2 out of one group of three products, 10 a*b and 11 b^2 out of one group of four.  Pins the device code
+ * generation against big integers (field.rs:552-642). */
 int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out);
 /* The window layout the MSM uses for n terms (host arithmetic, no GPU needed): window k covers bits
  * [pos[k], pos[k] + wid[k]) of s' = s + addk (addk as 8 little-endian 32-bit words); all windows but the last two are

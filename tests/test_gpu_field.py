@@ -80,6 +80,24 @@ def test_fe_mul_sq_to_bytes_2p20(eng, chain):
 
 
 @pytest.mark.parametrize("chain", [0, 1])
+def test_lockstep_products_2p20(eng, chain):
+    """fe_mul_chain_n<3> / <4> (fe26x.h: the seven products of a bucket addition, chained carries, issued column by
+    column): every slot of both group sizes against big integers, wide x loose operands with the bound extremes"""
+    rng = np.random.default_rng(2700 + chain)
+    n = 1 << 20
+    a = with_edges(rng, n, W_EVEN, W_ODD); b = with_edges(rng, n, L_EVEN, L_ODD)
+    b[:64] = b[:64][::-1].copy()
+    a[64:320] = np.array([[W_EVEN if i % 2 == 0 else W_ODD for i in range(10)]], np.uint32)     # all-maximal operands
+    b[64:320] = np.array([[L_EVEN if i % 2 == 0 else L_ODD for i in range(10)]], np.uint32)
+    va, vb = values(a), values(b)
+    ab = enc([x * y for x, y in zip(va, vb)]); bb = enc([y * y for y in vb])
+    assert np.array_equal(eng.selftest_field(8, a, b, chain), ab)
+    assert np.array_equal(eng.selftest_field(9, a, b, chain), bb)
+    assert np.array_equal(eng.selftest_field(10, a, b, chain), ab)
+    assert np.array_equal(eng.selftest_field(11, a, b, chain), bb)
+
+
+@pytest.mark.parametrize("chain", [0, 1])
 def test_fe_invert_pow_sub_chains(eng, chain):
     rng = np.random.default_rng(2700 + chain)
     n = 1 << 14
