@@ -22,7 +22,8 @@ import math
 MAC_PER_M = 100
 MAC_PER_S = 55
 INV = {"M": 11, "S": 254}          # fe_invert
-CHUNK = 16                         # points per lane sharing one inversion (Montgomery's trick)
+CHUNK = 16                         # points per lane sharing one inversion (Montgomery's trick): compression, ladder output
+PREP_CHUNK = 64                    # the same in the MSM's normaliser (msm.hip:k_prep_raw2<64, 4>)
 
 reference_mac = {"fixed_base": 47100, "x25519": 231000, "msm": 26500, "verify": 57000, "verify_bytes": 74400}
 
@@ -90,14 +91,14 @@ def msm(n, nwin, half, raw_points=True, filled_windows=None):
     filled_windows: windows that hold a digit for a reduced (< 2^253) scalar: all but the overflow window."""
     fw = (nwin - 1) if filled_windows is None else filled_windows
     acc = {"M": 7 * fw, "S": 0}
-    if raw_points:       # msm.hip:k_prep_raw<16>: 1 M prefix, 2 M unwind, 2 M (x, y), 2 M record, + 1/16 inversion
-        prep = _add({"M": 7, "S": 0}, _scaled(INV, 1.0 / CHUNK))
+    if raw_points:       # msm.hip:k_prep_raw2<64>: 1 M prefix, 2 M unwind, 2 M (x, y), 2 M record, + 1/64 inversion
+        prep = _add({"M": 7, "S": 0}, _scaled(INV, 1.0 / PREP_CHUNK))
     else:                # kernels.hip:k_prep_compressed: decompression + record
         prep = {"M": 21 + 2, "S": 255}
     red = _scaled(_reduce_per_bucket(), float(nwin) * half / n)
     c = _add(acc, prep, red)
     c["what"] = "%d windows x 7 M bucket adds + %s + bucket reduction %.1f M-equivalents per term (%d x %d buckets)" % (
-        fw, "8 M normalise (1/16 inversion)" if raw_points else "decompress (255 S + 23 M)", (mac(red)) / 100.0, nwin, half)
+        fw, "7.2 M + 4 S normalise (1/64 inversion)" if raw_points else "decompress (255 S + 23 M)", (mac(red)) / 100.0, nwin, half)
     return c
 
 

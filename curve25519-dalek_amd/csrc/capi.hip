@@ -170,6 +170,7 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreateWithFlags(&ctx->ev_sort, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_pts, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
     if (hipMalloc((void **)&ctx->d_slots, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4) != hipSuccess) return false;
     return hipHostMalloc(&ctx->h_msm, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
@@ -236,7 +237,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f};
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
     if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
@@ -252,6 +253,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_z) hipEventDestroy(ctx->ev_z);
     if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
     if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
+    if (ctx->ev_pts) hipEventDestroy(ctx->ev_pts);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
     if (ctx->d_slots) hipFree(ctx->d_slots);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);

@@ -30,7 +30,7 @@ struct c25519_ctx {
     uint32_t *d_table_ct = nullptr;   // radix-2^5 LDS window tables for the constant-time (full-scan) fixed-base kernel
     void *d_flag = nullptr;        // 256 bytes of device flags / small results
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr, ev_pts = nullptr;
     void *h_msm = nullptr;                               // pinned: C25519_MAX_SLOTS result slots
     uint32_t *d_slots = nullptr;                         // device: C25519_MAX_SLOTS result slots (written by this context and its peer)
     // a second set of streams / workspaces on the same device (shares the fixed-base tables): multi-pass MSM and
@@ -40,6 +40,7 @@ struct c25519_ctx {
     bool owns_table = true;
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
     devbuf tmp_a, tmp_b, tmp_c, tmp_c2, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
+    devbuf pts_all;                                            // gather records of passes 1.. of a multi-pass MSM (prepared ahead in one launch)
     std::string err;
 };
 

@@ -105,6 +105,14 @@ __device__ __forceinline__ void pts_store(u32 *pts, u64 idx, const feT &x, const
     uint4 *q = reinterpret_cast<uint4 *>(pts) + PTS_Q * idx;
     for (int i = 0; i < PTS_Q; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
 }
+// the same record as eight 16-byte pieces in registers (k_prep_raw2 stores them through LDS)
+__device__ __forceinline__ void pts_pieces(const feT &x, const feT &y, uint4 q[PTS_Q]) {
+    feT a = fe_carry(fe_add(y, x)), b = fe_carry(fe_sub(y, x)), c = fe_mul(fe_mul(x, y), fe_d2());
+    u32 t[32];
+    for (int i = 0; i < 10; i++) { t[i] = a.v[i]; t[10 + i] = b.v[i]; t[20 + i] = c.v[i]; }
+    t[30] = 0; t[31] = 0;
+    for (int i = 0; i < PTS_Q; i++) q[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+}
 __device__ __forceinline__ ge_aniels pts_from_q(const uint4 q[PTS_Q]) {
     u32 t[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
                  q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};

@@ -119,6 +119,105 @@ __global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in
         pts_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
     }
 }
+// The same normalisation with WAVE-COALESCED memory accesses.  k_prep_raw's lane t owns points t, t + T, ...: the 64 lanes
+// of a wave own 64 CONSECUTIVE points at every step, but each lane fetches its own 40-byte coordinates and stores its own
+// 128-byte record, so every memory instruction looks up 64 different cache lines -- 1664 look-ups per point and wave, on
+// the texture/L1 path that the accumulation of the previous pass (one gather per addition) and the sort also live on.
+// Here the wave DMAs the whole 10 KB block of its 64 points into LDS (global_load_lds_dwordx4, 8 lines per instruction),
+// the prefix products live in a [step][piece][lane] layout (8 lines per instruction), and the records go out through an
+// LDS transpose (piece c of record r at position (c + r) mod 8: conflict-free both ways) as eight fully coalesced
+// stores: 272 look-ups per point and wave.  The block of step j+1 (j-1 on the way back) is in flight during step j.
+template <int CH, int WPB>                                  // points per lane, waves per block
+__global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
+    C25519_PRIO_SIDE();
+    __shared__ uint4 stage_in[WPB * 640];                    // per wave: 64 points x 160 bytes
+    __shared__ uint4 stage_out[WPB * 512];                   // per wave: 64 records x 128 bytes
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const u32 lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const u64 T = (u64)gridDim.x * (64 * WPB), t = (u64)blockIdx.x * (64 * WPB) + threadIdx.x, w0 = t - lane;
+    if (w0 >= n) return;                                     // the whole wave is out of range
+    uint4 *sin = stage_in + wv * 640, *sout = stage_out + wv * 512;
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in);
+    const u64 last4 = n * 10 - 1;
+    int nj = 0;
+    while (nj < CH && w0 + (u64)nj * T < n) nj++;            // steps with at least one point of this wave in range
+#define C25519_PREP_ISSUE(j)                                                                                                   \
+    {                                                                                                                          \
+        const u64 b4 = (w0 + (u64)(j) * T) * 10;                                                                               \
+        _Pragma("unroll") for (int i = 0; i < 10; i++) {                                                                      \
+            u64 a = b4 + (u64)(i * 64) + lane;                                                                                 \
+            a = a > last4 ? last4 : a;                                                                                         \
+            __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + a), (lds_void *)(sin + i * 64), 16, 0, 0);                     \
+        }                                                                                                                      \
+    }
+    const uint4 *my4 = sin + lane * 10;
+    const uint2 *my2 = reinterpret_cast<const uint2 *>(sin) + lane * 20;
+    uint4 *pre4 = reinterpret_cast<uint4 *>(prefix) + (w0 / 64) * (u64)(CH * 3 * 64) + lane;
+    feT acc = fe_one();
+    bool affine = true;
+    C25519_PREP_ISSUE(0)
+#pragma unroll 1
+    for (int j = 0; j < nj; j++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint4 z0 = my4[5], z1 = my4[6];
+        const uint2 z2 = my2[14];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j + 1 < nj) C25519_PREP_ISSUE(j + 1)
+        if (t + (u64)j * T < n) {
+            const u64 l[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
+            affine = affine && (l[0] == 1) && ((l[1] | l[2] | l[3] | l[4]) == 0);
+            pre4[(j * 3 + 0) * 64] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+            pre4[(j * 3 + 1) * 64] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+            pre4[(j * 3 + 2) * 64] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
+            acc = fe_mul(acc, fe_from_limbs51(l));
+        }
+    }
+    feT inv = fe_one();
+    if (!affine) inv = fe_invert(acc);
+    const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
+    uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa;     // prefix product of the step about to be unwound
+    if (nj > 0) { pa = pre4[((nj - 1) * 3 + 0) * 64]; pb = pre4[((nj - 1) * 3 + 1) * 64]; pc = pre4[((nj - 1) * 3 + 2) * 64]; }
+    if (nj > 0) C25519_PREP_ISSUE(nj - 1)
+#pragma unroll 1
+    for (int j = nj - 1; j >= 0; j--) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint4 x0 = my4[0], x1 = my4[1], y1 = my4[3], y2 = my4[4], z0 = my4[5], z1 = my4[6];
+        const uint2 x2 = my2[4], y0 = my2[5], z2 = my2[14];
+        const uint4 a = pa, b = pb, c = pc;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (j > 0) {
+            pa = pre4[((j - 1) * 3 + 0) * 64]; pb = pre4[((j - 1) * 3 + 1) * 64]; pc = pre4[((j - 1) * 3 + 2) * 64];
+            C25519_PREP_ISSUE(j - 1)
+        }
+        const u64 lx[5] = {x0.x | (u64)x0.y << 32, x0.z | (u64)x0.w << 32, x1.x | (u64)x1.y << 32, x1.z | (u64)x1.w << 32, x2.x | (u64)x2.y << 32};
+        const u64 ly[5] = {y0.x | (u64)y0.y << 32, y1.x | (u64)y1.y << 32, y1.z | (u64)y1.w << 32, y2.x | (u64)y2.y << 32, y2.z | (u64)y2.w << 32};
+        const u64 lz[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
+        uint4 q[PTS_Q];
+        for (int i = 0; i < PTS_Q; i++) q[i] = make_uint4(0, 0, 0, 0);
+        if (t + (u64)j * T < n) {
+            if (affine) pts_pieces(fe_from_limbs51(lx), fe_from_limbs51(ly), q);
+            else {
+                feT pre;
+                pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
+                pre.v[8] = c.x; pre.v[9] = c.y;
+                const feT zi = fe_mul(inv, pre);
+                inv = fe_mul(inv, fe_from_limbs51(lz));
+                pts_pieces(fe_mul(fe_from_limbs51(lx), zi), fe_mul(fe_from_limbs51(ly), zi), q);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PTS_Q; i++) sout[lane * 8 + ((i + lane) & 7u)] = q[i];
+        uint4 *dst = reinterpret_cast<uint4 *>(pts) + PTS_Q * (dst0 + w0 + (u64)j * T);
+#pragma unroll
+        for (int i = 0; i < PTS_Q; i++) {
+            const u32 r = 8u * i + sub;                       // this lane stores piece coff of record r
+            const uint4 v = sout[i * 64 + lane];
+            if (w0 + (u64)j * T + r < n) dst[r * 8 + coff] = v;
+        }
+    }
+#undef C25519_PREP_ISSUE
+}
 __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { ge_p3 B = ge_basepoint(); pts_store(pts, dst, B.X, B.Y); }
 }
@@ -1146,7 +1245,7 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
     }
     hipStream_t st = ctx->stream;
-    static const int pipe = [] { int v = env_int("C25519_ACC_PIPE", 3); return (v < 0 || v > 3) ? 3 : v; }();   // A/B knob (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
+    static const int pipe = [] { int v = env_int("C25519_ACC_PIPE", 4); return (v < 0 || v > 4) ? 4 : v; }();   // A/B knob (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
     static const int acc_serial = env_int("C25519_ACC_SERIAL", 1);                                              // A/B knob
     if (wait_acc && acc_serial) HIPCHK(hipStreamWaitEvent(st, wait_acc, 0));
     // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
@@ -1160,7 +1259,10 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // (a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of the next pass -- measured
     //  18.2 - 20.3 ms per 2^24 terms against 16.5 on the same box: the masked kernel loses more than the sort gains;
     //  512-thread blocks, i.e. two waves per SIMD with 176 registers and all of LDS left for the sort kernels: 16.9 - 17.0
-    //  against 16.6 - 16.9; an LDS reservation to the same effect: 16.2 against 15.9)
+    //  against 16.6 - 16.9, and 15.5 against 15.1 - 15.3 with the cooperative gather; an LDS reservation to the same effect:
+    //  16.2 against 15.9; four waves per SIMD without a prefetched record, ten-column 124 / chained 110 VGPRs and no
+    //  scratch: 16.0 / 15.5 against 15.1 - 15.3 -- a wave issues one v_mad_u64_u32 per 11.7 cycles at best, so three waves
+    //  of the 168-register form are what saturates the multiplier, and nothing else fits beside them)
     if (acc_chain == 2) launch_accumulate_c2(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     else if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     else launch_accumulate_c0(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
@@ -1265,8 +1367,23 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
     else if (in_fmt == C25519_FMT_RAW160) {
         int32_t r = ctx_reserve(ctx, ctx->prefix, n * 48);
         if (r) return r;
-        constexpr int CH = 16;
-        hipLaunchKernelGGL(k_prep_raw<CH>, dim3(div_up64((n + CH - 1) / CH, 256)), dim3(256), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        static const int coalesced = env_int("C25519_PREP_COALESCED", 1);     // A/B knobs
+        static const int chunk = env_int("C25519_PREP_CHUNK", 64);
+        if (coalesced) {
+            static const int wpb = env_int("C25519_PREP_WPB", 4) == 1 ? 1 : 4;
+            const int CH = (chunk == 32 || chunk == 64 || chunk == 128) ? chunk : 16;
+            const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
+            // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
+            r = ctx_reserve(ctx, ctx->prefix, (size_t)blocks * wpb * CH * 3 * 64 * 16);
+            if (r) return r;
+#define C25519_PREP_LAUNCH(C, W) hipLaunchKernelGGL((k_prep_raw2<C, W>), dim3(blocks), dim3(64 * W), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0)
+            if (wpb == 1) { if (CH == 128) C25519_PREP_LAUNCH(128, 1); else if (CH == 64) C25519_PREP_LAUNCH(64, 1); else if (CH == 32) C25519_PREP_LAUNCH(32, 1); else C25519_PREP_LAUNCH(16, 1); }
+            else { if (CH == 128) C25519_PREP_LAUNCH(128, 4); else if (CH == 64) C25519_PREP_LAUNCH(64, 4); else if (CH == 32) C25519_PREP_LAUNCH(32, 4); else C25519_PREP_LAUNCH(16, 4); }
+#undef C25519_PREP_LAUNCH
+        } else {
+            constexpr int CH = 16;
+            hipLaunchKernelGGL(k_prep_raw<CH>, dim3(div_up64((n + CH - 1) / CH, 256)), dim3(256), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        }
     } else { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipGetLastError());
     return C25519_OK;
@@ -1312,14 +1429,23 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
 }
 
 // One bucket-method pass over at most MSM_PASS_MAX terms, enqueued on context c (ctx or its peer); results to d_slot.
-// Normalisation on the main stream, sort on the second one.  They do not really overlap: both are within 10 % of their
-// memory floor (1.1 GB and 0.7 GB per 2^21 terms), and whichever starts second is starved by the older waves.
+// Normalisation on the main stream, sort on the second one.
+// Where the gather records of the pass come from:
+//   ahead == nullptr                the pass prepares its own n points into the context's buffer
+//   ahead->launch                   this pass ALSO prepares the points of all later passes (ahead->n points from d_points
+//                                   on) into ahead->pts in the same launch, and records ahead->done: 3584 waves instead
+//                                   of 512 hide the latency of the normaliser's 64-step chains, and no later pass has
+//                                   a normalisation between the reduction before it and its accumulation
+//   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
+struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot,
-                                hipEvent_t wait_acc) {
-    int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256);
-    if (r) return r;
-    if (in_fmt == C25519_FMT_RAW160 && (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
-    uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
+                                hipEvent_t wait_acc, const pts_ahead *ahead = nullptr) {
+    int32_t r;
+    uint32_t *d_pts;
+    if (!ahead) {
+        if ((r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256))) return r;
+        d_pts = (uint32_t *)ctx->tmp_e.p;
+    } else d_pts = ahead->pts + ahead->offset * (PTS_BYTES / 4);
     hipEvent_t *ring = pass_ring(owner, ctx);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
     HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, ctx->stream));
@@ -1328,7 +1454,11 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     msm_plan pl;
     static const int sort_first = env_int("C25519_SORT_FIRST", 0);      // A/B knob: measured 2.26 (prep first) vs 2.34 ms (sort first) at 2^21 terms
     if (sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
-    if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r;
+    if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
+    else if (ahead->launch) {
+        if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
+        HIPCHK(hipEventRecord(ahead->done, ctx->stream));
+    } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
     if (!sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
@@ -1348,12 +1478,18 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     std::vector<ge_p3> cols(g.nwin, ge_identity());
     bool none = false, bad_scalar = false;
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
+    // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
+    // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
+    static const int ahead_knob = env_int("C25519_PREP_AHEAD", 1);          // A/B knob
+    const bool ahead = ahead_knob && passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160;
+    if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
-            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc))) {
+            pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p0 + i == 1};
+            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr))) {
                 if (ctx->err.empty()) ctx->err = c->err;
                 return r;
             }
