@@ -205,6 +205,36 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
         assert st == 0 and got == want
 
 
+@pytest.mark.parametrize("env", [{"C25519_PREP_CHUNK": "64"}, {"C25519_PREP_CHUNK": "32", "C25519_PREP_WPB": "1"}, {"C25519_PREP_CHUNK": "128", "C25519_PREP_WPB": "1"},
+                                 {"C25519_PREP_COALESCED": "0"}, {"C25519_ACC_PIPE": "3"}, {"C25519_ACC_PIPE": "4", "C25519_ACC_CHAIN": "0"},
+                                 {"C25519_MSM_PASS_LOG2": "16", "C25519_PREP_CHUNK": "64"}, {"C25519_MSM_PASS_LOG2": "16", "C25519_PREP_AHEAD": "0"}])
+def test_msm_kernel_variants_in_a_fresh_process(orc, env):
+    """The tuning knobs are read once per process: every form of the normaliser (points per inversion, waves per block, the
+    per-lane r1 kernel), of the gather (per lane / wave-cooperative) and of the pass split (records prepared ahead or per
+    pass, 2^16-term passes so that a small input runs many) must give the same MSM on ragged sizes -- last wave partly out
+    of range, last step of a lane out of range, fewer points than one block."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import util, curve25519_dalek_amd as pkg
+        from oracle import orc
+        eng = pkg.Engine(0)
+        L = util.L
+        for n in (1, 63, 65, 4097, 3 * 65536 + 5, 262144 + 64 * 37 + 1):
+            x = util.rand_scalars(500 + n, n)
+            pts = eng.mul_base_batch(x, out_fmt=2)
+            pts[::3] = eng.decompress_batch(eng.compress_batch(pts[::3]))[1]          # a third of the points affine (Z = 1)
+            want = orc.ed_compress(orc.ed_mul_base((sum(int.from_bytes(r.tobytes(), "little") ** 2 for r in x) %% L).to_bytes(32, "little")))
+            st, got = eng.msm_vartime(x, pts, in_fmt=2, out_fmt=0)
+            assert st == 0 and got == want, n
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    e = dict(os.environ); e.update(env)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-2000:])
+
+
 def test_msm_two_passes_odd_size(eng, orc):
     """3*2^20 + 17 terms: two passes of unequal length (msm.hip MSM_PASS_MAX), partial sums added on the host."""
     import torch
