@@ -237,6 +237,7 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 // D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
 __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
     C25519_PRIO_CHAIN();
+    // (two terms per thread and one 32-bit store per window instead of two 2-byte stores: 0.24 ms against 0.11)
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     u32 s[9];
@@ -405,9 +406,14 @@ __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ 
     const uint16_t *Dk = D + (u64)k * n;
     if ((((u64)k * n) & 7) == 0 && hi - lo == PART_CHUNK) {           // full, 16-byte aligned chunk: eight digits per load
         const uint4 *q = reinterpret_cast<const uint4 *>(Dk + lo);
-        for (int i = threadIdx.x; i < PART_CHUNK / 8; i += 256) {
-            uint4 v = q[i];
-            u32 x[4] = {v.x, v.y, v.z, v.w};
+        constexpr int LD = 8;                                          // PART_CHUNK / 8 / 256 <= 8 loads per thread, all in flight at once
+        uint4 v[LD];
+#pragma unroll
+        for (int r = 0; r < LD; r++) { const int i = threadIdx.x + 256 * r; v[r] = i < PART_CHUNK / 8 ? q[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int r = 0; r < LD; r++) {
+            if (threadIdx.x + 256 * r >= PART_CHUNK / 8) break;
+            u32 x[4] = {v[r].x, v[r].y, v[r].z, v[r].w};
 #pragma unroll
             for (int h = 0; h < 8; h++) {
                 u32 sl, e;
@@ -431,8 +437,15 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL
     const int k = blockIdx.x, tid = threadIdx.x, M = SL * nchunk;
     u32 *v = cc + (u64)k * M;
     const int per = (M + 1023) / 1024, i0 = tid * per, i1 = i0 + per < M ? i0 + per : M;
+    constexpr int REG = 16;                // a thread's counters stay in registers between the two sweeps when there are <= 16 of
+    u32 c[REG];                            // them (2^21 terms: exactly 16), with all its loads in flight at once
     u32 sum = 0;
-    for (int i = i0; i < i1; i++) sum += v[i];
+    if (per <= REG) {
+#pragma unroll
+        for (int r = 0; r < REG; r++) c[r] = (r < per && i0 + r < M) ? v[i0 + r] : 0u;
+#pragma unroll
+        for (int r = 0; r < REG; r++) sum += c[r];
+    } else for (int i = i0; i < i1; i++) sum += v[i];
     part[tid] = sum;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
@@ -442,10 +455,20 @@ __global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL
         __syncthreads();
     }
     u32 run = part[tid] - sum;
-    for (int i = i0; i < i1; i++) {
-        u32 c = v[i]; v[i] = run;
+    if (per <= REG) {
+#pragma unroll
+        for (int r = 0; r < REG; r++) {
+            const int i = i0 + r;
+            if (r < per && i < M) {
+                v[i] = run;
+                if (i % nchunk == 0) bin_base[(u64)k * (SL + 1) + i / nchunk] = run;
+                run += c[r];
+            }
+        }
+    } else for (int i = i0; i < i1; i++) {
+        u32 cv = v[i]; v[i] = run;
         if (i % nchunk == 0) bin_base[(u64)k * (SL + 1) + i / nchunk] = run;
-        run += c;
+        run += cv;
     }
     if (tid == 1023) { bin_base[(u64)k * (SL + 1) + SL] = part[1023]; base[(u64)k * (g.half + 1) + g.half] = part[1023]; }
 }
