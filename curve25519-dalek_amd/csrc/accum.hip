@@ -116,6 +116,8 @@ __global__ void __launch_bounds__(256) ACCUM_ATTR k_accumulate(const u32 *__rest
             if (it + 2 < len) e1 = list[lo + it + 2];
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (it + 1 < wmax) { C25519_COOP_ISSUE(e_next) }
+            // (the loop counter is wave-uniform here, so the first entry of a list could be CONVERTED -- 1 M instead of 7 M --
+            //  behind a uniform branch: 76 scratch accesses in the addition at the 168-register budget)
             if (active) acc = ge_madd_acc(acc, pts_from_q(q), neg);
             e = e_next;
         }
