@@ -897,7 +897,9 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
 //   compression is done once on the host (the per-level IVs below), and `data` has a fixed length per level, so no
 //   length padding is needed: a Merkle-Damgard chain over fixed-length inputs is collision resistant if the compression
 //   function is; 32-byte nodes give the 128-bit level of the z_i.
-//   level 0: data = hram_16j || s_16j || ... || hram_16j+15 || s_16j+15 (absent = zero bytes): 12 blocks per 16 signatures.
+//   level 0: data = hram_4j || s_4j || ... || hram_4j+3 || s_4j+3 (absent = zero bytes): 3 blocks per 4 signatures, one lane
+//            each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
+//            VGPRs -- a latency-bound kernel that did not fit beside the decompression; now 4096 waves).
 //   level l: data = four children: ONE compression per node.  These levels are pure latency (one dependent SHA-512
 //            compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
 constexpr int ZTREE_MAX_LEVELS = 16;
@@ -905,29 +907,26 @@ struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
     C25519_PRIO_CHAIN();
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    u64 m_out = (n + 15) / 16;
+    u64 m_out = (n + 3) / 4;
     if (j >= m_out) return;
     u64 hs[8];
     for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
+    u64 rec[48];                                          // 4 records of 96 bytes = 3 blocks
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 c = 4 * j + r;
+        const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
+#pragma unroll
+        for (int q = 0; q < 8; q++) rec[12 * r + q] = c < n ? bswap64(h[q]) : 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[12 * r + 8 + q] = c < n ? bswap64(sg[q]) : 0ull;
+    }
 #pragma unroll 1
-    for (int grp = 0; grp < 4; grp++) {                   // 4 records of 96 bytes = 3 blocks
-        u64 rec[48];
+    for (int blk = 0; blk < 3; blk++) {
+        u64 w[16];
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const u64 c = 16 * j + 4 * grp + r;
-            const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
-#pragma unroll
-            for (int q = 0; q < 8; q++) rec[12 * r + q] = c < n ? bswap64(h[q]) : 0ull;
-#pragma unroll
-            for (int q = 0; q < 4; q++) rec[12 * r + 8 + q] = c < n ? bswap64(sg[q]) : 0ull;
-        }
-#pragma unroll
-        for (int blk = 0; blk < 3; blk++) {
-            u64 w[16];
-#pragma unroll
-            for (int q = 0; q < 16; q++) w[q] = rec[16 * blk + q];
-            sha512_compress(hs, w);
-        }
+        for (int q = 0; q < 16; q++) w[q] = blk == 0 ? rec[q] : blk == 1 ? rec[16 + q] : rec[32 + q];
+        sha512_compress(hs, w);
     }
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
     for (int q = 0; q < 4; q++) o[q] = hs[q];
@@ -1603,7 +1602,7 @@ static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
     uint64_t count = n;                                  // inputs of level 0: signatures
     for (int l = 0; l < ZTREE_MAX_LEVELS; l++) {
         u64 w[16] = {0};
-        const char tag[] = "c25519-hip/verify_batch/z-tree/v2";
+        const char tag[] = "c25519-hip/verify_batch/z-tree/v3";
         static_assert(sizeof(tag) - 1 <= 64, "tag fits the first half of the block");
         uint8_t blk[128] = {0};
         memcpy(blk, tag, sizeof(tag) - 1);
@@ -1611,15 +1610,15 @@ static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
         w[13] = (u64)l; w[14] = count; w[15] = n;        // level, number of inputs of this level, batch size
         sha512_init(ivs.iv[l]);
         sha512_compress(ivs.iv[l], w);
-        count = l == 0 ? (count + 15) / 16 : (count + 3) / 4;
+        count = (count + 3) / 4;
     }
 }
 // the z_i of one pass (n signatures) by the device derivation; z16: room for 4 * ceil(n/4) entries.  t0 / t1: tree scratch
-// ((n/16 + 1) * 32 bytes each).  Enqueued on `sa`.
+// ((n/4 + 1) * 32 bytes each).  Enqueued on `sa`.
 static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hram, const uint8_t *d_sigs, uint64_t n, uint8_t *t0, uint8_t *t1, uint8_t *z16) {
     ztree_ivs ivs;
     ztree_make_ivs(n, ivs);
-    uint64_t mm = (n + 15) / 16; uint8_t *a = t0, *b = t1;
+    uint64_t mm = (n + 3) / 4; uint8_t *a = t0, *b = t1;
     uint32_t level = 1;
     hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, ivs, a);
     while (mm > 1024) {
@@ -1649,7 +1648,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     const unsigned nblk = div_up64(n, 256);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 16 + 2) * 32), oT1 = carve((n / 16 + 2) * 32), oP = carve((size_t)nblk * 40);
+    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32), oP = carve((size_t)nblk * 40);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1;
@@ -1813,7 +1812,7 @@ EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const
     int32_t r;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oM = carve(mlen + 64), oO = carve((n + 1) * 8), oS = carve(n * 64), oK = carve(n * 32), oH = carve(n * 64), oZ = carve((n + 4) * 16), oT0 = carve((n / 16 + 2) * 32), oT1 = carve((n / 16 + 2) * 32);
+    size_t oM = carve(mlen + 64), oO = carve((n + 1) * 8), oS = carve(n * 64), oK = carve(n * 32), oH = carve(n * 64), oZ = carve((n + 4) * 16), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     hipStream_t st = ctx->stream;
