@@ -39,10 +39,24 @@ for z in (0, 1):
     assert e.verify_batch(msgs, S, P, z) == 0
 assert not e.verify_each(msgs, S, P, True).any()
 hp = e.precomp_create(pts[:300]); st, r = e.precomp_msm_vartime(hp, s[:300], s[300:320], pts[300:320]); h.update(r)
+# the reference's overflow hunt (edwards.rs:2254-2261: 1000 chained scalar multiplications under debug assertions): the raw
+# projective output of one variable-base multiplication is the input of the next, in both table modes, 64 chains wide
+cur = pts[:64].copy(); cur_v = cur.copy(); prod = [1] * 64
+for it in range(200):
+    sc = util.rand_scalars(1000 + it, 64)
+    cur, ok = e.mul_batch(sc, cur, out_fmt=2); assert ok.all()
+    cur_v, ok = ev.mul_batch(sc, cur_v, out_fmt=2); assert ok.all()
+    prod = [(p * int.from_bytes(x.tobytes(), "little")) %% util.L for p, x in zip(prod, sc)]
+enc = e.compress_batch(cur); assert np.array_equal(enc, ev.compress_batch(cur_v))
+want, ok = e.mul_batch(np.frombuffer(b"".join(p.to_bytes(32, "little") for p in prod), np.uint8).reshape(64, 32), pts[:64]); assert np.array_equal(enc, want)
+h.update(enc.tobytes())
+# a multi-pass MSM with small passes (records prepared ahead, 64 points per inversion) and affine + projective inputs mixed
+big = util.rand_scalars(77, 300000); bp = ev.mul_base_batch(big, out_fmt=2); bp[::5] = e.decompress_batch(e.compress_batch(bp[::5]))[1]
+st, r = e.msm_vartime(big, bp); assert st == 0; h.update(r)
 rng = np.random.default_rng(9)
 a = rng.integers(0, 1 << 26, size=(4096, 10), dtype=np.uint64).astype(np.uint32); a[:, 1::2] >>= 1
 for chain in (0, 1):
-    for op in (0, 1, 2, 3, 4, 5, 6, 7):
+    for op in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11):
         h.update(e.selftest_field(op, a, a[::-1].copy(), chain).tobytes())
 print("DIGEST", h.hexdigest())
 '''
@@ -66,6 +80,7 @@ except pkg.EngineError as ex:
 
 def _run(code, lib):
     env = dict(os.environ)
+    env["C25519_MSM_PASS_LOG2"] = "16"; env["C25519_PREP_CHUNK"] = "64"      # many small passes, the largest normaliser chunk
     if lib:
         env["C25519_HIP_LIB"] = lib
     else:
