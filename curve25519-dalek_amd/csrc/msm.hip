@@ -527,14 +527,38 @@ __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ 
         for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
     }
 }
+// a long bucket's list is cut into segments of LONG_SEG entries: one work item each (k_long_segments)
+struct long_item { u32 gid, lo, hi, first; };
+// what the bucket order needs from one bucket with c entries: its length class (a 256-bin block-local histogram) and, for a
+// list beyond the cap, its long-bucket work items
+__device__ __forceinline__ void order_note_bucket(u32 c, u64 G, const msm_geom &g, const u32 *__restrict__ base, u32 *h, u32 max_items, long_item *__restrict__ items,
+                                                  u32 *__restrict__ counters, u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
+    atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u);
+    if (c > g.long_cap) {
+        const int k = (int)(G / g.half), b = (int)(G % g.half);
+        const u32 lo = base[(u64)k * (g.half + 1) + b], hi = lo + c;
+        const u32 nseg = (c + LONG_SEG - 1) / LONG_SEG;
+        const u32 first = atomicAdd(&counters[0], nseg);
+        const u32 lb = atomicAdd(&counters[1], 1u);
+        long_gids[lb] = (u32)G;
+        long_first[lb] = first;
+        // number of segments of this bucket is recomputed by the combiner from base[]
+        for (u32 sg = 0; sg < nseg && first + sg < max_items; sg++) {
+            long_item it; it.gid = (u32)G; it.lo = lo + sg * LONG_SEG; it.hi = (it.lo + LONG_SEG < hi) ? it.lo + LONG_SEG : hi; it.first = first;
+            items[first + sg] = it;
+        }
+    }
+}
 // pass 2: bin (window k, slice s) -> final order, bucket totals and bucket offsets.  The bin's entries live in
 // registers (18 per thread), LDS holds only the sorted copy: 74 KB per block, two blocks per CU.
 constexpr int PART_R = PART_CAP / 1024;
 __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
-                                                u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted) {
+                                                u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted,
+                                                u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items, u32 *__restrict__ counters,
+                                                u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
-    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *out = sm + 2 * PART_BPS_MAX;
+    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX;
     const int PART_BPS = 1 << g.bps_log2;
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
     const u32 b0 = bin_base[(u64)k * (SL + 1) + sidx], m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0;
@@ -542,6 +566,7 @@ __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u
     u32 *dst = sorted + (u64)k * n + b0;
     const bool fits = m <= (u32)PART_CAP;
     if (tid < PART_BPS) cnt[tid] = 0;
+    if (tid < 256) oh[tid] = 0;
     __syncthreads();
     u32 e[PART_R];
     if (fits) {
@@ -569,6 +594,11 @@ __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u
         base[(u64)k * (g.half + 1) + b] = b0 + cur[tid];
     }
     __syncthreads();
+    // the bucket order's length histogram and the long-bucket work list, while the counts are here (was k_order_hist,
+    // a launch of its own over the totals: 25 us in the gap between two accumulations)
+    if (tid < PART_BPS) order_note_bucket(cnt[tid], (u64)k * g.half + (u64)sidx * PART_BPS + tid, g, base, oh, max_items, items, counters, long_gids, long_first);
+    __syncthreads();
+    if (tid < 256 && oh[tid]) atomicAdd(&ord_hist[tid], oh[tid]);
     if (fits) {
 #pragma unroll
         for (int r = 0; r < PART_R; r++)
@@ -643,7 +673,6 @@ __global__ void __launch_bounds__(1024) k_scatter_sliced(const uint16_t *__restr
 // Counting sort of the (window, bucket) ids by list length (clamped to 255), longest first, so that a
 // wave's 64 lanes finish together (Poisson-distributed lengths otherwise cost ~25 % idle lanes) and the
 // long lists start first.  ord_hist: 256 global bins; perm: bucket ids in processing order.
-struct long_item { u32 gid, lo, hi, first; };
 // The same sweep over the bucket totals also emits the work list of the wave-cooperative long-bucket path (one item per
 // segment of LONG_SEG entries of a bucket longer than LONG_CAP), so the list exists before accumulation starts
 // (round 1 had a separate k_find_long on the second stream: a 16-VGPR scan that took 0.6 ms starved beside k_accumulate).
@@ -656,35 +685,17 @@ __global__ void __launch_bounds__(256) k_order_hist(const u32 *__restrict__ tota
     h[threadIdx.x] = 0;
     __syncthreads();
     u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < nb) {
-        const u32 c = totals[gid_off + gid];
-        atomicAdd(&h[255u - (c > 255u ? 255u : c)], 1u);
-        if (c > g.long_cap) {
-            const u64 G = gid + gid_off;
-            const int k = (int)(G / g.half), b = (int)(G % g.half);
-            const u32 lo = base[(u64)k * (g.half + 1) + b], hi = lo + c;
-            const u32 nseg = (c + LONG_SEG - 1) / LONG_SEG;
-            const u32 first = atomicAdd(&counters[0], nseg);
-            const u32 lb = atomicAdd(&counters[1], 1u);
-            long_gids[lb] = (u32)G;
-            long_first[lb] = first;
-            // number of segments of this bucket is recomputed by the combiner from base[]
-            for (u32 sg = 0; sg < nseg && first + sg < max_items; sg++) {
-                long_item it; it.gid = (u32)G; it.lo = lo + sg * LONG_SEG; it.hi = (it.lo + LONG_SEG < hi) ? it.lo + LONG_SEG : hi; it.first = first;
-                items[first + sg] = it;
-            }
-        }
-    }
+    if (gid < nb) order_note_bucket(totals[gid_off + gid], gid + gid_off, g, base, h, max_items, items, counters, long_gids, long_first);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ord_hist[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) {   // one block: exclusive scan of 256 bins
+    C25519_PRIO_CHAIN();
     __shared__ u32 p[256];
     u32 v = ord_hist[threadIdx.x];
     p[threadIdx.x] = v;
     __syncthreads();
     for (int off = 1; off < 256; off <<= 1) {
-    C25519_PRIO_CHAIN();
         u32 a = (int)threadIdx.x >= off ? p[threadIdx.x - off] : 0;
         __syncthreads();
         p[threadIdx.x] += a;
@@ -1244,13 +1255,13 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
     if (use_part) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
-        const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)2 * PART_BPS_MAX + PART_CAP) * 4;
+        const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, PART_CHUNK, cc);
         hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(1024), 0, st, cc, SL, pchunks, g, bin_base, base);
         hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, PART_CHUNK, cc, P1);
-        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted);
+        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     } else {
         size_t lds = (size_t)g.half * 4;
         static const int xswap = env_int("C25519_XCD_SWAP", 1);
@@ -1273,7 +1284,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     }
     // bucket order (longest lists first) and the long-bucket work list: still on the sort stream -- they only need the lists
-    hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
+    if (!use_part) hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     hipLaunchKernelGGL(k_order_scan, dim3(1), dim3(256), 0, st, ord_hist);
     hipLaunchKernelGGL(k_order_scatter, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, 0u, ord_hist, perm);
     HIPCHK(hipGetLastError());
