@@ -237,7 +237,8 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 // D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
 __global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
     C25519_PRIO_CHAIN();
-    // (two terms per thread and one 32-bit store per window instead of two 2-byte stores: 0.24 ms against 0.11)
+    // (two terms per thread and one 32-bit store per window instead of two 2-byte stores: 0.24 ms against 0.11; the block's
+    //  17 x 256 digits through LDS and out as 16-byte stores: 0.29 ms)
     u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     u32 s[9];
