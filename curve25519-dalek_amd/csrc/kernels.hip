@@ -53,15 +53,23 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
             carry = neg ? 1u : 0u;
             u32 tw[24];
             if (CT) {
+                // window.rs:54-76 on the GPU: every entry of the window is READ (wave-uniform LDS addresses) and the wanted
+                // one kept by selects.  The reads are pinned: without the asm LLVM sinks them under `hit` -- an exec-masked
+                // read behind s_cbranch_execz, i.e. a branch on whether any lane of the wave has this digit (found in round
+                // 2; tests/test_ct_isa.py asserts the instruction stream: 6 ds_read_b128 + 24 v_cndmask per entry, no
+                // exec-mask branch).  (The compare and the selects as one asm block with the condition in VCC: 3.04 ms
+                // against 2.81 for this form; unrolling the entry loop by 2 / 4: 2.84 / 2.83.)
 #pragma unroll
                 for (int i = 0; i < 24; i++) tw[i] = 0;
+                tw[0] = 1; tw[8] = 1;                                   // entry 0 is the identity (y+x = y-x = 1, 2dxy = 0): not scanned
 #pragma unroll 1
-                for (int ent = 0; ent < ENT; ent++) {
+                for (int ent = 1; ent < ENT; ent++) {
                     const uint4 *e = wtab + ent * 6;                    // wave-uniform address
                     const bool hit = (u32)ent == mag;
 #pragma unroll
                     for (int i = 0; i < 6; i++) {
-                        const uint4 v = e[i];
+                        uint4 v = e[i];
+                        asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
                         tw[4 * i] = hit ? v.x : tw[4 * i]; tw[4 * i + 1] = hit ? v.y : tw[4 * i + 1];
                         tw[4 * i + 2] = hit ? v.z : tw[4 * i + 2]; tw[4 * i + 3] = hit ? v.w : tw[4 * i + 3];
                     }

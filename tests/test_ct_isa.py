@@ -1,0 +1,104 @@
+"""Constant-time posture, checked on the COMPILED code (no GPU needed: hipcc -S for gfx950).
+
+The secret-scalar kernels promise what the reference's LookupTable::select promises (window.rs:54-76): every table
+entry of a window is read and the wanted one kept by a select -- no address and no branch depends on the scalar.  The
+source says so, but the compiler is free to turn `hit ? table[j] : acc` into a read that only the lanes with `hit` perform,
+behind a branch on "does any lane of the wave have this digit" (it did: round 2 found s_cbranch_execz around the LDS reads
+of k_mul_base<5, CT>).  So the property is asserted on the instruction stream:
+  * the scan loop of k_mul_base<5, 1024, *, CT>: 6 ds_read_b128 + 24 v_cndmask per entry, no exec-mask branch;
+  * the scan loop of k_var_base<*, *, CT>: only unconditional loads and selects, no exec-mask branch;
+  * the ladder loop of k_x25519: no exec-mask branch, and conditional swaps as v_cndmask."""
+import os
+import re
+import shutil
+import subprocess
+from collections import Counter
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "curve25519-dalek_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+pytestmark = pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+
+
+def _asm(tmp_path_factory, name):
+    out = tmp_path_factory.mktemp("isa") / (name + ".s")
+    subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), os.path.join(CSRC, name + ".hip")],
+                   check=True, capture_output=True, timeout=900)
+    return open(out).read().split("\n")
+
+
+def _functions(lines, pattern):
+    """-> {mangled name: body lines} for every function whose label matches"""
+    out = {}
+    for i, l in enumerate(lines):
+        m = re.match(r"^(" + pattern + r"\S*):", l)
+        if m:
+            end = next(j for j in range(i, len(lines)) if lines[j].startswith(".Lfunc_end"))
+            out[m.group(1)] = lines[i:end]
+    return out
+
+
+def _loops(body):
+    """-> [(label, Counter of opcodes)] for every backward branch (innermost loops come first in the text)"""
+    labels = {}
+    for a, x in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", x)
+        if m:
+            labels[m.group(1)] = a
+    res = []
+    for a, x in enumerate(body):
+        m = re.search(r"s_cbranch_\w+ (\.LBB\d+_\d+)", x)
+        if m and m.group(1) in labels and labels[m.group(1)] < a:
+            ops = Counter(y.split()[0] for y in body[labels[m.group(1)]:a + 1] if re.match(r"^\s+[a-z]", y))
+            res.append((m.group(1), ops))
+    return res
+
+
+def _exec_branches(ops):
+    return sum(v for k, v in ops.items() if k.startswith("s_cbranch_exec") or k.startswith("s_cbranch_vcc") or "saveexec" in k)
+
+
+@pytest.fixture(scope="module")
+def kernels_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "kernels")
+
+
+@pytest.fixture(scope="module")
+def single_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "single")
+
+
+def test_fixed_base_scan_reads_every_entry_without_a_branch(kernels_asm):
+    fns = _functions(kernels_asm, r"_ZN6c2551910k_mul_baseILi5ELi1024ELi\dELb1E")
+    assert len(fns) >= 2                                     # the output-format instantiations of the constant-time kernel
+    for name, body in fns.items():
+        scans = [ops for _, ops in _loops(body) if ops.get("ds_read_b128", 0) and not ops.get("v_mad_u64_u32", 0)]
+        assert len(scans) == 1, (name, [dict(o) for _, o in _loops(body)])
+        ops = scans[0]
+        assert ops["ds_read_b128"] == 6, (name, dict(ops))                      # one 96-byte entry per trip, always
+        assert ops.get("v_cndmask_b32_e64", 0) + ops.get("v_cndmask_b32_e32", 0) >= 24, (name, dict(ops))
+        assert _exec_branches(ops) == 0, (name, dict(ops))                      # the only branch is the scalar trip counter
+
+
+def test_variable_base_scan_has_no_data_dependent_branch(single_asm):
+    fns = _functions(single_asm, r"_ZN6c2551910k_var_baseILi\dELb\dELb1E")
+    assert len(fns) >= 2
+    for name, body in fns.items():
+        scans = [ops for _, ops in _loops(body) if sum(v for k, v in ops.items() if k.startswith("global_load")) and not ops.get("v_mad_u64_u32", 0)]
+        assert scans, name
+        for ops in scans:
+            assert _exec_branches(ops) == 0, (name, dict(ops))
+            assert ops.get("v_cndmask_b32_e64", 0) + ops.get("v_cndmask_b32_e32", 0) >= 40, (name, dict(ops))   # 4 x 10 limbs per entry
+
+
+def test_ladder_loop_has_no_data_dependent_branch(kernels_asm):
+    fns = _functions(kernels_asm, r"_ZN6c255198k_x25519E")
+    assert len(fns) == 1
+    body = next(iter(fns.values()))
+    ladders = [ops for _, ops in _loops(body) if ops.get("v_mad_u64_u32", 0) > 500]
+    assert len(ladders) == 1
+    ops = ladders[0]
+    assert _exec_branches(ops) == 0, dict(ops)
+    assert ops.get("v_cndmask_b32_e64", 0) + ops.get("v_cndmask_b32_e32", 0) >= 40, dict(ops)                   # cswap of (U, W) pairs
