@@ -22,7 +22,7 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(HERE, "liboracle.so")
+        path = os.environ.get("ORACLE_LIB") or os.path.join(HERE, "liboracle.so")      # ORACLE_LIB: the sanitizer build (tests)
         if not os.path.exists(path):
             build()
         _LIB = C.CDLL(path)

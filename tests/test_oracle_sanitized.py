@@ -1,0 +1,35 @@
+"""The CPU oracle under AddressSanitizer + UndefinedBehaviorSanitizer (oracle/Makefile: liboracle_san.so): the known-answer
+tests and the host transcript / restatement checks run once more against the instrumented build, in a process that preloads
+libasan.  The oracle is what every parity claim rests on; a stray out-of-bounds table or digit access in it must not pass
+as "bit-exact"."""
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE = os.path.join(ROOT, "oracle")
+
+
+def _libasan():
+    gcc = shutil.which("gcc")
+    if not gcc:
+        return None
+    p = subprocess.run([gcc, "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    return p if os.path.isabs(p) and os.path.exists(p) else None
+
+
+@pytest.mark.skipif(_libasan() is None, reason="gcc / libasan not available")
+def test_oracle_known_answers_under_asan_ubsan():
+    subprocess.check_call(["make", "-s", "-C", ORACLE, "liboracle_san.so"])
+    env = dict(os.environ)
+    env["ORACLE_LIB"] = os.path.join(ORACLE, "liboracle_san.so")
+    env["LD_PRELOAD"] = _libasan()
+    env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=1"
+    env["UBSAN_OPTIONS"] = "print_stacktrace=1:halt_on_error=1"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", os.path.join(ROOT, "tests", "test_oracle_kat.py")],
+                       env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "passed" in r.stdout and "failed" not in r.stdout
