@@ -32,6 +32,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# The binding unit of every kernel of this path is the 32 x 32 -> 64 bit integer multiply-add (v_mad_u64_u32).  The guide gives
+# no figure for it; its theoretical ceiling is one wave64 instruction per SIMD every 4 cycles = 16 lanes per clock per SIMD:
+SIMDS = 256 * 4
+MAC_LANES_PER_CLK_PER_SIMD = 16
 L_ORDER = 2**252 + 27742317777372353535851937790883648493
 
 # algorithmic bytes per unit and the kernel whose launches the roofline object describes
@@ -91,6 +95,7 @@ class Workload:
         self.rank, self.world, self.args = rank, world, args
         self.log2n, self.n = log2n, 1 << log2n
         self.variant = ""
+        self.force_collective = False
         self.result = {}
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xC25519 + 1000 * rank + {"msm": 1, "verify": 2, "fixed_base": 3, "x25519": 4}[name])
@@ -115,7 +120,8 @@ class Workload:
 
         def run():
             # this rank's partial sum, then the one exchange step (160 B per rank over RCCL) + fold
-            st, out = self.pkg.multi.msm_vartime_sharded(self.eng, self.xs, self.pts, E.FMT_RAW160, E.FMT_EDWARDS_Y)
+            # (under a launcher the collective runs even at world size 1, so that a one-GPU run exercises RCCL as well)
+            st, out = self.pkg.multi.msm_vartime_sharded(self.eng, self.xs, self.pts, E.FMT_RAW160, E.FMT_EDWARDS_Y, force_collective=self.force_collective)
             assert st == 0
             self.result["out"] = out
         self.run = run
@@ -186,8 +192,14 @@ class Workload:
 
     # -- kernel timings from the HIP events the library records on the launch streams -----------------------------------
     def kernel_times(self, steps):
-        """-> dict: dominant kernel ms per LAUNCH (averaged over the timed steps), launches per step, other figures"""
+        """-> dict: dominant kernel ms per LAUNCH (averaged over the timed steps), launches per step, other figures.  Durations
+        are HIP events the library records on its launch streams; the kernel names are the ones it launched
+        (c25519_last_kernel_name), not literals of this file."""
         eng = self.eng
+        lib = self.pkg.load_library()
+        lib.c25519_last_kernel_name.restype = __import__("ctypes").c_char_p
+        lib.c25519_last_kernel_name.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_int]
+        kname = lambda which: lib.c25519_last_kernel_name(eng.ctx, which).decode()
         if self.name in ("msm", "verify"):
             # the latest call's passes (the timed steps are identical; the ring keeps per-pass events)
             acc_ms, passes = eng.last_call_phase_ms(0)
@@ -199,16 +211,16 @@ class Workload:
                 dec_ms, _ = eng.last_call_phase_ms(3)
                 out["k_prep_compressed_R_ms_per_launch"] = dec_ms / passes
                 out["dominant_ms"] = max(dec_ms, acc_ms) / passes
-                out["dominant_kernel"] = "k_prep_compressed<0> (decompression of R_i)" if dec_ms >= acc_ms else "k_accumulate<3>"
+                out["dominant_is_prep"] = dec_ms >= acc_ms
+                out["dominant_kernel"] = kname(1) if dec_ms >= acc_ms else kname(0)
             else:
                 out["dominant_ms"] = acc_ms / passes
-                out["dominant_kernel"] = "k_accumulate<3>"
+                out["dominant_kernel"] = kname(0)
             return out
         k = min(steps, 64)
         dom = sum(eng.phase_ms(b, 0) for b in range(k)) / k
         rest = sum(eng.phase_ms(b, 1) for b in range(k)) / k
-        return {"passes_per_step": 1, "dominant_ms": dom, "other_kernels_ms": rest,
-                "dominant_kernel": {"fixed_base": "k_mul_base_*", "x25519": "k_x25519"}[self.name]}
+        return {"passes_per_step": 1, "dominant_ms": dom, "other_kernels_ms": rest, "dominant_kernel": kname(0)}
 
     def units_per_launch(self, kt):
         return float(self.n) / kt["passes_per_step"]
@@ -296,7 +308,7 @@ def time_steps(run, steps, warmup, barrier):
     return time.perf_counter() - t0
 
 
-def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling):
+def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling, clock_hz):
     """The JSON object of one workload."""
     name = w.name
     kt = w.kt                       # taken right after the timed steps (before the CPU leg makes other calls on the engine)
@@ -308,34 +320,48 @@ def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling):
     upl = w.units_per_launch(kt)
     algo_bytes = ALGO[name]["bytes"] * upl
     dom_ms = kt["dominant_ms"]
-    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
+    hbm_achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     # PMC traffic of the kernel the roofline object describes
-    pk = {"msm": "k_accumulate", "verify": "k_prep_compressed" if "prep" in kt.get("dominant_kernel", "") else "k_accumulate",
+    pk = {"msm": "k_accumulate", "verify": "k_prep_compressed" if kt.get("dominant_is_prep") else "k_accumulate",
           "fixed_base": "k_mul_base_comb" if w.variant == "comb" else ("k_mul_base<" if w.variant == "ct" else "k_mul_base_wide"), "x25519": "k_x25519"}[name]
     traffic, traffic_src = pmc_traffic(name if not w.variant else name + "_" + w.variant, pk)
     per_gpu = units / dt / world
+    kmac = costs.mac(w.kernel_cost(cost))                                  # multiply-adds per unit inside the dominant kernel
+    mac_achieved = (upl * kmac / (dom_ms * 1e-3)) if dom_ms else None       # MAC/s of the dominant kernel while it runs
+    mac_theory = SIMDS * MAC_LANES_PER_CLK_PER_SIMD * clock_hz
     res = {
         "metric": ALGO[name]["metric"], "value": units / dt, "unit": ALGO[name]["unit"],
         "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": "u32 limbs (radix 2^25.5), u64 accumulators", "data": "synthetic",
         "config": {"workload": w.describe(), "units_per_gpu": w.n, "units_per_step": int(total_units),
-                   "parallelism": (("%d-term MSM sharded over %d rank(s), all_gather of 160-B partials + fold" % (int(total_units), world)) if name == "msm" else "replicas x%d" % world)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                     "traffic": traffic, "traffic_source": traffic_src,
-                     "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms) else None,
+                   "parallelism": (("%d-term MSM sharded over %d rank(s), all_gather of the partial-result records + fold" % (int(total_units), world)) if name == "msm" else "replicas x%d" % world)},
+        # The roof that binds these kernels is integer multiply-add issue, not bytes: the object leads with it.
+        "roofline": {"bound": "valu_int_mac", "unit": "TMAC/s",
+                     "achieved": mac_achieved / 1e12 if mac_achieved else None,
+                     "peak": mac_peak / 1e12, "frac": (mac_achieved / mac_peak) if mac_achieved else None,
+                     "peak_measured": mac_peak / 1e12, "peak_measured_source": "c25519_microbench(0): 8 independent v_mad_u64_u32 chains, 8 waves per SIMD, on this GPU in this run",
+                     "peak_theoretical": mac_theory / 1e12,
+                     "peak_theoretical_source": "%d SIMDs x %d lanes/clk (one wave64 v_mad_u64_u32 per 4 cycles) x %.2f GHz" % (SIMDS, MAC_LANES_PER_CLK_PER_SIMD, clock_hz / 1e9),
+                     "frac_of_theoretical": (mac_achieved / mac_theory) if mac_achieved else None,
                      "kernel": kt["dominant_kernel"], "kernel_ms_per_launch": dom_ms, "launches_per_step": kt["passes_per_step"],
-                     "units_per_launch": upl, "algorithmic_bytes_per_unit": ALGO[name]["bytes"], "algorithmic_bytes_what": ALGO[name]["bytes_what"],
-                     "algorithmic_bytes": algo_bytes, "timings_ms": {k: v for k, v in kt.items() if isinstance(v, float)},
-                     "note": "`frac` prices the ALGORITHMIC bytes (what the caller hands over) against HBM: small, because the kernel is bound by "
-                             "v_mad_u64_u32 issue (see `valu`).  `traffic` is what the kernel actually moves per launch (PMC; table / point "
-                             "gathers): `traffic_frac` of HBM peak is the second roof these kernels sit under"},
-        "valu": {"bound": "v_mad_u64_u32 issue", "mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": ref_mac,
-                 "field_ops_per_unit": "%.1f M + %.1f S: %s" % (cost["M"], cost["S"], cost["what"]),
-                 "achieved": per_gpu * mac_impl / 1e12, "peak": mac_peak / 1e12, "unit": "TMAC/s (per GPU)",
-                 "frac": per_gpu * mac_impl / mac_peak, "peak_source": "c25519_microbench(0) on this GPU, this run",
-                 "dominant_kernel_frac": (upl * costs.mac(w.kernel_cost(cost)) / (dom_ms * 1e-3) / mac_peak) if dom_ms else None},
+                     "units_per_launch": upl, "mac_per_unit_in_kernel": kmac,
+                     "timings_ms": {k: v for k, v in kt.items() if isinstance(v, float)},
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     # the whole call (every kernel of the step, not only the dominant one) against the same roof
+                     "whole_call": {"mac_per_unit_implemented": mac_impl, "mac_per_unit_reference": ref_mac,
+                                    "field_ops_per_unit": "%.1f M + %.1f S: %s" % (cost["M"], cost["S"], cost["what"]),
+                                    "achieved": per_gpu * mac_impl / 1e12, "frac": per_gpu * mac_impl / mac_peak,
+                                    "frac_of_theoretical": per_gpu * mac_impl / mac_theory},
+                     # the byte side: algorithmic bytes per launch against HBM, and what the kernel really moves (PMC)
+                     "hbm": {"bound": "hbm", "achieved": hbm_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": (hbm_achieved / HBM_PEAK_GBS) if hbm_achieved else None,
+                             "algorithmic_bytes_per_unit": ALGO[name]["bytes"], "algorithmic_bytes_what": ALGO[name]["bytes_what"], "algorithmic_bytes": algo_bytes,
+                             "traffic": traffic, "traffic_source": traffic_src,
+                             "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms) else None,
+                             "note": "`frac` prices the ALGORITHMIC bytes (what the caller hands over) against HBM: small, because the kernel is bound by "
+                                     "v_mad_u64_u32 issue.  `traffic` is what the kernel actually moves per launch (PMC; table / point gathers): "
+                                     "`traffic_frac` of HBM peak is the second roof these kernels sit under"}},
         "cpu_baseline": cpu_baseline,
     }
     return res
@@ -363,7 +389,7 @@ def _kernel_cost(self, cost):
     if self.name == "msm":
         return {"M": 7 * (nwin - 1), "S": 0}
     if self.name == "verify":
-        return {"M": 23, "S": 255} if "prep" in self.kt.get("dominant_kernel", "") else {"M": 7 * (8 + nwin - 1), "S": 0}
+        return {"M": 23, "S": 255} if self.kt.get("dominant_is_prep") else {"M": 7 * (8 + nwin - 1), "S": 0}
     if self.name == "fixed_base":
         c = costs.compress_batch()
         return {"M": cost["M"] - c["M"], "S": cost["S"] - c["S"]}
@@ -458,6 +484,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    w.force_collective = use_dist
+    clock_hz = float(getattr(torch.cuda.get_device_properties(dev), "clock_rate", 2400000)) * 1e3      # kHz -> Hz (MI355X: 2.4 GHz)
     w.self_check()
     # live peak of the binding unit on THIS box (box-to-box spread is ~6 %): v_mad_u64_u32 issue rate, measured right
     # before the timed steps by the library's own probe kernel (c25519_microbench, kernels.hip), best of 100 runs.
@@ -478,8 +506,9 @@ def main():
     budget = float(os.environ.get("C25519_BENCH_CPU_S", "10"))
     res = None
     if rank == 0:
-        res = record(w, dt, args.steps, args.warmup, world, mac_peak, w.cpu_baseline(budget) if want_cpu else None, scaling)
+        res = record(w, dt, args.steps, args.warmup, world, mac_peak, w.cpu_baseline(budget) if want_cpu else None, scaling, clock_hz)
         res["ranks_seen_by_rccl"] = rccl_ranks
+        res["collective_executed_per_step"] = bool(use_dist and head == "msm")
     if use_dist:
         dist.barrier()
 
@@ -494,7 +523,7 @@ def main():
             max(eng.microbench(0, 4000) for _ in range(10))             # keep the clock up between workloads
             d = time_steps(ww.run, steps, warmup, barrier)
             ww.kt = ww.kernel_times(steps)
-            r = record(ww, d, steps, warmup, 1, mac_peak, ww.cpu_baseline(budget / 2) if (cpu and want_cpu) else None, "weak")
+            r = record(ww, d, steps, warmup, 1, mac_peak, ww.cpu_baseline(budget / 2) if (cpu and want_cpu) else None, "weak", clock_hz)
             for k in ("higher_is_better", "scaling", "vs_baseline", "dtype", "data", "n_gpus"):
                 r.pop(k, None)
             sub[key] = r

@@ -161,9 +161,8 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreate(&ctx->ev0); hipEventCreate(&ctx->ev1);
     // The second stream carries the latency-bound chains (hash tree, sort) that the VALU-bound kernels of the main stream
     // would otherwise starve (older waves win the issue arbiter): it is created with the highest priority.
-    static const int aux_prio = [] { const char *e = getenv("C25519_AUX_PRIO"); return e ? atoi(e) : 1; }();   // A/B knob
     int plo = 0, phi = 0;
-    if (aux_prio && hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo) {
+    if (hipDeviceGetStreamPriorityRange(&plo, &phi) == hipSuccess && phi < plo) {
         if (hipStreamCreateWithPriority(&ctx->aux, hipStreamNonBlocking, phi) != hipSuccess) return false;
     } else if (hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking) != hipSuccess) return false;
     hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming);
@@ -172,8 +171,9 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_pts, hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
-    if (hipMalloc((void **)&ctx->d_slots, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4) != hipSuccess) return false;
-    return hipHostMalloc(&ctx->h_msm, (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
+    // C25519_MAX_SLOTS pass slots + the context's own record (msm.hip drec)
+    if (hipMalloc((void **)&ctx->d_slots, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4) != hipSuccess) return false;
+    return hipHostMalloc(&ctx->h_msm, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
 }
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
 c25519_ctx *ctx_peer(c25519_ctx *ctx) {
@@ -318,6 +318,9 @@ EXPORT float c25519_last_call_phase_ms(c25519_ctx *ctx, int phase, uint32_t *pas
     return sum;
 }
 
+// name of the kernel that phase 0 (which = 0) / phase 3 (which = 1) of the latest entry point timed
+EXPORT const char *c25519_last_kernel_name(const c25519_ctx *ctx, int which) { return (ctx && which >= 0 && which < 2) ? ctx->kname[which] : ""; }
+
 // ---- fixed base --------------------------------------------------------------------------------
 int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -330,6 +333,8 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    ctx->kname[0] = secret ? "c25519::k_mul_base<5, 1024, OUT, true> (constant-time scan, radix-2^5 tables in LDS)"
+                           : (ctx->w >= 10 ? "c25519::k_mul_base_wide<OUT> (radix-2^w tables in HBM)" : ctx->w == 9 ? "c25519::k_mul_base_comb" : "c25519::k_mul_base<W, BS, OUT, false>");
     auto mul = [&](uint32_t *scratch, uint8_t *out_raw) -> hipError_t {
         return secret ? launch_mul_base_ct(d_scalars, n, ctx->d_table_ct, scratch, out_raw, ctx->num_cus, ctx->stream)
                       : launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, scratch, out_raw, ctx->num_cus, ctx->stream);
@@ -432,6 +437,7 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
+    ctx->kname[0] = "c25519::k_x25519";
     HIPCHK(launch_x25519(d_k, d_u, n, (uint32_t *)ctx->scratch.p, ctx->stream));
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     HIPCHK(launch_ratio_p32(0, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // U / W, 0 -> 0

@@ -605,20 +605,11 @@ static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_
     return hipGetLastError();
 }
 
-static int comb_block_size() {   // tuning knob (A/B on hardware): C25519_COMB_BS = 1024 | 768 | 512
-    static int bs = 0;
-    if (!bs) { const char *e = getenv("C25519_COMB_BS"); bs = e ? atoi(e) : 1024; if (bs != 768 && bs != 512) bs = 1024; }
-    return bs;
-}
 template <int BS, int OUT>
 static hipError_t launch_comb_bs(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st);
 template <int OUT>
 static hipError_t launch_comb(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st) {
-    switch (comb_block_size()) {
-    case 768: return launch_comb_bs<768, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
-    case 512: return launch_comb_bs<512, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
-    default: return launch_comb_bs<1024, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);
-    }
+    return launch_comb_bs<1024, OUT>(scalars, n, tab, scratch, out_raw, num_cus, st);     // (768 / 512-thread blocks measured slower in round 1)
 }
 template <int BS, int OUT>
 static hipError_t launch_comb_bs(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st) {
@@ -702,8 +693,7 @@ hipError_t launch_decompress_ristretto(const uint8_t *in, u64 n, uint8_t *out_ra
 // instead of 380, verify_batch 3.38 against 3.08 ms).  A 64 KB LDS reservation caps it at two blocks per CU.
 hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, bool shared, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    static const int cap = [] { const char *e = getenv("C25519_DEC_LDS"); return e ? atoi(e) : 65536; }();   // A/B knob
-    const unsigned lds = shared ? (unsigned)cap : 0u;
+    const unsigned lds = shared ? 65536u : 0u;
     if (fmt == 0) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
     else hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
     return hipGetLastError();

@@ -30,6 +30,8 @@
 #include <algorithm>
 #include <stdlib.h>
 #include <string.h>
+#include <stdexcept>
+#include <string>
 #include <vector>
 #include "../../include/c25519_hip.h"
 #include "devio.h"
@@ -83,45 +85,9 @@ namespace c25519 {
 // memory passes run at 3.6 - 5.2 TB/s and then contend with the sort on the second stream: no gain end to end), and
 // wave-coalesced record I/O transposed through LDS (8x fewer cache-line requests per instruction, but 40 + 30 + 32 LDS
 // dword accesses and four barriers per point: 0.47 ms).
-template <int CH>
-__global__ void __launch_bounds__(256) k_prep_raw(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
-    C25519_PRIO_SIDE();
-    const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    feT acc = fe_one();
-    bool affine = true;                 // every Z of this lane is literally 1 (points straight from a decompression,
-                                        // e.g. VerifyingKey.point): the shared inversion and the unwinding are skipped
-#pragma unroll 1
-    for (int j = 0; j < CH; j++) {
-        u64 idx = t + (u64)j * T;
-        if (idx >= n) break;
-        affine = affine && raw160_z_is_one(in, idx);
-        uint4 *q = reinterpret_cast<uint4 *>(prefix) + 3 * idx;
-        q[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]); q[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
-        q[2] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
-        acc = fe_mul(acc, raw160_fe(in, idx, 2));
-    }
-    feT inv = fe_one();
-    if (!affine) inv = fe_invert(acc);
-#pragma unroll 1
-    for (int j = CH - 1; j >= 0; j--) {
-        u64 idx = t + (u64)j * T;
-        if (idx >= n) continue;
-        if (affine) { pts_store(pts, dst0 + idx, raw160_fe(in, idx, 0), raw160_fe(in, idx, 1)); continue; }   // x = X, y = Y
-        const uint4 *q = reinterpret_cast<const uint4 *>(prefix) + 3 * idx;
-        uint4 a = q[0], b = q[1], c = q[2];
-        feT pre;
-        pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
-        pre.v[8] = c.x; pre.v[9] = c.y;
-        feT Z = raw160_fe(in, idx, 2);
-        feT zi = fe_mul(inv, pre);
-        inv = fe_mul(inv, Z);
-        pts_store(pts, dst0 + idx, fe_mul(raw160_fe(in, idx, 0), zi), fe_mul(raw160_fe(in, idx, 1), zi));
-    }
-}
-// The same normalisation with WAVE-COALESCED memory accesses.  k_prep_raw's lane t owns points t, t + T, ...: the 64 lanes
-// of a wave own 64 CONSECUTIVE points at every step, but each lane fetches its own 40-byte coordinates and stores its own
-// 128-byte record, so every memory instruction looks up 64 different cache lines -- 1664 look-ups per point and wave, on
+// WAVE-COALESCED memory accesses.  Lane t owns points t, t + T, ...: the 64 lanes of a wave own 64 CONSECUTIVE points at
+// every step; if each lane fetched its own 40-byte coordinates and stored its own 128-byte record (round 1's k_prep_raw),
+// every memory instruction would look up 64 different cache lines -- 1664 look-ups per point and wave, on
 // the texture/L1 path that the accumulation of the previous pass (one gather per addition) and the sort also live on.
 // Here the wave DMAs the whole 10 KB block of its 64 points into LDS (global_load_lds_dwordx4, 8 lines per instruction),
 // the prefix products live in a [step][piece][lane] layout (8 lines per instruction), and the records go out through an
@@ -301,11 +267,10 @@ __device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) {
 }
 
 // histogram of bucket occupancy for (window k = blockIdx.y, chunk j = blockIdx.x)
-template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_hist(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, u32 *__restrict__ counts) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 hist[];
-    const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
+    const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y;
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) hist[b] = 0;
     __syncthreads();
     u64 lo = (u64)j * chunk, hi = lo + chunk < n ? lo + chunk : n;
@@ -353,12 +318,11 @@ __global__ void __launch_bounds__(1024) k_scan_buckets(const u32 *__restrict__ t
     if (tid == 1023) base[(u64)k * (g.half + 1) + g.half] = part[1023];
 }
 // scatter term indices (sign in bit 31) into bucket order
-template <bool XCD_SWAP>
 __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D, u64 n, msm_geom g, u64 chunk, const u32 *__restrict__ starts,
                                                   const u32 *__restrict__ base, u32 *__restrict__ sorted) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 cursor[];
-    const int k = XCD_SWAP ? blockIdx.x : blockIdx.y, j = XCD_SWAP ? blockIdx.y : blockIdx.x, nchunk = XCD_SWAP ? gridDim.y : gridDim.x;
+    const int k = blockIdx.x, j = blockIdx.y, nchunk = gridDim.y;
     const u32 *st = starts + ((u64)k * nchunk + j) * g.half;
     const u32 *bs = base + (u64)k * (g.half + 1);
     for (int b = threadIdx.x; b < g.half; b += blockDim.x) cursor[b] = st[b] + bs[b];
@@ -868,6 +832,58 @@ __global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int
 }
 
 // ================================================================================================
+// result slots and partial-result RECORDS
+//
+// A pass leaves its window column sums and its counters in a slot (msm "result slots" below).  A slot doubles as the
+// fixed-size RECORD that travels between ranks / contexts in the multi-GPU decomposition: the flags area
+// also carries a header -- the number of terms the window layout was derived from (msm_layout is a function of it
+// alone), the number of passes summed into the record and a magic word -- so that whoever holds the records of all ranks
+// can add them column by column and do the Horner fold ONCE (c25519_fold_partial_records), without the rank's result
+// ever having been on its host.
+//   flags [0] a scalar has bit 255 set  [1] points that do not decode  [2] bad A  [3] bad R  [4] non-canonical s
+//         [5] bad message offsets       [8] terms (low word)  [9] terms (high word)  [10] passes  [11] magic
+// ================================================================================================
+constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11;
+constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
+// zero a slot and write its header; pre (may be null): counters a caller computed beforehand (whole-batch hashing in the
+// transcript z-mode: [0] non-canonical s, [1] bad message offsets), merged into flags [4] and [5]
+__global__ void __launch_bounds__(256) k_slot_init(u32 *__restrict__ slot, u32 terms_lo, u32 terms_hi, u32 passes, const u32 *__restrict__ pre) {
+    for (int i = threadIdx.x; i < C25519_SLOT_U32; i += 256) {
+        u32 v = 0;
+        const int f = i - MSM_MAX_WIN * 40;
+        if (f == REC_TERMS_LO) v = terms_lo;
+        else if (f == REC_TERMS_HI) v = terms_hi;
+        else if (f == REC_PASSES) v = passes;
+        else if (f == REC_MAGIC) v = REC_MAGIC_VALUE;
+        else if (f == 4 && pre) v = pre[0];
+        else if (f == 5 && pre) v = pre[1];
+        slot[i] = v;
+    }
+}
+// rec (+)= the column sums and counters of cnt slots that share one window layout (first: rec is overwritten)
+__global__ void __launch_bounds__(128) k_record_sum(u32 *__restrict__ rec, const u32 *__restrict__ slots, int cnt, int nwin, int first) {
+    C25519_PRIO_SIDE();
+    const int t = threadIdx.x;
+    if (t < nwin) {
+        ge_p3 acc = first ? p40_load(slots, t) : p40_load(rec, t);
+#pragma unroll 1
+        for (int i = first ? 1 : 0; i < cnt; i++) acc = ge_add(acc, p40_load(slots + (size_t)i * C25519_SLOT_U32, t));
+        p40_store(rec, t, acc);
+    } else if (t >= 64 && t < 80) {
+        const int f = t - 64, at = MSM_MAX_WIN * 40 + f;
+        if (f < 8) {                                          // counters add up
+            u32 v = first ? 0u : rec[at];
+            for (int i = 0; i < cnt; i++) v += slots[(size_t)i * C25519_SLOT_U32 + at];
+            rec[at] = v;
+        } else if (f == REC_PASSES) {
+            u32 v = first ? 0u : rec[at];
+            for (int i = 0; i < cnt; i++) v += slots[(size_t)i * C25519_SLOT_U32 + at];
+            rec[at] = v;
+        } else if (first) rec[at] = slots[at];                // header words: one layout for every pass
+    }
+}
+
+// ================================================================================================
 // verify_batch kernels
 // ================================================================================================
 // hram_i = SHA-512(R_i || A_i || M_i) (batch.rs:179-191): 64-byte digest out; flags[0] += non-canonical s,
@@ -1229,8 +1245,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     size_t oLS = carve((size_t)max_items * 160);
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
-    static const int sort2 = env_int("C25519_SORT2", 1);
-    const bool use_part = sort2 && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
+    const bool use_part = g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
     const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
     if (use_part) { oP1 = carve((size_t)g.nwin * n * 4); oCC = carve((size_t)g.nwin * SL * pchunks * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4); }
@@ -1243,12 +1258,6 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     pl.g = g; pl.n = n; pl.nb = nb; pl.nseg = nseg; pl.max_items = max_items; pl.max_long = max_long;
     pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8;
     pl.items = (long_item *)(ws + oLI); pl.lgids = (uint32_t *)(ws + oLG); pl.lfirst = (uint32_t *)(ws + oLF); pl.segs = (uint32_t *)(ws + oLS);
-    static const bool overlap = env_int("C25519_SORT_OVERLAP", 1) != 0;   // A/B knob: 0 = the main stream waits for the scalars and sorts itself
-    if (!overlap && sort_stream && sort_stream != ctx->stream) {
-        HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
-        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
-        sort_stream = nullptr;
-    }
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
@@ -1265,24 +1274,20 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     } else {
         size_t lds = (size_t)g.half * 4;
-        static const int xswap = env_int("C25519_XCD_SWAP", 1);
+        // (window, chunk) grid order: blockIdx.x = window, so that the chunk blocks of one window share an XCD's L2
         if (lds > 48 * 1024) {
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hist), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         }
-        if (xswap) hipLaunchKernelGGL(k_hist<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts);
-        else hipLaunchKernelGGL(k_hist<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts);
+        hipLaunchKernelGGL(k_hist, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts);
         hipLaunchKernelGGL(k_scan_chunks, dim3(div_up64(nb, 256)), dim3(256), 0, st, counts, nchunk, g, totals);
         hipLaunchKernelGGL(k_scan_buckets, dim3(g.nwin), dim3(1024), 0, st, totals, g, base);
-        static const int sparts = [] { int v = env_int("C25519_SCATTER_PARTS", 8); return (v == 2 || v == 4 || v == 8 || v == 16) ? v : 1; }();
+        constexpr int sparts = 8;                           // bucket-range slices of the scatter (k_scatter_sliced)
         const size_t lds_sliced = (size_t)g.half / sparts * 4 + (size_t)chunk * 2;
-        if (sparts > 1 && g.half >= 1024 * sparts && lds_sliced <= 160 * 1024) {
+        if (g.half >= 1024 * sparts && lds_sliced <= 160 * 1024) {
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_scatter_sliced), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sliced));
             hipLaunchKernelGGL(k_scatter_sliced, dim3(g.nwin, nchunk), dim3(1024), lds_sliced, st, D, n, g, chunk, sparts, counts, base, sorted);
-        } else if (xswap) hipLaunchKernelGGL(k_scatter<true>, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
-        else hipLaunchKernelGGL(k_scatter<false>, dim3(nchunk, g.nwin), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
+        } else hipLaunchKernelGGL(k_scatter, dim3(g.nwin, nchunk), dim3(1024), lds, st, D, n, g, chunk, counts, base, sorted);
     }
     // bucket order (longest lists first) and the long-bucket work list: still on the sort stream -- they only need the lists
     if (!use_part) hipLaunchKernelGGL(k_order_hist, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, base, g, (uint64_t)0, nb, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
@@ -1298,9 +1303,7 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
     }
     hipStream_t st = ctx->stream;
-    static const int pipe = [] { int v = env_int("C25519_ACC_PIPE", 4); return (v < 0 || v > 4) ? 4 : v; }();   // A/B knob (LDS-DMA staging as in k_mul_base_wide was tried here: -15 %)
-    static const int acc_serial = env_int("C25519_ACC_SERIAL", 1);                                              // A/B knob
-    if (wait_acc && acc_serial) HIPCHK(hipStreamWaitEvent(st, wait_acc, 0));
+    if (wait_acc) HIPCHK(hipStreamWaitEvent(st, wait_acc, 0));
     // long buckets are independent of k_accumulate (which skips them): fold them on the second stream meanwhile
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
@@ -1308,17 +1311,11 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(pl.max_long, 1024u)), dim3(64), 0, ctx->aux, pl.base, g, pl.counters, pl.max_items, pl.lgids, pl.lfirst, pl.segs, pl.buckets);
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    static const int acc_chain = env_int("C25519_ACC_CHAIN", 2);                                              // A/B knob: carry form of the field arithmetic in k_accumulate
-    // (a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of the next pass -- measured
-    //  18.2 - 20.3 ms per 2^24 terms against 16.5 on the same box: the masked kernel loses more than the sort gains;
-    //  512-thread blocks, i.e. two waves per SIMD with 176 registers and all of LDS left for the sort kernels: 16.9 - 17.0
-    //  against 16.6 - 16.9, and 15.5 against 15.1 - 15.3 with the cooperative gather; an LDS reservation to the same effect:
-    //  16.2 against 15.9; four waves per SIMD without a prefetched record, ten-column 124 / chained 110 VGPRs and no
-    //  scratch: 16.0 / 15.5 against 15.1 - 15.3 -- a wave issues one v_mad_u64_u32 per 11.7 cycles at best, so three waves
-    //  of the 168-register form are what saturates the multiplier, and nothing else fits beside them)
-    if (acc_chain == 2) launch_accumulate_c2(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
-    else if (acc_chain) launch_accumulate_c1(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
-    else launch_accumulate_c0(pipe, d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    // (measured in round 2 and dropped: a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of
+    //  the next pass -- 18.2 - 20.3 ms per 2^24 terms against 16.5; 512-thread blocks, i.e. two waves per SIMD with 176
+    //  registers: 16.9 - 17.0 against 16.6 - 16.9; an LDS reservation to the same effect: 16.2 against 15.9; four waves per SIMD
+    //  without a prefetched record: 16.0 / 15.5 against 15.1 - 15.3; un-serialised accumulations of neighbouring passes: +3 - 9 %)
+    ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
     HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
@@ -1353,6 +1350,63 @@ static int32_t slots_collect(c25519_ctx *ctx, int count) {
 }
 static inline uint32_t *dslot(c25519_ctx *ctx, int i) { return ctx->d_slots + (size_t)i * C25519_SLOT_U32; }
 static inline const uint32_t *hslot(c25519_ctx *ctx, int i) { return (const uint32_t *)ctx->h_msm + (size_t)i * C25519_SLOT_U32; }
+// the context's own record (slot C25519_MAX_SLOTS of d_slots / h_msm): where a call that answers on the host sums its passes
+static inline uint32_t *drec(c25519_ctx *ctx) { return dslot(ctx, C25519_MAX_SLOTS); }
+static int32_t rec_collect(c25519_ctx *ctx) {
+    HIPCHK(hipMemcpyAsync((uint32_t *)ctx->h_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32, drec(ctx), (size_t)C25519_SLOT_U32 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return C25519_OK;
+}
+static inline void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st) {
+    hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(256), 0, st, d_slot, (uint32_t)terms, (uint32_t)(terms >> 32), terms ? 1u : 0u, d_pre);
+}
+static_assert(C25519_PARTIAL_RECORD_BYTES == C25519_SLOT_U32 * 4, "record = slot");
+
+// Fold `count` records (HOST memory) into one point and one set of counters.  Records made with the same number of
+// terms share their window layout: their columns are added window by window and the Horner fold (pippenger.rs:159) runs
+// once; otherwise every record is folded on its own.  Pure host arithmetic over O(count x windows) points.
+static int32_t records_fold(const uint8_t *records, uint64_t count, ge_p3 &R, uint32_t flags[8], std::string *err) {
+    R = ge_identity();
+    for (int j = 0; j < 8; j++) flags[j] = 0;
+    bool same = true;
+    uint64_t terms0 = 0;
+    for (uint64_t i = 0; i < count; i++) {
+        uint32_t f[16];
+        memcpy(f, records + i * C25519_PARTIAL_RECORD_BYTES + (size_t)MSM_MAX_WIN * 160, sizeof f);
+        if (f[REC_MAGIC] != REC_MAGIC_VALUE) { if (err) *err = "fold: not a partial-result record (bad magic)"; return -(int32_t)hipErrorInvalidValue; }
+        for (int j = 0; j < 8; j++) flags[j] += f[j];
+        const uint64_t terms = (uint64_t)f[REC_TERMS_LO] | ((uint64_t)f[REC_TERMS_HI] << 32);
+        if (i == 0) terms0 = terms; else if (terms != terms0) same = false;
+    }
+    if (count == 0) return C25519_OK;
+    std::vector<uint32_t> cols((size_t)MSM_MAX_WIN * 40);
+    if (same) {
+        if (terms0 == 0) return C25519_OK;                  // empty shards only
+        msm_geom g;
+        msm_layout(terms0, g);
+        memcpy(cols.data(), records, (size_t)g.nwin * 160);
+        for (uint64_t i = 1; i < count; i++) {
+            const uint32_t *c = (const uint32_t *)(records + i * C25519_PARTIAL_RECORD_BYTES);
+            for (int k = 0; k < g.nwin; k++) {
+                const ge_p3 sum = ge_add(host_p40(&cols[(size_t)k * 40]), host_p40(c + (size_t)k * 40));
+                for (int q = 0; q < 10; q++) { cols[(size_t)k * 40 + q] = sum.X.v[q]; cols[(size_t)k * 40 + 10 + q] = sum.Y.v[q]; cols[(size_t)k * 40 + 20 + q] = sum.Z.v[q]; cols[(size_t)k * 40 + 30 + q] = sum.T.v[q]; }
+            }
+        }
+        R = msm_horner(cols.data(), g);
+        return C25519_OK;
+    }
+    for (uint64_t i = 0; i < count; i++) {
+        const uint32_t *c = (const uint32_t *)(records + i * C25519_PARTIAL_RECORD_BYTES);
+        const uint32_t *f = c + (size_t)MSM_MAX_WIN * 40;
+        const uint64_t terms = (uint64_t)f[REC_TERMS_LO] | ((uint64_t)f[REC_TERMS_HI] << 32);
+        if (terms == 0) continue;
+        msm_geom g;
+        msm_layout(terms, g);
+        memcpy(cols.data(), c, (size_t)g.nwin * 160);        // (records are only 4-byte aligned in general)
+        R = ge_add(R, msm_horner(cols.data(), g));
+    }
+    return C25519_OK;
+}
 
 // one-shot MSM over prepared points (extra.hip: precomputed tables): enqueue, collect, fold
 int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, ge_p3 &R) {
@@ -1418,28 +1472,18 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
     if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
     else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
     else if (in_fmt == C25519_FMT_RAW160) {
-        int32_t r = ctx_reserve(ctx, ctx->prefix, n * 48);
-        if (r) return r;
-        static const int coalesced = env_int("C25519_PREP_COALESCED", 1);     // A/B knobs
+        int32_t r;
         // points per lane and inversion: 64 when the launch still has >= 2048 waves (the records of the later passes of a
         // multi-pass call), 16 for one pass of 2^21 points (2^24 terms: 15.8 ms with 16 everywhere, 15.3 with 64)
-        static const int chunk_knob = env_int("C25519_PREP_CHUNK", 0);
-        const int chunk = chunk_knob ? chunk_knob : (n >= (1ull << 23) ? 64 : n >= (1ull << 22) ? 32 : 16);
-        if (coalesced) {
-            static const int wpb = env_int("C25519_PREP_WPB", 4) == 1 ? 1 : 4;
-            const int CH = (chunk == 32 || chunk == 64 || chunk == 128) ? chunk : 16;
-            const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
-            // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
-            r = ctx_reserve(ctx, ctx->prefix, (size_t)blocks * wpb * CH * 3 * 64 * 16);
-            if (r) return r;
-#define C25519_PREP_LAUNCH(C, W) hipLaunchKernelGGL((k_prep_raw2<C, W>), dim3(blocks), dim3(64 * W), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0)
-            if (wpb == 1) { if (CH == 128) C25519_PREP_LAUNCH(128, 1); else if (CH == 64) C25519_PREP_LAUNCH(64, 1); else if (CH == 32) C25519_PREP_LAUNCH(32, 1); else C25519_PREP_LAUNCH(16, 1); }
-            else { if (CH == 128) C25519_PREP_LAUNCH(128, 4); else if (CH == 64) C25519_PREP_LAUNCH(64, 4); else if (CH == 32) C25519_PREP_LAUNCH(32, 4); else C25519_PREP_LAUNCH(16, 4); }
-#undef C25519_PREP_LAUNCH
-        } else {
-            constexpr int CH = 16;
-            hipLaunchKernelGGL(k_prep_raw<CH>, dim3(div_up64((n + CH - 1) / CH, 256)), dim3(256), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
-        }
+        const int CH = n >= (1ull << 23) ? 64 : n >= (1ull << 22) ? 32 : 16;
+        constexpr int wpb = 4;
+        const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
+        // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
+        r = ctx_reserve(ctx, ctx->prefix, (size_t)blocks * wpb * CH * 3 * 64 * 16);
+        if (r) return r;
+        if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        else hipLaunchKernelGGL((k_prep_raw2<16, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
     } else { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipGetLastError());
     return C25519_OK;
@@ -1494,7 +1538,7 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
 //                                   a normalisation between the reduction before it and its accumulation
 //   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
 struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
-static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint32_t *d_slot,
+static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
                                 hipEvent_t wait_acc, const pts_ahead *ahead = nullptr) {
     int32_t r;
     uint32_t *d_pts;
@@ -1504,26 +1548,33 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     } else d_pts = ahead->pts + ahead->offset * (PTS_BYTES / 4);
     hipEvent_t *ring = pass_ring(owner, ctx);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
-    HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, ctx->stream));
+    slot_init(d_slot, terms, nullptr, ctx->stream);
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     msm_plan pl;
-    static const int sort_first = env_int("C25519_SORT_FIRST", 0);      // A/B knob: measured 2.26 (prep first) vs 2.34 ms (sort first) at 2^21 terms
-    if (sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
+    // (normalisation first, then the sort on the second stream: 2.26 against 2.34 ms at 2^21 terms the other way round)
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
     else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
-    if (!sort_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
+    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
 }
-static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
+// The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column
+// sums + counters + header) left at d_record.  Nothing here waits for the host.
+static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_record) {
     HIPCHK(hipSetDevice(ctx->device));
-    R = ge_identity();
-    if (n == 0) return C25519_OK;
+    if (in_fmt < 0 || in_fmt > 2) { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     if (n >= (1ull << 40)) { ctx->err = "msm: n must be < 2^40"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    if (n == 0) {                                           // the identity: an empty record (records_fold skips it)
+        ctx->last_passes.clear();
+        slot_init(d_record, 0, nullptr, ctx->stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        return C25519_OK;
+    }
     const uint64_t passes = n <= MSM_PASS_MAX ? 1 : (n + MSM_PASS - 1) / MSM_PASS, per = (n + passes - 1) / passes;
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     msm_geom g;
@@ -1531,42 +1582,81 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     pass_set ps;
     int32_t r;
     if ((r = passes_begin(ctx, passes, ps))) return r;
-    std::vector<ge_p3> cols(g.nwin, ge_identity());
-    bool none = false, bad_scalar = false;
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
-    static const int ahead_knob = env_int("C25519_PREP_AHEAD", 1);          // A/B knob
-    const bool ahead = ahead_knob && passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160;
+    const bool ahead = passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160;
     if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        if (p0 && ps.lanes > 1) {                          // the slots are reused: the peers wait until the previous batch has been summed
+            HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
+            for (int l = 1; l < ps.lanes; l++) HIPCHK(hipStreamWaitEvent(ps.c[l]->stream, ctx->ev_in, 0));
+        }
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p0 + i == 1};
-            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, dslot(ctx, i), prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr))) {
+            uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);     // a single pass writes the record itself
+            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr))) {
                 if (ctx->err.empty()) ctx->err = c->err;
                 return r;
             }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
-        if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
-        for (int i = 0; i < cnt; i++) {
-            const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
-            if (f[0]) bad_scalar = true;
-            if (f[1]) none = true;                         // the status must not depend on the split
-            for (int k = 0; k < g.nwin; k++) cols[k] = (passes == 1) ? host_p40(s + (size_t)k * 40) : ge_add(cols[k], host_p40(s + (size_t)k * 40));
-        }
+        if ((r = passes_join(ctx, ps))) return r;
+        if (passes > 1) hipLaunchKernelGGL(k_record_sum, dim3(1), dim3(128), 0, ctx->stream, d_record, ctx->d_slots, cnt, g.nwin, p0 == 0 ? 1 : 0);
     }
+    HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    if (bad_scalar) { ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
-    if (none) return C25519_NONE;
-    std::vector<uint32_t> flat((size_t)g.nwin * 40);
-    for (int k = 0; k < g.nwin; k++) for (int i = 0; i < 10; i++) {
-        flat[(size_t)k * 40 + i] = cols[k].X.v[i]; flat[(size_t)k * 40 + 10 + i] = cols[k].Y.v[i]; flat[(size_t)k * 40 + 20 + i] = cols[k].Z.v[i]; flat[(size_t)k * 40 + 30 + i] = cols[k].T.v[i];
+    return C25519_OK;
+}
+// flags of a folded MSM record -> status
+static int32_t msm_record_status(c25519_ctx *ctx, const uint32_t flags[8]) {
+    if (flags[0]) { if (ctx) ctx->err = "msm: a scalar has bit 255 set (Scalar invariant #1 violated)"; return -(int32_t)hipErrorInvalidValue; }
+    return flags[1] ? C25519_NONE : C25519_OK;            // the status does not depend on the split
+}
+static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
+    int32_t r = msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, drec(ctx));
+    if (r) return r;
+    if ((r = rec_collect(ctx))) return r;
+    uint32_t flags[8];
+    if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+    return msm_record_status(ctx, flags);
+}
+
+// This rank's (context's) share of a sharded MSM as a RECORD in device memory: enqueue only.  The records
+// of all ranks are exchanged (one all_gather over RCCL) and folded once by c25519_fold_partial_records.
+EXPORT int32_t c25519_msm_partial_record_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *d_record) {
+    return msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, (uint32_t *)d_record);
+}
+EXPORT int32_t c25519_fold_partial_records(c25519_ctx *ctx, const uint8_t *records, uint64_t count, int out_fmt, uint8_t *out) {
+    if (out_fmt < 0 || out_fmt > 2) { if (ctx) ctx->err = "fold: bad out_fmt"; return -(int32_t)hipErrorInvalidValue; }
+    ge_p3 R;
+    uint32_t flags[8];
+    int32_t r = records_fold(records, count, R, flags, ctx ? &ctx->err : nullptr);
+    if (r) return r;
+    if ((r = msm_record_status(ctx, flags))) return r;
+    host_encode(R, out_fmt, out);
+    return C25519_OK;
+}
+// A record holding a given point (host arithmetic; ctx-less): lets a participant that computed its partial sum elsewhere --
+// the host-pointer entry points, a CPU -- join the same fold.  status: C25519_OK or C25519_NONE.
+EXPORT int32_t c25519_partial_record_pack(const uint8_t *point160, int32_t status, const uint32_t *counters8, uint8_t *record) {
+    if (status != C25519_OK && status != C25519_NONE) return -(int32_t)hipErrorInvalidValue;
+    std::vector<uint32_t> rec(C25519_SLOT_U32, 0u);
+    msm_geom g;
+    msm_layout(1, g);                                     // terms = 1: window 0 sits at bit 0, so column 0 IS the point
+    const ge_p3 id = ge_identity(), P = host_from_raw160(point160);
+    for (int k = 0; k < g.nwin; k++) {
+        const ge_p3 &q = k == 0 ? P : id;
+        for (int i = 0; i < 10; i++) { rec[(size_t)k * 40 + i] = q.X.v[i]; rec[(size_t)k * 40 + 10 + i] = q.Y.v[i]; rec[(size_t)k * 40 + 20 + i] = q.Z.v[i]; rec[(size_t)k * 40 + 30 + i] = q.T.v[i]; }
     }
-    R = msm_horner(flat.data(), g);
+    uint32_t *f = rec.data() + (size_t)MSM_MAX_WIN * 40;
+    if (counters8) for (int j = 0; j < 8; j++) f[j] = counters8[j];
+    if (status == C25519_NONE) f[1] += 1;
+    f[REC_TERMS_LO] = 1; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE;
+    memcpy(record, rec.data(), C25519_PARTIAL_RECORD_BYTES);
     return C25519_OK;
 }
 
@@ -1651,7 +1741,7 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
 // d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
-                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const msm_geom &g, uint32_t *d_slot, hipEvent_t wait_acc) {
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -1669,7 +1759,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
     hipEvent_t *ring = pass_ring(owner, ctx);
     HIPCHK(hipEventRecord(ring[3], st));
-    HIPCHK(hipMemsetAsync(d_slot, 0, C25519_SLOT_U32 * 4, st));
+    slot_init(d_slot, terms, d_pre_flags, st);
     // Two independent chains: (S) decompress A_i and R_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
     // partly latency-bound (the tree levels).  They run on two streams and join before the accumulation.
     hipStream_t sa = ctx->aux;
@@ -1680,14 +1770,9 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2))) return r; }
     else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, true, st));
     HIPCHK(hipEventRecord(ring[4], st));
-    {   // R_i = the first half of every 64-byte signature.  In slices: the hash chain on the second stream is the critical
-        // path (hash -> tree -> z_i -> scalars -> sort), and against ONE long decompression kernel every kernel of that chain
-        // is the younger one and loses the issue arbiter; slices make the two streams take turns at being the older.
-        static const int chunks = std::max(1, env_int("C25519_DEC_CHUNKS", 1));
-        const uint64_t per = ((n + chunks - 1) / chunks + 255) & ~(uint64_t)255;
-        for (uint64_t lo = 0; lo < n; lo += per)
-            HIPCHK(launch_prep_compressed(0, d_sigs + lo * 64, 2, std::min(per, n - lo), d_pts, 1 + lo, d_cnt + 3, true, st));
-    }
+    // R_i = the first half of every 64-byte signature (stride 2)
+    ctx->kname[1] = "c25519::k_prep_compressed<0> (decompression of R_i)";
+    HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 3, true, st));
     HIPCHK(hipEventRecord(ring[5], st));
     // (A)
     const uint8_t *hr = d_hram_pre;
@@ -1717,6 +1802,83 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
 // batch was cut.
 static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 21 ? 21 : v); }();   // A/B knob
 static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
+// flags of a folded verify_batch record + its point -> the reference's verdict (precedence: key decoding, then ScalarFormat
+// for ANY non-canonical s, batch.rs:208-211, then Verify, :244-250)
+static int32_t verify_record_verdict(c25519_ctx *ctx, const ge_p3 &R, const uint32_t flags[8]) {
+    if (flags[5]) { if (ctx) ctx->err = "verify_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
+    if (flags[0]) { if (ctx) ctx->err = "verify_batch: internal error (batch scalar with bit 255 set)"; return -(int32_t)hipErrorInvalidValue; }
+    if (flags[2]) return C25519_NONE;                       // a key that VerifyingKey::from_bytes rejects
+    if (flags[4]) return C25519_SCALAR_FORMAT;
+    if (flags[3]) return C25519_VERIFY;                     // batch.rs:244 (an R that fails to decompress)
+    return ge_is_identity(R) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
+}
+// Every pass of a batch whose z_i are GIVEN (transcript z-mode: d_hram = H(R||A||M) of these n signatures followed by a
+// 64-byte trailer of counters -- [0] non-canonical s, [1] bad offsets -- as ed25519_batch_hram_dev leaves them; d_z16 = their
+// z_i), summed into ONE record at d_record: the reference's single equation (batch.rs:235-250) whatever the pass split.
+static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
+                                     uint64_t n, uint32_t *d_record) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
+    const uint32_t *d_pre = (const uint32_t *)(d_hram + n * 64);
+    if (n == 0) { ctx->last_passes.clear(); slot_init(d_record, 0, d_pre, ctx->stream); HIPCHK(hipGetLastError()); return C25519_OK; }
+    const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
+    msm_geom g;
+    msm_layout(2 * per + 1, g);
+    int32_t r;
+    pass_set ps;
+    if ((r = passes_begin(ctx, passes, ps))) return r;
+    hipEvent_t prev_acc = nullptr;
+    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
+        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        if (p0 && ps.lanes > 1) {
+            HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
+            for (int l = 1; l < ps.lanes; l++) HIPCHK(hipStreamWaitEvent(ps.c[l]->stream, ctx->ev_in, 0));
+        }
+        for (int i = 0; i < cnt; i++) {
+            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
+            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);
+            r = verify_pass_enqueue(ctx, c, nullptr, nullptr, 0, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, C25519_Z_TRANSCRIPT,
+                                    d_hram + lo * 64, d_z16 + lo * 16, (p0 + i == 0) ? d_pre : nullptr, g, 2 * per + 1, slot, prev_acc);
+            if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
+            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
+        }
+        if ((r = passes_join(ctx, ps))) return r;
+        if (passes > 1) hipLaunchKernelGGL(k_record_sum, dim3(1), dim3(128), 0, ctx->stream, d_record, ctx->d_slots, cnt, g.nwin, p0 == 0 ? 1 : 0);
+    }
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+// H(R_i || A_i || M_i) of n signatures to d_hram (n x 64 bytes) followed by a 64-byte trailer of counters ([0] signatures
+// with a non-canonical s, [1] bad message offsets): the per-signature half of the transcript z-mode, enqueue only.
+static int32_t batch_hram_enqueue(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint8_t *d_hram) {
+    HIPCHK(hipSetDevice(ctx->device));
+    uint32_t *fl = (uint32_t *)(d_hram + n * 64);
+    HIPCHK(hipMemsetAsync(fl, 0, 64, ctx->stream));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram, fl, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_batch_hram_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n,
+                                      uint8_t *d_hram) {
+    return batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram);
+}
+// the reference's z_i from the bytes its transcript absorbs (batch.rs:168-222): host arithmetic, no context, sequential
+EXPORT int32_t ed25519_batch_transcript_zs(const uint8_t *hram, const uint8_t *sigs, uint64_t n, uint8_t *z16) {
+    c25519_transcript_zs(hram, sigs, n, z16);
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_verify_batch_record_dev(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
+                                               uint64_t n, uint8_t *d_record) {
+    return verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram, d_z16, n, (uint32_t *)d_record);
+}
+EXPORT int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *records, uint64_t count) {
+    ge_p3 R;
+    uint32_t flags[8];
+    int32_t r = records_fold(records, count, R, flags, ctx ? &ctx->err : nullptr);
+    if (r) return r;
+    return verify_record_verdict(ctx, R, flags);
+}
+
 EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                              const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -1724,40 +1886,47 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
     if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int32_t r;
+    if (z_mode == C25519_Z_TRANSCRIPT) {
+        // the reference's sequential Merlin transcript (batch.rs:168-222) over the WHOLE batch, on one host core; then ONE
+        // equation over the whole batch (the passes' column sums are added on the device), exactly batch.rs:235-250
+        try {
+            if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 128))) return r;
+            uint8_t *d_hram_all = (uint8_t *)ctx->tmp_c2.p, *d_z_all = d_hram_all + n * 64 + 64;
+            if ((r = batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all))) return r;
+            std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
+            HIPCHK(hipMemcpyAsync(hh.data(), d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
+            HIPCHK(hipMemcpyAsync(d_z_all, hz.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));      // hz is a local buffer
+            if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx)))) return r;
+        } catch (const std::exception &e) { ctx->err = std::string("verify_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
+        if ((r = rec_collect(ctx))) return r;
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        ge_p3 R;
+        uint32_t flags[8];
+        if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+        return verify_record_verdict(ctx, R, flags);
+    }
+    // device z-mode: every pass derives its own z_i from its own tree and is its own random linear combination (summing
+    // passes with independent z_i would open a 2^126 birthday attack across passes); all passes run even after a failure so
+    // that the precedence does not depend on where the batch was cut
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
     msm_geom g;
     msm_layout(2 * per + 1, g);
-    int32_t r;
-    uint32_t pre_flags[4] = {0, 0, 0, 0};               // transcript mode: [0] non-canonical s, [1] bad offsets over the whole batch
-    uint8_t *d_hram_all = nullptr, *d_z_all = nullptr;
-    if (z_mode == C25519_Z_TRANSCRIPT) {
-        // the reference's sequential Merlin transcript (batch.rs:168-222) over the WHOLE batch, on one host core
-        if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 64))) return r;
-        d_hram_all = (uint8_t *)ctx->tmp_c2.p; d_z_all = d_hram_all + n * 64;
-        uint32_t *fl = (uint32_t *)ctx->d_flag;
-        HIPCHK(hipMemsetAsync(fl, 0, 16, ctx->stream));
-        HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all, fl, ctx->stream));
-        std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
-        HIPCHK(hipMemcpyAsync(hh.data(), d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(pre_flags, fl, 16, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
-        HIPCHK(hipMemcpyAsync(d_z_all, hz.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));      // hz is a local buffer
-    }
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
-    bool seen[5] = {false, false, false, false, false}, bad_off = pre_flags[1] != 0, bad_scalar = false;
+    bool seen[5] = {false, false, false, false, false}, bad_off = false, bad_scalar = false;
     hipEvent_t prev_acc = nullptr;
-    if (pre_flags[0]) seen[C25519_SCALAR_FORMAT] = true;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
-                                    d_hram_all ? d_hram_all + lo * 64 : nullptr, d_z_all ? d_z_all + lo * 16 : nullptr, g, dslot(ctx, i), prev_acc);
+                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
@@ -1766,12 +1935,9 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
             const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
             if (f[0]) bad_scalar = true;
             if (f[5]) bad_off = true;
-            int32_t v;
-            if (f[2]) v = C25519_NONE;                          // a key that VerifyingKey::from_bytes rejects
-            else if (f[4]) v = C25519_SCALAR_FORMAT;            // batch.rs:208-211
-            else if (f[3]) v = C25519_VERIFY;                   // batch.rs:244 (R fails to decompress)
-            else v = ge_is_identity(msm_horner(s, g)) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
-            seen[v] = true;
+            uint32_t fl[8] = {0, 0, f[2], f[3], f[4], 0, 0, 0};
+            const bool clean = !(f[2] | f[3] | f[4]);
+            seen[verify_record_verdict(nullptr, clean ? msm_horner(s, g) : ge_identity(), fl)] = true;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));

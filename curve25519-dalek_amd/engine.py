@@ -69,6 +69,13 @@ def load_library():
         "c25519_msm_vartime": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp]),
         "c25519_msm_partial_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
         "c25519_fold_partials": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_msm_partial_record_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
+        "c25519_fold_partial_records": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_partial_record_pack": (i32, [vp, i32, vp, vp]),
+        "ed25519_batch_hram_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, vp]),
+        "ed25519_batch_transcript_zs": (i32, [vp, vp, u64, vp]),
+        "ed25519_verify_batch_record_dev": (i32, [vp, vp, vp, vp, vp, vp, u64, vp]),
+        "ed25519_fold_verify_records": (i32, [vp, vp, u64]),
         "c25519_msm_vartime_multi": (i32, [vp, i32, vp, vp, u64, C.c_int, C.c_int, vp]),
         "ed25519_verify_batch_multi": (i32, [vp, i32, vp, vp, vp, vp, u64, C.c_uint32]),
         "ed25519_verify_batch_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_uint32]),
@@ -108,7 +115,8 @@ ABI_SYMBOLS = [
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
-    "c25519_fold_partials", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
+    "c25519_fold_partials", "c25519_msm_partial_record_dev", "c25519_fold_partial_records", "c25519_partial_record_pack",
+    "ed25519_batch_hram_dev", "ed25519_batch_transcript_zs", "ed25519_verify_batch_record_dev", "ed25519_fold_verify_records", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
@@ -118,6 +126,7 @@ ABI_SYMBOLS = [
 ]
 
 _PT = {FMT_EDWARDS_Y: 32, FMT_RISTRETTO: 32, FMT_RAW160: 160}
+PARTIAL_RECORD_BYTES = 9024      # C25519_PARTIAL_RECORD_BYTES
 
 
 def _np8(x, width):
@@ -272,6 +281,41 @@ class Engine:
         self._bind_stream()
         st = self._chk(self.lib.c25519_msm_partial_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out), (OK, NONE))
         return st, out.raw
+
+    def msm_partial_record_t(self, scalars, points, in_fmt=FMT_RAW160, out=None):
+        """This rank's share of a sharded MSM as a partial-result RECORD in device memory (uint8 tensor of
+        PARTIAL_RECORD_BYTES).  Enqueue only: nothing has waited for the host when this returns."""
+        n = self._t(scalars, 32)
+        assert self._t(points, _PT[in_fmt]) == n
+        if out is None:
+            out = self.torch.empty((PARTIAL_RECORD_BYTES,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_msm_partial_record_dev(self.ctx, scalars.data_ptr(), points.data_ptr(), n, in_fmt, out.data_ptr()))
+        return out
+
+    def batch_hram_t(self, msgs, msg_off, sigs, pks):
+        """H(R_i || A_i || M_i) of this shard: uint8 device tensor of n * 64 + 64 bytes (the trailer holds the counters of
+        ed25519_batch_hram_dev).  Enqueue only."""
+        n = self._t(sigs, 64)
+        assert self._t(pks, 32) == n and msg_off.numel() == n + 1
+        out = self.torch.empty((n * 64 + 64,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_batch_hram_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(), sigs.data_ptr(), pks.data_ptr(), n, out.data_ptr()))
+        return out
+
+    def verify_batch_record_t(self, sigs, pks, hram, z16, pk_points=None):
+        """This shard's share of the batch equation with GIVEN z_i (n x 16 device tensor) and its hram buffer from
+        batch_hram_t, as a partial-result record in device memory.  Enqueue only."""
+        n = self._t(sigs, 64)
+        assert self._t(pks, 32) == n and hram.numel() == n * 64 + 64 and z16.numel() == n * 16
+        assert hram.is_cuda and z16.is_cuda and z16.is_contiguous() and (n == 0 or z16.data_ptr() % 16 == 0)
+        if pk_points is not None:
+            assert self._t(pk_points, 160) == n
+        out = self.torch.empty((PARTIAL_RECORD_BYTES,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.ed25519_verify_batch_record_dev(self.ctx, sigs.data_ptr(), pks.data_ptr(), pk_points.data_ptr() if pk_points is not None else None,
+                                                           hram.data_ptr(), z16.data_ptr(), n, out.data_ptr()))
+        return out
 
     def fold_partials(self, partials, out_fmt=FMT_EDWARDS_Y):
         blob = b"".join(partials)
@@ -529,6 +573,52 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.c25519_scalar_invert_batch(self.ctx, s.ctypes.data, n, prod))
         return s, prod.raw
+
+
+def fold_partial_records(records, out_fmt=FMT_EDWARDS_Y):
+    """records: (count, PARTIAL_RECORD_BYTES) uint8 array on the HOST -> (status, bytes | None).  Host arithmetic in the C
+    library (c25519_fold_partial_records); needs no GPU."""
+    lib = load_library()
+    r = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, PARTIAL_RECORD_BYTES)
+    out = C.create_string_buffer(_PT[out_fmt])
+    st = lib.c25519_fold_partial_records(None, r.ctypes.data, r.shape[0], out_fmt, out)
+    if st < 0:
+        raise EngineError("c25519_fold_partial_records failed with status %d" % st)
+    return (st, out.raw if st == OK else None)
+
+
+def fold_verify_records(records):
+    """records of every rank's share of ONE batch equation -> the reference's verdict (status code)."""
+    lib = load_library()
+    r = np.ascontiguousarray(records, dtype=np.uint8).reshape(-1, PARTIAL_RECORD_BYTES)
+    st = lib.ed25519_fold_verify_records(None, r.ctypes.data, r.shape[0])
+    if st < 0:
+        raise EngineError("ed25519_fold_verify_records failed with status %d" % st)
+    return st
+
+
+def partial_record_pack(point160, status=OK, counters=None):
+    """A record holding a given 160-byte point (c25519_partial_record_pack) -> bytes."""
+    lib = load_library()
+    out = C.create_string_buffer(PARTIAL_RECORD_BYTES)
+    cnt = None
+    if counters is not None:
+        cnt = (C.c_uint32 * 8)(*[int(c) for c in counters])
+    st = lib.c25519_partial_record_pack(bytes(point160), status, cnt, out)
+    if st != 0:
+        raise EngineError("c25519_partial_record_pack failed with status %d" % st)
+    return out.raw
+
+
+def batch_transcript_zs(hram, sigs):
+    """The reference's z_i (batch.rs:168-222) from every H(R||A||M) (n, 64) and every signature (n, 64; s = bytes 32..63)
+    of the batch, on the host: -> (n, 16) uint8."""
+    lib = load_library()
+    h = _np8(hram, 64); g = _np8(sigs, 64); n = h.shape[0]
+    assert g.shape[0] == n
+    z = np.zeros((n, 16), dtype=np.uint8)
+    lib.ed25519_batch_transcript_zs(h.ctypes.data, g.ctypes.data, n, z.ctypes.data)
+    return z
 
 
 def msm_vartime_multi(engines, scalars, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):

@@ -1,18 +1,30 @@
 """Multi-GPU decomposition of the hot path: one process per GPU, torch.distributed
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
-* MSM is a sum over terms: rank r takes the contiguous term range shard_range(n, r, world), computes
-  its partial sum on its own GPU (c25519_msm_partial_dev), then ONE exchange step: an all_gather of
-  one 160-byte raw point per rank, followed by the same complete-addition fold on every rank.
-  RCCL has no elliptic-curve reduction operator, so the "all-reduce of partial sums" is
-  all_gather + local fold; the payload is 160 B per rank, i.e. latency-bound.
+* MSM is a sum over terms: rank r takes the contiguous term range shard_range(n, r, world) and runs the whole
+  single-GPU pipeline on it, which leaves a fixed-size partial-result RECORD in device memory
+  (c25519_msm_partial_record_dev: the window column sums of its terms + counters; nothing waits for the host).  Then
+  ONE exchange step: an all_gather of the records (9 KB per rank, device to device over RCCL), one copy to the host and
+  one fold (c25519_fold_partial_records: columns added rank by rank, ONE Horner fold) -- the same on every rank.
+  RCCL has no elliptic-curve reduction operator, so the "all-reduce of partial sums" is all_gather + fold; the payload
+  is latency-bound.
 * fixed-base, X25519 and (de)compression are independent units: replicas only, the batch is split with
   shard_range and no collective is involved.
-* verify_batch: every rank checks its own shard as an independent random linear combination (its own z_i);
-  the ONE verdict of the reference (batch.rs:146) is the worst shard verdict in the reference's precedence
-  (key decoding, ScalarFormat, Verify), agreed on with a single 4-byte all_reduce(MAX).
+* verify_batch, Z_TRANSCRIPT (the reference's derivation): the z_i come from ONE Merlin transcript over the whole batch
+  (batch.rs:168-222) however many ranks share it -- every rank hashes its shard (ed25519_batch_hram_dev), the hram_i and
+  s_i are all-gathered (96 bytes per signature), the sequential transcript runs on the host (every rank derives the same
+  z_i from the same bytes, which saves the scatter), every rank evaluates its share of the ONE batch equation with its
+  z_i (ed25519_verify_batch_record_dev), and the records are all-gathered and folded into the reference's single
+  identity check.  Same z_i, same equation, same verdict as the reference on one machine.
+* verify_batch, Z_DEVICE: every rank checks its shard as an independent random linear combination (its own z_i); the
+  verdict is the worst shard verdict in the reference's precedence, agreed on with a single 4-byte all_reduce(MAX).
+
+force_collective=True makes a world of ONE rank go through the collectives as well (the tests use it to run the RCCL
+calls on a single GPU).
 """
 import ctypes as C
+
+import numpy as np
 
 from . import engine as _e
 
@@ -35,47 +47,55 @@ def fold_partials(partials, out_fmt=_e.FMT_EDWARDS_Y):
     return out.raw
 
 
-def gather_fold(partial160, out_fmt=_e.FMT_EDWARDS_Y, group=None, device=None):
-    """The exchange step: all_gather this rank's 160-byte partial, fold on every rank.
-    Returns the same bytes on every rank."""
-    import torch
+def _dist_state(group, force_collective):
+    """-> (dist | None, world): dist is None when no collective has to run"""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return fold_partials([partial160], out_fmt)
+    if not (dist.is_available() and dist.is_initialized()):
+        return None, 1
     world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
-    mine = torch.frombuffer(bytearray(partial160), dtype=torch.uint8).to(dev)
-    allp = torch.empty((world * 160,), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(allp, mine, group=group)
-    rows = allp.view(world, 160).cpu().numpy()
-    return fold_partials([rows[i].tobytes() for i in range(world)], out_fmt)
+    if world == 1 and not force_collective:
+        return None, 1
+    return dist, world
 
 
-def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None):
-    """scalars_t / points_t: THIS rank's shard, already on its GPU.  -> (status, bytes).  status NONE if
-    any rank saw a point that does not decompress.  ONE collective per call: the all_gather carries the 160-byte partial
-    sum and the rank's status byte together (176 bytes per rank)."""
+def all_gather_rows(local_t, group=None, force_collective=False):
+    """The exchange step: every rank's 1-D uint8 tensor (same length everywhere) -> (world, length) numpy array on the
+    host, identical on every rank.  With the nccl backend the payload goes device to device (RCCL) and visits the host
+    once, after the collective; with gloo it is copied to the host first."""
     import torch
-    import torch.distributed as dist
-    st, part = eng.msm_partial_t(scalars_t, points_t, in_fmt)
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        if st == _e.NONE:
-            return _e.NONE, None
-        return _e.OK, fold_partials([part], out_fmt)
-    world = dist.get_world_size(group)
-    backend = dist.get_backend(group)
-    dev = scalars_t.device if backend == "nccl" else torch.device("cpu")
-    payload = bytearray(176)
-    payload[:160] = part if st == _e.OK else bytes(160)
-    payload[160] = 1 if st == _e.NONE else 0
-    mine = torch.frombuffer(payload, dtype=torch.uint8).to(dev)
-    allp = torch.empty((world * 176,), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(allp, mine, group=group)
-    rows = allp.view(world, 176).cpu().numpy()
-    if rows[:, 160].any():
-        return _e.NONE, None
-    return _e.OK, fold_partials([rows[i, :160].tobytes() for i in range(world)], out_fmt)
+    dist, world = _dist_state(group, force_collective)
+    if dist is None:
+        return local_t.detach().cpu().numpy().reshape(1, -1)
+    width = local_t.numel()
+    if dist.get_backend(group) == "nccl":
+        assert local_t.is_cuda, "the nccl backend exchanges device tensors"
+        allp = torch.empty((world * width,), dtype=torch.uint8, device=local_t.device)
+        dist.all_gather_into_tensor(allp, local_t.contiguous(), group=group)
+    else:
+        allp = torch.empty((world * width,), dtype=torch.uint8)
+        dist.all_gather_into_tensor(allp, local_t.detach().cpu().contiguous(), group=group)
+    return allp.cpu().numpy().reshape(world, width)
+
+
+def gather_fold(partial160, out_fmt=_e.FMT_EDWARDS_Y, group=None, device=None, force_collective=False):
+    """Exchange + fold for a participant that holds its partial sum as a 160-byte point on the HOST (e.g. from the
+    host-pointer entry points): the point is packed into a record and takes the same path as the device records."""
+    import torch
+    rec = torch.frombuffer(bytearray(_e.partial_record_pack(partial160)), dtype=torch.uint8)
+    dist, _ = _dist_state(group, force_collective)
+    if dist is not None and dist.get_backend(group) == "nccl":
+        rec = rec.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    st, out = _e.fold_partial_records(all_gather_rows(rec, group, force_collective), out_fmt)
+    assert st == _e.OK
+    return out
+
+
+def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None, force_collective=False):
+    """scalars_t / points_t: THIS rank's shard, already on its GPU.  -> (status, bytes | None), the same on every rank.
+    status NONE if any rank saw a point that does not decompress (the counters ride in the records).  ONE collective per
+    call, and this rank's result reaches the host only as part of the gathered records."""
+    rec = eng.msm_partial_record_t(scalars_t, points_t, in_fmt)
+    return _e.fold_partial_records(all_gather_rows(rec, group, force_collective), out_fmt)
 
 
 # the reference's error precedence (batch.rs:208-211 before :244-250; a key that does not decode never reaches
@@ -84,11 +104,11 @@ _VERDICT_RANK = {_e.OK: 0, _e.VERIFY: 1, _e.SCALAR_FORMAT: 2, _e.NONE: 3}
 _RANK_VERDICT = {v: k for k, v in _VERDICT_RANK.items()}
 
 
-def combine_verdicts(status, group=None, device=None):
+def combine_verdicts(status, group=None, device=None, force_collective=False):
     """all_reduce(MAX) of this rank's shard verdict in precedence order -> the batch verdict on every rank."""
     import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    dist, _ = _dist_state(group, force_collective)
+    if dist is None:
         return status
     backend = dist.get_backend(group)
     dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
@@ -97,7 +117,50 @@ def combine_verdicts(status, group=None, device=None):
     return _RANK_VERDICT[int(t.item())]
 
 
-def verify_batch_sharded(eng, msgs_t, msg_off_t, sigs_t, pks_t, z_mode=_e.Z_TRANSCRIPT, pk_points=None, group=None):
-    """THIS rank's shard of the batch (device tensors, as Engine.verify_batch_t) -> the verdict of the whole batch."""
-    st = eng.verify_batch_t(msgs_t, msg_off_t, sigs_t, pks_t, z_mode, pk_points=pk_points)
-    return combine_verdicts(st, group, sigs_t.device)
+def gather_transcript_inputs(hram_t, sigs_t, group=None, force_collective=False):
+    """Every rank's H(R||A||M) (device tensor from Engine.batch_hram_t, trailer excluded here) and s_i -> the whole batch's
+    (N, 64) hram and (N, 64) signature arrays on the host (only the s half of a signature is exchanged; the R half of the
+    returned rows is zero), in rank order, plus this rank's offset into them.  Two collectives: the shard sizes, then the
+    padded 96-byte rows."""
+    import torch
+    n = sigs_t.shape[0]
+    dist, world = _dist_state(group, force_collective)
+    pay = torch.cat([hram_t[:n * 64].reshape(n, 64), sigs_t.reshape(n, 64)[:, 32:]], dim=1).contiguous()      # (n, 96)
+    if dist is None:
+        rows = pay.cpu().numpy()
+        sizes, lo = [n], 0
+    else:
+        nccl = dist.get_backend(group) == "nccl"
+        dev = sigs_t.device if nccl else torch.device("cpu")
+        cnt = torch.tensor([n], dtype=torch.int64, device=dev)
+        allc = torch.empty((world,), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allc, cnt, group=group)
+        sizes = [int(v) for v in allc.cpu().tolist()]
+        nmax = max(max(sizes), 1)
+        padded = torch.zeros((nmax * 96,), dtype=torch.uint8, device=pay.device)
+        padded[:n * 96] = pay.reshape(-1)
+        g = all_gather_rows(padded, group, force_collective).reshape(world, nmax, 96)
+        rows = np.concatenate([g[r, :sizes[r]] for r in range(world)], axis=0) if sum(sizes) else np.zeros((0, 96), np.uint8)
+        lo = sum(sizes[:dist.get_rank(group)])
+    total = rows.shape[0]
+    hram = np.ascontiguousarray(rows[:, :64])
+    sigs = np.zeros((total, 64), dtype=np.uint8)
+    sigs[:, 32:] = rows[:, 64:]
+    return hram, sigs, lo
+
+
+def verify_batch_sharded(eng, msgs_t, msg_off_t, sigs_t, pks_t, z_mode=_e.Z_TRANSCRIPT, pk_points=None, group=None, force_collective=False):
+    """THIS rank's shard of the batch (device tensors, as Engine.verify_batch_t) -> the verdict of the whole batch, the
+    same on every rank.  Z_TRANSCRIPT: the reference's z_i and its single equation over the whole batch (module
+    docstring); Z_DEVICE: independent shard checks."""
+    import torch
+    if z_mode != _e.Z_TRANSCRIPT:
+        st = eng.verify_batch_t(msgs_t, msg_off_t, sigs_t, pks_t, z_mode, pk_points=pk_points)
+        return combine_verdicts(st, group, sigs_t.device, force_collective)
+    n = sigs_t.shape[0]
+    hram_t = eng.batch_hram_t(msgs_t, msg_off_t, sigs_t, pks_t)
+    hram_all, sigs_all, lo = gather_transcript_inputs(hram_t, sigs_t, group, force_collective)
+    z_all = _e.batch_transcript_zs(hram_all, sigs_all)                      # sequential, one host core (the reference's algorithm)
+    z_t = torch.from_numpy(np.ascontiguousarray(z_all[lo:lo + n])).to(sigs_t.device)
+    rec = eng.verify_batch_record_t(sigs_t, pks_t, hram_t, z_t, pk_points=pk_points)
+    return _e.fold_verify_records(all_gather_rows(rec, group, force_collective))

@@ -159,6 +159,23 @@ int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_
 int32_t c25519_msm_partial_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *out160);
 int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64_t count, int out_fmt, uint8_t *out);
 
+/* The same decomposition WITHOUT the partial sum ever visiting the host (what curve25519-dalek_amd/multi.py runs, one
+ * process per GPU): c25519_msm_partial_record_dev only ENQUEUES on the context's stream and leaves a fixed-size RECORD in
+ * device memory -- the window column sums of this rank's terms (the reference's `columns`, pippenger.rs:146-151, before
+ * the Horner fold :159), its counters (a point that does not decode, a scalar with bit 255 set) and the number of terms
+ * the window layout was derived from.  The exchange step is ONE all_gather of C25519_PARTIAL_RECORD_BYTES per rank
+ * (RCCL, device to device), one copy to the host, and c25519_fold_partial_records: records with the same layout are
+ * added column by column and folded once; the others are folded one by one (host arithmetic over count x <= 56 points;
+ * ctx may be NULL).  Returns C25519_NONE iff any rank saw a point that does not decode.  The result is bit-identical to
+ * c25519_msm_vartime over all terms on one context.  d_record: device pointer, 16-byte aligned. */
+#define C25519_PARTIAL_RECORD_BYTES 9024
+int32_t c25519_msm_partial_record_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint8_t *d_record);
+int32_t c25519_fold_partial_records(c25519_ctx *ctx, const uint8_t *records, uint64_t count, int out_fmt, uint8_t *out);
+/* A record that holds a given 160-byte point: lets a participant whose partial sum was computed elsewhere (the host-pointer
+ * entry points, another library) join the same fold.  status: C25519_OK or C25519_NONE; counters8 (may be NULL): eight
+ * u32 counters in the order of the record's flags.  Host arithmetic, no context. */
+int32_t c25519_partial_record_pack(const uint8_t *point160, int32_t status, const uint32_t *counters8, uint8_t *record);
+
 /* One process driving several GPUs (SURVEY.md 8e for a host without torch / RCCL, e.g. the Rust shim): the terms are cut
  * into nctx contiguous shards, shard r runs the whole single-GPU path on ctxs[r] (contexts on different devices, or
  * several on one) from its own host thread, and the nctx partial sums are folded on the host -- the one exchange step of
@@ -195,6 +212,28 @@ int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, co
                                       const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                                   const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_points, uint64_t n, uint32_t z_mode);
+
+/* ---- verify_batch across ranks with the reference's ONE transcript (C25519_Z_TRANSCRIPT; SURVEY.md 8e: "the sequential
+ * transcript runs once on the host and the z_i are scattered") -- the building blocks multi.verify_batch_sharded and
+ * ed25519_verify_batch_multi are made of:
+ *   1. ed25519_batch_hram_dev      this rank's H(R_i || A_i || M_i) (batch.rs:179-191) to device memory: n x 64 bytes followed
+ *                                  by a 64-byte trailer of counters (u32 [0] signatures with a non-canonical s, [1] bad
+ *                                  message offsets); enqueue only.  d_hram needs room for n x 64 + 64 bytes.
+ *   2. (exchange)                  every hram and every s reaches whoever runs the transcript -- one all_gather
+ *   3. ed25519_batch_transcript_zs the reference's Merlin/STROBE transcript over the WHOLE batch (batch.rs:168-222), HOST
+ *                                  pointers, no context: hram n x 64, sigs n x 64 (s = bytes 32..63) -> z16 n x 16
+ *   4. ed25519_verify_batch_record_dev   this rank's share of the batch equation (batch.rs:213-244) with ITS z_i (d_z16) and
+ *                                  its hram buffer from step 1 (trailer included), as a partial-result record in device
+ *                                  memory (layout and size as c25519_msm_partial_record_dev); enqueue only
+ *   5. (exchange) + ed25519_fold_verify_records   the records of all ranks -> the reference's single identity check
+ *                                  (batch.rs:246-250) and error precedence; HOST pointer, ctx may be NULL.
+ * The z_i, the equation and the verdict are those of the reference on the whole batch, whatever the number of ranks. */
+int32_t ed25519_batch_hram_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n,
+                               uint8_t *d_hram);
+int32_t ed25519_batch_transcript_zs(const uint8_t *hram, const uint8_t *sigs, uint64_t n, uint8_t *z16);
+int32_t ed25519_verify_batch_record_dev(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
+                                        uint64_t n, uint8_t *d_record);
+int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *records, uint64_t count);
 
 /* diagnostics for the tests that pin the z derivation: the z_i a batch of n <= 1.5 x 2^20 signatures gets, 16 bytes each
  * to the HOST buffer out_z16 (HOST pointers throughout).  z_mode 0: little-endian u128, the reference's values;

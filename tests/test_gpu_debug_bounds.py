@@ -80,7 +80,7 @@ except pkg.EngineError as ex:
 
 def _run(code, lib):
     env = dict(os.environ)
-    env["C25519_MSM_PASS_LOG2"] = "16"; env["C25519_PREP_CHUNK"] = "64"      # many small passes, the largest normaliser chunk
+    env["C25519_MSM_PASS_LOG2"] = "16"                                       # many small passes
     if lib:
         env["C25519_HIP_LIB"] = lib
     else:

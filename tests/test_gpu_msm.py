@@ -205,14 +205,13 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
         assert st == 0 and got == want
 
 
-@pytest.mark.parametrize("env", [{"C25519_PREP_CHUNK": "64"}, {"C25519_PREP_CHUNK": "32", "C25519_PREP_WPB": "1"}, {"C25519_PREP_CHUNK": "128", "C25519_PREP_WPB": "1"},
-                                 {"C25519_PREP_COALESCED": "0"}, {"C25519_ACC_PIPE": "3"}, {"C25519_ACC_PIPE": "4", "C25519_ACC_CHAIN": "0"},
-                                 {"C25519_MSM_PASS_LOG2": "16", "C25519_PREP_CHUNK": "64"}, {"C25519_MSM_PASS_LOG2": "16", "C25519_PREP_AHEAD": "0"}])
+@pytest.mark.parametrize("env", [{}, {"C25519_MSM_PASS_LOG2": "16"}, {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "1"},
+                                 {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
-    """The tuning knobs are read once per process: every form of the normaliser (points per inversion, waves per block, the
-    per-lane r1 kernel), of the gather (per lane / wave-cooperative) and of the pass split (records prepared ahead or per
-    pass, 2^16-term passes so that a small input runs many) must give the same MSM on ragged sizes -- last wave partly out
-    of range, last step of a lane out of range, fewer points than one block."""
+    """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
+    run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
+    batches), with records prepared ahead (two or three stream sets) or per pass (one); every split must give the same MSM
+    on ragged sizes -- last wave partly out of range, last step of a lane out of range, fewer points than one block."""
     import os, subprocess, sys, textwrap
     code = textwrap.dedent("""
         import sys, numpy as np
@@ -221,7 +220,7 @@ def test_msm_kernel_variants_in_a_fresh_process(orc, env):
         from oracle import orc
         eng = pkg.Engine(0)
         L = util.L
-        for n in (1, 63, 65, 4097, 3 * 65536 + 5, 262144 + 64 * 37 + 1):
+        for n in (1, 63, 65, 4097, 3 * 65536 + 5, 262144 + 64 * 37 + 1, 18 * 65536 + 77):
             x = util.rand_scalars(500 + n, n)
             pts = eng.mul_base_batch(x, out_fmt=2)
             pts[::3] = eng.decompress_batch(eng.compress_batch(pts[::3]))[1]          # a third of the points affine (Z = 1)

@@ -113,20 +113,25 @@ def test_sharded_verify_verdict_precedence_gloo():
 
 
 class _FakeEngine:
-    """Stands in for Engine in the CPU tests: the per-rank MSM partial and the per-rank verify verdict come from the
-    oracle (in production: c25519_msm_partial_dev / ed25519_verify_batch_keys_dev on this rank's GPU); everything else --
-    sharding, the NONE agreement, the exchange, the fold, the verdict combination -- is the production code of multi.py."""
+    """Stands in for Engine in the CPU tests: what the GPU computes per rank -- the MSM partial record, H(R||A||M), the
+    share of the batch equation for given z_i, the shard verdict of the device z-mode -- comes from the oracle; everything
+    else -- sharding, the exchange of the records, the fold, the ONE transcript over the gathered hram / s, the verdict --
+    is the production code of multi.py and of the library's host-side fold."""
 
     def __init__(self, orc, bad_point_rank=None, rank=0):
         self.orc, self.bad_point_rank, self.rank = orc, bad_point_rank, rank
         self.calls = 0
 
-    def msm_partial_t(self, scalars_t, points_t, in_fmt):
+    def msm_partial_record_t(self, scalars_t, points_t, in_fmt):
+        import torch
+        import curve25519_dalek_amd as pkg
         self.calls += 1
-        if self.bad_point_rank == self.rank:
-            return 1, b"\0" * 160                                    # NONE: a point of this shard does not decode
-        xs = [bytes(r) for r in scalars_t.numpy()]; ps = [bytes(r) for r in points_t.numpy()]
-        return 0, self.orc.ed_msm(xs, ps) if xs else self.orc.ed_identity()
+        if self.bad_point_rank == self.rank:                         # NONE: a point of this shard does not decode
+            rec = pkg.engine.partial_record_pack(self.orc.ed_identity(), pkg.engine.NONE)
+        else:
+            xs = [bytes(r) for r in scalars_t.numpy()]; ps = [bytes(r) for r in points_t.numpy()]
+            rec = pkg.engine.partial_record_pack(self.orc.ed_msm(xs, ps) if xs else self.orc.ed_identity())
+        return torch.frombuffer(bytearray(rec), dtype=torch.uint8)
 
     def verify_batch_t(self, msgs_t, msg_off_t, sigs_t, pks_t, z_mode, pk_points=None):
         self.calls += 1
@@ -134,6 +139,45 @@ class _FakeEngine:
         n = sigs_t.shape[0]
         M = [blob[int(off[i]):int(off[i + 1])] for i in range(n)]
         return self.orc.ed25519_verify_batch(M, [bytes(r) for r in sigs_t.numpy()], [bytes(r) for r in pks_t.numpy()])
+
+    def batch_hram_t(self, msgs_t, msg_off_t, sigs_t, pks_t):
+        import hashlib
+        import numpy as np
+        import torch
+        off = msg_off_t.numpy(); blob = bytes(msgs_t.numpy()); n = sigs_t.shape[0]
+        out = bytearray(n * 64 + 64)
+        bad_s = 0
+        for i in range(n):
+            sg = bytes(sigs_t[i].numpy())
+            out[64 * i:64 * i + 64] = hashlib.sha512(sg[:32] + bytes(pks_t[i].numpy()) + blob[int(off[i]):int(off[i + 1])]).digest()
+            bad_s += int(int.from_bytes(sg[32:], "little") >= L)
+        out[n * 64:n * 64 + 4] = int(bad_s).to_bytes(4, "little")
+        return torch.frombuffer(out, dtype=torch.uint8)
+
+    def verify_batch_record_t(self, sigs_t, pks_t, hram_t, z_t, pk_points=None):
+        """-sum z_i s_i B + sum z_i R_i + sum (z_i h_i) A_i (batch.rs:213-244) with the given z_i, as a record"""
+        import torch
+        import curve25519_dalek_amd as pkg
+        orc = self.orc
+        self.calls += 1
+        n = sigs_t.shape[0]
+        hr = bytes(hram_t.numpy()); zz = bytes(z_t.numpy())
+        counters = [0] * 8
+        counters[4] = int.from_bytes(hr[n * 64:n * 64 + 4], "little")
+        scal, pts, bsum = [], [], 0
+        for i in range(n):
+            sg = bytes(sigs_t[i].numpy())
+            z = int.from_bytes(zz[16 * i:16 * i + 16], "little")
+            h = int.from_bytes(hr[64 * i:64 * i + 64], "little") % L
+            R = orc.ed_decompress(sg[:32]); A = orc.ed_decompress(bytes(pks_t[i].numpy()))
+            okR, okA = R is not None, A is not None
+            counters[3] += int(not okR); counters[2] += int(not okA)
+            bsum += z * (int.from_bytes(sg[32:], "little") % L)
+            scal += [z.to_bytes(32, "little"), (z * h % L).to_bytes(32, "little")]
+            pts += [R if okR else orc.ed_identity(), A if okA else orc.ed_identity()]
+        scal.append(((-bsum) % L).to_bytes(32, "little")); pts.append(orc.ed_basepoint())
+        rec = pkg.engine.partial_record_pack(orc.ed_msm(scal, pts), pkg.engine.OK, counters)
+        return torch.frombuffer(bytearray(rec), dtype=torch.uint8)
 
 
 def _sharded_worker(rank, world, port, q):
@@ -158,30 +202,43 @@ def _sharded_worker(rank, world, port, q):
     st, got = pkg.multi.msm_vartime_sharded(eng, torch.from_numpy(x[lo:hi].copy()), torch.from_numpy(pts[lo:hi].copy()), E.FMT_RAW160, E.FMT_EDWARDS_Y)
     want = orc.ed_compress(orc.ed_msm([x[i].tobytes() for i in range(n)], [pts[i].tobytes() for i in range(n)]))
     out["msm"] = (st == 0 and got == want and eng.calls == 1)
-    # a point that does not decode on ONE rank -> NONE on EVERY rank (Option::None of the reference), no fold
+    # a point that does not decode on ONE rank -> NONE on EVERY rank (Option::None of the reference), no result
     eng = _FakeEngine(orc, bad_point_rank=1, rank=rank)
     st, got = pkg.multi.msm_vartime_sharded(eng, torch.from_numpy(x[lo:hi].copy()), torch.from_numpy(pts[lo:hi].copy()), E.FMT_RAW160, E.FMT_EDWARDS_Y)
     out["msm_none"] = (st == E.NONE and got is None)
-    # ---- verify_batch_sharded: the batch verdict from the shard verdicts ---------------------------------------------------
-    m = 24
+    # ---- verify_batch_sharded: both z-modes ---------------------------------------------------------------------------------
+    m = 25                                                  # odd: the two shards differ in size
     seeds = rng.integers(0, 256, size=(m, 32), dtype=np.uint8); msgs = rng.integers(0, 256, size=(m, 19), dtype=np.uint8)
     pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=1)
-    res = []
-    for bad_at, kind in ((None, None), (3, "verify"), (m - 2, "verify"), (m - 2, "scalar"), (3, "scalar")):
-        sg = sigs.copy()
-        if kind == "verify":
-            sg[bad_at, 5] ^= 1
-        elif kind == "scalar":
-            sg[bad_at, 63] |= 0x20
-        if bad_at == 3 and kind == "scalar":
-            sg[m - 2, 5] ^= 1                                # Verify on the other rank: ScalarFormat still wins
-        lo, hi = pkg.multi.shard_range(m, rank, world)
-        off = np.arange(0, 19 * (hi - lo + 1), 19, dtype=np.int64)
-        eng = _FakeEngine(orc, rank=rank)
-        v = pkg.multi.verify_batch_sharded(eng, torch.from_numpy(msgs[lo:hi].reshape(-1).copy()), torch.from_numpy(off), torch.from_numpy(sg[lo:hi].copy()),
-                                          torch.from_numpy(pks[lo:hi].copy()))
-        res.append(v)
-    out["verify"] = res
+    res = {E.Z_TRANSCRIPT: [], E.Z_DEVICE: []}
+    for z_mode in (E.Z_TRANSCRIPT, E.Z_DEVICE):
+        for bad_at, kind in ((None, None), (3, "verify"), (m - 2, "verify"), (m - 2, "scalar"), (3, "scalar")):
+            sg = sigs.copy()
+            if kind == "verify":
+                sg[bad_at, 5] ^= 1
+            elif kind == "scalar":
+                sg[bad_at, 63] |= 0x20
+            if bad_at == 3 and kind == "scalar":
+                sg[m - 2, 5] ^= 1                                # Verify on the other rank: ScalarFormat still wins
+            lo, hi = pkg.multi.shard_range(m, rank, world)
+            off = np.arange(0, 19 * (hi - lo + 1), 19, dtype=np.int64)
+            eng = _FakeEngine(orc, rank=rank)
+            v = pkg.multi.verify_batch_sharded(eng, torch.from_numpy(msgs[lo:hi].reshape(-1).copy()), torch.from_numpy(off), torch.from_numpy(sg[lo:hi].copy()),
+                                              torch.from_numpy(pks[lo:hi].copy()), z_mode=z_mode)
+            res[z_mode].append(v)
+    out["verify_transcript"] = res[E.Z_TRANSCRIPT]
+    out["verify_device"] = res[E.Z_DEVICE]
+    # ---- the z_i of the sharded transcript mode are the ONE transcript's: equal to the oracle's over the whole batch --------------
+    lo, hi = pkg.multi.shard_range(m, rank, world)
+    off = np.arange(0, 19 * (hi - lo + 1), 19, dtype=np.int64)
+    eng = _FakeEngine(orc, rank=rank)
+    hram_t = eng.batch_hram_t(torch.from_numpy(msgs[lo:hi].reshape(-1).copy()), torch.from_numpy(off), torch.from_numpy(sigs[lo:hi].copy()), torch.from_numpy(pks[lo:hi].copy()))
+    hram_all, sigs_all, mylo = pkg.multi.gather_transcript_inputs(hram_t, torch.from_numpy(sigs[lo:hi].copy()))
+    z_all = E.batch_transcript_zs(hram_all, sigs_all)
+    import hashlib
+    hr = [hashlib.sha512(sigs[i, :32].tobytes() + pks[i].tobytes() + msgs[i].tobytes()).digest() for i in range(m)]
+    want_z = orc.batch_transcript_zs(hr, [sigs[i, 32:].tobytes() for i in range(m)])
+    out["one_transcript"] = (mylo == lo and z_all.tobytes() == b"".join(want_z) and sigs_all[:, 32:].tobytes() == sigs[:, 32:].tobytes())
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
@@ -204,7 +261,9 @@ def test_sharded_entry_points_control_flow_gloo():
     OK, SCALAR_FORMAT, VERIFY = 0, 2, 3
     for _, out in res:
         assert out["msm"] and out["msm_none"]
-        assert out["verify"] == [OK, VERIFY, VERIFY, SCALAR_FORMAT, SCALAR_FORMAT]
+        assert out["verify_transcript"] == [OK, VERIFY, VERIFY, SCALAR_FORMAT, SCALAR_FORMAT]
+        assert out["verify_device"] == [OK, VERIFY, VERIFY, SCALAR_FORMAT, SCALAR_FORMAT]
+        assert out["one_transcript"]
 
 
 def test_bench_gpus_flag_fails_loudly_without_the_gpus():

@@ -17,7 +17,7 @@ label, line = sys.argv[1], sys.argv[2]
 try:
     d = json.loads(line)
     t = d["roofline"]["timings_ms"]
-    print("%-44s %8.3f ms/step  %.3e %s  valu %.3f  dom %.3f ms  %s" % (label, d["ms_per_step"], d["value"], d["unit"], d["valu"]["frac"], d["roofline"]["kernel_ms_per_launch"] or -1,
+    print("%-44s %8.3f ms/step  %.3e %s  valu %.3f  dom %.3f ms  %s" % (label, d["ms_per_step"], d["value"], d["unit"], d["roofline"]["whole_call"]["frac"], d["roofline"]["kernel_ms_per_launch"] or -1,
           " ".join("%s=%.3f" % (k[:14], v) for k, v in t.items())))
 except Exception as e:
     print("%-44s FAILED %s %s" % (label, e, line[:200]))
