@@ -192,6 +192,23 @@ EXPORT void orc_merlin_simple(const char *proto, const char *l1, const uint8_t *
     merlin_transcript t; merlin_new(&t, proto); merlin_append_message(&t, l1, m, n); merlin_challenge_bytes(&t, l2, out, outlen);
 }
 
+/* A STROBE-128 op script: pins every operation Merlin uses (incl. KEY with arbitrary data, which the batch transcript only
+   reaches with 32 zero bytes) against the independent reference in tests/pyref.py.  ops: nops x 6 bytes
+   {op (0 meta_ad, 1 ad, 2 prf, 3 key), more, LE32 length}; data: the absorbed bytes, concatenated; out: the PRF outputs. */
+EXPORT void orc_strobe_script(const uint8_t *proto, size_t proto_len, const uint8_t *ops, size_t nops, const uint8_t *data, uint8_t *out) {
+    strobe128 s; strobe_new(&s, proto, proto_len);
+    for (size_t i = 0; i < nops; i++) {
+        const uint8_t *o = ops + 6 * i;
+        size_t n = (size_t)o[2] | ((size_t)o[3] << 8) | ((size_t)o[4] << 16) | ((size_t)o[5] << 24);
+        switch (o[0]) {
+        case 0: strobe_meta_ad(&s, data, n, o[1]); data += n; break;
+        case 1: strobe_ad(&s, data, n, o[1]); data += n; break;
+        case 2: strobe_prf(&s, out, n, o[1]); out += n; break;
+        default: strobe_key(&s, data, n, o[1]); data += n; break;
+        }
+    }
+}
+
 /* ---------------- Ed25519 ---------------- */
 enum { ST_OK = 0, ST_NONE = 1, ST_SCALAR_FORMAT = 2, ST_VERIFY = 3, ST_ARRAY_LENGTH = 4 };
 

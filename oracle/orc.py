@@ -208,6 +208,23 @@ def merlin_simple(proto, l1, msg, l2, outlen):
 
 
 # ---- Ed25519 ----
+def strobe_script(proto, ops):
+    """ops: list of (name, more, payload) with name in meta_ad / ad / prf / key; payload = bytes to absorb, or the number of
+    bytes to squeeze for prf.  -> the concatenated PRF outputs (orc_strobe_script)."""
+    code = {"meta_ad": 0, "ad": 1, "prf": 2, "key": 3}
+    enc, data, outlen = b"", b"", 0
+    for name, more, payload in ops:
+        n = payload if name == "prf" else len(payload)
+        enc += bytes([code[name], 1 if more else 0]) + int(n).to_bytes(4, "little")
+        if name == "prf":
+            outlen += n
+        else:
+            data += payload
+    o = _out(max(outlen, 1))
+    lib().orc_strobe_script(proto, C.c_size_t(len(proto)), enc, C.c_size_t(len(ops)), data, o)
+    return o.raw[:outlen]
+
+
 def ed25519_pubkey(sk):
     return _call_b("orc_ed25519_pubkey", _b(sk, 32))
 

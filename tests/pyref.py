@@ -134,3 +134,182 @@ def ed25519_verify_cofactorless(pk, msg, sig):
     k = sha512_modl(sig[:32], pk, msg)
     Rc = ed_add(ed_mul(s, B), ed_neg(ed_mul(k, A)))
     return ed_compress(Rc) == sig[:32]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# STROBE-128/1600 + Merlin, written from the public specifications (FIPS 202; STROBE v1.0.2, strobe.sourceforge.io/specs;
+# merlin.cool/transcript) in their GENERAL form -- every operation goes through one `operate(flags, data, more)` that derives
+# its duplex behaviour from the flag bits (cbefore / cafter), the Keccak round constants and rotation offsets are GENERATED
+# (LFSR / (x, y) -> (y, 2x + 3y) walk), and the state is a byte array.  It shares nothing with oracle/hashes.h or
+# csrc/transcript_host.h (which special-case the four operations they need, keep the state as 25 lanes and take their
+# constants from a table): it is the third opinion on the z_i of verify_batch, including the KEY operation of the RNG
+# finalisation (transcript.rs:157-173) that Merlin's published conformance vector never exercises.
+# ---------------------------------------------------------------------------------------------------------------------
+def _keccak_constants():
+    rc, r = [], 1
+    for _ in range(24):
+        c = 0
+        for j in range(7):                          # rc(t) of FIPS 202 algorithm 5: an LFSR over x^8 + x^6 + x^5 + x^4 + 1
+            if r & 1:
+                c |= 1 << ((1 << j) - 1)
+            r <<= 1
+            if r & 0x100:
+                r ^= 0x171
+        rc.append(c)
+    rot = [[0] * 5 for _ in range(5)]
+    x, y = 1, 0
+    for t in range(24):                             # FIPS 202 algorithm 2 (rho)
+        rot[x][y] = ((t + 1) * (t + 2) // 2) % 64
+        x, y = y, (2 * x + 3 * y) % 5
+    return rc, rot
+
+
+_KRC, _KROT = _keccak_constants()
+_M64 = (1 << 64) - 1
+
+
+def keccak_f1600(state):
+    """state: bytearray(200), permuted in place"""
+    a = [[int.from_bytes(state[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
+    rol = lambda v, n: ((v << n) | (v >> (64 - n))) & _M64 if n else v
+    for rnd in range(24):
+        c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
+        d = [c[(x - 1) % 5] ^ rol(c[(x + 1) % 5], 1) for x in range(5)]
+        a = [[a[x][y] ^ d[x] for y in range(5)] for x in range(5)]
+        b = [[0] * 5 for _ in range(5)]
+        for x in range(5):
+            for y in range(5):
+                b[y][(2 * x + 3 * y) % 5] = rol(a[x][y], _KROT[x][y])
+        a = [[b[x][y] ^ ((~b[(x + 1) % 5][y]) & b[(x + 2) % 5][y]) for y in range(5)] for x in range(5)]
+        a[0][0] ^= _KRC[rnd]
+    for x in range(5):
+        for y in range(5):
+            state[8 * (x + 5 * y):8 * (x + 5 * y) + 8] = a[x][y].to_bytes(8, "little")
+
+
+def sponge(rate, suffix, msg, outlen):
+    """plain Keccak sponge on keccak_f1600 (SHA3-256: rate 136, suffix 0x06; SHAKE128: rate 168, suffix 0x1f): pins the permutation"""
+    st = bytearray(200)
+    m = bytearray(msg) + bytes([suffix])
+    m += bytes((-len(m)) % rate)
+    m[-1] |= 0x80
+    for off in range(0, len(m), rate):
+        for i in range(rate):
+            st[i] ^= m[off + i]
+        keccak_f1600(st)
+    out = b""
+    while len(out) < outlen:
+        out += bytes(st[:rate])
+        if len(out) < outlen:
+            keccak_f1600(st)
+    return out[:outlen]
+
+
+class Strobe128:
+    """STROBE v1.0.2, security level 128, Keccak-f[1600]; section 6 of the specification ("Strobe-128/1600")."""
+    I, A, C, T, M, K = 1, 2, 4, 8, 16, 32
+
+    def __init__(self, proto):
+        self.R = 200 - 128 // 4 - 2                                  # N - sec/4 - 2 = 166
+        self.st = bytearray(200)
+        self.pos = self.posbegin = 0
+        self.I0 = None
+        self.cur_flags = None
+        # S = F(0x01 || R+2 || 0x01 || 0x00 || 0x01 || 12*8 || "STROBEv1.0.2")  (cSHAKE-style domain separation, section 5)
+        dom = bytes([1, self.R + 2, 1, 0, 1, 12 * 8]) + b"STROBEv1.0.2"
+        self.st[:len(dom)] = dom
+        keccak_f1600(self.st)
+        self.operate(self.A | self.M, proto)
+
+    def _run_f(self):
+        self.st[self.pos] ^= self.posbegin
+        self.st[self.pos + 1] ^= 0x04
+        self.st[self.R + 1] ^= 0x80
+        keccak_f1600(self.st)
+        self.pos = self.posbegin = 0
+
+    def _duplex(self, data, cbefore, cafter, force_f):
+        data = bytearray(data)
+        for i in range(len(data)):
+            if cbefore:
+                data[i] ^= self.st[self.pos]
+            self.st[self.pos] ^= data[i]
+            if cafter:
+                data[i] = self.st[self.pos]
+            self.pos += 1
+            if self.pos == self.R:
+                self._run_f()
+        if force_f and self.pos != 0:
+            self._run_f()
+        return bytes(data)
+
+    def _begin_op(self, flags):
+        if flags & self.T:                                           # (no transport operations in Merlin; kept for generality)
+            if self.I0 is None:
+                self.I0 = flags & self.I
+            flags ^= self.I0
+        old, self.posbegin = self.posbegin, self.pos + 1
+        self._duplex(bytes([old, flags]), False, False, bool(flags & (self.C | self.K)))
+
+    def operate(self, flags, data, more=False):
+        """data: bytes to absorb, or an int = number of bytes to produce (operations with I set and A set: PRF)"""
+        if more:
+            assert flags == self.cur_flags
+        else:
+            self._begin_op(flags)
+            self.cur_flags = flags
+        if isinstance(data, int):
+            data = bytes(data)
+        cafter = (flags & (self.C | self.I | self.T)) == (self.C | self.T)
+        cbefore = bool(flags & self.C) and not cafter
+        processed = self._duplex(data, cbefore, cafter, False)
+        if (flags & (self.I | self.A)) == (self.I | self.A):
+            return processed                                         # output to the application (PRF, recv_CLR, ...)
+        if (flags & (self.I | self.T)) == self.T:
+            return processed                                         # output to the transport
+        return None
+
+
+class MerlinTranscript:
+    """merlin.cool/transcript/ops.html; the reference's copy is ed25519-dalek/src/batch/transcript.rs:39-207"""
+
+    def __init__(self, label):
+        self.s = Strobe128(b"Merlin v1.0")
+        self.append_message(b"dom-sep", label)
+
+    def append_message(self, label, msg):
+        S = self.s
+        S.operate(S.M | S.A, label)
+        S.operate(S.M | S.A, len(msg).to_bytes(4, "little"), more=True)
+        S.operate(S.A, msg)
+
+    def challenge_bytes(self, label, n):
+        S = self.s
+        S.operate(S.M | S.A, label)
+        S.operate(S.M | S.A, n.to_bytes(4, "little"), more=True)
+        return S.operate(S.I | S.A | S.C, n)
+
+    def rng_finalize(self, random32):
+        """build_rng().finalize(rng): meta-AD "rng", then KEY with the 32 bytes the external RNG supplied (transcript.rs:157-173)"""
+        S = self.s
+        S.operate(S.M | S.A, b"rng")
+        S.operate(S.A | S.C, random32)
+        return self
+
+    def rng_fill(self, n):
+        """TranscriptRng::fill_bytes (transcript.rs:200-206)"""
+        S = self.s
+        S.operate(S.M | S.A, n.to_bytes(4, "little"))
+        return S.operate(S.I | S.A | S.C, n)
+
+
+def batch_transcript_zs(hrams, ss):
+    """The z_i of ed25519_dalek::verify_batch (batch.rs:168-222): hrams = [H(R||A||M)] (64 bytes each), ss = [s] (32 bytes each)
+    -> list of 16-byte strings (little-endian u128).  ZeroRng leaves merlin's zero-initialised buffer unchanged (batch.rs:49-76)."""
+    t = MerlinTranscript(b"ed25519 batch verification")
+    for h in hrams:
+        t.append_message(b"hram", h)
+    for s in ss:
+        t.append_message(b"sig.s", s)
+    t.rng_finalize(bytes(32))
+    return [t.rng_fill(16) for _ in hrams]
