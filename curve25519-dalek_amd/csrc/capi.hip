@@ -14,6 +14,7 @@
 #include "ctx.h"
 #include "sc_sha.h"
 #include "msm_internal.h"
+#include "ffi.h"
 
 using namespace c25519;
 
@@ -43,11 +44,10 @@ int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes) {
 }
 
 // ---- fixed-base table, built by the `create` logic of edwards.rs:1131-1141 -----------------------
-// entry j (1..HALF) of window i = j * 2^(W i) * B, as canonical (y+x, y-x, 2dxy); entry 0 = identity.
-static void build_basepoint_table(int W, std::vector<uint32_t> &out) {
+// entry j (1..HALF) of window i = j * 2^(W i) * P (P = B for the context's own tables), as canonical (y+x, y-x, 2dxy); entry 0 = identity.
+static void build_window_table(ge_p3 base, int W, std::vector<uint32_t> &out) {
     const int NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1;
     std::vector<ge_p3> pts((size_t)NWIN * HALF);
-    ge_p3 base = ge_basepoint();
     for (int i = 0; i < NWIN; i++) {
         ge_p3 acc = base;
         for (int j = 0; j < HALF; j++) {
@@ -208,7 +208,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     const int wide = (w >= 10 && w <= 20) ? w : (w == 0 ? 16 : 0);   // default: radix 2^16 (measured best table size / speed point)
     ctx->w = (w >= 4 && w <= 6) ? w : 9;       // 4..6: per-position LDS window tables; 9: signed comb (also bootstraps the wide table)
     std::vector<uint32_t> tab;
-    if (ctx->w == 9) build_comb_table(tab); else build_basepoint_table(ctx->w, tab);
+    if (ctx->w == 9) build_comb_table(tab); else build_window_table(ge_basepoint(), ctx->w, tab);
     if (hipMalloc(&ctx->d_table, tab.size() * 4) != hipSuccess ||
         hipMemcpy(ctx->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
         hipMalloc(&ctx->d_flag, 256) != hipSuccess) {
@@ -218,7 +218,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     }
     {   // constant-time path: radix-2^5 window tables (52 x 17 entries x 96 B)
         std::vector<uint32_t> tct;
-        build_basepoint_table(C25519_CT_W, tct);
+        build_window_table(ge_basepoint(), C25519_CT_W, tct);
         if (hipMalloc(&ctx->d_table_ct, tct.size() * 4) != hipSuccess || hipMemcpy(ctx->d_table_ct, tct.data(), tct.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
             fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
             c25519_ctx_destroy(ctx);
@@ -254,6 +254,10 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
     if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
     if (ctx->ev_pts) hipEventDestroy(ctx->ev_pts);
+    if (ctx->s_h2d) { hipStreamSynchronize(ctx->s_h2d); hipStreamDestroy(ctx->s_h2d); }
+    if (ctx->s_d2h) { hipStreamSynchronize(ctx->s_d2h); hipStreamDestroy(ctx->s_d2h); }
+    for (int i = 0; i < c25519_ctx::FFI_MAXCH; i++) { if (ctx->ev_up[i]) hipEventDestroy(ctx->ev_up[i]); if (ctx->ev_kd[i]) hipEventDestroy(ctx->ev_kd[i]); }
+    if (ctx->ev_ffi) hipEventDestroy(ctx->ev_ffi);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
     if (ctx->d_slots) hipFree(ctx->d_slots);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);
@@ -266,10 +270,8 @@ EXPORT int32_t c25519_ctx_set_stream(c25519_ctx *ctx, void *hip_stream) {
     if ((hipStream_t)hip_stream == ctx->stream) return C25519_OK;
     // the context's workspaces may still be in use by work enqueued on the old stream: the new stream starts after it
     if (ctx->own_stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); ctx->own_stream = false; }
-    else {
-        HIPCHK(hipEventRecord(ctx->ev_rebind, ctx->stream));
-        HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_rebind, 0));
-    }
+    else if (hipEventRecord(ctx->ev_rebind, ctx->stream) == hipSuccess) HIPCHK(hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_rebind, 0));
+    else (void)hipGetLastError();     // the caller has already destroyed the old stream: nothing of ours can be pending on it
     ctx->stream = (hipStream_t)hip_stream;
     return C25519_OK;
 }
@@ -289,9 +291,12 @@ EXPORT float c25519_last_kernel_ms(c25519_ctx *ctx) {
 
 // phase of one ring entry: 0 = events 0 -> 1 (the dominant kernel), 1 = 1 -> 2 (what follows it), 2 = 3 -> 2 (a whole
 // MSM / verify_batch pass), 3 = 4 -> 5 (decompression of R inside a verify_batch pass)
-static float ring_phase_ms(hipEvent_t *ev, int phase) {
+static float ring_phase_ms(hipEvent_t *ev, int phase, uint8_t kind) {
     static const int from[4] = {0, 1, 3, 4}, to[4] = {1, 2, 2, 5};
     if (phase < 0 || phase > 3) return -1.f;
+    // events 3..5 are only recorded by MSM (kind 1: phase 2) and verify_batch (kind 2: phases 2 and 3) passes; a ring entry
+    // last written by another kind of call would report the stale events of an older pass
+    if ((phase == 2 && kind == 0) || (phase == 3 && kind != 2)) return -1.f;
     float ms = -1.f;
     if (hipEventSynchronize(ev[2]) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, ev[from[phase]], ev[to[phase]]) != hipSuccess) return -1.f;
@@ -301,7 +306,8 @@ static float ring_phase_ms(hipEvent_t *ev, int phase) {
 EXPORT float c25519_phase_ms(c25519_ctx *ctx, uint32_t back, int phase) {
     if (back >= ctx->ncalls || back >= (uint32_t)c25519_ctx::RING) return -1.f;
     hipSetDevice(ctx->device);
-    return ring_phase_ms(ctx->ring[(ctx->ncalls - 1 - back) % c25519_ctx::RING], phase);
+    const int idx = (int)((ctx->ncalls - 1 - back) % c25519_ctx::RING);
+    return ring_phase_ms(ctx->ring[idx], phase, ctx->ring_kind[idx]);
 }
 // the same summed over every pass of the most recent MSM / verify_batch call (passes alternate between the context
 // and its peer); *passes (may be NULL) receives their number.  -1 if the call had more passes than the ring holds.
@@ -311,18 +317,77 @@ EXPORT float c25519_last_call_phase_ms(c25519_ctx *ctx, int phase, uint32_t *pas
     hipSetDevice(ctx->device);
     float sum = 0.f;
     for (auto &pr : ctx->last_passes) {
-        float ms = ring_phase_ms(pr.first->ring[pr.second], phase);
+        float ms = ring_phase_ms(pr.first->ring[pr.second], phase, pr.first->ring_kind[pr.second]);
         if (ms < 0) return -1.f;
         sum += ms;
     }
     return sum;
 }
 
+// ---- host-pointer staging (ffi.h) ---------------------------------------------------------------------------------
+static inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+int32_t ffi_begin(c25519_ctx *ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (!ctx->s_h2d) {
+        HIPCHK(hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < c25519_ctx::FFI_MAXCH; i++) {
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_up[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ctx->ev_kd[i], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventCreateWithFlags(&ctx->ev_ffi, hipEventDisableTiming));
+    }
+    ctx->ffi_t0 = wall_ms();
+    HIPCHK(hipEventRecord(ctx->ev_ffi, ctx->stream));            // the staging buffers may still be in use (wipes of the previous call)
+    HIPCHK(hipStreamWaitEvent(ctx->s_h2d, ctx->ev_ffi, 0));
+    return C25519_OK;
+}
+int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
+    const hipError_t e1 = hipStreamSynchronize(ctx->s_d2h), e2 = hipStreamSynchronize(ctx->s_h2d);
+    ctx->ffi_ms = wall_ms() - ctx->ffi_t0; ctx->ffi_h2d = h2d_bytes; ctx->ffi_d2h = d2h_bytes;
+    if (e1 != hipSuccess) return c25519_fail(ctx, e1, "hipStreamSynchronize(d2h)");
+    if (e2 != hipSuccess) return c25519_fail(ctx, e2, "hipStreamSynchronize(h2d)");
+    return C25519_OK;
+}
+// wall-clock milliseconds and bytes moved each way by the latest host-pointer call of this context (-1 if none)
+EXPORT double c25519_last_ffi_ms(const c25519_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes) {
+    if (h2d_bytes) *h2d_bytes = ctx->ffi_h2d;
+    if (d2h_bytes) *d2h_bytes = ctx->ffi_d2h;
+    return ctx->ffi_ms;
+}
+// page-locked host memory for callers that want their buffers DMA-able without a first-touch penalty (ffi.h)
+EXPORT void *c25519_host_alloc(size_t bytes) {
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+EXPORT void c25519_host_free(void *p) { if (p) hipHostFree(p); }
+// wipes device staging on EVERY exit path of a host-pointer entry point (after the copy streams have drained)
+struct wipe_on_exit {
+    c25519_ctx *ctx; void *p[4]; size_t n[4]; int cnt = 0;
+    explicit wipe_on_exit(c25519_ctx *c) : ctx(c) {}
+    void add(void *q, size_t bytes) { if (q && bytes && cnt < 4) { p[cnt] = q; n[cnt++] = bytes; } }
+    ~wipe_on_exit() { for (int i = 0; i < cnt; i++) hipMemsetAsync(p[i], 0, n[i], ctx->stream); }
+};
+// release the workspaces a large call left behind (a 2^24-term MSM keeps ~2.6 GB: the records prepared ahead, the
+// normaliser's prefix products, the staging copies of host-pointer calls); the next call re-allocates what it needs
+EXPORT int32_t c25519_ctx_trim(c25519_ctx *ctx) {
+    HIPCHK(hipSetDevice(ctx->device));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (c25519_ctx *c = ctx; c; c = c->peer) {
+        if (c != ctx && c->stream) HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
+        devbuf *bufs[] = {&c->scratch, &c->prefix, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_c2, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->pts_all};
+        for (devbuf *b : bufs) if (b->p) { HIPCHK(hipFree(b->p)); b->p = nullptr; b->cap = 0; }
+    }
+    return C25519_OK;
+}
+
 // name of the kernel that phase 0 (which = 0) / phase 3 (which = 1) of the latest entry point timed
 EXPORT const char *c25519_last_kernel_name(const c25519_ctx *ctx, int which) { return (ctx && which >= 0 && which < 2) ? ctx->kname[which] : ""; }
 
 // ---- fixed base --------------------------------------------------------------------------------
-int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret) {
+int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret, const uint32_t *table_ct) {
     HIPCHK(hipSetDevice(ctx->device));
     if (out_fmt != C25519_FMT_EDWARDS_Y && out_fmt != C25519_FMT_RISTRETTO && out_fmt != C25519_FMT_RAW160) { ctx->err = "mul_base: out_fmt must be 0, 1 or 2"; return -(int32_t)hipErrorInvalidValue; }
     if (out_fmt == C25519_FMT_EDWARDS_Y) {
@@ -330,13 +395,13 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     }
     if (out_fmt == C25519_FMT_RISTRETTO) { int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256); if (r) return r; }
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     ctx->kname[0] = secret ? "c25519::k_mul_base<5, 1024, OUT, true> (constant-time scan, radix-2^5 tables in LDS)"
                            : (ctx->w >= 10 ? "c25519::k_mul_base_wide<OUT> (radix-2^w tables in HBM)" : ctx->w == 9 ? "c25519::k_mul_base_comb" : "c25519::k_mul_base<W, BS, OUT, false>");
     auto mul = [&](uint32_t *scratch, uint8_t *out_raw) -> hipError_t {
-        return secret ? launch_mul_base_ct(d_scalars, n, ctx->d_table_ct, scratch, out_raw, ctx->num_cus, ctx->stream)
+        return secret ? launch_mul_base_ct(d_scalars, n, table_ct ? table_ct : ctx->d_table_ct, scratch, out_raw, ctx->num_cus, ctx->stream)
                       : launch_mul_base(ctx->w, d_scalars, n, ctx->d_table, scratch, out_raw, ctx->num_cus, ctx->stream);
     };
     if (out_fmt == C25519_FMT_RAW160) {
@@ -361,42 +426,89 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
     return C25519_OK;
 }
 EXPORT int32_t c25519_mul_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
-    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, ctx_secret_default(ctx));
+    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, ctx_secret_default(ctx), nullptr);
 }
 // the same for scalars the caller declares PUBLIC: always the fast tables (addresses depend on the scalar)
 EXPORT int32_t c25519_mul_base_batch_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
-    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, false);
+    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, false, nullptr);
 }
 
-// host-pointer wrapper helper
-struct staged {
-    c25519_ctx *ctx; devbuf &buf; uint8_t *p;
-    staged(c25519_ctx *c, devbuf &b) : ctx(c), buf(b), p(nullptr) {}
-    int32_t up(const void *host, size_t bytes) {
-        int32_t r = ctx_reserve(ctx, buf, bytes ? bytes : 16); if (r) return r;
-        p = (uint8_t *)buf.p;
-        if (bytes) { hipError_t e = hipMemcpyAsync(p, host, bytes, hipMemcpyHostToDevice, ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "H2D"); }
-        return 0;
-    }
-    int32_t alloc(size_t bytes) { int32_t r = ctx_reserve(ctx, buf, bytes ? bytes : 16); p = (uint8_t *)buf.p; return r; }
-    int32_t down(void *host, size_t bytes) {
-        if (!bytes) return 0;
-        hipError_t e = hipMemcpyAsync(host, p, bytes, hipMemcpyDeviceToHost, ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "D2H");
-        e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) return c25519_fail(ctx, e, "sync");
-        return 0;
-    }
-};
-
-EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out) {
+static inline int32_t reserve2(c25519_ctx *ctx, devbuf &a, size_t na, devbuf &b, size_t nb) { int32_t r = ctx_reserve(ctx, a, na ? na : 16); return r ? r : ctx_reserve(ctx, b, nb ? nb : 16); }
+static int32_t mul_base_host(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out, bool secret, bool clamp, const uint32_t *table_ct) {
     HIPCHK(hipSetDevice(ctx->device));
-    size_t osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
-    staged in(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
+    if (out_fmt < 0 || out_fmt > 2) { ctx->err = "mul_base: out_fmt must be 0, 1 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    const size_t osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
-    if ((r = in.up(scalars, n * 32)) || (r = o.alloc(n * osz))) return r;
-    if ((r = c25519_mul_base_batch_dev(ctx, in.p, n, out_fmt, o.p))) return r;
-    r = o.down(out, n * osz);
-    if (ctx_secret_default(ctx) && n) hipMemsetAsync(in.p, 0, n * 32, ctx->stream);      // the staged scalars
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * osz))) return r;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
+    wipe_on_exit wipe(ctx);
+    if (secret) wipe.add(d_in, n * 32);                   // the staged scalars
+    const ffi_in in = {scalars, d_in, 32};
+    const ffi_out o = {out, d_out, osz};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 18), &in, 1, &o, 1, [&](uint64_t lo, uint64_t m) -> int32_t {
+        if (clamp) HIPCHK(launch_clamp(d_in + lo * 32, m, d_in + lo * 32, ctx->stream));
+        return mul_base_impl(ctx, d_in + lo * 32, m, out_fmt, d_out + lo * osz, secret, table_ct);
+    });
+}
+EXPORT int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out) {
+    return mul_base_host(ctx, scalars, n, out_fmt, out, ctx_secret_default(ctx), false, nullptr);
+}
+// EdwardsPoint::mul_base_clamped (edwards.rs:948-956): out[i] = clamp_integer(bytes[i]) * B, the scalar NOT reduced mod l
+EXPORT int32_t c25519_mul_base_clamped_batch_dev(c25519_ctx *ctx, const uint8_t *d_bytes, uint64_t n, int out_fmt, uint8_t *d_out) {
+    HIPCHK(hipSetDevice(ctx->device));
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 32 + 16))) return r;
+    HIPCHK(launch_clamp(d_bytes, n, (uint8_t *)ctx->tmp_c2.p, ctx->stream));
+    r = mul_base_impl(ctx, (const uint8_t *)ctx->tmp_c2.p, n, out_fmt, d_out, ctx_secret_default(ctx), nullptr);
+    if (n) hipMemsetAsync(ctx->tmp_c2.p, 0, n * 32, ctx->stream);      // the clamped secrets, on every path
     return r;
+}
+EXPORT int32_t c25519_mul_base_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, uint64_t n, int out_fmt, uint8_t *out) {
+    return mul_base_host(ctx, bytes, n, out_fmt, out, ctx_secret_default(ctx), true, nullptr);
+}
+
+// ---- constant-time fixed-base tables for a caller's point: EdwardsBasepointTable::create(&P) (edwards.rs:1131-1141) and
+// RistrettoBasepointTable::create (ristretto.rs:1080-1110), then `&scalar * &table` (edwards.rs:1192-1209).  The table has the
+// layout of the context's own constant-time table (radix 2^5: 52 windows x 17 entries, staged in LDS by the kernel) and is
+// ALWAYS read with the full-window scan of window.rs:54-76, whatever the context's flags: these tables exist for secret scalars
+// (Pedersen commitments a*G + b*H, ElGamal keys ...).
+struct c25519_basetable { uint32_t *d_table; };
+EXPORT c25519_basetable *c25519_basetable_create(c25519_ctx *ctx, const uint8_t *point, int in_fmt) {
+    if (hipSetDevice(ctx->device) != hipSuccess) return nullptr;
+    ge_p3 P;
+    if (in_fmt == C25519_FMT_RAW160) P = host_from_raw160(point);
+    else if (in_fmt == C25519_FMT_EDWARDS_Y || in_fmt == C25519_FMT_RISTRETTO) {
+        u32 w[8];
+        memcpy(w, point, 32);
+        const bool ok = in_fmt == C25519_FMT_EDWARDS_Y ? ge_decompress(P, w) : ris_decompress(P, w);
+        if (!ok) { ctx->err = "basetable_create: the point does not decode"; return nullptr; }
+    } else { ctx->err = "basetable_create: bad in_fmt"; return nullptr; }
+    std::vector<uint32_t> tab;
+    try { build_window_table(P, C25519_CT_W, tab); } catch (const std::exception &e) { ctx->err = std::string("basetable_create: ") + e.what(); return nullptr; }
+    c25519_basetable *t = new (std::nothrow) c25519_basetable{nullptr};
+    if (!t) return nullptr;
+    if (hipMalloc((void **)&t->d_table, tab.size() * 4) != hipSuccess || hipMemcpy(t->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+        ctx->err = "basetable_create: device allocation failed";
+        if (t->d_table) hipFree(t->d_table);
+        delete t;
+        return nullptr;
+    }
+    return t;
+}
+EXPORT void c25519_basetable_destroy(c25519_ctx *ctx, c25519_basetable *t) {
+    if (!t) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(t->d_table);
+    delete t;
+}
+EXPORT int32_t c25519_mul_table_batch_dev(c25519_ctx *ctx, const c25519_basetable *t, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out) {
+    if (!t) { ctx->err = "mul_table: null table"; return -(int32_t)hipErrorInvalidValue; }
+    return mul_base_impl(ctx, d_scalars, n, out_fmt, d_out, true, t->d_table);
+}
+EXPORT int32_t c25519_mul_table_batch(c25519_ctx *ctx, const c25519_basetable *t, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out) {
+    if (!t) { ctx->err = "mul_table: null table"; return -(int32_t)hipErrorInvalidValue; }
+    return mul_base_host(ctx, scalars, n, out_fmt, out, true, false, t->d_table);
 }
 
 // ---- X25519 --------------------------------------------------------------------------------------
@@ -405,7 +517,7 @@ EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k,
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48)) || (r = ctx_reserve(ctx, ctx->tmp_e, n * 32 + 256))) return r;
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     HIPCHK(launch_clamp(d_k, n, (uint8_t *)ctx->tmp_e.p, ctx->stream));
@@ -422,19 +534,21 @@ EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k,
 }
 EXPORT int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint64_t n, uint8_t *out) {
     HIPCHK(hipSetDevice(ctx->device));
-    staged in(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
     int32_t r;
-    if ((r = in.up(k, n * 32)) || (r = o.alloc(n * 32))) return r;
-    if ((r = c25519_x25519_base_batch_dev(ctx, in.p, n, o.p))) return r;
-    r = o.down(out, n * 32);
-    if (n) hipMemsetAsync(in.p, 0, n * 32, ctx->stream);      // the staged secrets
-    return r;
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 32))) return r;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
+    wipe_on_exit wipe(ctx);
+    wipe.add(d_in, n * 32);                               // the staged secrets
+    const ffi_in in = {k, d_in, 32};
+    const ffi_out o = {out, d_out, 32};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 18), &in, 1, &o, 1,
+                        [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_x25519_base_batch_dev(ctx, d_in + lo * 32, m, d_out + lo * 32); });
 }
 EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     ctx->kname[0] = "c25519::k_x25519";
@@ -447,40 +561,76 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
 }
-EXPORT int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out) {
+// contributory (may be null): n bytes, 1 where the shared secret is non-zero -- SharedSecret::was_contributory
+// (x25519-dalek/src/x25519.rs:335: a low-order u gives the all-zero output, montgomery.rs:403-412)
+__global__ void __launch_bounds__(256) k_nonzero32(const uint8_t *__restrict__ in, uint64_t n, uint8_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint4 *q = reinterpret_cast<const uint4 *>(in) + 2 * i;
+    const uint4 a = q[0], b = q[1];
+    flag[i] = ((a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) != 0u) ? 1 : 0;
+}
+EXPORT int32_t c25519_x25519_contributory_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out, uint8_t *d_contributory) {
+    int32_t r = c25519_x25519_batch_dev(ctx, d_k, d_u, n, d_out);
+    if (r || !d_contributory || !n) return r;
+    hipLaunchKernelGGL(k_nonzero32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_out, n, d_contributory);
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+static int32_t x25519_host(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, uint8_t *contributory) {
     HIPCHK(hipSetDevice(ctx->device));
-    staged a(ctx, ctx->tmp_a), b(ctx, ctx->tmp_b), o(ctx, ctx->tmp_c);
     int32_t r;
-    if ((r = a.up(k, n * 32)) || (r = b.up(u, n * 32)) || (r = o.alloc(n * 32))) return r;
-    if ((r = c25519_x25519_batch_dev(ctx, a.p, b.p, n, o.p))) return r;
-    r = o.down(out, n * 32);
-    if (n) hipMemsetAsync(a.p, 0, n * 32, ctx->stream);      // the staged secret scalars
-    return r;
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 32)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 33 + 16))) return r;
+    uint8_t *d_k = (uint8_t *)ctx->tmp_a.p, *d_u = (uint8_t *)ctx->tmp_b.p, *d_out = (uint8_t *)ctx->tmp_c.p, *d_fl = d_out + n * 32;
+    wipe_on_exit wipe(ctx);
+    wipe.add(d_k, n * 32);                                // the staged secret scalars ...
+    wipe.add(d_out, n * 32);                              // ... and the shared secrets, on every path
+    const ffi_in in[2] = {{k, d_k, 32}, {u, d_u, 32}};
+    const ffi_out o[2] = {{out, d_out, 32}, {contributory, d_fl, 1}};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 18), in, 2, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return c25519_x25519_contributory_batch_dev(ctx, d_k + lo * 32, d_u + lo * 32, m, d_out + lo * 32, contributory ? d_fl + lo : nullptr);
+    });
+}
+EXPORT int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out) { return x25519_host(ctx, k, u, n, out, nullptr); }
+EXPORT int32_t c25519_x25519_contributory_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, uint8_t *contributory) {
+    return x25519_host(ctx, k, u, n, out, contributory);
 }
 
 // ---- (de)compression -------------------------------------------------------------------------------
+static int32_t decompress_enqueue(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int in_fmt, uint8_t *d_out, uint8_t *d_ok) {
+    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_decompress_edwards(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
+    else HIPCHK(launch_decompress_ristretto(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
+    return C25519_OK;
+}
 EXPORT int32_t c25519_decompress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int in_fmt, uint8_t *d_out, uint8_t *d_ok) {
     HIPCHK(hipSetDevice(ctx->device));
     if (in_fmt != C25519_FMT_EDWARDS_Y && in_fmt != C25519_FMT_RISTRETTO) { ctx->err = "decompress: in_fmt must be 0 or 1"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 4, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_decompress_edwards(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
-    else HIPCHK(launch_decompress_ristretto(d_in, n, d_out, d_ok, (uint32_t *)ctx->d_flag, ctx->stream));
+    int32_t r = decompress_enqueue(ctx, d_in, n, in_fmt, d_out, d_ok);
+    if (r) return r;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
-    uint32_t bad = 0;
-    HIPCHK(hipMemcpyAsync(&bad, ctx->d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t *bad = (uint32_t *)ctx->h_msm;              // pinned
+    HIPCHK(hipMemcpyAsync(bad, ctx->d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    return bad ? C25519_NONE : C25519_OK;
+    return *bad ? C25519_NONE : C25519_OK;
 }
 EXPORT int32_t c25519_decompress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int in_fmt, uint8_t *out, uint8_t *ok) {
     HIPCHK(hipSetDevice(ctx->device));
-    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b), k(ctx, ctx->tmp_c);
+    if (in_fmt != C25519_FMT_EDWARDS_Y && in_fmt != C25519_FMT_RISTRETTO) { ctx->err = "decompress: in_fmt must be 0 or 1"; return -(int32_t)hipErrorInvalidValue; }
     int32_t r;
-    if ((r = a.up(in, n * 32)) || (r = o.alloc(n * 160)) || (r = k.alloc(n))) return r;
-    int32_t st = c25519_decompress_batch_dev(ctx, a.p, n, in_fmt, o.p, k.p);
-    if (st < 0) return st;
-    if ((r = o.down(out, n * 160)) || (r = k.down(ok, n))) return r;
-    return st;
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 160)) || (r = ctx_reserve(ctx, ctx->tmp_c, n + 16))) return r;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p, *d_ok = (uint8_t *)ctx->tmp_c.p;
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 4, ctx->stream));
+    const ffi_in i1 = {in, d_in, 32};
+    const ffi_out o[2] = {{out, d_out, 160}, {ok, d_ok, 1}};
+    r = ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 17), &i1, 1, o, 2,
+                     [&](uint64_t lo, uint64_t m) -> int32_t { return decompress_enqueue(ctx, d_in + lo * 32, m, in_fmt, d_out + lo * 160, d_ok + lo); });
+    if (r) return r;
+    uint32_t *bad = (uint32_t *)ctx->h_msm;
+    HIPCHK(hipMemcpyAsync(bad, ctx->d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return *bad ? C25519_NONE : C25519_OK;
 }
 EXPORT int32_t c25519_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, uint64_t n, int out_fmt, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -505,11 +655,13 @@ EXPORT int32_t c25519_compress_batch_dev(c25519_ctx *ctx, const uint8_t *d_in, u
 }
 EXPORT int32_t c25519_compress_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, int out_fmt, uint8_t *out) {
     HIPCHK(hipSetDevice(ctx->device));
-    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
     int32_t r;
-    if ((r = a.up(in, n * 160)) || (r = o.alloc(n * 32))) return r;
-    if ((r = c25519_compress_batch_dev(ctx, a.p, n, out_fmt, o.p))) return r;
-    return o.down(out, n * 32);
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 160, ctx->tmp_b, n * 32))) return r;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
+    const ffi_in i1 = {in, d_in, 160};
+    const ffi_out o = {out, d_out, 32};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 17), &i1, 1, &o, 1,
+                        [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_compress_batch_dev(ctx, d_in + lo * 160, m, out_fmt, d_out + lo * 32); });
 }
 
 // ---- EdwardsPoint::to_montgomery_batch (edwards.rs:595-612) -------------------------------------------------
@@ -525,11 +677,13 @@ EXPORT int32_t c25519_to_montgomery_batch_dev(c25519_ctx *ctx, const uint8_t *d_
 }
 EXPORT int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, uint64_t n, uint8_t *out) {
     HIPCHK(hipSetDevice(ctx->device));
-    staged a(ctx, ctx->tmp_a), o(ctx, ctx->tmp_b);
     int32_t r;
-    if ((r = a.up(in, n * 160)) || (r = o.alloc(n * 32))) return r;
-    if ((r = c25519_to_montgomery_batch_dev(ctx, a.p, n, o.p))) return r;
-    return o.down(out, n * 32);
+    if ((r = reserve2(ctx, ctx->tmp_a, n * 160, ctx->tmp_b, n * 32))) return r;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
+    const ffi_in i1 = {in, d_in, 160};
+    const ffi_out o = {out, d_out, 32};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 17), &i1, 1, &o, 1,
+                        [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_to_montgomery_batch_dev(ctx, d_in + lo * 160, m, d_out + lo * 32); });
 }
 
 // ---- diagnostics -------------------------------------------------------------------------------------

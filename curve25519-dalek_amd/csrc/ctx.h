@@ -24,6 +24,7 @@ struct c25519_ctx {
     // decompression of R}
     static const int RING = 64, RING_EV = 6;
     hipEvent_t ring[RING][RING_EV] = {};
+    uint8_t ring_kind[RING] = {};      // who recorded the entry: 0 a per-item call (events 0..2), 1 an MSM pass (0..3), 2 a verify_batch pass (0..5)
     uint64_t ncalls = 0;
     std::vector<std::pair<c25519_ctx *, int>> last_passes;   // (context, ring index) of every pass of the latest MSM / verify_batch call
     uint32_t *d_table = nullptr;   // fixed-base table of algorithm `w` (LDS window / comb tables: canonical words; radix-2^C: limb records)
@@ -44,6 +45,12 @@ struct c25519_ctx {
     // names of the kernels the latest entry point launched: [0] its dominant kernel (k_mul_base*, k_x25519, k_var_base, k_accumulate),
     // [1] the decompression of R_i in a verify_batch pass -- what c25519_phase_ms phases 0 and 3 time
     const char *kname[2] = {"", ""};
+    // host-pointer entry points (ffi.h): copy streams, per-chunk events, figures of the latest host-pointer call
+    static const int FFI_MAXCH = 8;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    hipEvent_t ev_up[FFI_MAXCH] = {}, ev_kd[FFI_MAXCH] = {}, ev_ffi = nullptr;
+    double ffi_t0 = 0, ffi_ms = -1;                      // wall-clock of the latest host-pointer call
+    uint64_t ffi_h2d = 0, ffi_d2h = 0;                   // bytes it moved each way
     std::string err;
 };
 
@@ -52,6 +59,9 @@ int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
 c25519_ctx *ctx_peer(c25519_ctx *ctx);      // nullptr if it cannot be created
 // out[i] = scalars[i] * B.  secret: constant-time table scan (k_mul_base<5, CT>) and wiped scratch; otherwise the context's
 // fast tables (the radix-2^16 HBM tables by default), whose addresses depend on the scalar.
-int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret);
+// table_ct (may be null = the context's basepoint table): a caller's constant-time window table (c25519_basetable)
+int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out, bool secret, const uint32_t *table_ct = nullptr);
 int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok, bool ct);
+// ring entry of a per-item call (events 0..2)
+inline hipEvent_t *ctx_ring_item(c25519_ctx *ctx) { const int idx = (int)(ctx->ncalls++ % c25519_ctx::RING); ctx->ring_kind[idx] = 0; return ctx->ring[idx]; }
 inline bool ctx_secret_default(const c25519_ctx *ctx) { return !(ctx->flags & 0x100u); }   // !C25519_FLAG_VARTIME_TABLES

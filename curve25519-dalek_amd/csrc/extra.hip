@@ -20,6 +20,8 @@
 #include "kernels.h"
 #include "ctx.h"
 #include "msm_internal.h"
+#include "ffi.h"
+#include <stdexcept>
 
 using namespace c25519;
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -177,7 +179,7 @@ EXPORT c25519_precomp *c25519_precomp_create(c25519_ctx *ctx, const uint8_t *sta
     bool ok = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16) == 0 && hipMemsetAsync(bad, 0, 16, ctx->stream) == hipSuccess &&
               hipMemcpyAsync(ctx->tmp_b.p, static_points, n * psz, hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
               msm_merged_build(ctx, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, p->m, p->d_table, bad) == C25519_OK &&
-              hipMemcpyAsync(hb, bad, 8, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess && hipStreamSynchronize(ctx->stream) == hipSuccess;
+              hipStreamSynchronize(ctx->stream) == hipSuccess && hipMemcpy(hb, bad, 8, hipMemcpyDeviceToHost) == hipSuccess;
     if (ok && hb[0] != 0) { ctx->err = "precomp_create: a static point does not decode"; ok = false; }
     else if (!ok && ctx->err.empty()) ctx->err = "precomp_create: a HIP call failed";
     if (!ok) { hipFree(p->d_table); delete p; return nullptr; }
@@ -214,10 +216,10 @@ EXPORT int32_t c25519_precomp_msm_vartime(c25519_ctx *ctx, const c25519_precomp 
         HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, dyn_scalars, n_dyn * 32, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, dyn_points, n_dyn * psz, hipMemcpyHostToDevice, st));
         if ((r = prep_points(ctx, (const uint8_t *)ctx->tmp_b.p, n_dyn, in_fmt, d_pts, 0, bad))) return r;
-        uint32_t hb = 0;
-        HIPCHK(hipMemcpyAsync(&hb, bad, 4, hipMemcpyDeviceToHost, st));
         ge_p3 Rd;
-        if ((r = msm_core(ctx, (const uint8_t *)ctx->tmp_a.p, n_dyn, d_pts, Rd))) return r;      // synchronises: hb is final
+        if ((r = msm_core(ctx, (const uint8_t *)ctx->tmp_a.p, n_dyn, d_pts, Rd))) return r;      // synchronises the stream
+        uint32_t hb = 0;
+        HIPCHK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost));                                  // (a blocking copy: nothing is pending into this frame on any path)
         if (hb) return C25519_NONE;
         R = ns ? ge_add(R, Rd) : Rd;
     }
@@ -289,11 +291,11 @@ EXPORT int32_t c25519_double_and_compress_batch(c25519_ctx *ctx, const uint8_t *
     if (n == 0) return C25519_OK;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 160)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 32))) return r;
-    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, in, n * 160, hipMemcpyHostToDevice, ctx->stream));
-    if ((r = c25519_double_and_compress_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, n, (uint8_t *)ctx->tmp_b.p))) return r;
-    HIPCHK(hipMemcpyAsync(out, ctx->tmp_b.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return C25519_OK;
+    uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
+    const ffi_in i1 = {in, d_in, 160};
+    const ffi_out o = {out, d_out, 32};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 17), &i1, 1, &o, 1,
+                        [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_double_and_compress_batch_dev(ctx, d_in + lo * 160, m, d_out + lo * 32); });
 }
 
 // ---- Scalar::invert_batch ------------------------------------------------------------------------------------------------
@@ -331,56 +333,130 @@ EXPORT int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t
 // different devices, or several on one device -- every shard runs the full single-GPU path on its own context from its own
 // host thread, and the partial sums (verdicts) are folded on the host: the exchange step is nctx x 160 bytes (4 bytes)
 // over PCIe instead of an all_gather over xGMI.  Results are identical to the single-context calls by construction.
+static bool ctxs_ok(c25519_ctx **ctxs, int32_t nctx) {
+    if (nctx < 1 || !ctxs) return false;
+    for (int32_t r = 0; r < nctx; r++) if (!ctxs[r]) return false;
+    return true;
+}
+static inline void shard_of(uint64_t n, int nctx, int r, uint64_t &lo, uint64_t &cnt) {
+    const uint64_t base = n / nctx, rem = n % nctx;
+    lo = r * base + std::min<uint64_t>(r, rem); cnt = base + ((uint64_t)r < rem ? 1 : 0);
+}
+// run fn(r) for every context, context 0 on the calling thread; nothing thrown by a worker or by thread creation leaves this function
+template <class F>
+static int32_t on_every_context(c25519_ctx *ctx0, int32_t nctx, F &&fn) {
+    try {
+        std::vector<std::thread> th;
+        std::vector<int> threw(nctx, 0);
+        auto guarded = [&](int r) { try { fn(r); } catch (...) { threw[r] = 1; } };
+        for (int r = 1; r < nctx; r++) th.emplace_back(guarded, r);
+        guarded(0);
+        for (auto &t : th) t.join();
+        for (int r = 0; r < nctx; r++) if (threw[r]) { ctx0->err = "multi: a worker failed (out of memory?)"; return -(int32_t)hipErrorOutOfMemory; }
+        return C25519_OK;
+    } catch (const std::exception &e) {
+        ctx0->err = std::string("multi: ") + e.what();     // (a std::thread that was started and not joined would terminate: emplace_back is the only thrower, before any later start)
+        return -(int32_t)hipErrorOutOfMemory;
+    }
+}
 EXPORT int32_t c25519_msm_vartime_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out) {
-    if (nctx < 1 || !ctxs || !ctxs[0]) return -(int32_t)hipErrorInvalidValue;
+    if (!ctxs_ok(ctxs, nctx)) return -(int32_t)hipErrorInvalidValue;
     c25519_ctx *ctx = ctxs[0];
     if (out_fmt < 0 || out_fmt > 2 || in_fmt < 0 || in_fmt > 2) { ctx->err = "msm_multi: bad format"; return -(int32_t)hipErrorInvalidValue; }
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
-    std::vector<std::vector<uint8_t>> part(nctx, std::vector<uint8_t>(160));
-    std::vector<int32_t> st(nctx, C25519_OK);
-    auto run = [&](int r) {
-        const uint64_t base = n / nctx, rem = n % nctx, lo = r * base + std::min<uint64_t>(r, rem), cnt = base + ((uint64_t)r < rem ? 1 : 0);
-        st[r] = c25519_msm_vartime(ctxs[r], scalars + lo * 32, points + lo * psz, cnt, in_fmt, C25519_FMT_RAW160, part[r].data());
-    };
-    std::vector<std::thread> th;
-    for (int r = 1; r < nctx; r++) th.emplace_back(run, r);
-    run(0);
-    for (auto &t : th) t.join();
-    bool none = false;
-    for (int r = 0; r < nctx; r++) {
-        if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
-        if (st[r] == C25519_NONE) none = true;
-    }
-    if (none) return C25519_NONE;
-    std::vector<uint8_t> all((size_t)nctx * 160);
-    for (int r = 0; r < nctx; r++) memcpy(&all[(size_t)r * 160], part[r].data(), 160);
-    return c25519_fold_partials(ctx, all.data(), (uint64_t)nctx, out_fmt, out);
+    try {
+        std::vector<uint8_t> part((size_t)nctx * 160);
+        std::vector<int32_t> st(nctx, C25519_OK);
+        int32_t r0 = on_every_context(ctx, nctx, [&](int r) {
+            uint64_t lo, cnt;
+            shard_of(n, nctx, r, lo, cnt);
+            st[r] = c25519_msm_vartime(ctxs[r], scalars + lo * 32, points + lo * psz, cnt, in_fmt, C25519_FMT_RAW160, &part[(size_t)r * 160]);
+        });
+        if (r0) return r0;
+        bool none = false;
+        for (int r = 0; r < nctx; r++) {
+            if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+            if (st[r] == C25519_NONE) none = true;
+        }
+        if (none) return C25519_NONE;
+        return c25519_fold_partials(ctx, part.data(), (uint64_t)nctx, out_fmt, out);
+    } catch (const std::exception &e) { ctx->err = std::string("msm_multi: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
 }
+// verify_batch over several contexts.  C25519_Z_TRANSCRIPT: the reference's ONE transcript over the whole batch and its single
+// equation -- every context hashes its shard, the host runs the transcript once over all hram_i / s_i, every
+// context evaluates its share of the equation with its z_i and leaves a record, the records are folded into one identity
+// check.  C25519_Z_DEVICE: independent shard checks, worst verdict in the reference's precedence.
 EXPORT int32_t ed25519_verify_batch_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                           uint64_t n, uint32_t z_mode) {
-    if (nctx < 1 || !ctxs || !ctxs[0]) return -(int32_t)hipErrorInvalidValue;
+    if (!ctxs_ok(ctxs, nctx)) return -(int32_t)hipErrorInvalidValue;
     c25519_ctx *ctx = ctxs[0];
     if (n == 0) return C25519_OK;
+    if (z_mode > 1) { ctx->err = "verify_batch_multi: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
     for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) { ctx->err = "verify_batch_multi: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
-    std::vector<int32_t> st(nctx, C25519_OK);
-    auto run = [&](int r) {
-        const uint64_t base = n / nctx, rem = n % nctx, lo = r * base + std::min<uint64_t>(r, rem), cnt = base + ((uint64_t)r < rem ? 1 : 0);
-        if (cnt == 0) return;
-        // this shard's offsets, rebased to its first message
-        std::vector<uint64_t> off(cnt + 1);
-        for (uint64_t i = 0; i <= cnt; i++) off[i] = msg_off[lo + i] - msg_off[lo];
-        st[r] = ed25519_verify_batch(ctxs[r], msgs + msg_off[lo], off.data(), sigs + lo * 64, pks + lo * 32, cnt, z_mode);
-    };
-    std::vector<std::thread> th;
-    for (int r = 1; r < nctx; r++) th.emplace_back(run, r);
-    run(0);
-    for (auto &t : th) t.join();
-    // every shard is its own random linear combination; the batch verdict is the worst shard verdict in the reference's
-    // precedence (key decoding, then ScalarFormat, batch.rs:208-211, then Verify, :244-250)
-    bool seen[5] = {false, false, false, false, false};
-    for (int r = 0; r < nctx; r++) {
-        if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
-        seen[st[r]] = true;
-    }
-    return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
+    try {
+        std::vector<int32_t> st(nctx, C25519_OK);
+        if (z_mode == C25519_Z_DEVICE) {
+            int32_t r0 = on_every_context(ctx, nctx, [&](int r) {
+                uint64_t lo, cnt;
+                shard_of(n, nctx, r, lo, cnt);
+                if (cnt == 0) return;
+                std::vector<uint64_t> off(cnt + 1);          // this shard's offsets, rebased to its first message
+                for (uint64_t i = 0; i <= cnt; i++) off[i] = msg_off[lo + i] - msg_off[lo];
+                st[r] = ed25519_verify_batch(ctxs[r], msgs + msg_off[lo], off.data(), sigs + lo * 64, pks + lo * 32, cnt, z_mode);
+            });
+            if (r0) return r0;
+            bool seen[5] = {false, false, false, false, false};
+            for (int r = 0; r < nctx; r++) {
+                if (st[r] < 0) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+                seen[st[r]] = true;
+            }
+            return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
+        }
+        // ---- strict z-mode: hash per shard, ONE transcript, equation per shard, ONE identity check ------------------------------
+        std::vector<uint8_t> hram(n * 64), z16(n * 16), records((size_t)nctx * C25519_PARTIAL_RECORD_BYTES);
+        struct shard_dev { uint8_t *sig, *pk, *hr, *z, *rec; };
+        std::vector<shard_dev> dv(nctx, shard_dev{nullptr, nullptr, nullptr, nullptr, nullptr});
+        auto fail = [&](int r, hipError_t e, const char *what) { st[r] = c25519_fail(ctxs[r], e, what); };
+        int32_t r0 = on_every_context(ctx, nctx, [&](int r) {            // phase 1: upload the shard, hash it, hram back to the host
+            c25519_ctx *c = ctxs[r];
+            uint64_t lo, cnt;
+            shard_of(n, nctx, r, lo, cnt);
+            hipError_t e;
+            if ((e = hipSetDevice(c->device)) != hipSuccess) return fail(r, e, "hipSetDevice");
+            const uint64_t mlen = msg_off[lo + cnt] - msg_off[lo];
+            // tmp_c: sigs 64 cnt | pks 32 cnt | hram 64 cnt + 64 | z 16 cnt | record ;  tmp_a: messages ;  tmp_b: offsets
+            size_t off = 0;
+            auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+            const size_t oS = carve(cnt * 64), oK = carve(cnt * 32), oH = carve(cnt * 64 + 64), oZ = carve(cnt * 16 + 16), oR = carve(C25519_PARTIAL_RECORD_BYTES);
+            if ((st[r] = ctx_reserve(c, c->tmp_c, off)) || (st[r] = ctx_reserve(c, c->tmp_a, mlen + 64)) || (st[r] = ctx_reserve(c, c->tmp_b, (cnt + 1) * 8))) return;
+            uint8_t *ws = (uint8_t *)c->tmp_c.p;
+            dv[r] = shard_dev{ws + oS, ws + oK, ws + oH, ws + oZ, ws + oR};
+            std::vector<uint64_t> offs(cnt + 1);
+            for (uint64_t i = 0; i <= cnt; i++) offs[i] = msg_off[lo + i] - msg_off[lo];
+            if (mlen && (e = hipMemcpyAsync(c->tmp_a.p, msgs + msg_off[lo], mlen, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(r, e, "H2D");
+            if ((e = hipMemcpyAsync(c->tmp_b.p, offs.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(r, e, "H2D");
+            if (cnt && (e = hipMemcpyAsync(dv[r].sig, sigs + lo * 64, cnt * 64, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(r, e, "H2D");
+            if (cnt && (e = hipMemcpyAsync(dv[r].pk, pks + lo * 32, cnt * 32, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(r, e, "H2D");
+            if ((st[r] = ed25519_batch_hram_dev(c, (const uint8_t *)c->tmp_a.p, (const uint64_t *)c->tmp_b.p, mlen, dv[r].sig, dv[r].pk, cnt, dv[r].hr))) return;
+            if (cnt && (e = hipMemcpyAsync(&hram[lo * 64], dv[r].hr, cnt * 64, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return fail(r, e, "D2H");
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(r, e, "hipStreamSynchronize");       // (offs is a local buffer)
+        });
+        if (r0) return r0;
+        for (int r = 0; r < nctx; r++) if (st[r]) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+        ed25519_batch_transcript_zs(hram.data(), sigs, n, z16.data());          // batch.rs:168-222, once, over the whole batch
+        r0 = on_every_context(ctx, nctx, [&](int r) {                           // phase 2: this shard's share of the equation
+            c25519_ctx *c = ctxs[r];
+            uint64_t lo, cnt;
+            shard_of(n, nctx, r, lo, cnt);
+            hipError_t e;
+            if ((e = hipSetDevice(c->device)) != hipSuccess) return fail(r, e, "hipSetDevice");
+            if (cnt && (e = hipMemcpyAsync(dv[r].z, &z16[lo * 16], cnt * 16, hipMemcpyHostToDevice, c->stream)) != hipSuccess) return fail(r, e, "H2D");
+            if ((st[r] = ed25519_verify_batch_record_dev(c, dv[r].sig, dv[r].pk, nullptr, dv[r].hr, dv[r].z, cnt, dv[r].rec))) return;
+            if ((e = hipMemcpyAsync(&records[(size_t)r * C25519_PARTIAL_RECORD_BYTES], dv[r].rec, C25519_PARTIAL_RECORD_BYTES, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return fail(r, e, "D2H");
+            if ((e = hipStreamSynchronize(c->stream)) != hipSuccess) return fail(r, e, "hipStreamSynchronize");
+        });
+        if (r0) return r0;
+        for (int r = 0; r < nctx; r++) if (st[r]) { if (r) ctx->err = ctxs[r]->err; return st[r]; }
+        return ed25519_fold_verify_records(ctx, records.data(), (uint64_t)nctx);
+    } catch (const std::exception &e) { ctx->err = std::string("verify_batch_multi: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
 }

@@ -39,6 +39,8 @@
 #include "kernels.h"
 #include "ctx.h"
 #include "msm_internal.h"
+#include "ffi.h"
+#include <functional>
 
 using namespace c25519;
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -1522,8 +1524,9 @@ static int32_t passes_join(c25519_ctx *ctx, pass_set &ps) {
     }
     return C25519_OK;
 }
-static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
+static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind) {
     const int idx = (int)(c->ncalls++ % c25519_ctx::RING);
+    c->ring_kind[idx] = kind;
     owner->last_passes.push_back({c, idx});
     return c->ring[idx];
 }
@@ -1539,14 +1542,15 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c) {
 //   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
 struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
-                                hipEvent_t wait_acc, const pts_ahead *ahead = nullptr) {
+                                hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr) {
     int32_t r;
     uint32_t *d_pts;
+    if (wait_in) HIPCHK(hipStreamWaitEvent(ctx->stream, wait_in, 0));      // host-pointer calls: this pass's inputs are still on their way up
     if (!ahead) {
         if ((r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256))) return r;
         d_pts = (uint32_t *)ctx->tmp_e.p;
     } else d_pts = ahead->pts + ahead->offset * (PTS_BYTES / 4);
-    hipEvent_t *ring = pass_ring(owner, ctx);
+    hipEvent_t *ring = pass_ring(owner, ctx, 1);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
     slot_init(d_slot, terms, nullptr, ctx->stream);
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
@@ -1563,7 +1567,13 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
 }
 // The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column
 // sums + counters + header) left at d_record.  Nothing here waits for the host.
-static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_record) {
+// fetch (host-pointer calls, may be null): called right before pass [lo, lo + m) is enqueued; it starts the upload of that pass's
+// scalars and points on the copy stream and returns the event the pass has to wait for -- so pass i computes while the inputs
+// of pass i+1 travel.  pass_terms (0 = default): terms per pass, smaller for host-pointer calls so that the link and the
+// kernels overlap at a finer grain.
+typedef std::function<int32_t(uint64_t lo, uint64_t m, hipEvent_t *ready)> msm_fetch;
+static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_record,
+                                  const msm_fetch *fetch = nullptr, uint64_t pass_terms = 0) {
     HIPCHK(hipSetDevice(ctx->device));
     if (in_fmt < 0 || in_fmt > 2) { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     if (n >= (1ull << 40)) { ctx->err = "msm: n must be < 2^40"; return -(int32_t)hipErrorInvalidValue; }
@@ -1575,7 +1585,8 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         return C25519_OK;
     }
-    const uint64_t passes = n <= MSM_PASS_MAX ? 1 : (n + MSM_PASS - 1) / MSM_PASS, per = (n + passes - 1) / passes;
+    const uint64_t PT = pass_terms ? pass_terms : MSM_PASS, PTMAX = pass_terms ? pass_terms + pass_terms / 2 : MSM_PASS_MAX;
+    const uint64_t passes = n <= PTMAX ? 1 : (n + PT - 1) / PT, per = (n + passes - 1) / passes;
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     msm_geom g;
     msm_layout(per, g);                                   // one layout for every pass: their column sums add up window by window
@@ -1585,7 +1596,8 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
-    const bool ahead = passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160;
+    // (not with a fetch: the later passes' points are not on the device yet)
+    const bool ahead = passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160 && !fetch;
     if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
@@ -1598,7 +1610,9 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p0 + i == 1};
             uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);     // a single pass writes the record itself
-            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr))) {
+            hipEvent_t in_ev = nullptr;
+            if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
+            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr, in_ev))) {
                 if (ctx->err.empty()) ctx->err = c->err;
                 return r;
             }
@@ -1677,14 +1691,38 @@ EXPORT int32_t c25519_msm_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars,
 }
 EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out) {
     HIPCHK(hipSetDevice(ctx->device));
-    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    if (out_fmt < 0 || out_fmt > 2 || in_fmt < 0 || in_fmt > 2) { ctx->err = "msm: bad format"; return -(int32_t)hipErrorInvalidValue; }
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16))) return r;
-    if (n) {
-        HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream));
-    }
-    return c25519_msm_vartime_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, out_fmt, out);
+    uint8_t *d_s = (uint8_t *)ctx->tmp_a.p, *d_p = (uint8_t *)ctx->tmp_b.p;
+    if ((r = ffi_begin(ctx))) return r;
+    // The inputs go up pass by pass on the copy stream while the previous pass computes.  Raw points are 192 bytes per term:
+    // the link (56 GB/s = 0.29 G terms/s) is slower than the kernels (1.1 G terms/s), so passes are small (2^19 terms)
+    // and what remains after the last byte has arrived is one small pass; compressed points (64 bytes per term) are bound
+    // by their decompression instead.
+    uint64_t up = 0;
+    int slot = 0;
+    const msm_fetch fetch = [&](uint64_t lo, uint64_t m, hipEvent_t *ready) -> int32_t {
+        HIPCHK(hipMemcpyAsync(d_s + lo * 32, scalars + lo * 32, m * 32, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_p + lo * psz, points + lo * psz, m * psz, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipEventRecord(ctx->ev_up[slot], ctx->s_h2d));
+        *ready = ctx->ev_up[slot];
+        slot = (slot + 1) % c25519_ctx::FFI_MAXCH;
+        up += m * (32 + psz);
+        return C25519_OK;
+    };
+    ge_p3 R;
+    uint32_t flags[8];
+    const uint64_t pass_terms = n >= (1ull << 20) ? (in_fmt == C25519_FMT_RAW160 ? (1ull << 19) : (1ull << 20)) : 0;
+    r = msm_record_enqueue(ctx, d_s, d_p, n, in_fmt, drec(ctx), &fetch, pass_terms);
+    if (!r) r = rec_collect(ctx);
+    const int32_t r2 = ffi_end(ctx, up, 0);
+    if (r || (r = r2)) return r;
+    if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+    if ((r = msm_record_status(ctx, flags))) return r;
+    host_encode(R, out_fmt, out);
+    return C25519_OK;
 }
 // fold of per-rank partial sums: plain complete additions, identical on every rank
 EXPORT int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64_t count, int out_fmt, uint8_t *out) {
@@ -1739,9 +1777,15 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
 // d_pk_points (may be NULL): the keys' decompressed points, n x 160 raw -- what VerifyingKey carries beside its bytes
 // (verifying.rs:64-71), so that, like the reference (batch.rs:236), the batch does not decompress A_i again.
 // d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
+// stage (host-pointer calls, may be null): called right before the first kernels that need an input array are enqueued, in the
+// order 0 = signatures, 1 = key bytes, 2 = messages + offsets, 3 = the keys' points (only if given); it starts the upload of
+// that array's slice for THIS pass on the copy stream and returns the event to wait for.  So R_i is being decompressed
+// while the keys and messages travel, and the hash chain runs while the (five times larger) key points travel.
+typedef std::function<int32_t(int what, hipEvent_t *ready)> verify_stage;
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
-                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc) {
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc,
+                                   const verify_stage *stage = nullptr) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -1757,23 +1801,43 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     uint64_t *partial = (uint64_t *)(ws + oP);
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
-    hipEvent_t *ring = pass_ring(owner, ctx);
+    hipEvent_t *ring = pass_ring(owner, ctx, 2);
     HIPCHK(hipEventRecord(ring[3], st));
     slot_init(d_slot, terms, d_pre_flags, st);
-    // Two independent chains: (S) decompress A_i and R_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
+    // Two independent chains: (S) decompress R_i and A_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
     // partly latency-bound (the tree levels).  They run on two streams and join before the accumulation.
     hipStream_t sa = ctx->aux;
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
+    hipEvent_t ev_sig = nullptr, ev_pk = nullptr, ev_msg = nullptr, ev_pts = nullptr;
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     hipLaunchKernelGGL(k_prep_basepoint, dim3(1), dim3(64), 0, st, d_pts, (uint64_t)0);
-    if (d_pk_points) { if ((r = prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2))) return r; }
-    else HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, true, st));
-    HIPCHK(hipEventRecord(ring[4], st));
-    // R_i = the first half of every 64-byte signature (stride 2)
-    ctx->kname[1] = "c25519::k_prep_compressed<0> (decompression of R_i)";
-    HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 3, true, st));
-    HIPCHK(hipEventRecord(ring[5], st));
+    auto prep_A = [&]() -> int32_t {
+        if (d_pk_points) {
+            if (stage) { int32_t q = (*stage)(3, &ev_pts); if (q) return q; HIPCHK(hipStreamWaitEvent(st, ev_pts, 0)); }
+            return prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2);
+        }
+        HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, true, st));
+        return C25519_OK;
+    };
+    auto prep_R = [&]() -> int32_t {   // R_i = the first half of every 64-byte signature (stride 2)
+        HIPCHK(hipEventRecord(ring[4], st));
+        ctx->kname[1] = "c25519::k_prep_compressed<0> (decompression of R_i)";
+        HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 3, true, st));
+        HIPCHK(hipEventRecord(ring[5], st));
+        return C25519_OK;
+    };
+    if (stage) {
+        // host-pointer call: in the order the inputs arrive -- signatures, then R_i decompresses while keys and messages travel
+        if ((r = (*stage)(0, &ev_sig))) return r;
+        HIPCHK(hipStreamWaitEvent(st, ev_sig, 0));
+        if ((r = prep_R())) return r;
+        if ((r = (*stage)(1, &ev_pk)) || (r = (*stage)(2, &ev_msg))) return r;
+        HIPCHK(hipStreamWaitEvent(sa, ev_sig, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_pk, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_msg, 0));
+        if (!d_pk_points) { HIPCHK(hipStreamWaitEvent(st, ev_pk, 0)); if ((r = prep_A())) return r; }
+    } else {
+        if ((r = prep_A()) || (r = prep_R())) return r;
+    }
     // (A)
     const uint8_t *hr = d_hram_pre;
     if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4); hr = hram; }
@@ -1791,6 +1855,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block
     hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
     HIPCHK(hipGetLastError());
+    if (stage && d_pk_points && (r = prep_A())) return r;   // the keys' points come last: only the accumulation needs them
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
 }
@@ -1879,8 +1944,10 @@ EXPORT int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *recor
     return verify_record_verdict(ctx, R, flags);
 }
 
-EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
-                                             const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
+// pass_stage (host-pointer calls, device z-mode; may be null): (first signature of the pass, its length, which array, event out)
+typedef std::function<int32_t(uint64_t lo, uint64_t m, int what, hipEvent_t *ready)> verify_fetch;
+static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                 const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode, const verify_fetch *fetch) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
@@ -1925,8 +1992,9 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
         for (int i = 0; i < cnt; i++) {
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            const verify_stage stage = [&](int what, hipEvent_t *ready) -> int32_t { return (*fetch)(lo, m, what, ready); };
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
-                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc);
+                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
@@ -1946,6 +2014,10 @@ EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_m
     return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
 }
 
+EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                             const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
+    return verify_batch_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, d_pk_points, n, z_mode, nullptr);
+}
 EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                         const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
     return ed25519_verify_batch_keys_dev(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, nullptr, n, z_mode);
@@ -1959,20 +2031,50 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
                                          const uint8_t *pk_points, uint64_t n, uint32_t z_mode) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
+    if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
     if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
-    uint64_t mlen = msg_off[n];
+    const uint64_t mlen = msg_off[n];
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||
         (r = ctx_reserve(ctx, ctx->scratch, n * 32 + (pk_points ? n * 160 : 0) + 16)))
         return r;
-    if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_c.p, sigs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    uint8_t *d_pk = (uint8_t *)ctx->scratch.p, *d_pp = pk_points ? d_pk + n * 32 : nullptr;
-    HIPCHK(hipMemcpyAsync(d_pk, pks, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (pk_points) HIPCHK(hipMemcpyAsync(d_pp, pk_points, n * 160, hipMemcpyHostToDevice, ctx->stream));
-    return ed25519_verify_batch_keys_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, (const uint8_t *)ctx->tmp_c.p,
-                                         d_pk, d_pp, n, z_mode);
+    uint8_t *d_msg = (uint8_t *)ctx->tmp_a.p, *d_sig = (uint8_t *)ctx->tmp_c.p, *d_pk = (uint8_t *)ctx->scratch.p, *d_pp = pk_points ? d_pk + n * 32 : nullptr;
+    uint64_t *d_off = (uint64_t *)ctx->tmp_b.p;
+    if ((r = ffi_begin(ctx))) return r;
+    uint64_t up = 0;
+    if (z_mode == C25519_Z_TRANSCRIPT) {
+        // the whole batch is hashed before anything else can start and the sequential host transcript dominates: upload everything
+        if (mlen) HIPCHK(hipMemcpyAsync(d_msg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_sig, sigs, n * 64, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_pk, pks, n * 32, hipMemcpyHostToDevice, ctx->s_h2d));
+        if (pk_points) HIPCHK(hipMemcpyAsync(d_pp, pk_points, n * 160, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipEventRecord(ctx->ev_up[0], ctx->s_h2d));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_up[0], 0));
+        up = mlen + (n + 1) * 8 + n * 96 + (pk_points ? n * 160 : 0);
+        r = verify_batch_impl(ctx, d_msg, d_off, mlen, d_sig, d_pk, d_pp, n, z_mode, nullptr);
+    } else {
+        // device z-mode: every array goes up right before the first kernels that need it (verify_pass_enqueue), pass by pass
+        int slot = 0;
+        const verify_fetch fetch = [&](uint64_t lo, uint64_t m, int what, hipEvent_t *ready) -> int32_t {
+            if (what == 0) { HIPCHK(hipMemcpyAsync(d_sig + lo * 64, sigs + lo * 64, m * 64, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 64; }
+            else if (what == 1) { HIPCHK(hipMemcpyAsync(d_pk + lo * 32, pks + lo * 32, m * 32, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 32; }
+            else if (what == 2) {
+                // the kernels index the blob through ABSOLUTE offsets: this pass's offsets and the bytes they span, in place
+                const uint64_t b0 = msg_off[lo], b1 = msg_off[lo + m];
+                if (b1 > b0) HIPCHK(hipMemcpyAsync(d_msg + b0, msgs + b0, b1 - b0, hipMemcpyHostToDevice, ctx->s_h2d));
+                HIPCHK(hipMemcpyAsync(d_off + lo, msg_off + lo, (m + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+                up += (b1 - b0) + (m + 1) * 8;
+            } else { HIPCHK(hipMemcpyAsync(d_pp + lo * 160, pk_points + lo * 160, m * 160, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 160; }
+            HIPCHK(hipEventRecord(ctx->ev_up[slot], ctx->s_h2d));
+            *ready = ctx->ev_up[slot];
+            slot = (slot + 1) % c25519_ctx::FFI_MAXCH;
+            return C25519_OK;
+        };
+        r = verify_batch_impl(ctx, d_msg, d_off, mlen, d_sig, d_pk, d_pp, n, z_mode, &fetch);
+    }
+    const int32_t r2 = ffi_end(ctx, up, 0);
+    return (r < 0 || !r2) ? r : r2;
 }
 EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                     uint64_t n, uint32_t z_mode) {

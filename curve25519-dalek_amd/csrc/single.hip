@@ -24,6 +24,7 @@
 #include "sc_sha.h"
 #include "kernels.h"
 #include "ctx.h"
+#include "ffi.h"
 
 using namespace c25519;
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -294,7 +295,7 @@ int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t 
     if ((r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + n + 256))) return r;
     uint32_t *p40 = (uint32_t *)ctx->tmp_e.p;
     uint8_t *okbuf = d_ok ? d_ok : (uint8_t *)ctx->tmp_e.p + n * 160;
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
     if ((r = var_base_launch(ctx, d_scalars, d_points, n, in_fmt, false, ct, p40, okbuf))) return r;
@@ -315,21 +316,44 @@ int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t 
 EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
     return mul_batch_impl(ctx, d_scalars, d_points, n, in_fmt, out_fmt, d_out, d_ok, !(ctx->flags & C25519_FLAG_VARTIME_TABLES));
 }
-EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok) {
+// wipes device staging on every exit path of a host-pointer entry point (after the copy streams have drained)
+struct wipe_guard {
+    c25519_ctx *ctx; void *p[4]; size_t n[4]; int cnt = 0;
+    explicit wipe_guard(c25519_ctx *c) : ctx(c) {}
+    void add(void *q, size_t bytes) { if (q && bytes && cnt < 4) { p[cnt] = q; n[cnt++] = bytes; } }
+    ~wipe_guard() { for (int i = 0; i < cnt; i++) hipMemsetAsync(p[i], 0, n[i], ctx->stream); }
+};
+static int32_t mul_batch_host(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok, bool clamp) {
     HIPCHK(hipSetDevice(ctx->device));
-    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * osz + n + 16))) return r;
-    if (n == 0) return C25519_OK;
-    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, points, n * psz, hipMemcpyHostToDevice, ctx->stream));
-    uint8_t *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
-    if ((r = c25519_mul_batch_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint8_t *)ctx->tmp_b.p, n, in_fmt, out_fmt, dout, dok))) return r;
-    HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
-    if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (!(ctx->flags & C25519_FLAG_VARTIME_TABLES)) HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // staged secret scalars
-    return C25519_OK;
+    uint8_t *ds = (uint8_t *)ctx->tmp_a.p, *dp = (uint8_t *)ctx->tmp_b.p, *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
+    const bool secret = ctx_secret_default(ctx);
+    wipe_guard wipe(ctx);
+    if (secret) { wipe.add(ds, n * 32); wipe.add(dout, n * osz); }        // staged secret scalars and the products (e.g. shared secrets)
+    const ffi_in in[2] = {{scalars, ds, 32}, {points, dp, psz}};
+    const ffi_out o[2] = {{out, dout, osz}, {ok, dok, 1}};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), in, 2, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
+        if (clamp) HIPCHK(launch_clamp(ds + lo * 32, m, ds + lo * 32, ctx->stream));
+        return mul_batch_impl(ctx, ds + lo * 32, dp + lo * psz, m, in_fmt, out_fmt, dout + lo * osz, dok + lo, secret);
+    });
+}
+EXPORT int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok) {
+    return mul_batch_host(ctx, scalars, points, n, in_fmt, out_fmt, out, ok, false);
+}
+// EdwardsPoint::mul_clamped (edwards.rs:932-946): out[i] = clamp_integer(bytes[i]) * points[i], the scalar NOT reduced mod l
+EXPORT int32_t c25519_mul_clamped_batch_dev(c25519_ctx *ctx, const uint8_t *d_bytes, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
+    HIPCHK(hipSetDevice(ctx->device));
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 32 + 16))) return r;
+    HIPCHK(launch_clamp(d_bytes, n, (uint8_t *)ctx->tmp_c2.p, ctx->stream));
+    r = mul_batch_impl(ctx, (const uint8_t *)ctx->tmp_c2.p, d_points, n, in_fmt, out_fmt, d_out, d_ok, ctx_secret_default(ctx));
+    if (n) hipMemsetAsync(ctx->tmp_c2.p, 0, n * 32, ctx->stream);      // the clamped secrets, on every path
+    return r;
+}
+EXPORT int32_t c25519_mul_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok) {
+    return mul_batch_host(ctx, bytes, points, n, in_fmt, out_fmt, out, ok, true);
 }
 
 // ---- double base: out[i] = a[i] * A[i] + b[i] * B ----------------------------------------------------------
@@ -343,7 +367,7 @@ EXPORT int32_t c25519_double_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_a,
     uint32_t *P40 = (uint32_t *)ctx->tmp_e.p, *Q40 = P40 + n * 40;
     uint8_t *okbuf = d_ok ? d_ok : (uint8_t *)ctx->tmp_e.p + 2 * n * 160;
     hipStream_t st = ctx->stream;
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipEventRecord(ring[0], st));
     if ((r = var_base_launch(ctx, d_a, d_A, n, in_fmt, false, false, P40, okbuf))) return r;          // a * A (vartime by contract)
@@ -364,20 +388,15 @@ EXPORT int32_t c25519_double_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_a,
 EXPORT int32_t c25519_double_base_batch(c25519_ctx *ctx, const uint8_t *a, const uint8_t *A, const uint8_t *b, uint64_t n, int in_fmt, int out_fmt,
                                         uint8_t *out, uint8_t *ok) {
     HIPCHK(hipSetDevice(ctx->device));
-    size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, 2 * n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * osz + n + 16))) return r;
-    if (n == 0) return C25519_OK;
-    uint8_t *da = (uint8_t *)ctx->tmp_a.p, *db = da + n * 32;
-    HIPCHK(hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, A, n * psz, hipMemcpyHostToDevice, ctx->stream));
-    uint8_t *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
-    if ((r = c25519_double_base_batch_dev(ctx, da, (const uint8_t *)ctx->tmp_b.p, db, n, in_fmt, out_fmt, dout, dok))) return r;
-    HIPCHK(hipMemcpyAsync(out, dout, n * osz, hipMemcpyDeviceToHost, ctx->stream));
-    if (ok) HIPCHK(hipMemcpyAsync(ok, dok, n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return C25519_OK;
+    uint8_t *da = (uint8_t *)ctx->tmp_a.p, *db = da + n * 32, *dA = (uint8_t *)ctx->tmp_b.p, *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
+    const ffi_in in[3] = {{a, da, 32}, {b, db, 32}, {A, dA, psz}};
+    const ffi_out o[2] = {{out, dout, osz}, {ok, dok, 1}};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), in, 3, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return c25519_double_base_batch_dev(ctx, da + lo * 32, dA + lo * psz, db + lo * 32, m, in_fmt, out_fmt, dout + lo * osz, dok + lo);
+    });
 }
 
 // ---- per-signature verify ---------------------------------------------------------------------------------
@@ -395,7 +414,7 @@ EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, c
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     uint8_t *hram = ws + oH, *kscal = ws + oK, *sscal = ws + oS, *s_ok = ws + oSo, *a_ok = ws + oAo, *sbad = ws + oSt, *rcheck = ws + oRc;
     uint32_t *P40 = (uint32_t *)(ws + oP), *Q40 = (uint32_t *)(ws + oQ);
-    hipEvent_t *ring = ctx->ring[ctx->ncalls++ % c25519_ctx::RING];
+    hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
     HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
@@ -417,18 +436,21 @@ EXPORT int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const u
                                    uint64_t n, int strict, uint8_t *status) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
-    uint64_t mlen = msg_off[n];
+    for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) { ctx->err = "verify_each: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t mlen = msg_off[n];
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64 + n * 32 + n + 64))) return r;
-    uint8_t *dsig = (uint8_t *)ctx->tmp_c.p, *dpk = dsig + n * 64, *dst = dpk + n * 32;
-    if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dsig, sigs, n * 64, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dpk, pks, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((r = ed25519_verify_each_dev(ctx, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, dsig, dpk, n, strict, dst))) return r;
-    HIPCHK(hipMemcpyAsync(status, dst, n, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return C25519_OK;
+    uint8_t *dmsg = (uint8_t *)ctx->tmp_a.p, *dsig = (uint8_t *)ctx->tmp_c.p, *dpk = dsig + n * 64, *dst = dpk + n * 32;
+    uint64_t *doff = (uint64_t *)ctx->tmp_b.p;
+    // the message blob and the offsets go up whole (the kernels index the blob through the offsets); signatures and keys in chunks
+    if ((r = ffi_begin(ctx))) return r;
+    if (mlen) HIPCHK(hipMemcpyAsync(dmsg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
+    HIPCHK(hipMemcpyAsync(doff, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+    const ffi_in in[2] = {{sigs, dsig, 64}, {pks, dpk, 32}};
+    const ffi_out o = {status, dst, 1};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), in, 2, &o, 1, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return ed25519_verify_each_dev(ctx, dmsg, doff + lo, mlen, dsig + lo * 64, dpk + lo * 32, m, strict, dst + lo);
+    }, true, mlen + (n + 1) * 8);
 }
 
 // ---- key generation / signing -------------------------------------------------------------------------------
@@ -485,20 +507,21 @@ EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, c
 EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
-    uint64_t mlen = msg_off[n];
+    for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) { ctx->err = "sign_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t mlen = msg_off[n];
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 128 + 64))) return r;
-    uint8_t *dseed = (uint8_t *)ctx->tmp_c.p, *dpk = dseed + n * 32, *dsig = dpk + n * 32;
-    if (mlen) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, msgs, mlen, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(dseed, seeds, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    if ((r = ed25519_sign_batch_dev(ctx, dseed, (const uint8_t *)ctx->tmp_a.p, (const uint64_t *)ctx->tmp_b.p, mlen, n, dpk, dsig))) {
-        hipMemsetAsync(dseed, 0, n * 32, ctx->stream);
-        return r;
-    }
-    HIPCHK(hipMemcpyAsync(pks, dpk, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipMemcpyAsync(sigs, dsig, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    HIPCHK(hipMemsetAsync(dseed, 0, n * 32, ctx->stream));
-    return C25519_OK;
+    uint8_t *dmsg = (uint8_t *)ctx->tmp_a.p, *dseed = (uint8_t *)ctx->tmp_c.p, *dpk = dseed + n * 32, *dsig = dpk + n * 32;
+    uint64_t *doff = (uint64_t *)ctx->tmp_b.p;
+    wipe_guard wipe(ctx);
+    wipe.add(dseed, n * 32);                              // the staged secret keys, on every path
+    if ((r = ffi_begin(ctx))) return r;
+    if (mlen) HIPCHK(hipMemcpyAsync(dmsg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
+    HIPCHK(hipMemcpyAsync(doff, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+    const ffi_in in = {seeds, dseed, 32};
+    const ffi_out o[2] = {{pks, dpk, 32}, {sigs, dsig, 64}};
+    // one chunk: ed25519_sign_batch_dev reads its error flag back (a synchronisation per call)
+    return ffi_pipeline(ctx, n, n, &in, 1, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return ed25519_sign_batch_dev(ctx, dseed + lo * 32, dmsg, doff + lo, mlen, m, dpk + lo * 32, dsig + lo * 64);
+    }, true, mlen + (n + 1) * 8);
 }

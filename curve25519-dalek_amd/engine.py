@@ -55,6 +55,21 @@ def load_library():
         "c25519_mul_base_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_mul_base_batch": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_mul_base_batch_vartime_dev": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_mul_base_clamped_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_mul_base_clamped_batch": (i32, [vp, vp, u64, C.c_int, vp]),
+        "c25519_basetable_create": (vp, [vp, vp, C.c_int]),
+        "c25519_basetable_destroy": (None, [vp, vp]),
+        "c25519_mul_table_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, vp]),
+        "c25519_mul_table_batch": (i32, [vp, vp, vp, u64, C.c_int, vp]),
+        "c25519_x25519_contributory_batch_dev": (i32, [vp, vp, vp, u64, vp, vp]),
+        "c25519_x25519_contributory_batch": (i32, [vp, vp, vp, u64, vp, vp]),
+        "c25519_mul_clamped_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_mul_clamped_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_host_alloc": (vp, [C.c_size_t]),
+        "c25519_host_free": (None, [vp]),
+        "c25519_last_ffi_ms": (C.c_double, [vp, vp, vp]),
+        "c25519_ctx_trim": (i32, [vp]),
+        "c25519_last_kernel_name": (C.c_char_p, [vp, C.c_int]),
         "c25519_x25519_batch_dev": (i32, [vp, vp, vp, u64, vp]),
         "c25519_x25519_batch": (i32, [vp, vp, vp, u64, vp]),
         "c25519_x25519_base_batch_dev": (i32, [vp, vp, u64, vp]),
@@ -112,6 +127,9 @@ def load_library():
 
 ABI_SYMBOLS = [
     "c25519_ctx_create", "c25519_ctx_destroy", "c25519_ctx_set_stream", "c25519_ctx_synchronize", "c25519_last_error",
+    "c25519_mul_base_clamped_batch_dev", "c25519_mul_base_clamped_batch", "c25519_basetable_create", "c25519_basetable_destroy", "c25519_mul_table_batch_dev",
+    "c25519_mul_table_batch", "c25519_x25519_contributory_batch_dev", "c25519_x25519_contributory_batch", "c25519_mul_clamped_batch_dev", "c25519_mul_clamped_batch",
+    "c25519_host_alloc", "c25519_host_free", "c25519_last_ffi_ms", "c25519_ctx_trim", "c25519_last_kernel_name",
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
@@ -380,28 +398,99 @@ class Engine:
         return pks, sigs
 
     # -- host-buffer API (numpy in / numpy out) ---------------------------------------------------
-    def mul_base_batch(self, scalars, out_fmt=FMT_EDWARDS_Y):
+    @staticmethod
+    def _out(out, n, width):
+        """the caller's output buffer (reuse it: a fresh allocation pays first-touch page faults inside the copy) or a new one"""
+        if out is None:
+            return np.empty((n, width) if width > 1 else (n,), dtype=np.uint8)
+        assert out.dtype == np.uint8 and out.flags["C_CONTIGUOUS"] and out.size == n * width
+        return out
+
+    def mul_base_batch(self, scalars, out_fmt=FMT_EDWARDS_Y, out=None):
         s = _np8(scalars, 32); n = s.shape[0]
-        out = np.empty((n, _PT[out_fmt]), dtype=np.uint8)
+        out = self._out(out, n, _PT[out_fmt])
         self._bind_stream()
         self._chk(self.lib.c25519_mul_base_batch(self.ctx, s.ctypes.data, n, out_fmt, out.ctypes.data))
         return out
 
-    def x25519_base_batch(self, k):
+    def mul_base_clamped_batch(self, raw, out_fmt=FMT_EDWARDS_Y, out=None):
+        """EdwardsPoint::mul_base_clamped (edwards.rs:948): clamp_integer(raw_i) * B, not reduced mod l"""
+        s = _np8(raw, 32); n = s.shape[0]
+        out = self._out(out, n, _PT[out_fmt])
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_base_clamped_batch(self.ctx, s.ctypes.data, n, out_fmt, out.ctypes.data))
+        return out
+
+    def mul_clamped_batch(self, raw, points, in_fmt=FMT_RAW160, out_fmt=FMT_EDWARDS_Y):
+        """EdwardsPoint::mul_clamped (edwards.rs:932): clamp_integer(raw_i) * P_i"""
+        s = _np8(raw, 32); p = _np8(points, _PT[in_fmt]); n = s.shape[0]
+        assert p.shape[0] == n
+        out = np.empty((n, _PT[out_fmt]), dtype=np.uint8); ok = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_clamped_batch(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out.ctypes.data, ok.ctypes.data))
+        return out, ok
+
+    # -- constant-time fixed-base tables for a caller's point (EdwardsBasepointTable::create / RistrettoBasepointTable::create)
+    def basetable_create(self, point, in_fmt=FMT_EDWARDS_Y):
+        b = bytes(point)
+        assert len(b) == _PT[in_fmt]
+        self._bind_stream()
+        h = self.lib.c25519_basetable_create(self.ctx, b, in_fmt)
+        if not h:
+            raise EngineError("basetable_create failed: %s" % self.lib.c25519_last_error(self.ctx).decode())
+        return h
+
+    def basetable_destroy(self, h):
+        self.lib.c25519_basetable_destroy(self.ctx, h)
+
+    def mul_table_batch(self, h, scalars, out_fmt=FMT_EDWARDS_Y, out=None):
+        s = _np8(scalars, 32); n = s.shape[0]
+        out = self._out(out, n, _PT[out_fmt])
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_table_batch(self.ctx, h, s.ctypes.data, n, out_fmt, out.ctypes.data))
+        return out
+
+    def mul_table_batch_t(self, h, scalars, out_fmt=FMT_EDWARDS_Y, out=None):
+        n = self._t(scalars, 32)
+        if out is None:
+            out = self.torch.empty((n, _PT[out_fmt]), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_mul_table_batch_dev(self.ctx, h, scalars.data_ptr(), n, out_fmt, out.data_ptr()))
+        return out
+
+    def last_ffi(self):
+        """-> (wall-clock ms, bytes up, bytes down) of the latest host-pointer call"""
+        a, b = C.c_uint64(0), C.c_uint64(0)
+        ms = float(self.lib.c25519_last_ffi_ms(self.ctx, C.byref(a), C.byref(b)))
+        return ms, int(a.value), int(b.value)
+
+    def trim(self):
+        self._chk(self.lib.c25519_ctx_trim(self.ctx))
+
+    def x25519_base_batch(self, k, out=None):
         """X25519 public keys x25519(k_i, 9) through the fixed-base path (x25519.rs:105-109)."""
         k = _np8(k, 32); n = k.shape[0]
-        out = np.empty((n, 32), dtype=np.uint8)
+        out = self._out(out, n, 32)
         self._bind_stream()
         self._chk(self.lib.c25519_x25519_base_batch(self.ctx, k.ctypes.data, n, out.ctypes.data))
         return out
 
-    def x25519_batch(self, k, u):
+    def x25519_batch(self, k, u, out=None):
         k = _np8(k, 32); u = _np8(u, 32); n = k.shape[0]
         assert u.shape[0] == n
-        out = np.empty((n, 32), dtype=np.uint8)
+        out = self._out(out, n, 32)
         self._bind_stream()
         self._chk(self.lib.c25519_x25519_batch(self.ctx, k.ctypes.data, u.ctypes.data, n, out.ctypes.data))
         return out
+
+    def x25519_contributory_batch(self, k, u):
+        """-> (shared secrets (n, 32), was_contributory (n,)): x25519.rs:335 as a batched flag"""
+        k = _np8(k, 32); u = _np8(u, 32); n = k.shape[0]
+        assert u.shape[0] == n
+        out = np.empty((n, 32), dtype=np.uint8); fl = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_x25519_contributory_batch(self.ctx, k.ctypes.data, u.ctypes.data, n, out.ctypes.data, fl.ctypes.data))
+        return out, fl
 
     def decompress_batch(self, enc, in_fmt=FMT_EDWARDS_Y):
         e = _np8(enc, 32); n = e.shape[0]

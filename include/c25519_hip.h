@@ -12,7 +12,11 @@
  *     retained after return.
  *   - `_dev` entry points take DEVICE pointers (HBM) and enqueue on the context's HIP stream;
  *     those that return a verdict/point to the host synchronise that stream.  The un-suffixed
- *     twins take HOST pointers and do the H2D/D2H copies themselves.
+ *     twins take HOST pointers and move the data themselves: the batch is cut into chunks (passes), and chunk c+1 travels up
+ *     on a copy stream while chunk c computes and chunk c-1 travels down, so a call costs about max(link, kernels), not
+ *     their sum.  Any host memory works; pageable memory whose pages have been touched moves at the link rate on this
+ *     platform, but an OUTPUT buffer that has never been written (a fresh allocation) pays first-touch page faults at
+ *     ~5 GB/s: reuse output buffers, or take them from c25519_host_alloc.
  *   - return value: int32 status.  0 OK; 1 NONE (a point failed to decompress: the Rust side maps
  *     it to Option::None); 2 SCALAR_FORMAT; 3 VERIFY; 4 ARRAY_LENGTH (mirrors
  *     ed25519-dalek/src/errors.rs:21-42 InternalError); negative = -(hipError_t) runtime failure.
@@ -48,7 +52,9 @@ extern "C" {
 
 /* ed25519_verify_batch z_mode: how the 128-bit batch coefficients z_i are derived.
  * C25519_Z_TRANSCRIPT (0, the default of every host-language wrapper): byte for byte the reference's derivation --
- *   ONE Merlin/STROBE-128 transcript over the whole batch (batch.rs:168-222, batch/transcript.rs), whatever n is.  It is
+ *   ONE Merlin/STROBE-128 transcript over the whole batch (batch.rs:168-222, batch/transcript.rs), whatever n is and
+ *   however many passes, contexts (ed25519_verify_batch_multi) or ranks (multi.verify_batch_sharded) share the batch, and
+ *   ONE equation over the whole batch (batch.rs:235-250: the partial sums of passes / contexts / ranks are added).  It is
  *   a sequential sponge (about 1.7 Keccak-f per signature), so it runs on one host core and bounds the call near
  *   2-3 x 10^6 signatures/s; the curve arithmetic still runs on the GPU.
  * C25519_Z_DEVICE (1, explicit opt-in, NOT the reference's derivation and not a reviewed standard construction):
@@ -93,6 +99,18 @@ int32_t c25519_ctx_set_stream(c25519_ctx *ctx, void *hip_stream);
 /* Block until everything enqueued on the context's stream has finished. */
 int32_t c25519_ctx_synchronize(c25519_ctx *ctx);
 const char *c25519_last_error(const c25519_ctx *ctx);
+/* Page-locked host memory (hipHostMalloc) for input / output buffers of the host-pointer entry points: DMA-able as is, never
+ * pays a first-touch fault.  c25519_last_ffi_ms: wall-clock milliseconds of the most recent host-pointer call of this
+ * context and the bytes it moved each way (either pointer may be NULL); -1 before the first such call. */
+void *c25519_host_alloc(size_t bytes);
+void c25519_host_free(void *p);
+double c25519_last_ffi_ms(const c25519_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes);
+/* Release the workspaces earlier calls left allocated (a 2^24-term MSM keeps ~2.6 GB: gather records prepared ahead, the
+ * normaliser's prefix products, staging copies of host-pointer calls).  Synchronises the context; the next call
+ * re-allocates what it needs.  For long-lived contexts that see an occasional very large call. */
+int32_t c25519_ctx_trim(c25519_ctx *ctx);
+/* name of the kernel that c25519_phase_ms phase 0 (which = 0) / phase 3 (which = 1) of the latest entry point timed */
+const char *c25519_last_kernel_name(const c25519_ctx *ctx, int which);
 /* milliseconds the device spent in the most recent entry point's kernels (hipEvent pair on the
  * context's stream); valid after the call returned / the stream was synchronised. */
 float c25519_last_kernel_ms(c25519_ctx *ctx);
@@ -115,11 +133,36 @@ int32_t c25519_mul_base_batch(c25519_ctx *ctx, const uint8_t *scalars, uint64_t 
 /* the same for scalars the caller declares PUBLIC: always the context's fast tables (variable-time table access). */
 int32_t c25519_mul_base_batch_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out);
 
+/* EdwardsPoint::mul_base_clamped (edwards.rs:948-956): out[i] = clamp_integer(bytes[i]) * B -- the clamped integer is NOT
+ * reduced mod l (scalar.rs:1407; legal for point multiplication, scalar.rs:197-222).  Secrets: constant-time tables unless the
+ * context was created with C25519_FLAG_VARTIME_TABLES; the clamped copies are wiped. */
+int32_t c25519_mul_base_clamped_batch_dev(c25519_ctx *ctx, const uint8_t *d_bytes, uint64_t n, int out_fmt, uint8_t *d_out);
+int32_t c25519_mul_base_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, uint64_t n, int out_fmt, uint8_t *out);
+
+/* ---- constant-time fixed-base tables for a CALLER'S point -----------------------------------------------------------------
+ * replaces EdwardsBasepointTable::create(&P) (edwards.rs:1131-1141, generic over the basepoint; radices :1246-1292) and
+ * RistrettoBasepointTable::create (ristretto.rs:1080-1110), then `&scalar * &table` = mul_base on that table
+ * (edwards.rs:1192-1209).  create: point = 32 bytes (fmt 0 / 1) or 160 bytes (fmt 2), HOST pointer; the table (radix 2^5:
+ * 52 windows x 17 affine Niels entries, the layout of the context's own constant-time table) is built once and stays in device
+ * memory.  mul_table: out[i] = scalars[i] * P, ALWAYS with the full-window scan of window.rs:54-76 (no address and no
+ * branch depends on the scalar), whatever the context's flags -- these tables exist for secret scalars: Pedersen commitments
+ * a*G + b*H, ElGamal / DH keys on a fixed generator.  out_fmt 0 / 1 / 2; fmt 1 gives RistrettoBasepointTable's result. */
+typedef struct c25519_basetable c25519_basetable;
+c25519_basetable *c25519_basetable_create(c25519_ctx *ctx, const uint8_t *point, int in_fmt);
+void c25519_basetable_destroy(c25519_ctx *ctx, c25519_basetable *t);
+int32_t c25519_mul_table_batch_dev(c25519_ctx *ctx, const c25519_basetable *t, const uint8_t *d_scalars, uint64_t n, int out_fmt, uint8_t *d_out);
+int32_t c25519_mul_table_batch(c25519_ctx *ctx, const c25519_basetable *t, const uint8_t *scalars, uint64_t n, int out_fmt, uint8_t *out);
+
 /* ---- X25519: out[i] = x25519(k[i], u[i]) -------------------------------------------------------
  * replaces x25519-dalek/src/x25519.rs:390 = MontgomeryPoint(u).mul_clamped(k) (montgomery.rs:150,
  * :183-211): k is clamped inside, bit 255 of u ignored, u >= p reduced, low-order u -> all-zero. */
 int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out);
 int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out);
+/* The same with SharedSecret::was_contributory (x25519-dalek/src/x25519.rs:335) as a batched flag: contributory[i] = 1 iff
+ * out[i] is not all-zero (a low-order u[i] gives the all-zero shared secret, montgomery.rs:403-412).  MontgomeryPoint::
+ * mul_clamped (montgomery.rs:150-162) is exactly this function: k is clamped inside. */
+int32_t c25519_x25519_contributory_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out, uint8_t *d_contributory);
+int32_t c25519_x25519_contributory_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, uint8_t *contributory);
 /* X25519 public keys: out[i] = x25519(k[i], 9), computed the way x25519-dalek does it -- PublicKey::from(&secret) =
  * EdwardsPoint::mul_base_clamped(secret).to_montgomery() (x25519.rs:105-109, :255-259; edwards.rs:948, :574-590) --
  * i.e. through the fixed-base tables and the birational map (Z+Y)/(Z-Y), 12x cheaper than the ladder. */
@@ -196,8 +239,12 @@ int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const u
                                  const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode);
 int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off,
                              const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint32_t z_mode);
-/* verify_batch over several contexts / GPUs from one process: contiguous shards of the signatures, each its own random
- * linear combination on ctxs[r]; the verdict is the worst shard verdict in the reference's precedence. */
+/* verify_batch over several contexts / GPUs from one process, contiguous shards of the signatures.  C25519_Z_TRANSCRIPT: the
+ * reference's ONE transcript over the whole batch and its single equation -- every context hashes its shard, the host runs
+ * the transcript once over all H(R||A||M) and s, every context evaluates its share of the equation with its z_i, and the
+ * partial sums are folded into one identity check: z_i, equation and verdict are those of the reference whatever nctx is.
+ * C25519_Z_DEVICE: each shard is its own random linear combination; the verdict is the worst shard verdict in the
+ * reference's precedence. */
 int32_t ed25519_verify_batch_multi(c25519_ctx **ctxs, int32_t nctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                    uint64_t n, uint32_t z_mode);
 /* The same check for callers that hold VerifyingKey values: the reference's VerifyingKey keeps the decompressed
@@ -248,6 +295,10 @@ int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64
  * ok (may be NULL): n bytes, 0 where a compressed point did not decode (that output is unspecified). */
 int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
 int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
+
+/* EdwardsPoint::mul_clamped (edwards.rs:932-946): out[i] = clamp_integer(bytes[i]) * points[i] (not reduced mod l). */
+int32_t c25519_mul_clamped_batch_dev(c25519_ctx *ctx, const uint8_t *d_bytes, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
+int32_t c25519_mul_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
 
 /* ---- double base: out[i] = a[i] * A[i] + b[i] * B ---------------------------------------------------------
  * replaces backend::vartime_double_base_mul (backend.rs:267 -> scalar_mul/vartime_double_base.rs:23-72;
