@@ -16,7 +16,8 @@ At N = 1 the same line carries, as `sub`, the other BASELINE configurations time
 steps each, their own HIP-event kernel timings): configs[2] verify_batch of 2^20 signatures (VerifyingKey mode, device
 z-mode; plus the strict-transcript z-mode at 2^14 and 2^20), configs[1] 2^20 fixed-base multiplications (radix-2^16
 tables and the constant-time scan), configs[4] 2^20 X25519 ladders -- each with its own `roofline`, `valu` and
-`cpu_baseline` objects.  `--workload X` makes X the headline and drops `sub`.
+`cpu_baseline` objects -- and, as `ffi_path`, the same workloads through the HOST-POINTER entry points a Rust caller binds
+(wall-clock per call, units/s, achieved PCIe GB/s against the link peak).  `--workload X` makes X the headline and drops both.
 """
 import argparse
 import glob
@@ -558,8 +559,8 @@ def main():
         run_sub("x25519_2p20", wx, steps=min(args.steps, 5))
         del wx
         res["sub"] = sub
-        res["side"] = side_numbers(pkg, eng, torch, dev)
-        res["side"]["ctx_create_first_in_process_ms"] = t_ctx
+        res["ffi_path"] = ffi_path(pkg, eng, torch, dev)
+        res["ffi_path"]["ctx_create_first_in_process_ms"] = t_ctx
 
     if rank == 0:
         print(json.dumps(res))
@@ -567,28 +568,70 @@ def main():
         dist.destroy_process_group()
 
 
-def side_numbers(pkg, eng, torch, dev):
-    """PCIe-inclusive and first-call figures (never `value`): host-pointer entry points, context creation."""
+LINK_PEAK_GBS = 64.0   # PCIe Gen5 x16 per direction (measured with hipMemcpy on this pool: 56 - 57 GB/s, profiles/r03_pcie_probe.txt)
+
+
+def ffi_path(pkg, eng, torch, dev):
+    """The same workloads THROUGH THE HOST-POINTER ENTRY POINTS a Rust caller binds (include/c25519_hip.h, un-suffixed twins):
+    host buffers in, host buffers out, wall-clock of the call (best of a few), bytes moved and the achieved link rate against
+    the PCIe peak.  Output buffers are allocated once and reused, as a caller that cares about throughput does (a fresh
+    buffer pays first-touch page faults inside the copy: `fresh_output_ms`).  Never the headline `value`."""
     import numpy as np
     E = pkg.engine
+    lib = eng.lib
     out = {}
-    t0 = time.perf_counter(); e2 = pkg.Engine(dev.index); torch.cuda.synchronize(dev); out["ctx_create_again_ms"] = (time.perf_counter() - t0) * 1e3
     rng = np.random.default_rng(5)
     n = 1 << 20
+
+    def best(fn, reps=4):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+        return min(ts)
+
+    def rec(key, ms, units, e=eng, **extra):
+        _, up, down = e.last_ffi()
+        r = {"ms_per_call": ms, "units_per_s": units / (ms * 1e-3), "bytes_up": up, "bytes_down": down,
+             "link_GBps": (up + down) / (ms * 1e-3) / 1e9, "link_peak_GBps": LINK_PEAK_GBS, "link_frac": (up + down) / (ms * 1e-3) / 1e9 / LINK_PEAK_GBS}
+        r.update(extra)
+        out[key] = r
+
     s = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); s[:, 31] &= 0x0F
-    t0 = time.perf_counter(); e2.mul_base_batch(s); out["first_call_mul_base_2p20_host_ms"] = (time.perf_counter() - t0) * 1e3
-    t0 = time.perf_counter(); e2.mul_base_batch(s); out["mul_base_2p20_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
-    out["mul_base_2p20_host_pointers_per_s"] = n / (out["mul_base_2p20_host_pointers_ms"] * 1e-3)
+    buf = np.zeros((n, 32), np.uint8)
+    eng.mul_base_batch(s[:4096])
+    fresh = best(lambda: eng.mul_base_batch(s), 3)
+    rec("mul_base_2p20_constant_time", best(lambda: eng.mul_base_batch(s, out=buf)), n, fresh_output_ms=fresh)
+    t0 = time.perf_counter(); ev = pkg.Engine(dev.index, flags=E.FLAG_VARTIME_TABLES); torch.cuda.synchronize(dev); t_ctx2 = (time.perf_counter() - t0) * 1e3
+    ev.mul_base_batch(s[:4096])
+    rec("mul_base_2p20_vartime_tables", best(lambda: ev.mul_base_batch(s, out=buf)), n, e=ev)
+    ev.close()
     k = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); u = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
-    e2.x25519_batch(k[:1024], u[:1024])
-    t0 = time.perf_counter(); e2.x25519_batch(k, u); out["x25519_2p20_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
+    eng.x25519_batch(k[:4096], u[:4096])
+    rec("x25519_2p20", best(lambda: eng.x25519_batch(k, u, out=buf), 3), n)
     m = 1 << 21
     x = rng.integers(0, 256, size=(m, 32), dtype=np.uint8); x[:, 31] &= 0x0F
-    pts = e2.mul_base_batch(x, out_fmt=E.FMT_RAW160)
-    e2.msm_vartime(x[:4096], pts[:4096])
-    t0 = time.perf_counter(); e2.msm_vartime(x, pts); out["msm_2p21_host_pointers_ms"] = (time.perf_counter() - t0) * 1e3
-    out["note"] = "wall-clock including pageable-host H2D/D2H copies (PCIe); ctx_create builds the fixed-base tables on the device"
-    e2.close()
+    dpts = eng.mul_base_batch_vartime_t(torch.from_numpy(x).to(dev), E.FMT_RAW160)
+    pts = dpts.cpu().numpy(); enc = eng.compress_batch_t(dpts).cpu().numpy()
+    del dpts
+    eng.msm_vartime(x[:4096], pts[:4096])
+    rec("msm_2p21_raw_points", best(lambda: eng.msm_vartime(x, pts)), m)
+    rec("msm_2p21_compressed_points", best(lambda: eng.msm_vartime(x, enc, in_fmt=E.FMT_EDWARDS_Y)), m)
+    del pts, enc
+    dmsg = torch.from_numpy(u).to(dev).reshape(-1)
+    doff = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)
+    dpk, dsig = eng.sign_batch_t(torch.from_numpy(k).to(dev), dmsg, doff)
+    hmsg = np.ascontiguousarray(u.reshape(-1)); hoff = doff.cpu().numpy().astype(np.uint64); hsig = dsig.cpu().numpy(); hpk = dpk.cpu().numpy()
+
+    def vb(zmode):
+        eng._bind_stream()
+        st = lib.ed25519_verify_batch_keys(eng.ctx, hmsg.ctypes.data, hoff.ctypes.data, hsig.ctypes.data, hpk.ctypes.data, None, n, zmode)
+        assert st == 0, st
+    vb(E.Z_DEVICE)
+    rec("verify_batch_2p20_device_z_keys_as_bytes", best(lambda: vb(E.Z_DEVICE)), n)
+    rec("verify_batch_2p20_strict_transcript_keys_as_bytes", best(lambda: vb(E.Z_TRANSCRIPT), 1), n)
+    out["ctx_create_again_ms"] = t_ctx2
+    out["note"] = ("host pointers in, host pointers out: chunks / passes / input arrays travel on copy streams while the previous chunk computes "
+                   "(csrc/ffi.h); pageable numpy buffers, outputs reused; link_frac = (bytes up + bytes down) / wall-clock / PCIe Gen5 x16 peak")
     return out
 
 
