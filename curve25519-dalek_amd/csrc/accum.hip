@@ -35,7 +35,7 @@ namespace c25519 {
 // flight during addition i; the wave's own vmcnt(0) orders DMA -> ds_read, lgkmcnt(0) orders ds_read -> next DMA.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
-             const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets) {
+             const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets, int cont) {
     const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in_range = tid < count;                     // every lane of a wave keeps loading for the others
     const u64 gid = in_range ? perm[tid] : 0;
@@ -43,7 +43,9 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
     const u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
     const bool mine = in_range && hi - lo <= g.long_cap;   // long lists belong to k_long_segments
     const u32 *list = sorted + (u64)k * n;
-    ge_p3 acc = ge_identity();
+    // cont: the bucket sums of the previous pass on this stream set are the starting point (one bucket reduction per call
+    // instead of one per pass: msm.hip msm_record_enqueue)
+    ge_p3 acc = (cont && mine) ? p40_load(buckets, gid) : ge_identity();
     __shared__ uint4 stage[(256 / 64) * 8 * 64];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
@@ -88,8 +90,8 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
 
 }  // namespace c25519
 
-const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, hipStream_t st) {
+const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, int cont, hipStream_t st) {
     using namespace c25519;
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, pts, sorted, base, perm, count, n, g, buckets);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, pts, sorted, base, perm, count, n, g, buckets, cont);
     return "c25519::k_accumulate (lockstep field products, wave-cooperative gather)";
 }

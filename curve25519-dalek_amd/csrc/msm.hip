@@ -398,46 +398,51 @@ __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ 
         cc[((u64)k * SL + sidx) * nchunk + j] = sm[sidx] + sm[SL + sidx] + sm[2 * SL + sidx] + sm[3 * SL + sidx];
 }
 // one block per window: exclusive scan of cc in (slice, chunk) order, in place; bin_base[k][s] (SL+1 entries); base[k][half]
-__global__ void __launch_bounds__(1024) k_part_scan(u32 *__restrict__ cc, int SL, int nchunk, msm_geom g, u32 *__restrict__ bin_base, u32 *__restrict__ base) {
+// Every global access is wave-coalesced (tiles of 8192 counters go through LDS, where each thread then owns 8 consecutive ones).
+// Round 2's form gave each thread 16 - 32 consecutive counters straight from memory: every load instruction of a wave touched 64
+// cache lines, and beside k_accumulate -- whose gathers keep the texture path busy -- the kernel took 520 - 620 us instead of
+// its 37 us alone (profiles/r03_msm_2p24_timeline.txt), which made the sort the critical path of a multi-pass MSM.
+// (Blocks of 256 threads: the single-block-per-window form below serves round 2's digit-matrix path of the precomputed tables.)
+constexpr int SCAN_PER = 16, SCAN_TILE = 256 * SCAN_PER;
+__global__ void __launch_bounds__(256) k_part_scan(u32 *__restrict__ cc, int SL, int nchunk, msm_geom g, u32 *__restrict__ bin_base, u32 *__restrict__ base) {
     C25519_PRIO_CHAIN();
-    __shared__ u32 part[1024];
-    const int k = blockIdx.x, tid = threadIdx.x, M = SL * nchunk;
+    __shared__ u32 tile[SCAN_TILE + SCAN_TILE / 32];         // element a lives at a + a / 32: a thread's consecutive elements and a wave's 64 consecutive ones are both (almost) conflict-free
+    __shared__ u32 wsum[4];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, M = SL * nchunk;
     u32 *v = cc + (u64)k * M;
-    const int per = (M + 1023) / 1024, i0 = tid * per, i1 = i0 + per < M ? i0 + per : M;
-    constexpr int REG = 16;                // a thread's counters stay in registers between the two sweeps when there are <= 16 of
-    u32 c[REG];                            // them (2^21 terms: exactly 16), with all its loads in flight at once
-    u32 sum = 0;
-    if (per <= REG) {
+    u32 carry = 0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < M; t0 += SCAN_TILE) {
 #pragma unroll
-        for (int r = 0; r < REG; r++) c[r] = (r < per && i0 + r < M) ? v[i0 + r] : 0u;
-#pragma unroll
-        for (int r = 0; r < REG; r++) sum += c[r];
-    } else for (int i = i0; i < i1; i++) sum += v[i];
-    part[tid] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        u32 x = tid >= off ? part[tid - off] : 0;
+        for (int r = 0; r < SCAN_PER; r++) { const int a = r * 256 + tid, e = t0 + a; tile[a + (a >> 5)] = e < M ? v[e] : 0u; }
         __syncthreads();
-        part[tid] += x;
-        __syncthreads();
-    }
-    u32 run = part[tid] - sum;
-    if (per <= REG) {
+        u32 x[SCAN_PER], sum = 0;
 #pragma unroll
-        for (int r = 0; r < REG; r++) {
-            const int i = i0 + r;
-            if (r < per && i < M) {
-                v[i] = run;
-                if (i % nchunk == 0) bin_base[(u64)k * (SL + 1) + i / nchunk] = run;
-                run += c[r];
+        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; x[q] = tile[a + (a >> 5)]; sum += x[q]; }
+        u32 inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(inc, off, 64); if (lane >= off) inc += y; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u32 wbase = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const u32 ws = wsum[i]; wbase += i < w ? ws : 0u; total += ws; }
+        u32 run = carry + wbase + inc - sum;
+#pragma unroll
+        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; tile[a + (a >> 5)] = run; run += x[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAN_PER; r++) {
+            const int a = r * 256 + tid, e = t0 + a;
+            if (e < M) {
+                const u32 val = tile[a + (a >> 5)];
+                v[e] = val;
+                if (e % nchunk == 0) bin_base[(u64)k * (SL + 1) + e / nchunk] = val;
             }
         }
-    } else for (int i = i0; i < i1; i++) {
-        u32 cv = v[i]; v[i] = run;
-        if (i % nchunk == 0) bin_base[(u64)k * (SL + 1) + i / nchunk] = run;
-        run += cv;
+        carry += total;
+        __syncthreads();
     }
-    if (tid == 1023) { bin_base[(u64)k * (SL + 1) + SL] = part[1023]; base[(u64)k * (g.half + 1) + g.half] = part[1023]; }
+    if (tid == 0) { bin_base[(u64)k * (SL + 1) + SL] = carry; base[(u64)k * (g.half + 1) + g.half] = carry; }
 }
 // pass 1: chunk j of window k -> runs per slice in P1[k][..]
 __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ D, u64 n, msm_geom g, int SL, int PART_CHUNK, const u32 *__restrict__ gofs, u32 *__restrict__ P1) {
@@ -494,6 +499,246 @@ __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ 
         for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
     }
 }
+// ---- one sweep over the SCALARS instead of three over a digit matrix ---------------------------------------------------
+// Rounds 1-2 wrote every window digit to a u16 matrix D[window][term] (k_digits: 64 MB of scalars in, 71 MB out per 2^21
+// terms) and then read it twice, window-major (k_part_hist: slice counts per chunk; k_part1: the partition) -- 277 MB
+// and three launches before the first entry reaches its slice; and k_digits indexed its scalar words with a runtime
+// window position, i.e. through scratch (0.10 ms for 135 MB).  Here a block owns a CHUNK of terms for ALL windows: a lane
+// keeps SWEEP_TPT scalars (s' = s + addk, nine words each) in registers and treats each as a shift register -- the window
+// layout is contiguous (msm_layout: pos[k+1] = pos[k] + wid[k]), so window k is always the low wid[k] bits and the next
+// window arrives by a funnel shift with a wave-uniform amount: no dynamic register index, no digit matrix.
+//   k_sweep_count    slice counts of every (window, slice) for this chunk   (64 MB in; cc out)
+//   k_part_scan      unchanged
+//   k_sweep_scatter  per window: count per wave and slice, scan, stage the entries by slice in LDS, copy whole runs out
+//                    (the body of round 2's k_part1 inside the window loop; 64 MB in, 143 MB out)
+// Deterministic like the kernels they replace (offsets come from exact counts, not from atomics on a global cursor).
+constexpr int SWEEP_TPT = 8, SWEEP_THREADS = 1024, SWEEP_WAVES = SWEEP_THREADS / 64, SWEEP_CHUNK = SWEEP_THREADS * SWEEP_TPT;
+// (eight words per scalar: s' = s + addk < 2^256 whenever bit 255 of s is clear, and a scalar with bit 255 set fails the call
+//  anyway (bad_scalar); a term beyond n is loaded as s = 0, whose digits are all zero: s' = addk puts 2^(wid-1) into every signed
+//  window and 0 into the unsigned ones -- it is skipped like any zero digit)
+struct sweep_regs { u32 s[SWEEP_TPT][8]; };
+__device__ __forceinline__ void sweep_load(const uint8_t *__restrict__ scalars, u64 n, u64 lo, const msm_geom &g, sweep_regs &R, u32 *__restrict__ bad_scalar) {
+#pragma unroll
+    for (int r = 0; r < SWEEP_TPT; r++) {
+        const u64 t = lo + (u64)r * SWEEP_THREADS + threadIdx.x;
+        u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < n) load8(scalars, t, w);
+        if (bad_scalar && (w[7] >> 31)) atomicOr(bad_scalar, 1u);
+        u32 carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const u64 v = (u64)w[i] + g.addk[i] + carry; R.s[r][i] = (u32)v; carry = (u32)(v >> 32); }
+    }
+}
+// the low `wd` bits of term r, then the next window moves down (wd < 32, wave-uniform)
+__device__ __forceinline__ u32 sweep_take(sweep_regs &R, int r, int wd) {
+    const u32 v = R.s[r][0] & ((1u << wd) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) R.s[r][i] = __funnelshift_r(R.s[r][i], R.s[r][i + 1], (u32)wd);
+    R.s[r][7] >>= wd;
+    return v;
+}
+// Counting: LDS atomics of many waves on ONE set of counters serialise badly (a 1024-thread block per chunk with shared
+// counters: 297 us per 2^21 terms), private counters per wave do not (round 2's k_part_hist: 45 us).  A chunk is counted by one
+// block of four waves, each wave with its own [window][slice] counters (4 x 17 x 128 x 4 B = 35 KB per block).
+__device__ __forceinline__ u32 take8(u32 s[8], int wd) {
+    const u32 v = s[0] & ((1u << wd) - 1u);
+#pragma unroll
+    for (int i = 0; i < 7; i++) s[i] = __funnelshift_r(s[i], s[i + 1], (u32)wd);
+    s[7] >>= wd;
+    return v;
+}
+// zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket
+// counters) -- zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain
+// waits 30 - 180 us for a dispatch slot.  bad_scalar (a word of the sort workspace, outside zero_words, zeroed by
+// k_part2 of the previous use) is ORed into the result slot by the bucket reduction.
+// zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket
+// counters) -- zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain
+// waits 30 - 180 us for a dispatch slot.  bad_blk[j] = 1 if a scalar of chunk j has bit 255 set (k_seg_scan ORs them into one
+// word, the bucket reduction ORs that into the result slot: the sort itself never touches the slot).
+__global__ void __launch_bounds__(256) k_sweep_count(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, int nchunk, u32 *__restrict__ cc, u32 *__restrict__ bad_blk,
+                                                     u32 *__restrict__ zero_words, int nzero) {
+    C25519_PRIO_CHAIN();
+    extern __shared__ u32 sm[];                               // [4 waves][nwin][SL] + 1
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
+    const int j = blockIdx.x, NC = g.nwin * SL, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i <= 4 * NC; i += 256) sm[i] = 0;
+    __syncthreads();
+    u32 *mine = sm + w * NC, *bad = sm + 4 * NC;
+    const u64 lo = (u64)blockIdx.x * SWEEP_CHUNK;
+    constexpr int B = 8;                                      // scalars in flight per lane; SWEEP_CHUNK / 256 per lane in all
+#pragma unroll 1
+    for (int r0 = 0; r0 < SWEEP_CHUNK / 256; r0 += B) {
+        u32 s[B][8];
+#pragma unroll
+        for (int r = 0; r < B; r++) {
+            const u64 t = lo + (u64)(r0 + r) * 256 + threadIdx.x;
+            u32 wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (t < n) load8(scalars, t, wv);
+            if (wv[7] >> 31) *bad = 1u;
+            u32 carry = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const u64 v = (u64)wv[i] + g.addk[i] + carry; s[r][i] = (u32)v; carry = (u32)(v >> 32); }
+        }
+#pragma unroll 1
+        for (int k = 0; k < g.nwin; k++) {
+            const int wd = g.wid[k];
+#pragma unroll
+            for (int r = 0; r < B; r++) {
+                u32 sl, e;
+                if (part_entry(take8(s[r], wd), k, g, 0u, sl, e)) atomicAdd(&mine[k * SL + sl], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < NC; i += 256) cc[(u64)i * nchunk + j] = sm[i] + sm[NC + i] + sm[2 * NC + i] + sm[3 * NC + i];      // i = k * SL + slice
+    if (threadIdx.x == 0) bad_blk[j] = *bad;
+}
+// Segmented scan of the chunk counters: the M = SL x nchunk counters of a window are cut into SCAN_SEGS segments, one 256-thread
+// block each (the scan of a window no longer grows with the number of chunks, and every block fits the hole one retiring
+// k_accumulate block leaves); a block leaves the exclusive scan of ITS segment in place and the segment total in seg_tot.
+// Consumers add the totals of the segments before theirs (seg_offset): eight loads of words that stay in L2.
+constexpr int SCAN_SEGS = 8;
+__global__ void __launch_bounds__(256) k_seg_scan(u32 *__restrict__ cc, int M, u32 *__restrict__ seg_tot, const u32 *__restrict__ bad_blk, int nchunk, u32 *__restrict__ bad_ws, u32 *__restrict__ bad_sticky) {
+    C25519_PRIO_CHAIN();
+    if (blockIdx.x == 0 && blockIdx.y == 0) {                  // one word out of the chunks' bad-scalar flags (bad_sticky: ORed over the passes of a call)
+        u32 any = 0;
+        for (int i = threadIdx.x; i < nchunk; i += 256) any |= bad_blk[i];
+        any = __syncthreads_or((int)any);
+        if (threadIdx.x == 0) { *bad_ws = any ? 1u : 0u; if (any && bad_sticky) atomicOr(bad_sticky, 1u); }
+    }
+    __shared__ u32 tile[SCAN_TILE + SCAN_TILE / 32];
+    __shared__ u32 wsum[4];
+    const int gseg = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seglen = M / SCAN_SEGS;
+    u32 *v = cc + (u64)k * M + (u64)gseg * seglen;
+    u32 carry = 0;
+#pragma unroll 1
+    for (int t0 = 0; t0 < seglen; t0 += SCAN_TILE) {
+#pragma unroll
+        for (int r = 0; r < SCAN_PER; r++) { const int a = r * 256 + tid, e = t0 + a; tile[a + (a >> 5)] = e < seglen ? v[e] : 0u; }
+        __syncthreads();
+        u32 x[SCAN_PER], sum = 0;
+#pragma unroll
+        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; x[q] = tile[a + (a >> 5)]; sum += x[q]; }
+        u32 inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(inc, off, 64); if (lane >= off) inc += y; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        u32 wbase = 0, total = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const u32 ws = wsum[i]; wbase += i < w ? ws : 0u; total += ws; }
+        u32 run = carry + wbase + inc - sum;
+#pragma unroll
+        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; tile[a + (a >> 5)] = run; run += x[q]; }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < SCAN_PER; r++) { const int a = r * 256 + tid, e = t0 + a; if (e < seglen) v[e] = tile[a + (a >> 5)]; }
+        carry += total;
+        __syncthreads();
+    }
+    if (tid == 0) seg_tot[k * SCAN_SEGS + gseg] = carry;
+}
+// offset of counter idx of a window: its scanned value within its segment + the totals of the segments before it
+__device__ __forceinline__ u32 seg_offset(const u32 *__restrict__ cc_k, const u32 *__restrict__ seg_tot_k, u32 idx, u32 seglen) {
+    u32 v = cc_k[idx];
+    const u32 sg = idx / seglen;
+#pragma unroll
+    for (u32 q = 0; q < (u32)SCAN_SEGS; q++) v += q < sg ? seg_tot_k[q] : 0u;
+    return v;
+}
+__device__ __forceinline__ u32 seg_total(const u32 *__restrict__ seg_tot_k) {
+    u32 v = 0;
+#pragma unroll
+    for (int q = 0; q < SCAN_SEGS; q++) v += seg_tot_k[q];
+    return v;
+}
+// Block shape, measured in round 3 (2^24 terms, one box, profiles/r03_sort_block_shapes.txt): 1024 threads x 8 scalars (chunks of 8192
+// terms, runs of ~64 entries) 14.5 - 14.8 ms; 512 threads 14.6; 256 threads with a 256-thread k_part2 16.0.  Beside k_accumulate
+// (three waves of 168 VGPRs per SIMD = 504 of 512 registers) a block only starts in the holes retiring accumulate blocks leave, and
+// small blocks do start sooner -- but the work of a call is conserved, not hidden: what counts is how long the sort takes ALONE
+// (363 us per 2^21 terms in this form, 710 us in the 256-thread forms), so the shapes that are fastest alone are kept.
+__global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, const u32 *__restrict__ cc, const u32 *__restrict__ seg_tot,
+                                                                 u32 *__restrict__ P1) {
+    C25519_PRIO_CHAIN();
+    extern __shared__ u32 sm[];
+    constexpr int NW = SWEEP_WAVES;
+    u32 *cntb = sm;                        // [2][NW][SL]: per-wave counts, then per-wave cursors; double-buffered across windows
+    u32 *ls = sm + 2 * NW * SL;            // [SL]: start of each slice in the staging buffer
+    u32 *stot = ls + SL;                   // [SL]: entries of each slice
+    u32 *gdst = stot + SL;                 // [SL]: where this chunk's run of each slice goes in P1 (prefetched: a wave that fetched
+                                           //       the offset of each of its runs right before copying it paid a global-load latency per run)
+    u32 *stage = gdst + SL;                // [SWEEP_CHUNK]
+    const int j = blockIdx.x, nchunk = gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const u32 seglen = (u32)(SL * nchunk) / SCAN_SEGS;
+    const u64 lo = (u64)j * SWEEP_CHUNK;
+    sweep_regs R;
+    sweep_load(scalars, n, lo, g, R, nullptr);
+    for (int i = threadIdx.x; i < 2 * NW * SL; i += SWEEP_THREADS) cntb[i] = 0;
+    __syncthreads();
+    // Three barriers per window.  A barrier that every wave has passed also says that every wave has finished the previous window,
+    // so the copy-out of window k-1 needs no barrier of its own: nothing it reads (stage, ls, stot, gdst) is written before barrier 1
+    // of window k, and the counters of window k+1 are zeroed between barriers 1 and 2 of window k.
+#pragma unroll 1
+    for (int k = 0; k < g.nwin; k++) {
+        const int wd = g.wid[k];
+        u32 *cnt = cntb + (k & 1) * NW * SL, *cnt_next = cntb + ((k + 1) & 1) * NW * SL;
+        u32 my_gofs = 0;                                                   // in flight during the counting (SL <= SWEEP_THREADS - 64: never a lane of wave 0)
+        if ((int)threadIdx.x >= SWEEP_THREADS - SL)
+            my_gofs = seg_offset(cc + (u64)k * SL * nchunk, seg_tot + k * SCAN_SEGS, (u32)(threadIdx.x - (SWEEP_THREADS - SL)) * (u32)nchunk + (u32)j, seglen);
+        u32 ent[SWEEP_TPT], slc[SWEEP_TPT];
+#pragma unroll
+        for (int r = 0; r < SWEEP_TPT; r++) {
+            const u32 v = sweep_take(R, r, wd);
+            slc[r] = 0xffffffffu;
+            u32 sl, e;
+            if (part_entry(v, k, g, (u32)lo + (u32)r * SWEEP_THREADS + threadIdx.x, sl, e)) { slc[r] = sl; ent[r] = e; atomicAdd(&cnt[w * SL + sl], 1u); }
+        }
+        __syncthreads();                                                   // 1: the counts of this window are complete
+        if (w == 0) {
+            // one wave: per slice the exclusive prefix over the waves, the slice totals, their exclusive scan, and the waves'
+            // cursors (slice start + prefix); lane-consecutive slices, so every LDS access is conflict-free (SL <= 448: 7 per lane)
+            const int per = (SL + 63) >> 6;
+            u32 tot[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int sidx = q * 64 + lane;
+                u32 run = 0;
+                if (q < per && sidx < SL) for (int ww = 0; ww < NW; ww++) run += cnt[ww * SL + sidx];
+                tot[q] = run;
+            }
+            // slices are numbered q * 64 + lane: scan the q-th totals across the lanes, carrying the wave total from q to q + 1
+            u32 carry = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                if (q < per) {
+                    u32 inc = tot[q];
+                    for (int off = 1; off < 64; off <<= 1) { const u32 x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+                    const u32 start = carry + inc - tot[q];
+                    carry += __shfl(inc, 63, 64);
+                    const int sidx = q * 64 + lane;
+                    if (sidx < SL) {
+                        ls[sidx] = start; stot[sidx] = tot[q];
+                        u32 run = start;
+                        for (int ww = 0; ww < NW; ww++) { const u32 c = cnt[ww * SL + sidx]; cnt[ww * SL + sidx] = run; run += c; }
+                    }
+                }
+            }
+        } else {
+            for (int i = threadIdx.x - 64; i < NW * SL; i += SWEEP_THREADS - 64) cnt_next[i] = 0;
+            if ((int)threadIdx.x >= SWEEP_THREADS - SL) gdst[threadIdx.x - (SWEEP_THREADS - SL)] = my_gofs;      // (the previous window's copy-out is over: barrier 1)
+        }
+        __syncthreads();                                                   // 2: cursors ready, next window's counters zero
+#pragma unroll
+        for (int r = 0; r < SWEEP_TPT; r++)
+            if (slc[r] != 0xffffffffu) stage[atomicAdd(&cnt[w * SL + slc[r]], 1u)] = ent[r];
+        __syncthreads();                                                   // 3: the staging buffer holds the entries slice by slice
+        for (int sidx = w; sidx < SL; sidx += NW) {                       // each wave copies whole runs
+            const u32 len = stot[sidx], src = ls[sidx];
+            u32 *dst = P1 + (u64)k * n + gdst[sidx];
+            for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
+        }
+    }
+}
+
 // a long bucket's list is cut into segments of LONG_SEG entries: one work item each (k_long_segments)
 struct long_item { u32 gid, lo, hi, first; };
 // what the bucket order needs from one bucket with c entries: its length class (a 256-bin block-local histogram) and, for a
@@ -519,16 +764,24 @@ __device__ __forceinline__ void order_note_bucket(u32 c, u64 G, const msm_geom &
 // pass 2: bin (window k, slice s) -> final order, bucket totals and bucket offsets.  The bin's entries live in
 // registers (18 per thread), LDS holds only the sorted copy: 74 KB per block, two blocks per CU.
 constexpr int PART_R = PART_CAP / 1024;
-__global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
+__global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
                                                 u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted,
                                                 u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items, u32 *__restrict__ counters,
-                                                u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
+                                                u32 *__restrict__ long_gids, u32 *__restrict__ long_first, int nchunk, const u32 *__restrict__ seg_tot) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX;
     const int PART_BPS = 1 << g.bps_log2;
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
-    const u32 b0 = bin_base[(u64)k * (SL + 1) + sidx], m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0;
+    u32 b0, m;
+    if (seg_tot) {                                             // segmented counters (k_seg_scan): bin_base = the chunk counters themselves
+        const u32 *cc_k = bin_base + (u64)k * SL * nchunk, *st_k = seg_tot + k * SCAN_SEGS;
+        const u32 seglen = (u32)(SL * nchunk) / SCAN_SEGS;
+        b0 = seg_offset(cc_k, st_k, (u32)sidx * (u32)nchunk, seglen);
+        const u32 b1 = sidx + 1 < SL ? seg_offset(cc_k, st_k, (u32)(sidx + 1) * (u32)nchunk, seglen) : seg_total(st_k);
+        m = b1 - b0;
+        if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b1;      // number of entries of the window
+    } else { b0 = bin_base[(u64)k * (SL + 1) + sidx]; m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0; }
     const u32 *src = P1 + (u64)k * n + b0;
     u32 *dst = sorted + (u64)k * n + b0;
     const bool fits = m <= (u32)PART_CAP;
@@ -595,6 +848,7 @@ __global__ void __launch_bounds__(1024, 8) k_part2(const u32 *__restrict__ P1, u
         }
     }
 }
+
 
 // Scatter in bucket-range slices.  A window's sorted list is 4n bytes (8 MB at n = 2^21) and every 128-byte line of it
 // collects its 32 entries from 32 different chunk blocks over the whole kernel: written in one sweep, the lines leave
@@ -670,6 +924,30 @@ __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) 
     }
     ord_hist[threadIdx.x] = p[threadIdx.x] - v;
 }
+// the same with the scan inside: every block scans the 256-bin histogram itself (read-only) and takes its slots from a
+// separate cursor array (zeroed by k_sweep_count) -- one launch less in the chain
+__global__ void __launch_bounds__(256) k_order_place(const u32 *__restrict__ totals, u64 nb, const u32 *__restrict__ ord_hist, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
+    C25519_PRIO_CHAIN();
+    __shared__ u32 h[256], start[256], basep[256];
+    const u32 mine = ord_hist[threadIdx.x];
+    u32 inc = mine;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(inc, off, 64); if (lane >= off) inc += y; }
+    h[threadIdx.x] = 0;
+    if (lane == 63) basep[w] = inc;                          // wave totals (basep reused below)
+    __syncthreads();
+    u32 wb = 0;
+    for (int i = 0; i < w; i++) wb += basep[i];
+    start[threadIdx.x] = wb + inc - mine;
+    __syncthreads();
+    const u64 gid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u32 bin = 0, local = 0;
+    if (gid < nb) { const u32 c = totals[gid]; bin = 255u - (c > 255u ? 255u : c); local = atomicAdd(&h[bin], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) basep[threadIdx.x] = start[threadIdx.x] + atomicAdd(&ord_cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (gid < nb) perm[basep[bin] + local] = (u32)gid;
+}
 __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ totals, u64 nb, u32 gid_off, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
     C25519_PRIO_CHAIN();
     __shared__ u32 h[256], basep[256];
@@ -727,7 +1005,7 @@ __global__ void __launch_bounds__(64) k_long_segments(const u32 *__restrict__ pt
 // one wave per long bucket: sum its segment sums -> buckets[gid]
 __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ base, msm_geom g, const u32 *__restrict__ counters, u32 max_items,
                                                      const u32 *__restrict__ long_gids, const u32 *__restrict__ long_first,
-                                                     const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets) {
+                                                     const u32 *__restrict__ seg_sums, u32 *__restrict__ buckets, int cont) {
     C25519_PRIO_LONG();
 #pragma unroll 1
     for (u32 lb = blockIdx.x; lb < counters[1]; lb += gridDim.x) {
@@ -743,7 +1021,7 @@ __global__ void __launch_bounds__(64) k_long_combine(const u32 *__restrict__ bas
             for (u32 s = threadIdx.x; s < nseg && first + s < max_items; s += 64) acc = ge_add(acc, p40_load(seg_sums, first + s));
             acc = wave_sum(acc);
         }
-        if (threadIdx.x == 0) p40_store(buckets, gid, acc);
+        if (threadIdx.x == 0) p40_store(buckets, gid, cont ? ge_add(acc, p40_load(buckets, gid)) : acc);      // cont: on top of the earlier passes' sum
     }
 }
 
@@ -802,9 +1080,12 @@ __device__ __forceinline__ void wave_weighted_sum(ge_p3 &S, ge_p3 &W, int shift,
 }
 constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A
 // level A: block (one wave) = segment `seg` of window k.  direct: the window has a single segment, write col_k itself.
-__global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct) {
+// bad_ws (may be null): the sort's "a scalar has bit 255 set" word, ORed into the slot's flag 0 (the sort does not touch the slot)
+__global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
+                                                 const u32 *__restrict__ bad_ws) {
     C25519_PRIO_SIDE();
     const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg, lane = threadIdx.x;
+    if (bad_ws && blockIdx.x == 0 && lane == 0 && *bad_ws) atomicOr(cols + MSM_MAX_WIN * 40, 1u);
     const int b0 = seg * RED_SEG + lane * RED_LB;
     const u32 *B = buckets + (u64)k * half * 40;
     const ge_p3 id = ge_identity();
@@ -1221,13 +1502,16 @@ static inline uint32_t *slot_flags(uint32_t *slot) { return slot + MSM_MAX_WIN *
 // set: two accumulations side by side only share the multipliers, while a sort beside an accumulation is free.
 struct msm_plan {
     msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
-    uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs; long_item *items;
+    uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs, *bad_ws, *bad_sticky = nullptr; long_item *items;
     hipStream_t sort_stream;
 };
 // md (may be null): merged layout -- d_scalars holds n_scalars scalars, the sort runs over md->K * md->ns digit-terms
+// n_carve (0 = n): the number of terms the workspace is carved for -- passes that CONTINUE each other's bucket sums (msm_record_enqueue)
+// must find the buckets at the same address although the last pass is shorter
 int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
-                         const msm_merged *md = nullptr) {
+                         const msm_merged *md = nullptr, uint64_t n_carve = 0) {
     const uint64_t n = md ? (uint64_t)md->K * md->ns : n_scalars;
+    const uint64_t nc = n_carve > n ? n_carve : n;
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
     while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
     if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
@@ -1237,43 +1521,64 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // workspace carve-up (tmp_d): D | counts | base | sorted | buckets | segment pairs | flags | perm | long-bucket lists
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oD = carve((size_t)g.nwin * n * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
-    size_t oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oT = carve(nb * 4);
-    size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(256 + 1024), oPerm = carve(nb * 4);
+    size_t oD = carve((size_t)g.nwin * nc * 2), oC = carve((size_t)g.nwin * nchunk * g.half * 4), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
+    size_t oS = carve((size_t)g.nwin * nc * 4), oK = carve(nb * 160), oT = carve(nb * 4);
+    size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(8192), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
-    const uint64_t entries = (uint64_t)g.nwin * n;
+    const uint64_t entries = (uint64_t)g.nwin * nc;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
     const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
     size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     size_t oLS = carve((size_t)max_items * 160);
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
     const bool use_part = g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
-    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK);
+    // (the merged layout of the precomputed tables keeps round 2's digit-matrix kernels: its terms are (window, scalar) pairs)
+    const bool sweep = use_part && !md && (g.half >> g.bps_log2) <= std::min(SWEEP_THREADS - 64, 448) && (g.half >> g.bps_log2) >= SCAN_SEGS;
+    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = sweep ? SWEEP_CHUNK : part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
-    if (use_part) { oP1 = carve((size_t)g.nwin * n * 4); oCC = carve((size_t)g.nwin * SL * pchunks * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4); }
+    if (use_part) { oP1 = carve((size_t)g.nwin * nc * 4); oCC = carve((size_t)g.nwin * SL * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
     if (r) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
-    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
+    // small words of the chain (u32 index): [8..] long-bucket counters, [64..319] bucket-order histogram, [320..575] its cursors,
+    // [576] "a scalar has bit 255 set" (ORed into the result slot by the bucket reduction: the sort itself never touches the slot),
+    // [1024..] segment totals of the chunk-counter scan
+    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *ord_cursor = flags + 320, *bad_ws = flags + 576, *seg_tot = flags + 1024, *perm = (uint32_t *)(ws + oPerm);
+    constexpr int ZERO_WORDS = 576;
     pl.g = g; pl.n = n; pl.nb = nb; pl.nseg = nseg; pl.max_items = max_items; pl.max_long = max_long;
-    pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8;
+    pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8; pl.bad_ws = bad_ws;
     pl.items = (long_item *)(ws + oLI); pl.lgids = (uint32_t *)(ws + oLG); pl.lfirst = (uint32_t *)(ws + oLF); pl.segs = (uint32_t *)(ws + oLS);
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
-    HIPCHK(hipMemsetAsync(flags, 0, 256 + 1024, st));
-    if (md) hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md->ns, 256)), dim3(256), 0, st, d_scalars, n_scalars, md->ns, md->c, md->K, D, slot_flags(d_slot));
-    else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, slot_flags(d_slot));
+    if (sweep) {
+        uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC);
+        uint32_t *bad_blk = (uint32_t *)(ws + oBB);           // one word per chunk (the bin bases of round 2's scan are not needed here)
+        const size_t ldsc = ((size_t)4 * g.nwin * SL + 1) * 4, lds1 = ((size_t)2 * SWEEP_WAVES * SL + 3 * SL + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_sweep_count, dim3(pchunks), dim3(256), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
+        hipLaunchKernelGGL(k_seg_scan, dim3(SCAN_SEGS, g.nwin), dim3(256), 0, st, cc, SL * pchunks, seg_tot, bad_blk, pchunks, bad_ws, pl.bad_sticky);
+        hipLaunchKernelGGL(k_sweep_scatter, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, cc, seg_tot, P1);
+        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, cc, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst, pchunks, seg_tot);
+        hipLaunchKernelGGL(k_order_place, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist, ord_cursor, perm);
+        HIPCHK(hipGetLastError());
+        return C25519_OK;
+    }
+    HIPCHK(hipMemsetAsync(flags, 0, 4096, st));
+    if (md) hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md->ns, 256)), dim3(256), 0, st, d_scalars, n_scalars, md->ns, md->c, md->K, D, bad_ws);
+    else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, d_scalars, n, g, D, pl.bad_sticky ? pl.bad_sticky : bad_ws);
     if (use_part) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC), *bin_base = (uint32_t *)(ws + oBB);
         const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, PART_CHUNK, cc);
-        hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(1024), 0, st, cc, SL, pchunks, g, bin_base, base);
+        hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(256), 0, st, cc, SL, pchunks, g, bin_base, base);
         hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, PART_CHUNK, cc, P1);
-        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
+        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst, 0, (const uint32_t *)nullptr);
     } else {
         size_t lds = (size_t)g.half * 4;
         // (window, chunk) grid order: blockIdx.x = window, so that the chunk blocks of one window share an XCD's L2
@@ -1298,7 +1603,10 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }
-int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc) {
+// cont: the accumulation starts from the bucket sums the previous pass on this workspace left (no reduction happened in between);
+// reduce: the buckets are reduced into d_slot now (the last pass of a stream set; always, for the single-pass callers)
+int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont = false, bool reduce = true,
+                        const uint32_t *d_bad_sticky = nullptr) {
     const msm_geom &g = pl.g;
     if (pl.sort_stream && pl.sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
         HIPCHK(hipEventRecord(ctx->ev_sort, pl.sort_stream));
@@ -1310,20 +1618,27 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     hipLaunchKernelGGL(k_long_segments, dim3(std::min<uint32_t>(pl.max_items, 2048u)), dim3(64), 0, ctx->aux, d_pts, pl.sorted, pl.n, g, pl.items, pl.counters, pl.max_items, pl.segs);
-    hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(pl.max_long, 1024u)), dim3(64), 0, ctx->aux, pl.base, g, pl.counters, pl.max_items, pl.lgids, pl.lfirst, pl.segs, pl.buckets);
-    HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
+    hipLaunchKernelGGL(k_long_combine, dim3(std::min<uint32_t>(pl.max_long, 1024u)), dim3(64), 0, ctx->aux, pl.base, g, pl.counters, pl.max_items, pl.lgids, pl.lfirst, pl.segs, pl.buckets, cont ? 1 : 0);
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
     // (measured in round 2 and dropped: a CU-masked stream for this kernel -- 1/8 or 1/4 of the CUs kept free for the sort of
     //  the next pass -- 18.2 - 20.3 ms per 2^24 terms against 16.5; 512-thread blocks, i.e. two waves per SIMD with 176
     //  registers: 16.9 - 17.0 against 16.6 - 16.9; an LDS reservation to the same effect: 16.2 against 15.9; four waves per SIMD
     //  without a prefetched record: 16.0 / 15.5 against 15.1 - 15.3; un-serialised accumulations of neighbouring passes: +3 - 9 %)
-    ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, st);
+    ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, cont ? 1 : 0, st);
     HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
-    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // long-bucket path (aux stream) done
-    hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, st, pl.buckets, g.half, pl.nseg, pl.SW, d_slot, pl.nseg == 1 ? 1 : 0);
-    if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, st, pl.SW, pl.nseg, d_slot);
-    HIPCHK(hipGetLastError());
+    // The bucket reduction runs on the SECOND (high-priority) stream, behind the long-bucket kernels it depends on anyway.  On the
+    // main stream its few small blocks had normal priority: once the sort of the next pass stopped being late (round 3) the next
+    // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
+    // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
+    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));
+    if (reduce) {
+        hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, ctx->aux, pl.buckets, g.half, pl.nseg, pl.SW, d_slot, pl.nseg == 1 ? 1 : 0, d_bad_sticky ? d_bad_sticky : pl.bad_ws);
+        if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, ctx->aux, pl.SW, pl.nseg, d_slot);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));     // what follows on the main stream (the next pass of this stream set, the read-back) comes after the long buckets / the reduction
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     return C25519_OK;
 }
@@ -1542,28 +1857,32 @@ static hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind) {
 //   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
 struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
-                                hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr) {
+                                hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr,
+                                bool cont = false, bool reduce = true, uint64_t n_carve = 0, uint32_t *d_bad_sticky = nullptr) {
     int32_t r;
     uint32_t *d_pts;
     if (wait_in) HIPCHK(hipStreamWaitEvent(ctx->stream, wait_in, 0));      // host-pointer calls: this pass's inputs are still on their way up
     if (!ahead) {
-        if ((r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256))) return r;
+        if ((r = ctx_reserve(ctx, ctx->tmp_e, std::max(n, n_carve) * PTS_BYTES + 256))) return r;
         d_pts = (uint32_t *)ctx->tmp_e.p;
     } else d_pts = ahead->pts + ahead->offset * (PTS_BYTES / 4);
     hipEvent_t *ring = pass_ring(owner, ctx, 1);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
-    slot_init(d_slot, terms, nullptr, ctx->stream);
-    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));     // the sort does not touch the slot: it need not wait for k_slot_init's dispatch
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream);            // (a continuing pass adds its counters to the slot of its stream set)
     msm_plan pl;
+    pl.bad_sticky = d_bad_sticky;
     // (normalisation first, then the sort on the second stream: 2.26 against 2.34 ms at 2^21 terms the other way round)
+    static const int serial_sort = env_int("C25519_PROFILE_SERIAL_SORT", 0);     // profiling: the sort only starts after the normaliser, so that its kernels can be timed alone
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
     else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
-    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl))) return r;
-    return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
+    if (serial_sort) { HIPCHK(hipEventRecord(ctx->ev_z, ctx->stream)); HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_z, 0)); }
+    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve))) return r;
+    return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc, cont, reduce, d_bad_sticky);
 }
 // The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column
 // sums + counters + header) left at d_record.  Nothing here waits for the host.
@@ -1592,6 +1911,8 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     msm_layout(per, g);                                   // one layout for every pass: their column sums add up window by window
     pass_set ps;
     int32_t r;
+    uint32_t *sticky = (uint32_t *)ctx->d_flag + 40;      // "a scalar has bit 255 set", ORed over the passes of the call
+    HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
     if ((r = passes_begin(ctx, passes, ps))) return r;
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
@@ -1599,28 +1920,29 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // (not with a fetch: the later passes' points are not on the device yet)
     const bool ahead = passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160 && !fetch;
     if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
-    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
-        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
-        if (p0 && ps.lanes > 1) {                          // the slots are reused: the peers wait until the previous batch has been summed
-            HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
-            for (int l = 1; l < ps.lanes; l++) HIPCHK(hipStreamWaitEvent(ps.c[l]->stream, ctx->ev_in, 0));
+    // ONE bucket reduction per stream set, not one per pass: the passes dealt to a stream set run one after the other anyway, so
+    // each continues from the bucket sums its predecessor left (k_accumulate `cont`) and only the last one reduces them into the
+    // set's slot -- for 2^24 terms 2 reductions instead of 8 (0.24 ms each, and each a handful of small blocks that starved
+    // beside the other set's accumulation), and the sort of pass i+2 no longer queues behind the reduction of pass i.
+    const int L = ps.lanes;
+    for (uint64_t p = 0; p < passes; p++) {
+        const uint64_t lo = p * per, m = std::min(per, n - lo);
+        const int l = (int)(p % L);
+        c25519_ctx *c = ps.c[l];
+        const bool first = p < (uint64_t)L, last = p + L >= passes;
+        pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p == 1};
+        uint32_t *slot = passes == 1 ? d_record : dslot(ctx, l);         // a single pass writes the record itself
+        hipEvent_t in_ev = nullptr;
+        if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
+        if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p >= 1) ? &ah : nullptr, in_ev,
+                                  !first, last, per, sticky))) {
+            if (ctx->err.empty()) ctx->err = c->err;
+            return r;
         }
-        for (int i = 0; i < cnt; i++) {
-            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
-            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
-            pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p0 + i == 1};
-            uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);     // a single pass writes the record itself
-            hipEvent_t in_ev = nullptr;
-            if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
-            if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p0 + i >= 1) ? &ah : nullptr, in_ev))) {
-                if (ctx->err.empty()) ctx->err = c->err;
-                return r;
-            }
-            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
-        }
-        if ((r = passes_join(ctx, ps))) return r;
-        if (passes > 1) hipLaunchKernelGGL(k_record_sum, dim3(1), dim3(128), 0, ctx->stream, d_record, ctx->d_slots, cnt, g.nwin, p0 == 0 ? 1 : 0);
+        prev_acc = L > 1 ? c->ev_acc : nullptr;
     }
+    if ((r = passes_join(ctx, ps))) return r;
+    if (passes > 1) hipLaunchKernelGGL(k_record_sum, dim3(1), dim3(128), 0, ctx->stream, d_record, ctx->d_slots, (int)std::min<uint64_t>((uint64_t)L, passes), g.nwin, 1);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
