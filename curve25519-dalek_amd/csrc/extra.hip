@@ -17,6 +17,7 @@
 #include "../../include/c25519_hip.h"
 #include "devio.h"
 #include "sc_sha.h"
+#include "sc28.h"
 #include "kernels.h"
 #include "ctx.h"
 #include "msm_internal.h"
@@ -114,50 +115,48 @@ __global__ void __launch_bounds__(256) k_double_compress(const uint8_t *__restri
 }
 
 // ---- Scalar::invert_batch_alloc, scalar.rs:802-856 (all inputs must be non-zero) -----------------------------
-// x^(l-2) in Montgomery form by square-and-multiply over the bits of l - 2
-__device__ __forceinline__ sc52 sc_montgomery_invert(const sc52 &xm) {
+// x^(l-2) by square-and-multiply over the bits of l - 2, on 28-bit limbs (sc28.h: no Montgomery form on the device)
+__device__ __forceinline__ sc28 sc28_invert(const sc28 &x) {
     // l - 2 = 2^252 + 27742317777372353535851937790883648491, little-endian 64-bit words
     const u64 e[4] = {0x5812631a5cf5d3ebull, 0x14def9dea2f79cd6ull, 0x0000000000000000ull, 0x1000000000000000ull};
-    sc52 r = sc_R();                      // 1 in Montgomery form
+    sc28 r = sc28_zero();
+    r.v[0] = 1;
 #pragma unroll 1
     for (int i = 252; i >= 0; i--) {
-        r = sc_montgomery_mul(r, r);
-        if ((e[i >> 6] >> (i & 63)) & 1) r = sc_montgomery_mul(r, xm);
+        r = sc28_mul(r.v, r.v);
+        if ((e[i >> 6] >> (i & 63)) & 1) r = sc28_mul(r.v, x.v);
     }
     return r;
 }
 template <int CH>
-__global__ void __launch_bounds__(256) k_scalar_invert(uint8_t *__restrict__ io, u64 n, u64 *__restrict__ prefix, u64 *__restrict__ partial_inv) {
+__global__ void __launch_bounds__(256) k_scalar_invert(uint8_t *__restrict__ io, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ partial_inv) {
     const u64 T = (u64)gridDim.x * blockDim.x, t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
-    sc52 acc = sc_R();
+    sc28 acc = sc28_zero();
+    acc.v[0] = 1;
 #pragma unroll 1
     for (int j = 0; j < CH; j++) {
         u64 idx = t + (u64)j * T;
         if (idx >= n) break;
         u32 w[8];
         load8(io, idx, w);
-        sc52 xm = sc_montgomery_mul(sc_from_words(w), sc_RR());      // as_montgomery
-        for (int q = 0; q < 5; q++) prefix[idx * 5 + q] = acc.v[q];
-        acc = sc_montgomery_mul(acc, xm);
+        for (int q = 0; q < 10; q++) prefix[idx * 10 + q] = acc.v[q];
+        acc = sc28_mul(acc.v, sc28_from_words(w).v);
     }
-    acc = sc_montgomery_invert(acc);                                  // still in Montgomery form
+    acc = sc28_invert(acc);
     // product of all inverses of this lane's chunk (the reference returns the product over the whole batch)
-    { u128 z[9]; for (int q = 0; q < 9; q++) z[q] = q < 5 ? (u128)acc.v[q] : (u128)0; sc52 plain = sc_montgomery_reduce(z); for (int q = 0; q < 5; q++) partial_inv[t * 5 + q] = plain.v[q]; }
+    for (int q = 0; q < 10; q++) partial_inv[t * 10 + q] = acc.v[q];
 #pragma unroll 1
     for (int j = CH - 1; j >= 0; j--) {
         u64 idx = t + (u64)j * T;
         if (idx >= n) continue;
         u32 w[8];
         load8(io, idx, w);
-        sc52 xm = sc_montgomery_mul(sc_from_words(w), sc_RR());
-        sc52 pre;
-        for (int q = 0; q < 5; q++) pre.v[q] = prefix[idx * 5 + q];
-        sc52 invm = sc_montgomery_mul(acc, pre);                      // (1/x) in Montgomery form
-        acc = sc_montgomery_mul(acc, xm);
-        u128 z[9];
-        for (int q = 0; q < 9; q++) z[q] = q < 5 ? (u128)invm.v[q] : (u128)0;
-        sc_to_words(sc_montgomery_reduce(z), w);                      // from_montgomery
+        sc28 pre;
+        for (int q = 0; q < 10; q++) pre.v[q] = prefix[idx * 10 + q];
+        const sc28 inv = sc28_mul(acc.v, pre.v);                       // 1 / x
+        acc = sc28_mul(acc.v, sc28_from_words(w).v);
+        sc28_to_words(inv, w);
         store8(io, idx, w);
     }
 }
@@ -304,24 +303,32 @@ EXPORT int32_t c25519_scalar_invert_batch(c25519_ctx *ctx, uint8_t *io, uint64_t
     HIPCHK(hipSetDevice(ctx->device));
     sc52 prod = sc_zero(); prod.v[0] = 1;
     if (n) {
-        constexpr int CH = 16;
-        const uint64_t lanes = (n + CH - 1) / CH;
-        const unsigned grid = dup64(lanes, 256);
-        const uint64_t T = (uint64_t)grid * 256;
-        int32_t r;
-        if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40 + 64)) || (r = ctx_reserve(ctx, ctx->tmp_c, T * 40 + 64))) return r;
-        HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, io, n * 32, hipMemcpyHostToDevice, ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->tmp_c.p, 0, T * 40, ctx->stream));
-        hipLaunchKernelGGL(k_scalar_invert<CH>, dim3(grid), dim3(256), 0, ctx->stream, (uint8_t *)ctx->tmp_a.p, n, (uint64_t *)ctx->tmp_b.p, (uint64_t *)ctx->tmp_c.p);
-        HIPCHK(hipGetLastError());
-        std::vector<uint64_t> parts(T * 5);
-        HIPCHK(hipMemcpyAsync(io, ctx->tmp_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(parts.data(), ctx->tmp_c.p, T * 40, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // zeroize (scalar.rs:852)
-        HIPCHK(hipMemsetAsync(ctx->tmp_b.p, 0, n * 40, ctx->stream));
-        const uint64_t active = n < T ? n : T;     // lane t owns elements t, t+T, ...: every lane below n is active
-        for (uint64_t t = 0; t < active; t++) { sc52 q; for (int j = 0; j < 5; j++) q.v[j] = parts[t * 5 + j]; prod = sc_mul(prod, q); }
+        try {
+            constexpr int CH = 16;
+            const uint64_t lanes = (n + CH - 1) / CH;
+            const unsigned grid = dup64(lanes, 256);
+            const uint64_t T = (uint64_t)grid * 256;
+            int32_t r;
+            if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40 + 64)) || (r = ctx_reserve(ctx, ctx->tmp_c, T * 40 + 64))) return r;
+            HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, io, n * 32, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->tmp_c.p, 0, T * 40, ctx->stream));
+            hipLaunchKernelGGL(k_scalar_invert<CH>, dim3(grid), dim3(256), 0, ctx->stream, (uint8_t *)ctx->tmp_a.p, n, (uint32_t *)ctx->tmp_b.p, (uint32_t *)ctx->tmp_c.p);
+            HIPCHK(hipGetLastError());
+            std::vector<uint32_t> parts(T * 10);
+            HIPCHK(hipMemcpyAsync(io, ctx->tmp_a.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(parts.data(), ctx->tmp_c.p, T * 40, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            HIPCHK(hipMemsetAsync(ctx->tmp_a.p, 0, n * 32, ctx->stream));   // zeroize (scalar.rs:852)
+            HIPCHK(hipMemsetAsync(ctx->tmp_b.p, 0, n * 40, ctx->stream));
+            const uint64_t active = n < T ? n : T;     // lane t owns elements t, t+T, ...: every lane below n is active
+            for (uint64_t t = 0; t < active; t++) {    // the product over the lanes, on the host (5 x 52 Montgomery form, sc_sha.h)
+                sc28 q28;
+                for (int j = 0; j < 10; j++) q28.v[j] = parts[t * 10 + j];
+                u32 w[8];
+                sc28_to_words(q28, w);
+                prod = sc_mul(prod, sc_from_words(w));
+            }
+        } catch (const std::exception &e) { ctx->err = std::string("scalar_invert_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
     }
     if (prod_inv) { u32 w[8]; sc_to_words(prod, w); memcpy(prod_inv, w, 32); }
     return C25519_OK;

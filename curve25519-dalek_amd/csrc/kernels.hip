@@ -96,6 +96,105 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
     }
 }
 
+// ---- constant-time fixed base for SMALL batches: a scalar's windows split between two threads of the block -----------------
+// The 85 KB table allows one block per compute unit, so a batch of n <= 2^17 scalars in 1024-thread blocks uses n / 1024 of the
+// 256 compute units (2^16 scalars: 64 of them, 0.78 ms), and smaller blocks leave every SIMD with a single wave that issues at
+// half rate.  Here thread t < BS/2 of a block does windows 0 .. 25 of scalar t and thread t + BS/2 windows 26 .. 51 of the SAME
+// scalar (after running the recoding's carry chain over the lower half: a handful of integer operations), so 2^16 scalars fill
+// all 256 compute units with two waves per SIMD; the two partial points meet through LDS (the table's space, no longer
+// needed) and one complete addition.  The part is uniform per wave, so the scan reads stay wave-uniform LDS addresses and the
+// kernel is as constant-time as k_mul_base<5, CT> (tests/test_ct_isa.py covers both).
+template <int BS, int OUT>
+__global__ void __launch_bounds__(BS) k_mul_base_ct_split(const uint8_t *__restrict__ scalars, u64 n, const uint4 *__restrict__ gtab, u32 *__restrict__ scratch,
+                                                          uint8_t *__restrict__ out_raw) {
+    constexpr int W = C25519_CT_W, NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1, PER = BS / 2, WLO = NWIN / 2;
+    extern __shared__ uint4 lds[];
+    for (int i = threadIdx.x; i < NWIN * ENT * 6; i += BS) lds[i] = gtab[i];
+    __syncthreads();
+    const int part = threadIdx.x >= PER ? 1 : 0, j = threadIdx.x - part * PER;        // wave-uniform: PER is a multiple of 64
+    const int win0 = part ? WLO : 0, win1 = part ? NWIN : WLO;
+#pragma unroll 1
+    for (u64 base = (u64)blockIdx.x * PER; base < n; base += (u64)gridDim.x * PER) {   // block-uniform trip count (barriers inside)
+        const u64 idx = base + j;
+        const bool valid = idx < n;
+        u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) load8(scalars, idx, s);
+        u32 carry = 0;
+#pragma unroll 1
+        for (int win = 0; win < win0; win++) {               // the recoding's carry into this thread's first window (scalar.rs:1136-1147)
+            const u32 d = (s[0] & (2u * HALF - 1u)) + carry;
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = (s[i] >> W) | (s[i + 1] << (32 - W));
+            s[7] >>= W;
+            carry = d >= (u32)HALF ? 1u : 0u;
+        }
+        ge_p3 P = ge_identity();
+        const uint4 *wtab = lds + win0 * ENT * 6;
+#pragma unroll 1
+        for (int win = win0; win < win1; win++) {
+            u32 d = (s[0] & (2u * HALF - 1u)) + carry;
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = (s[i] >> W) | (s[i + 1] << (32 - W));
+            s[7] >>= W;
+            const bool neg = (win != NWIN - 1) && (d >= (u32)HALF);
+            const u32 mag = neg ? 2u * HALF - d : d;
+            carry = neg ? 1u : 0u;
+            u32 tw[24];
+#pragma unroll
+            for (int i = 0; i < 24; i++) tw[i] = 0;
+            tw[0] = 1; tw[8] = 1;                           // entry 0 is the identity: not scanned
+#pragma unroll 1
+            for (int ent = 1; ent < ENT; ent++) {           // window.rs:54-76: every entry read (wave-uniform address), one kept by selects
+                const uint4 *e = wtab + ent * 6;
+                const bool hit = (u32)ent == mag;
+#pragma unroll
+                for (int i = 0; i < 6; i++) {
+                    uint4 v = e[i];
+                    asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));      // pinned: LLVM would sink the reads under `hit` (kernels.hip k_mul_base)
+                    tw[4 * i] = hit ? v.x : tw[4 * i]; tw[4 * i + 1] = hit ? v.y : tw[4 * i + 1];
+                    tw[4 * i + 2] = hit ? v.z : tw[4 * i + 2]; tw[4 * i + 3] = hit ? v.w : tw[4 * i + 3];
+                }
+            }
+            aniels_words_cneg(tw, neg);
+            P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
+            wtab += ENT * 6;
+        }
+        // the upper halves go through LDS (the table's space: every wave is past its last table read after the barrier)
+        __syncthreads();
+        uint4 *xch = lds + (size_t)j * 10;
+        if (part) {
+            u32 t[40];
+            for (int i = 0; i < 10; i++) { t[i] = P.X.v[i]; t[10 + i] = P.Y.v[i]; t[20 + i] = P.Z.v[i]; t[30 + i] = P.T.v[i]; }
+            for (int i = 0; i < 10; i++) xch[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+        }
+        __syncthreads();
+        if (!part) {
+            u32 t[40];
+            for (int i = 0; i < 10; i++) { const uint4 v = xch[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
+            ge_p3 Q;
+            for (int i = 0; i < 10; i++) { Q.X.v[i] = t[i]; Q.Y.v[i] = t[10 + i]; Q.Z.v[i] = t[20 + i]; Q.T.v[i] = t[30 + i]; }
+            P = ge_add(P, Q);
+            if (valid) {
+                if (OUT == 1) raw160_store(out_raw, idx, P);
+                else if (OUT == 2) {
+                    uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
+                    u32 o[40];
+                    for (int i = 0; i < 10; i++) { o[i] = P.X.v[i]; o[10 + i] = P.Y.v[i]; o[20 + i] = P.Z.v[i]; o[30 + i] = P.T.v[i]; }
+                    for (int i = 0; i < 10; i++) q[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+                } else p32_store(scratch, idx, P.X, P.Y, P.Z);
+            }
+        }
+        // a further iteration needs the table again: restore it (only batches that outgrow the grid take this path)
+        __syncthreads();
+        if (base + (u64)gridDim.x * PER < n) {
+            for (int i = threadIdx.x; i < NWIN * ENT * 6; i += BS) lds[i] = gtab[i];
+            __syncthreads();
+        }
+    }
+    // secrets do not stay in LDS: the exchanged partial points are wiped
+    for (int i = threadIdx.x; i < PER * 10; i += BS) lds[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ================================================================================================
 // K2c fixed-base batch, signed multi-table comb (context flags = 9; bootstraps the wide tables): 31 mixed additions + 4 doublings per
 //     scalar instead of 43 additions.
@@ -644,8 +743,30 @@ hipError_t launch_mul_base(int w, const uint8_t *scalars, u64 n, const uint32_t 
 
 // constant-time fixed base (secret scalars): radix-2^5 LDS tables with the full-window scan.  out_raw / scratch as launch_mul_base;
 // p40: write P40 records to scratch instead
+template <int BS>
+static hipError_t launch_ct_split(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
+    constexpr int NWIN = (256 + C25519_CT_W - 1) / C25519_CT_W, ENT = (1 << (C25519_CT_W - 1)) + 1;
+    const size_t lds_bytes = (size_t)NWIN * ENT * 96;      // (the exchange of BS/2 x 160 bytes reuses it: 80 KB <= 85 KB at BS = 1024)
+    unsigned grid = div_up(n, BS / 2);
+    if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+#define C25519_CT_SPLIT_LAUNCH(OUTV)                                                                                                   \
+    {                                                                                                                                  \
+        auto kfn = k_mul_base_ct_split<BS, OUTV>;                                                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        if (e != hipSuccess) return e;                                                                                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab_ct), scratch, out_raw); \
+    }
+    if (p40) C25519_CT_SPLIT_LAUNCH(2) else if (out_raw) C25519_CT_SPLIT_LAUNCH(1) else C25519_CT_SPLIT_LAUNCH(0)
+#undef C25519_CT_SPLIT_LAUNCH
+    return hipGetLastError();
+}
 hipError_t launch_mul_base_ct(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
     if (n == 0) return hipSuccess;
+    // small batches: two threads per scalar, one block per compute unit (k_mul_base_ct_split); the block grows with the batch
+    const u64 per_cu = (n + (u64)num_cus - 1) / (u64)num_cus;
+    if (per_cu <= 128) return launch_ct_split<256>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+    if (per_cu <= 256) return launch_ct_split<512>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+    if (per_cu <= 512) return launch_ct_split<1024>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
     return launch_mul_base_w<C25519_CT_W, 1024, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
 }
 

@@ -22,6 +22,7 @@
 #include "../../include/c25519_hip.h"
 #include "devio.h"
 #include "sc_sha.h"
+#include "sc28.h"
 #include "kernels.h"
 #include "ctx.h"
 #include "ffi.h"
@@ -153,11 +154,11 @@ __global__ void __launch_bounds__(256) k_hram_reduce(const uint8_t *__restrict__
     u32 h16[16];
     for (int j = 0; j < 16; j++) h16[j] = hw[j];
     u32 kw[8];
-    sc_to_words(sc_from_wide(h16), kw);
+    sc28_to_words(sc28_from_wide(h16), kw);
     store8(kscal, i, kw);
     u32 s[8];
     load8(sigs, 2 * i + 1, s);
-    bool canon = sc_is_canonical(s);
+    bool canon = sc28_words_canonical(s);
     s_ok[i] = canon ? 1 : 0;
     if (!canon) { for (int j = 0; j < 8; j++) s[j] = 0; }   // keep the fixed-base kernel's precondition (< 2^255)
     store8(sscal, i, s);
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     st.finish();
     u32 d[16], r[8];
     sha512_digest_words(st.h, d);
-    sc_to_words(sc_from_wide(d), r);
+    sc28_to_words(sc28_from_wide(d), r);
     store8(rscal, i, r);
 }
 // s_i = k_i * a_i + r_i mod l;  sig_i = R_i || s_i      (k_i = H(R||A||M) mod l given as 64-byte digests)
@@ -246,8 +247,9 @@ __global__ void __launch_bounds__(256) k_sign_finish(const uint8_t *__restrict__
     for (int j = 0; j < 16; j++) h16[j] = hw[j];
     u32 a[8], r[8], R[8], s[8];
     load8(scal_a, i, a); load8(rscal, i, r); load8(Renc, i, R);
-    sc52 sv = sc_add(sc_mul(sc_from_wide(h16), sc_reduce256(a)), sc_from_words(r));
-    sc_to_words(sv, s);
+    // S = r + k a mod l (signing.rs:899): k reduced, a the clamped integer as it is (k a < 2^508: sc28_mul reduces the full product)
+    const sc28 sv = sc28_add(sc28_mul(sc28_from_wide(h16).v, sc28_from_words(a).v), sc28_from_words(r));
+    sc28_to_words(sv, s);
     store8(sigs, 2 * i, R);
     store8(sigs, 2 * i + 1, s);
 }

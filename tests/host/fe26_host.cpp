@@ -103,3 +103,22 @@ void h_sha512(const uint8_t *m, size_t n, uint8_t *o) {
 }
 void h_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint64_t n, uint8_t *zs) { c25519_transcript_zs(hrams, sigs, n, zs); }
 }
+
+// ---- device scalar arithmetic on 28-bit limbs (csrc/sc28.h) --------------------------------------------------------------
+#include "../../curve25519-dalek_amd/csrc/sc28.h"
+extern "C" {
+void h_sc28_from_wide(const uint8_t *a, uint8_t *o) { u32 x[16], r[8]; memcpy(x, a, 64); sc28_to_words(sc28_from_wide(x), r); memcpy(o, r, 32); }
+void h_sc28_mul_5x10(const uint8_t *z16, const uint8_t *b, uint8_t *o) {
+    u32 zw[4], bw[8], zl[5], r[8]; memcpy(zw, z16, 16); memcpy(bw, b, 32);
+    sc28_limbs_from_words<4, 5>(zw, zl);
+    sc28_to_words(sc28_mul_5x10(zl, sc28_from_words(bw).v), r); memcpy(o, r, 32);
+}
+void h_sc28_mul(const uint8_t *a, const uint8_t *b, uint8_t *o) {
+    u32 aw[8], bw[8], r[8]; memcpy(aw, a, 32); memcpy(bw, b, 32);
+    sc28_to_words(sc28_mul(sc28_from_words(aw).v, sc28_from_words(bw).v), r); memcpy(o, r, 32);
+}
+void h_sc28_add(const uint8_t *a, const uint8_t *b, uint8_t *o) { u32 aw[8], bw[8], r[8]; memcpy(aw, a, 32); memcpy(bw, b, 32); sc28_to_words(sc28_add(sc28_from_words(aw), sc28_from_words(bw)), r); memcpy(o, r, 32); }
+void h_sc28_neg(const uint8_t *a, uint8_t *o) { u32 aw[8], r[8]; memcpy(aw, a, 32); sc28_to_words(sc28_neg(sc28_from_words(aw)), r); memcpy(o, r, 32); }
+int h_sc28_canonical(const uint8_t *a) { u32 x[8]; memcpy(x, a, 32); return sc28_words_canonical(x); }
+void h_sc28_roundtrip(const uint8_t *a, uint8_t *o) { u32 x[8], r[8]; memcpy(x, a, 32); sc28_to_words(sc28_from_words(x), r); memcpy(o, r, 32); }
+}

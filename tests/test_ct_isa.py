@@ -82,6 +82,20 @@ def test_fixed_base_scan_reads_every_entry_without_a_branch(kernels_asm):
         assert _exec_branches(ops) == 0, (name, dict(ops))                      # the only branch is the scalar trip counter
 
 
+def test_fixed_base_split_kernel_scan_is_the_same(kernels_asm):
+    """k_mul_base_ct_split (small batches: a scalar's windows split between two threads): the same scan -- 6 LDS reads and 24
+    selects per entry, no exec-mask branch -- in every block-size / output-format instantiation; the part a thread works on is
+    uniform per wave, so the table addresses stay wave-uniform"""
+    fns = _functions(kernels_asm, r"_ZN6c2551919k_mul_base_ct_splitILi\d+ELi\dE")
+    assert len(fns) >= 6, sorted(fns)
+    for name, body in fns.items():
+        scans = [ops for _, ops in _loops(body) if ops.get("ds_read_b128", 0) == 6 and not ops.get("v_mad_u64_u32", 0)]
+        assert len(scans) == 1, (name, [dict(o) for _, o in _loops(body)])
+        ops = scans[0]
+        assert ops.get("v_cndmask_b32_e64", 0) + ops.get("v_cndmask_b32_e32", 0) >= 24, (name, dict(ops))
+        assert _exec_branches(ops) == 0, (name, dict(ops))
+
+
 def test_variable_base_scan_has_no_data_dependent_branch(single_asm):
     fns = _functions(single_asm, r"_ZN6c2551910k_var_baseILi\dELb\dELb1E")
     assert len(fns) >= 2

@@ -36,7 +36,7 @@ def host(request):
     """Both forms of fe_mul / fe_sq (fe26.h C25519_CHAIN: independent column sums, chained carries)."""
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libfe26host%d.so" % request.param)
-    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "sc_sha.h", "transcript_host.h", "constants_gen.h")]
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DC25519_CHAIN=%d" % request.param, "-o", so, src])
     return C.CDLL(so)
@@ -221,3 +221,41 @@ def test_scalar_sha_transcript_host_vs_oracle(host, orc):
         got = call(host, "h_transcript_zs", b"".join(hr), b"".join(sg), C.c_uint64(n), out=16 * n)
         want = b"".join(orc.batch_transcript_zs(hr, [s[32:] for s in sg]))
         assert got == want
+
+
+def test_sc28_device_scalar_arithmetic_vs_bigint(host):
+    """csrc/sc28.h -- the scalar arithmetic the verify_batch / sign / verify kernels run (radix 2^28, folding with l = 2^252 + c) --
+    against Python integers: wide reduction (Scalar::from_bytes_mod_order_wide, scalar.rs:248), 128-bit x scalar and scalar x
+    unreduced-255-bit products (batch.rs:213-233, signing.rs:899), add / neg, the canonical check (scalar.rs:259-263), at random
+    values and at the extremes where a fold's bound is tight"""
+    rng = random.Random(28)
+    C_ = L - 2**252
+    wides = [0, 1, L - 1, L, L + 1, 2**252 - 1, 2**252, 2**512 - 1, 2**512 - L, (2**260 - 1) << 252, ((2**260 - 1) << 252) + 2**252 - 1,
+             2**511, 2**384, 2**385 - 1, 2**266, 2**253, 2**254 - 1, 7 * L, (2**259) * L % 2**512, L * (2**259 - 1)]
+    wides += [rng.getrandbits(512) for _ in range(3000)] + [rng.getrandbits(rng.randrange(1, 513)) for _ in range(1000)]
+    for w in wides:
+        assert b2i(call(host, "h_sc28_from_wide", w.to_bytes(64, "little"))) == w % L, hex(w)
+    zs = [0, 1, 2**128 - 1, 2**127, 2**127 - 1, 2**64] + [rng.getrandbits(128) for _ in range(2000)]
+    bs = [0, 1, L - 1, L - 2, 2**252, 2**252 - 1, C_, L // 2] + [rng.randrange(L) for _ in range(60)]
+    for z in zs[:40]:
+        for b in bs:
+            assert b2i(call(host, "h_sc28_mul_5x10", z.to_bytes(16, "little"), i2b(b))) == z * b % L, (z, b)
+    for z in zs[40:]:
+        b = rng.randrange(L)
+        assert b2i(call(host, "h_sc28_mul_5x10", z.to_bytes(16, "little"), i2b(b))) == z * b % L
+    full = [0, 1, L - 1, 2**255 - 1, 2**255 - 8, 2**254 + 2**253, 2**252 + 1] + [rng.getrandbits(255) for _ in range(40)]
+    for a in full:
+        for b in full[:12] + [rng.randrange(L) for _ in range(20)]:
+            assert b2i(call(host, "h_sc28_mul", i2b(a), i2b(b))) == a * b % L, (a, b)
+    for _ in range(2000):
+        a, b = rng.randrange(L), rng.randrange(L)
+        assert b2i(call(host, "h_sc28_add", i2b(a), i2b(b))) == (a + b) % L
+        assert b2i(call(host, "h_sc28_neg", i2b(a))) == (-a) % L
+        assert b2i(call(host, "h_sc28_roundtrip", i2b(a))) == a
+    for a, b in ((0, 0), (L - 1, L - 1), (L - 1, 1), (1, L - 1), (0, L - 1)):
+        assert b2i(call(host, "h_sc28_add", i2b(a), i2b(b))) == (a + b) % L
+    assert b2i(call(host, "h_sc28_neg", i2b(0))) == 0
+    assert b2i(call(host, "h_sc28_roundtrip", i2b(2**256 - 1))) == 2**256 - 1
+    for v, want in [(0, 1), (1, 1), (L - 1, 1), (L, 0), (L + 1, 0), (2**255 - 1, 0), (2**255, 0), (2**256 - 1, 0), (2**252, 1), (2**252 + C_ - 1, 1)] + \
+                   [(rng.getrandbits(256), None) for _ in range(300)] + [(L - d, None) for d in range(-40, 40)]:
+        assert host.h_sc28_canonical(i2b(v)) == (want if want is not None else int(v < L)), hex(v)

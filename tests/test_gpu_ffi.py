@@ -289,3 +289,26 @@ def test_trim_then_reuse(eng):
     eng.trim()
     st2, r2 = eng.msm_vartime(s, pts, 2, 0)
     assert st == 0 and st2 == 0 and r1 == r2
+
+
+@pytest.mark.parametrize("n", [1, 127, 129, 32768, 32769, 65536, 65537, 131072, 131073, 200000])
+def test_constant_time_fixed_base_small_batches(eng, orc, n):
+    """every launch shape of the constant-time fixed-base path (k_mul_base_ct_split with 256 / 512 / 1024-thread blocks for small
+    batches: a scalar's windows split between two threads; k_mul_base<5, CT> beyond) against the radix-2^16 tables (an independent
+    algorithm) on all outputs and against the oracle on the edge scalars, in the three output formats"""
+    import torch
+    s = util.rand_scalars(1000 + n % 977, n)
+    edge = util.edge_scalars()
+    k = min(n, edge.shape[0])
+    s[:k] = edge[:k]
+    d = torch.from_numpy(s).cuda()
+    for fmt in (0, 2, 1):
+        got = eng.mul_base_batch_t(d, fmt).cpu().numpy()
+        want = eng.mul_base_batch_vartime_t(d, fmt).cpu().numpy()
+        if fmt == 2:
+            assert np.array_equal(eng.compress_batch(got[:4096]), eng.compress_batch(want[:4096]))
+        else:
+            assert np.array_equal(got, want), (n, fmt)
+    got = eng.mul_base_batch_t(d, 0).cpu().numpy()
+    for i in list(range(k)) + [n - 1]:
+        assert got[i].tobytes() == orc.ed_compress(orc.ed_mul_base(s[i].tobytes())), i
