@@ -657,6 +657,9 @@ __device__ __forceinline__ u32 seg_total(const u32 *__restrict__ seg_tot_k) {
 // (three waves of 168 VGPRs per SIMD = 504 of 512 registers) a block only starts in the holes retiring accumulate blocks leave, and
 // small blocks do start sooner -- but the work of a call is conserved, not hidden: what counts is how long the sort takes ALONE
 // (363 us per 2^21 terms in this form, 710 us in the 256-thread forms), so the shapes that are fastest alone are kept.
+// (verify_batch, where the sort runs beside the decompression of R_i -- capped at two waves per SIMD, so a 256-thread block does
+//  co-reside -- was tried with 256-thread sort kernels as well: the decompression stretched from 1.29 to 1.53 ms and the call from
+//  2.88 to 2.96 ms.  Same conclusion.)
 __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, const u32 *__restrict__ cc, const u32 *__restrict__ seg_tot,
                                                                  u32 *__restrict__ P1) {
     C25519_PRIO_CHAIN();
