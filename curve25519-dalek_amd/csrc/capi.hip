@@ -362,13 +362,6 @@ EXPORT void *c25519_host_alloc(size_t bytes) {
     return p;
 }
 EXPORT void c25519_host_free(void *p) { if (p) hipHostFree(p); }
-// wipes device staging on EVERY exit path of a host-pointer entry point (after the copy streams have drained)
-struct wipe_on_exit {
-    c25519_ctx *ctx; void *p[4]; size_t n[4]; int cnt = 0;
-    explicit wipe_on_exit(c25519_ctx *c) : ctx(c) {}
-    void add(void *q, size_t bytes) { if (q && bytes && cnt < 4) { p[cnt] = q; n[cnt++] = bytes; } }
-    ~wipe_on_exit() { for (int i = 0; i < cnt; i++) hipMemsetAsync(p[i], 0, n[i], ctx->stream); }
-};
 // release the workspaces a large call left behind (a 2^24-term MSM keeps ~2.6 GB: the records prepared ahead, the
 // normaliser's prefix products, the staging copies of host-pointer calls); the next call re-allocates what it needs
 EXPORT int32_t c25519_ctx_trim(c25519_ctx *ctx) {
@@ -395,6 +388,9 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     }
     if (out_fmt == C25519_FMT_RISTRETTO) { int32_t r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256); if (r) return r; }
+    stream_wipe wipe(ctx->stream);                        // the projective scratch records and prefix products are secret-derived
+    if (secret && out_fmt == C25519_FMT_EDWARDS_Y) { wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48); }
+    if (secret && out_fmt == C25519_FMT_RISTRETTO) wipe.add(ctx->tmp_e.p, n * 160);
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
@@ -411,15 +407,10 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
         HIPCHK(mul(nullptr, (uint8_t *)ctx->tmp_e.p));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
         HIPCHK(launch_compress_ristretto((const uint8_t *)ctx->tmp_e.p, n, d_out, ctx->stream));
-        if (secret) HIPCHK(hipMemsetAsync(ctx->tmp_e.p, 0, n * 160, ctx->stream));
     } else {
         HIPCHK(mul((uint32_t *)ctx->scratch.p, nullptr));
         HIPCHK(hipEventRecord(ring[1], ctx->stream));
         HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
-        if (secret) {           // the projective scratch records and prefix products are secret-derived: wipe
-            HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));
-            HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
-        }
     }
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
@@ -441,7 +432,7 @@ static int32_t mul_base_host(c25519_ctx *ctx, const uint8_t *scalars, uint64_t n
     int32_t r;
     if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * osz))) return r;
     uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
-    wipe_on_exit wipe(ctx);
+    stream_wipe wipe(ctx->stream);
     if (secret) wipe.add(d_in, n * 32);                   // the staged scalars
     const ffi_in in = {scalars, d_in, 32};
     const ffi_out o = {out, d_out, osz};
@@ -517,6 +508,8 @@ EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k,
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48)) || (r = ctx_reserve(ctx, ctx->tmp_e, n * 32 + 256))) return r;
+    stream_wipe wipe(ctx->stream);                        // secret-derived intermediates, on every exit path
+    wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48); wipe.add(ctx->tmp_e.p, n * 32);
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
@@ -525,9 +518,6 @@ EXPORT int32_t c25519_x25519_base_batch_dev(c25519_ctx *ctx, const uint8_t *d_k,
     else HIPCHK(launch_mul_base(ctx->w, (const uint8_t *)ctx->tmp_e.p, n, ctx->d_table, (uint32_t *)ctx->scratch.p, nullptr, ctx->num_cus, ctx->stream));
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     HIPCHK(launch_ratio_p32(1, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // (Z+Y)/(Z-Y)
-    HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // secret-derived intermediates: wipe
-    HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
-    HIPCHK(hipMemsetAsync(ctx->tmp_e.p, 0, n * 32, ctx->stream));
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
@@ -537,7 +527,7 @@ EXPORT int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint6
     int32_t r;
     if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 32))) return r;
     uint8_t *d_in = (uint8_t *)ctx->tmp_a.p, *d_out = (uint8_t *)ctx->tmp_b.p;
-    wipe_on_exit wipe(ctx);
+    stream_wipe wipe(ctx->stream);
     wipe.add(d_in, n * 32);                               // the staged secrets
     const ffi_in in = {k, d_in, 32};
     const ffi_out o = {out, d_out, 32};
@@ -548,6 +538,8 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+    stream_wipe wipe(ctx->stream);                        // the projective result is secret-derived: wiped on every exit path
+    wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48);
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
@@ -555,8 +547,6 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     HIPCHK(launch_x25519(d_k, d_u, n, (uint32_t *)ctx->scratch.p, ctx->stream));
     HIPCHK(hipEventRecord(ring[1], ctx->stream));
     HIPCHK(launch_ratio_p32(0, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // U / W, 0 -> 0
-    HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream));   // the projective result is secret-derived: wipe
-    HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream));
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
@@ -582,7 +572,7 @@ static int32_t x25519_host(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, 
     int32_t r;
     if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 32)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 33 + 16))) return r;
     uint8_t *d_k = (uint8_t *)ctx->tmp_a.p, *d_u = (uint8_t *)ctx->tmp_b.p, *d_out = (uint8_t *)ctx->tmp_c.p, *d_fl = d_out + n * 32;
-    wipe_on_exit wipe(ctx);
+    stream_wipe wipe(ctx->stream);
     wipe.add(d_k, n * 32);                                // the staged secret scalars ...
     wipe.add(d_out, n * 32);                              // ... and the shared secrets, on every path
     const ffi_in in[2] = {{k, d_k, 32}, {u, d_u, 32}};

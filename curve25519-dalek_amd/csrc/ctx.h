@@ -54,6 +54,16 @@ struct c25519_ctx {
     std::string err;
 };
 
+// Zeroes device buffers on the given stream when it goes out of scope: secret-derived scratch is wiped on EVERY exit path of an
+// entry point (also the early returns of a failed launch), after whatever the entry point enqueued before.
+struct stream_wipe {
+    hipStream_t st; void *p[6]; size_t n[6]; int cnt = 0;
+    explicit stream_wipe(hipStream_t s) : st(s) {}
+    stream_wipe(const stream_wipe &) = delete;
+    void add(void *q, size_t bytes) { if (q && bytes && cnt < 6) { p[cnt] = q; n[cnt++] = bytes; } }
+    ~stream_wipe() { for (int i = 0; i < cnt; i++) (void)hipMemsetAsync(p[i], 0, n[i], st); }
+};
+
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);
 int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
 c25519_ctx *ctx_peer(c25519_ctx *ctx);      // nullptr if it cannot be created

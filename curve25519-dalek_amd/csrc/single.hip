@@ -306,9 +306,10 @@ int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t 
         hipLaunchKernelGGL(k_p40_to_raw, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, d_out);
     } else {
         if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
+        stream_wipe wipe(ctx->stream);                    // (declared before the launches: also wiped if one of them fails)
+        if (ct) { wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48); }
         hipLaunchKernelGGL(k_p40_add_to_p32, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, p40, (const uint32_t *)nullptr, n, (uint32_t *)ctx->scratch.p);
         HIPCHK(launch_compress_p32((const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));
-        if (ct) { HIPCHK(hipMemsetAsync(ctx->scratch.p, 0, n * 128, ctx->stream)); HIPCHK(hipMemsetAsync(ctx->prefix.p, 0, n * 48, ctx->stream)); }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(ring[2], ctx->stream));
@@ -318,13 +319,6 @@ int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t 
 EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
     return mul_batch_impl(ctx, d_scalars, d_points, n, in_fmt, out_fmt, d_out, d_ok, !(ctx->flags & C25519_FLAG_VARTIME_TABLES));
 }
-// wipes device staging on every exit path of a host-pointer entry point (after the copy streams have drained)
-struct wipe_guard {
-    c25519_ctx *ctx; void *p[4]; size_t n[4]; int cnt = 0;
-    explicit wipe_guard(c25519_ctx *c) : ctx(c) {}
-    void add(void *q, size_t bytes) { if (q && bytes && cnt < 4) { p[cnt] = q; n[cnt++] = bytes; } }
-    ~wipe_guard() { for (int i = 0; i < cnt; i++) hipMemsetAsync(p[i], 0, n[i], ctx->stream); }
-};
 static int32_t mul_batch_host(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok, bool clamp) {
     HIPCHK(hipSetDevice(ctx->device));
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;
@@ -332,7 +326,7 @@ static int32_t mul_batch_host(c25519_ctx *ctx, const uint8_t *scalars, const uin
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * osz + n + 16))) return r;
     uint8_t *ds = (uint8_t *)ctx->tmp_a.p, *dp = (uint8_t *)ctx->tmp_b.p, *dout = (uint8_t *)ctx->tmp_c.p, *dok = dout + n * osz;
     const bool secret = ctx_secret_default(ctx);
-    wipe_guard wipe(ctx);
+    stream_wipe wipe(ctx->stream);
     if (secret) { wipe.add(ds, n * 32); wipe.add(dout, n * osz); }        // staged secret scalars and the products (e.g. shared secrets)
     const ffi_in in[2] = {{scalars, ds, 32}, {points, dp, psz}};
     const ffi_out o[2] = {{out, dout, osz}, {ok, dok, 1}};
@@ -501,8 +495,8 @@ EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, c
     if (r) return r;
     HIPCHK(e);
     uint32_t fl[4] = {0, 0, 0, 0};                              // bad message offsets (k_hram) -> error, like verify_batch
-    HIPCHK(hipMemcpyAsync(fl, ctx->d_flag, 16, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HIPCHK(hipMemcpy(fl, ctx->d_flag, 16, hipMemcpyDeviceToHost));      // (blocking: no copy is ever pending into this frame)
     if (fl[1]) { ctx->err = "sign_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
     return C25519_OK;
 }
@@ -515,7 +509,7 @@ EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const u
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 128 + 64))) return r;
     uint8_t *dmsg = (uint8_t *)ctx->tmp_a.p, *dseed = (uint8_t *)ctx->tmp_c.p, *dpk = dseed + n * 32, *dsig = dpk + n * 32;
     uint64_t *doff = (uint64_t *)ctx->tmp_b.p;
-    wipe_guard wipe(ctx);
+    stream_wipe wipe(ctx->stream);
     wipe.add(dseed, n * 32);                              // the staged secret keys, on every path
     if ((r = ffi_begin(ctx))) return r;
     if (mlen) HIPCHK(hipMemcpyAsync(dmsg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));

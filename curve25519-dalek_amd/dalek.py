@@ -13,6 +13,10 @@ error behaviour), batched, on top of Engine.  Reference entry points mirrored:
   VartimeEdwardsPrecomputation                curve25519-dalek/src/edwards.rs:1037-1076
   RistrettoPoint::double_and_compress_batch   curve25519-dalek/src/ristretto.rs:564
   Scalar::invert_batch                        curve25519-dalek/src/scalar.rs:802
+  EdwardsBasepointTable::create / mul_base    curve25519-dalek/src/edwards.rs:1131-1141 / :1192-1209   (any basepoint)
+  RistrettoBasepointTable::create             curve25519-dalek/src/ristretto.rs:1080-1110
+  EdwardsPoint::mul_base_clamped / mul_clamped   curve25519-dalek/src/edwards.rs:948 / :932
+  SharedSecret::was_contributory              x25519-dalek/src/x25519.rs:335
 
 Values cross this layer as the reference's wire types: Scalar = 32 canonical LE bytes,
 CompressedEdwardsY / CompressedRistretto / MontgomeryPoint = 32 bytes.
@@ -76,6 +80,56 @@ class EdwardsPoint:
         return [out[i].tobytes() for i in range(out.shape[0])]
 
 
+    @staticmethod
+    def mul_base_clamped(raw_bytes, engine=None):
+        """[clamp_integer(b_i) * B] as CompressedEdwardsY bytes (edwards.rs:948-956; the clamped integer is not reduced mod l)."""
+        eng = engine or default_engine()
+        out = eng.mul_base_clamped_batch(_cat(raw_bytes, 32), _e.FMT_EDWARDS_Y)
+        return [out[i].tobytes() for i in range(out.shape[0])]
+
+    @staticmethod
+    def mul_clamped(points, raw_bytes, engine=None):
+        """[clamp_integer(b_i) * P_i] (edwards.rs:932-946): P_i as CompressedEdwardsY, results likewise; None where P_i does not decode."""
+        if len(points) != len(raw_bytes):
+            raise AssertionError("mul_clamped: points and scalars must have equal length")
+        eng = engine or default_engine()
+        out, ok = eng.mul_clamped_batch(_cat(raw_bytes, 32), _cat(points, 32), _e.FMT_EDWARDS_Y, _e.FMT_EDWARDS_Y)
+        return [out[i].tobytes() if ok[i] else None for i in range(out.shape[0])]
+
+
+class EdwardsBasepointTable:
+    """edwards.rs:1125-1209 for ANY basepoint: `create(&P)` builds the window table once, `mul_base(&s)` = `&s * &table`
+    multiplies secret scalars by P with constant-time table scans (window.rs:54-76) whatever the engine's flags."""
+
+    _fmt = _e.FMT_EDWARDS_Y
+
+    def __init__(self, basepoint, engine=None):
+        self.eng = engine or default_engine()
+        self.point = bytes(basepoint)
+        self.h = self.eng.basetable_create(self.point, self._fmt)
+
+    @classmethod
+    def create(cls, basepoint, engine=None):
+        return cls(basepoint, engine)
+
+    def basepoint(self):
+        return self.point
+
+    def mul_base(self, scalars):
+        out = self.eng.mul_table_batch(self.h, _cat(scalars, 32), self._fmt)
+        return [out[i].tobytes() for i in range(out.shape[0])]
+
+    def close(self):
+        if self.h:
+            self.eng.basetable_destroy(self.h)
+            self.h = None
+
+
+class RistrettoBasepointTable(EdwardsBasepointTable):
+    """ristretto.rs:1080-1110: the same table over a CompressedRistretto basepoint, results as CompressedRistretto."""
+    _fmt = _e.FMT_RISTRETTO
+
+
 class RistrettoPoint:
     @staticmethod
     def vartime_multiscalar_mul(scalars, points, engine=None):
@@ -101,6 +155,27 @@ def x25519(ks, us, engine=None):
     eng = engine or default_engine()
     out = eng.x25519_batch(_cat(ks, 32), _cat(us, 32))
     return [out[i].tobytes() for i in range(out.shape[0])]
+
+
+class SharedSecret:
+    """x25519-dalek/src/x25519.rs:301-345: the 32 bytes of a Diffie-Hellman result and was_contributory() (:335)."""
+    __slots__ = ("bytes", "contributory")
+
+    def __init__(self, b, contributory):
+        self.bytes, self.contributory = bytes(b), bool(contributory)
+
+    def as_bytes(self):
+        return self.bytes
+
+    def was_contributory(self):
+        return self.contributory
+
+
+def diffie_hellman(secrets, their_publics, engine=None):
+    """StaticSecret::diffie_hellman (x25519.rs:219-222), batched -> [SharedSecret]"""
+    eng = engine or default_engine()
+    out, fl = eng.x25519_contributory_batch(_cat(secrets, 32), _cat(their_publics, 32))
+    return [SharedSecret(out[i].tobytes(), fl[i]) for i in range(out.shape[0])]
 
 
 class VerifyingKey:

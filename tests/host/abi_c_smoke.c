@@ -65,6 +65,34 @@ int main(void) {
     if (ed25519_verify_batch_multi(both, 2, vmsg, voff, &vsig[0][0], &vpk[0][0], 2, 0) != C25519_OK) return 15;
     memcpy(pts[1], bp, 32);
     if (c25519_msm_vartime_multi(both, 2, &sc[0][0], &pts[0][0], 2, C25519_FMT_EDWARDS_Y, C25519_FMT_EDWARDS_Y, sum) != C25519_OK || memcmp(sum, enc[1], 32)) return 16;
+    /* (r3) a constant-time table for a caller's point: 8 * (3 B) == 24 B through c25519_basetable_create / c25519_mul_table_batch */
+    uint8_t three[1][32] = {{3}}, p3[32], s24[1][32] = {{24}}, e24[32], t24[32];
+    if (c25519_mul_base_batch(ctx, &three[0][0], 1, C25519_FMT_EDWARDS_Y, p3) != C25519_OK) return 17;
+    c25519_basetable *tab = c25519_basetable_create(ctx, p3, C25519_FMT_EDWARDS_Y);
+    if (!tab) { fprintf(stderr, "basetable: %s\n", c25519_last_error(ctx)); return 18; }
+    if (c25519_mul_table_batch(ctx, tab, &s[1][0], 1, C25519_FMT_EDWARDS_Y, t24) != C25519_OK) return 19;
+    if (c25519_mul_base_batch(ctx, &s24[0][0], 1, C25519_FMT_EDWARDS_Y, e24) != C25519_OK || memcmp(t24, e24, 32)) { fprintf(stderr, "mul_table mismatch\n"); return 20; }
+    c25519_basetable_destroy(ctx, tab);
+    /* (r3) buffers from c25519_host_alloc, mul_base_clamped == x25519 public key in Edwards form, was_contributory on a low-order point */
+    uint8_t *hb = (uint8_t *)c25519_host_alloc(4 * 32);
+    if (!hb) return 21;
+    memcpy(hb, k[0], 32);
+    if (c25519_mul_base_clamped_batch(ctx, hb, 1, C25519_FMT_EDWARDS_Y, hb + 32) != C25519_OK) return 22;
+    uint8_t zero_u[32] = {0}, fl[1] = {9};
+    if (c25519_x25519_contributory_batch(ctx, k[0], zero_u, 1, hb + 64, fl) != C25519_OK || fl[0] != 0) return 23;          /* u = 0 is of low order: all-zero secret */
+    if (c25519_x25519_contributory_batch(ctx, k[0], u[0], 1, hb + 64, fl) != C25519_OK || fl[0] != 1 || memcmp(hb + 64, want, 32)) return 24;
+    uint64_t up = 0, down = 0;
+    if (c25519_last_ffi_ms(ctx, &up, &down) < 0 || up != 64 || down != 33) return 25;
+    c25519_host_free(hb);
+    /* (r3) the multi-rank exchange without torch: two partial-result records (a packed point each) fold to the sum */
+    uint8_t raw3[160], raw5[160], recs[2 * C25519_PARTIAL_RECORD_BYTES], folded[32];
+    uint8_t five[1][32] = {{5}};
+    if (c25519_mul_base_batch(ctx, &three[0][0], 1, C25519_FMT_RAW160, raw3) != C25519_OK || c25519_mul_base_batch(ctx, &five[0][0], 1, C25519_FMT_RAW160, raw5) != C25519_OK) return 26;
+    if (c25519_partial_record_pack(raw3, C25519_OK, NULL, recs) != C25519_OK || c25519_partial_record_pack(raw5, C25519_OK, NULL, recs + C25519_PARTIAL_RECORD_BYTES) != C25519_OK) return 27;
+    if (c25519_fold_partial_records(NULL, recs, 2, C25519_FMT_EDWARDS_Y, folded) != C25519_OK || memcmp(folded, enc[1], 32)) { fprintf(stderr, "record fold mismatch\n"); return 28; }
+    if (c25519_partial_record_pack(raw5, C25519_NONE, NULL, recs + C25519_PARTIAL_RECORD_BYTES) != C25519_OK) return 29;
+    if (c25519_fold_partial_records(NULL, recs, 2, C25519_FMT_EDWARDS_Y, folded) != C25519_NONE) return 30;
+    if (c25519_ctx_trim(ctx) != C25519_OK) return 31;
     c25519_ctx_destroy(ctx2);
     c25519_ctx_destroy(ctx);
     printf("abi_c_smoke ok\n");

@@ -312,3 +312,26 @@ def test_constant_time_fixed_base_small_batches(eng, orc, n):
     got = eng.mul_base_batch_t(d, 0).cpu().numpy()
     for i in list(range(k)) + [n - 1]:
         assert got[i].tobytes() == orc.ed_compress(orc.ed_mul_base(s[i].tobytes())), i
+
+
+def test_reference_named_front_end_round3(eng, orc):
+    """dalek.py names added in round 3: EdwardsBasepointTable::create / RistrettoBasepointTable::create, mul_base_clamped,
+    mul_clamped, diffie_hellman + SharedSecret::was_contributory -- against the oracle"""
+    from curve25519_dalek_amd import dalek
+    P = orc.ed_mul_base(i2b(424242))
+    s = [util.rand_scalars(5, 9)[i].tobytes() for i in range(9)]
+    t = dalek.EdwardsBasepointTable.create(orc.ed_compress(P), engine=eng)
+    assert t.mul_base(s) == [orc.ed_compress(orc.ed_mul(P, x)) for x in s] and t.basepoint() == orc.ed_compress(P)
+    t.close()
+    r = dalek.RistrettoBasepointTable.create(orc.ris_compress(P), engine=eng)
+    Pd = orc.ris_decompress(orc.ris_compress(P))
+    assert r.mul_base(s) == [orc.ris_compress(orc.ed_mul(Pd, x)) for x in s]
+    r.close()
+    raw = [util.rand_bytes(6, 9)[i].tobytes() for i in range(9)]
+    assert dalek.EdwardsPoint.mul_base_clamped(raw, engine=eng) == [orc.ed_compress(orc.ed_mul_base(clamp(b))) for b in raw]
+    pts = [orc.ed_compress(orc.ed_mul_base(x)) for x in s]
+    got = dalek.EdwardsPoint.mul_clamped(pts + [(2).to_bytes(32, "little")], raw + [raw[0]], engine=eng)
+    assert got[:9] == [orc.ed_compress(orc.ed_mul(orc.ed_decompress(p), clamp(b))) for p, b in zip(pts, raw)] and got[9] is None
+    ss = dalek.diffie_hellman(raw, [orc.x25519(b, (9).to_bytes(32, "little")) for b in raw[:8]] + [bytes(32)], engine=eng)
+    assert [x.was_contributory() for x in ss] == [True] * 8 + [False] and ss[8].as_bytes() == bytes(32)
+    assert ss[0].as_bytes() == orc.x25519(raw[0], orc.x25519(raw[0], (9).to_bytes(32, "little")))

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): kernel-trace stats and PMC passes for every workload of bench.py.
 # Raw output under gpurun_out/prof_rNN/, summaries under gpurun_out/profiles_rNN/ (copy those to profiles/).
-#   bash tools/profile_all.sh r02 [nopmc]
+#   bash tools/profile_all.sh r03 [nopmc]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=$R/gpurun_out/profiles_$TAG
 RAW=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $RAW
@@ -22,7 +22,8 @@ for w in msm msm_2p21 verify fixed_base_ct fixed_base x25519; do
   python $R/tools/rocprof_summary.py $RAW/kt_$w/${w}_results.db > $OUT/${TAG}_${w}_kernel_stats.txt 2>&1
   grep -h '"metric"' $RAW/kt_$w.log >> $OUT/${TAG}_${w}_kernel_stats.txt
 done
-python $R/tools/rocprof_timeline.py $RAW/kt_msm_2p21/msm_2p21_results.db k_prep_raw > $OUT/${TAG}_msm_2p21_timeline.txt 2>&1
+python $R/tools/rocprof_timeline.py $RAW/kt_msm_2p21/msm_2p21_results.db k_slot_init > $OUT/${TAG}_msm_2p21_timeline.txt 2>&1
+python $R/tools/timeline_tail.py $RAW/kt_msm/msm_results.db 75 15 > $OUT/${TAG}_msm_2p24_last_call_timeline.txt 2>&1
 python $R/tools/rocprof_timeline.py $RAW/kt_verify/verify_results.db k_prep_basepoint > $OUT/${TAG}_verify_timeline.txt 2>&1
 [ "$2" = "nopmc" ] && { ls -la $OUT; exit 0; }
 # PMC passes: counters only with --kernel-trace (never with sys/hip/hsa tracing); separate passes per counter group
