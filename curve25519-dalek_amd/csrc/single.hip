@@ -469,10 +469,14 @@ static int32_t sign_body(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t 
     hipStream_t st = ctx->stream;
     const bool secret = ctx_secret_default(ctx);
     int32_t r;
+    // A = a*B and R = r*B (the nonce is as secret as the key) in ONE fixed-base launch over the 2n scalars a || r: the nonce
+    // r = H(prefix || M) does not depend on A, and a batch of 2^16 signatures is two launches' worth of latency otherwise
+    // (2 x (0.21 + 0.10) ms of a 0.83 ms call, profiles/r03_sign_keygen_2p16.txt).  rscal = a + 32 n, Renc = AR + 32 n.
     hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, st, d_seeds, n, a, prefix);
-    if ((r = mul_base_impl(ctx, a, n, C25519_FMT_EDWARDS_Y, d_pks, secret))) return r;              // A = a*B
     hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, msgs_len, n, rscal);
-    if ((r = mul_base_impl(ctx, rscal, n, C25519_FMT_EDWARDS_Y, Renc, secret))) return r;           // R = r*B (the nonce is as secret as the key)
+    uint8_t *AR = Renc - n * 32;
+    if ((r = mul_base_impl(ctx, a, 2 * n, C25519_FMT_EDWARDS_Y, AR, secret))) return r;
+    HIPCHK(hipMemcpyAsync(d_pks, AR, n * 32, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_place_R, dim3(dup(n, 256)), dim3(256), 0, st, Renc, n, d_sigs);
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
     HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
@@ -487,11 +491,12 @@ EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, c
     int32_t r;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oA = carve(n * 32), oPre = carve(n * 32), oR = carve(n * 32), oRe = carve(n * 32), oH = carve(n * 64);
+    // a || r contiguous (one fixed-base launch over both, sign_body), then the prefixes; then A || R encodings, then the hashes
+    size_t oA = carve(2 * n * 32), oPre = carve(n * 32), oAR = carve(2 * n * 32), oH = carve(n * 64);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
-    r = sign_body(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, ws + oA, ws + oPre, ws + oR, ws + oRe, ws + oH);
-    hipError_t e = hipMemsetAsync(ws, 0, oRe, ctx->stream);     // wipe secret scalars / prefixes / nonces on EVERY exit path
+    r = sign_body(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, ws + oA, ws + oPre, ws + oA + n * 32, ws + oAR + n * 32, ws + oH);
+    hipError_t e = hipMemsetAsync(ws, 0, oAR, ctx->stream);     // wipe secret scalars / nonces / prefixes on EVERY exit path
     if (r) return r;
     HIPCHK(e);
     uint32_t fl[4] = {0, 0, 0, 0};                              // bad message offsets (k_hram) -> error, like verify_batch

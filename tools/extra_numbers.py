@@ -23,11 +23,15 @@ def rnd(n, w=32):
 
 
 def best(eng, f, reps=5):
+    """best GPU time of the WHOLE call (torch events on the stream the engine launches on; c25519_last_kernel_ms brackets only
+    the last fixed-base launch of a multi-kernel call -- round 2's and the first round-3 sign_batch figure were that)"""
     for _ in range(40):
         eng.microbench(0, 4000)             # sustained clock first (see bench.py)
     f(); b = 1e9
     for _ in range(reps):
-        f(); b = min(b, eng.last_kernel_ms())
+        t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+        t0.record(); f(); t1.record(); t1.synchronize()
+        b = min(b, t0.elapsed_time(t1))
     return b
 
 
