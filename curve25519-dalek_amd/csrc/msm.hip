@@ -539,8 +539,9 @@ __device__ __forceinline__ u32 sweep_take(sweep_regs &R, int r, int wd) {
     return v;
 }
 // Counting: LDS atomics of many waves on ONE set of counters serialise badly (a 1024-thread block per chunk with shared
-// counters: 297 us per 2^21 terms), private counters per wave do not (round 2's k_part_hist: 45 us).  A chunk is counted by one
-// block of four waves, each wave with its own [window][slice] counters (4 x 17 x 128 x 4 B = 35 KB per block).
+// counters: 297 us per 2^21 terms), private counters per wave do not.  A chunk is counted by one block of CT / 64 waves, each
+// wave with its own [window][slice] counters: as many waves as LDS allows (16 x 17 x 128 x 4 B = 139 KB at c = 16: the grid is one
+// block per compute unit, so what matters is how many waves share the chunk: 84 / 56 / 48 us with 4 / 8 / 16).
 __device__ __forceinline__ u32 take8(u32 s[8], int wd) {
     const u32 v = s[0] & ((1u << wd) - 1u);
 #pragma unroll
@@ -550,29 +551,27 @@ __device__ __forceinline__ u32 take8(u32 s[8], int wd) {
 }
 // zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket
 // counters) -- zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain
-// waits 30 - 180 us for a dispatch slot.  bad_scalar (a word of the sort workspace, outside zero_words, zeroed by
-// k_part2 of the previous use) is ORed into the result slot by the bucket reduction.
-// zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket
-// counters) -- zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain
 // waits 30 - 180 us for a dispatch slot.  bad_blk[j] = 1 if a scalar of chunk j has bit 255 set (k_seg_scan ORs them into one
 // word, the bucket reduction ORs that into the result slot: the sort itself never touches the slot).
-__global__ void __launch_bounds__(256) k_sweep_count(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, int nchunk, u32 *__restrict__ cc, u32 *__restrict__ bad_blk,
-                                                     u32 *__restrict__ zero_words, int nzero) {
+template <int CT>                                            // threads per block: CT / 64 waves, each with its own counters
+__global__ void __launch_bounds__(CT) k_sweep_count(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, int nchunk, u32 *__restrict__ cc, u32 *__restrict__ bad_blk,
+                                                    u32 *__restrict__ zero_words, int nzero) {
     C25519_PRIO_CHAIN();
-    extern __shared__ u32 sm[];                               // [4 waves][nwin][SL] + 1
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
+    constexpr int CW = CT / 64;
+    extern __shared__ u32 sm[];                               // [CW waves][nwin][SL] + 1
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += CT) zero_words[i] = 0;
     const int j = blockIdx.x, NC = g.nwin * SL, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i <= 4 * NC; i += 256) sm[i] = 0;
+    for (int i = threadIdx.x; i <= CW * NC; i += CT) sm[i] = 0;
     __syncthreads();
-    u32 *mine = sm + w * NC, *bad = sm + 4 * NC;
+    u32 *mine = sm + w * NC, *bad = sm + CW * NC;
     const u64 lo = (u64)blockIdx.x * SWEEP_CHUNK;
-    constexpr int B = 8;                                      // scalars in flight per lane; SWEEP_CHUNK / 256 per lane in all
+    constexpr int B = 8;                                      // scalars in flight per lane; SWEEP_CHUNK / CT per lane in all
 #pragma unroll 1
-    for (int r0 = 0; r0 < SWEEP_CHUNK / 256; r0 += B) {
+    for (int r0 = 0; r0 < SWEEP_CHUNK / CT; r0 += B) {
         u32 s[B][8];
 #pragma unroll
         for (int r = 0; r < B; r++) {
-            const u64 t = lo + (u64)(r0 + r) * 256 + threadIdx.x;
+            const u64 t = lo + (u64)(r0 + r) * CT + threadIdx.x;
             u32 wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             if (t < n) load8(scalars, t, wv);
             if (wv[7] >> 31) *bad = 1u;
@@ -591,7 +590,12 @@ __global__ void __launch_bounds__(256) k_sweep_count(const uint8_t *__restrict__
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < NC; i += 256) cc[(u64)i * nchunk + j] = sm[i] + sm[NC + i] + sm[2 * NC + i] + sm[3 * NC + i];      // i = k * SL + slice
+    for (int i = threadIdx.x; i < NC; i += CT) {             // i = k * SL + slice
+        u32 v = 0;
+#pragma unroll
+        for (int q = 0; q < CW; q++) v += sm[q * NC + i];
+        cc[(u64)i * nchunk + j] = v;
+    }
     if (threadIdx.x == 0) bad_blk[j] = *bad;
 }
 // Segmented scan of the chunk counters: the M = SL x nchunk counters of a window are cut into SCAN_SEGS segments, one 256-thread
@@ -665,26 +669,39 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     constexpr int NW = SWEEP_WAVES;
-    u32 *cntb = sm;                        // [2][NW][SL]: per-wave counts, then per-wave cursors; double-buffered across windows
+    // per-(slice, wave) counters in ONE flat array, slice-major: counter (s, w) at s * NW + (w ^ ((s >> 2) & (NW - 1))) -- the order of
+    // the waves inside a slice does not matter, and this swizzle spreads a wave's counters of 64 consecutive slices over all 64 banks.
+    // In that order the counters ARE the layout of the staging buffer, so the cursors are simply the exclusive scan of the flat array.
+    u32 *cnt = sm;                         // [SL * NW]: counts of the current window (a wave only ever adds to its own counters)
+    u32 *cur = sm + NW * SL;               // [SL * NW]: cursors into the staging buffer
     u32 *ls = sm + 2 * NW * SL;            // [SL]: start of each slice in the staging buffer
-    u32 *stot = ls + SL;                   // [SL]: entries of each slice
-    u32 *gdst = stot + SL;                 // [SL]: where this chunk's run of each slice goes in P1 (prefetched: a wave that fetched
+    u32 *send = ls + SL;                   // [SL]: its end
+    u32 *gdst = send + SL;                 // [SL]: where this chunk's run of each slice goes in P1 (prefetched: a wave that fetched
                                            //       the offset of each of its runs right before copying it paid a global-load latency per run)
     u32 *stage = gdst + SL;                // [SWEEP_CHUNK]
+    __shared__ u32 wtot[NW];
     const int j = blockIdx.x, nchunk = gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const u32 seglen = (u32)(SL * nchunk) / SCAN_SEGS;
     const u64 lo = (u64)j * SWEEP_CHUNK;
     sweep_regs R;
     sweep_load(scalars, n, lo, g, R, nullptr);
-    for (int i = threadIdx.x; i < 2 * NW * SL; i += SWEEP_THREADS) cntb[i] = 0;
+    const int total = NW * SL, ept = total >= SWEEP_THREADS ? total / SWEEP_THREADS : 1;      // 1, 2 or 4 counters per thread (SL <= 256)
+    const int base = (int)threadIdx.x * ept;
+    for (int i = threadIdx.x; i < total; i += SWEEP_THREADS) cnt[i] = 0;
     __syncthreads();
-    // Three barriers per window.  A barrier that every wave has passed also says that every wave has finished the previous window,
-    // so the copy-out of window k-1 needs no barrier of its own: nothing it reads (stage, ls, stot, gdst) is written before barrier 1
-    // of window k, and the counters of window k+1 are zeroed between barriers 1 and 2 of window k.
+    // Four barriers per window.  (1) counts complete -> block-wide exclusive scan of the flat counter array by ALL threads (ept
+    // consecutive counters each, one wave scan by shuffles, wave totals through LDS: barrier 2) -> cursors, slice starts and ends
+    // (3) -> staging (4) -> copy-out.  Round 3's first form let wave 0 walk all sixteen waves' counters of every slice (32 dependent LDS
+    // accesses per slice while fifteen waves idled), the second let every wave do that for itself: 45 us of a 150 us kernel either
+    // way (a build with the phase disabled).  A software-pipelined form with three barriers per window -- window k-1 staged while
+    // window k is counted, copied out while the counters of window k are scanned -- measures the same as this one (144 / 137 us on
+    // two boxes): the kernel's time is LDS atomics (two per entry) and their latency, not barriers.  The counters are zeroed by
+    // the scan itself.  A barrier that every wave has passed
+    // also says that every wave has finished the previous window, so the copy-out of window k-1 needs no barrier of its own: nothing
+    // it reads (stage, ls, send, gdst) is written before barrier 1 of window k.
 #pragma unroll 1
     for (int k = 0; k < g.nwin; k++) {
         const int wd = g.wid[k];
-        u32 *cnt = cntb + (k & 1) * NW * SL, *cnt_next = cntb + ((k + 1) & 1) * NW * SL;
         u32 my_gofs = 0;                                                   // in flight during the counting (SL <= SWEEP_THREADS - 64: never a lane of wave 0)
         if ((int)threadIdx.x >= SWEEP_THREADS - SL)
             my_gofs = seg_offset(cc + (u64)k * SL * nchunk, seg_tot + k * SCAN_SEGS, (u32)(threadIdx.x - (SWEEP_THREADS - SL)) * (u32)nchunk + (u32)j, seglen);
@@ -694,49 +711,45 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *
             const u32 v = sweep_take(R, r, wd);
             slc[r] = 0xffffffffu;
             u32 sl, e;
-            if (part_entry(v, k, g, (u32)lo + (u32)r * SWEEP_THREADS + threadIdx.x, sl, e)) { slc[r] = sl; ent[r] = e; atomicAdd(&cnt[w * SL + sl], 1u); }
+            if (part_entry(v, k, g, (u32)lo + (u32)r * SWEEP_THREADS + threadIdx.x, sl, e)) {
+                slc[r] = sl * NW + ((u32)w ^ ((sl >> 2) & (NW - 1)));
+                ent[r] = e;
+                atomicAdd(&cnt[slc[r]], 1u);
+            }
         }
         __syncthreads();                                                   // 1: the counts of this window are complete
-        if (w == 0) {
-            // one wave: per slice the exclusive prefix over the waves, the slice totals, their exclusive scan, and the waves'
-            // cursors (slice start + prefix); lane-consecutive slices, so every LDS access is conflict-free (SL <= 448: 7 per lane)
-            const int per = (SL + 63) >> 6;
-            u32 tot[8];
+        u32 v4[4], tsum = 0;
 #pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const int sidx = q * 64 + lane;
-                u32 run = 0;
-                if (q < per && sidx < SL) for (int ww = 0; ww < NW; ww++) run += cnt[ww * SL + sidx];
-                tot[q] = run;
-            }
-            // slices are numbered q * 64 + lane: scan the q-th totals across the lanes, carrying the wave total from q to q + 1
-            u32 carry = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                if (q < per) {
-                    u32 inc = tot[q];
-                    for (int off = 1; off < 64; off <<= 1) { const u32 x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
-                    const u32 start = carry + inc - tot[q];
-                    carry += __shfl(inc, 63, 64);
-                    const int sidx = q * 64 + lane;
-                    if (sidx < SL) {
-                        ls[sidx] = start; stot[sidx] = tot[q];
-                        u32 run = start;
-                        for (int ww = 0; ww < NW; ww++) { const u32 c = cnt[ww * SL + sidx]; cnt[ww * SL + sidx] = run; run += c; }
-                    }
-                }
-            }
-        } else {
-            for (int i = threadIdx.x - 64; i < NW * SL; i += SWEEP_THREADS - 64) cnt_next[i] = 0;
-            if ((int)threadIdx.x >= SWEEP_THREADS - SL) gdst[threadIdx.x - (SWEEP_THREADS - SL)] = my_gofs;      // (the previous window's copy-out is over: barrier 1)
+        for (int e = 0; e < 4; e++) {
+            v4[e] = 0;
+            if (e < ept && base + e < total) { v4[e] = cnt[base + e]; cnt[base + e] = 0; }
+            tsum += v4[e];
         }
-        __syncthreads();                                                   // 2: cursors ready, next window's counters zero
+        u32 inc = tsum;
+        for (int off = 1; off < 64; off <<= 1) { const u32 x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();                                                   // 2: the wave totals of the scan
+        u32 run = inc - tsum;
+#pragma unroll
+        for (int q = 0; q < NW; q++) run += q < w ? wtot[q] : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            if (e < ept && base + e < total) {
+                const int idx = base + e;
+                cur[idx] = run;
+                if ((idx & (NW - 1)) == 0) ls[idx / NW] = run;
+                if ((idx & (NW - 1)) == NW - 1) send[idx / NW] = run + v4[e];
+            }
+            run += v4[e];
+        }
+        if ((int)threadIdx.x >= SWEEP_THREADS - SL) gdst[threadIdx.x - (SWEEP_THREADS - SL)] = my_gofs;      // (the previous window's copy-out is over: barrier 1)
+        __syncthreads();                                                   // 3: cursors, slice starts and ends
 #pragma unroll
         for (int r = 0; r < SWEEP_TPT; r++)
-            if (slc[r] != 0xffffffffu) stage[atomicAdd(&cnt[w * SL + slc[r]], 1u)] = ent[r];
-        __syncthreads();                                                   // 3: the staging buffer holds the entries slice by slice
+            if (slc[r] != 0xffffffffu) stage[atomicAdd(&cur[slc[r]], 1u)] = ent[r];
+        __syncthreads();                                                   // 4: the staging buffer holds the entries slice by slice
         for (int sidx = w; sidx < SL; sidx += NW) {                       // each wave copies whole runs
-            const u32 len = stot[sidx], src = ls[sidx];
+            const u32 src = ls[sidx], len = send[sidx] - src;
             u32 *dst = P1 + (u64)k * n + gdst[sidx];
             for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
         }
@@ -776,6 +789,9 @@ __global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX;
     const int PART_BPS = 1 << g.bps_log2;
+    // (one block per bin: persistent blocks -- two per compute unit, each walking bins b, b + grid, ... -- were tried against the
+    //  4.25 rounds of 512 blocks this grid runs as: 177 us instead of 105; the hardware overlaps a retiring block's copy-out with
+    //  its successor's loads, a loop with barriers does not)
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
     u32 b0, m;
     if (seg_tot) {                                             // segmented counters (k_seg_scan): bin_base = the chunk counters themselves
@@ -1541,7 +1557,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
     const bool use_part = g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
     // (the merged layout of the precomputed tables keeps round 2's digit-matrix kernels: its terms are (window, scalar) pairs)
-    const bool sweep = use_part && !md && (g.half >> g.bps_log2) <= std::min(SWEEP_THREADS - 64, 448) && (g.half >> g.bps_log2) >= SCAN_SEGS;
+    const bool sweep = use_part && !md && (g.half >> g.bps_log2) <= 256 && (g.half >> g.bps_log2) >= SCAN_SEGS;      // (k_sweep_scatter: at most four counters per thread)
     const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = sweep ? SWEEP_CHUNK : part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
     if (use_part) { oP1 = carve((size_t)g.nwin * nc * 4); oCC = carve((size_t)g.nwin * SL * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
@@ -1563,11 +1579,17 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     if (sweep) {
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC);
         uint32_t *bad_blk = (uint32_t *)(ws + oBB);           // one word per chunk (the bin bases of round 2's scan are not needed here)
-        const size_t ldsc = ((size_t)4 * g.nwin * SL + 1) * 4, lds1 = ((size_t)2 * SWEEP_WAVES * SL + 3 * SL + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
+        // counting block: as many waves (each with private counters) as fit LDS -- 48 / 56 / 84 us per 2^21 terms with 16 / 8 / 4
+        const int CT = ((size_t)16 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 1024 : ((size_t)8 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 512 : 256;
+        const size_t ldsc = ((size_t)(CT / 64) * g.nwin * SL + 1) * 4, lds1 = ((size_t)2 * SWEEP_WAVES * SL + 3 * SL + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_sweep_count, dim3(pchunks), dim3(256), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
+        if (CT == 1024) hipLaunchKernelGGL(k_sweep_count<1024>, dim3(pchunks), dim3(1024), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
+        else if (CT == 512) hipLaunchKernelGGL(k_sweep_count<512>, dim3(pchunks), dim3(512), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
+        else hipLaunchKernelGGL(k_sweep_count<256>, dim3(pchunks), dim3(256), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
         hipLaunchKernelGGL(k_seg_scan, dim3(SCAN_SEGS, g.nwin), dim3(256), 0, st, cc, SL * pchunks, seg_tot, bad_blk, pchunks, bad_ws, pl.bad_sticky);
         hipLaunchKernelGGL(k_sweep_scatter, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, cc, seg_tot, P1);
         hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, cc, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst, pchunks, seg_tot);
