@@ -22,7 +22,7 @@
 //   fold      total.mul_by_pow_2(w_k) + column (pippenger.rs:159) over the window sums: on the host, through the
 //             same ge26.h formulas (a serial chain of ~250 doublings is a latency-bound tail that a single CPU core
 //             finishes faster than a single GPU lane), ONCE per call: passes leave their column sums in device slots
-//   passes    inputs beyond 3 * 2^20 terms are cut into passes of ~2^21 terms (the multi-GPU decomposition, in time),
+//   passes    inputs beyond 2.6 M terms are cut into passes of <= 1.75 M terms (the multi-GPU decomposition, in time),
 //             enqueued back to back on two stream sets by one host thread; no pass waits for the host
 //
 // Window width c is chosen per call from n (reference: w = 6/7/8, pippenger.rs:81-87).
@@ -1838,14 +1838,18 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 
 // ---- passes -------------------------------------------------------------------------------------------------------
 // The window width stops at c = 16 (the two-pass sort keeps a (window, slice) bin in LDS), so beyond ~2^22 terms the
-// lists per bucket only get longer: larger inputs are cut into passes of about 2^21 terms -- the same decomposition the
+// lists per bucket only get longer: larger inputs are cut into passes of at most 1.75 M terms -- the same decomposition the
 // multi-GPU path uses across ranks.  This also bounds the workspace (~0.5 GB per stream set) for any n.
 // Passes are independent and nothing in them waits for the host, so ONE host thread deals them alternately to the
 // caller's context and a peer context (own streams and workspaces on the same GPU): the low-VALU two thirds of a pass
 // (normalise, sort, reduce) overlap the accumulation of its neighbour.  (Round 1 used a host thread per stream set and
 // a stream synchronisation + host fold per pass.)
-static const int MSM_PASS_LOG2 = [] { int v = env_int("C25519_MSM_PASS_LOG2", 21); return v < 16 ? 16 : (v > 22 ? 22 : v); }();   // A/B knob: 2^22-term passes measure 17.3 against 16.9 ms per 2^24 terms (the 537 MB point array of a pass is past the MALL: k_accumulate 2.76 ms per 2^22 terms against 2 x 1.22)
-static const uint64_t MSM_PASS = 1ull << MSM_PASS_LOG2, MSM_PASS_MAX = 3ull << (MSM_PASS_LOG2 - 1);
+// Pass size: the 128-byte gather records of a pass should stay resident in the 256 MiB MALL while k_accumulate gathers each of
+// them 16 times -- 1.75 M terms = 224 MB (2^21 terms = 268 MB spill: k_accumulate 0.61 - 0.62 ns per term against 0.59 - 0.60, the
+// 2^24-term call 14.32 - 14.54 ms in 8 passes against 14.10 - 14.18 in 10, profiles/r03_ab_pass_size.txt; with the bucket
+// continuation a pass more costs a sort's fixed part, not a reduction).  C25519_MSM_PASS_LOG2 (tests: many small passes) overrides.
+static const uint64_t MSM_PASS = []() -> uint64_t { const char *e = getenv("C25519_MSM_PASS_LOG2"); if (!e) return (uint64_t)1750000; int v = atoi(e); return 1ull << (v < 16 ? 16 : (v > 22 ? 22 : v)); }();
+static const uint64_t MSM_PASS_MAX = MSM_PASS + MSM_PASS / 2;
 static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
 
 struct pass_set { c25519_ctx *c[4]; int lanes; };

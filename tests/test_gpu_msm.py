@@ -235,9 +235,9 @@ def test_msm_kernel_variants_in_a_fresh_process(orc, env):
 
 
 def test_msm_two_passes_odd_size(eng, orc):
-    """3*2^20 + 17 terms: two passes of unequal length (msm.hip MSM_PASS_MAX), partial sums added on the host."""
+    """just past the single-pass limit (msm.hip MSM_PASS_MAX = 2 625 000 terms): two passes of unequal length, column sums added on the device."""
     import torch
-    n = (3 << 20) + 17
+    n = 2625000 + 17
     g = torch.Generator(device="cuda"); g.manual_seed(31337)
     dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
     dx[:, 31] &= 0x0F
@@ -273,10 +273,10 @@ def test_msm_maximally_skewed_digits(eng, orc, log2n):
     assert st == 0 and got == want2
 
 
-@pytest.mark.parametrize("n", [65535, 65536, 65537, (1 << 17) + 3, (1 << 18) + 5, (1 << 19) - 3, (1 << 20) - 1, (3 << 20), (3 << 20) + 1])
+@pytest.mark.parametrize("n", [65535, 65536, 65537, (1 << 17) + 3, (1 << 18) + 5, (1 << 19) - 3, (1 << 20) - 1, 2625000, 2625001, (3 << 20) + 1])
 def test_msm_window_and_path_boundaries(eng, orc, n):
     """Sizes at which the window width, the sort path (one-pass below 2^16 terms or c < 13, two-pass partition sort
-    above) and the pass splitting (above 3 * 2^20) change: sum-of-squares identity on device-generated points."""
+    above) and the pass splitting (above 2 625 000 terms) change: sum-of-squares identity on device-generated points."""
     import torch
     g = torch.Generator(device="cuda"); g.manual_seed(77 + n)
     dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
