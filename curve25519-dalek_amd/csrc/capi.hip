@@ -534,6 +534,15 @@ EXPORT int32_t c25519_x25519_base_batch(c25519_ctx *ctx, const uint8_t *k, uint6
     return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 18), &in, 1, &o, 1,
                         [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_x25519_base_batch_dev(ctx, d_in + lo * 32, m, d_out + lo * 32); });
 }
+// the ladder + the batched division for n units on stream st; scratch / prefix: n x 128 / n x 48 bytes of the caller's
+static int32_t x25519_enqueue(c25519_ctx *ctx, hipStream_t st, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint32_t *scratch, uint32_t *prefix, uint8_t *d_out, hipEvent_t *ring) {
+    if (ring) HIPCHK(hipEventRecord(ring[0], st));
+    HIPCHK(launch_x25519(d_k, d_u, n, scratch, st));
+    if (ring) HIPCHK(hipEventRecord(ring[1], st));
+    HIPCHK(launch_ratio_p32(0, scratch, prefix, n, d_out, st));   // U / W, 0 -> 0
+    if (ring) HIPCHK(hipEventRecord(ring[2], st));
+    return C25519_OK;
+}
 EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, const uint8_t *d_u, uint64_t n, uint8_t *d_out) {
     HIPCHK(hipSetDevice(ctx->device));
     int32_t r;
@@ -542,12 +551,8 @@ EXPORT int32_t c25519_x25519_batch_dev(c25519_ctx *ctx, const uint8_t *d_k, cons
     wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48);
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
-    HIPCHK(hipEventRecord(ring[0], ctx->stream));
     ctx->kname[0] = "c25519::k_x25519";
-    HIPCHK(launch_x25519(d_k, d_u, n, (uint32_t *)ctx->scratch.p, ctx->stream));
-    HIPCHK(hipEventRecord(ring[1], ctx->stream));
-    HIPCHK(launch_ratio_p32(0, (const uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, n, d_out, ctx->stream));   // U / W, 0 -> 0
-    HIPCHK(hipEventRecord(ring[2], ctx->stream));
+    if ((r = x25519_enqueue(ctx, ctx->stream, d_k, d_u, n, (uint32_t *)ctx->scratch.p, (uint32_t *)ctx->prefix.p, d_out, ring))) return r;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     return C25519_OK;
 }
@@ -572,14 +577,26 @@ static int32_t x25519_host(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, 
     int32_t r;
     if ((r = reserve2(ctx, ctx->tmp_a, n * 32, ctx->tmp_b, n * 32)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 33 + 16))) return r;
     uint8_t *d_k = (uint8_t *)ctx->tmp_a.p, *d_u = (uint8_t *)ctx->tmp_b.p, *d_out = (uint8_t *)ctx->tmp_c.p, *d_fl = d_out + n * 32;
+    if ((r = ctx_reserve(ctx, ctx->scratch, n * 128)) || (r = ctx_reserve(ctx, ctx->prefix, n * 48))) return r;
     stream_wipe wipe(ctx->stream);
     wipe.add(d_k, n * 32);                                // the staged secret scalars ...
-    wipe.add(d_out, n * 32);                              // ... and the shared secrets, on every path
+    wipe.add(d_out, n * 32);                              // ... the shared secrets ...
+    wipe.add(ctx->scratch.p, n * 128); wipe.add(ctx->prefix.p, n * 48);      // ... and their projective forms, on every path
     const ffi_in in[2] = {{k, d_k, 32}, {u, d_u, 32}};
     const ffi_out o[2] = {{out, d_out, 32}, {contributory, d_fl, 1}};
-    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 18), in, 2, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
-        return c25519_x25519_contributory_batch_dev(ctx, d_k + lo * 32, d_u + lo * 32, m, d_out + lo * 32, contributory ? d_fl + lo : nullptr);
-    });
+    // chunks alternate between the context's two streams (each with its own slice of the scratch): 2^20 ladders host to host in
+    // 10.6 ms when the chunks' kernels follow each other (8.9 ms of kernel for the whole batch in one launch), see profiles
+    // ... and are tapered: 1/8, 3/8, 3/8, 1/8 of the batch (what is not hidden is the first upload and the last download, and a ladder
+    // kernel wants a large launch: 2^20 ladders in 9.6 ms this way, 10.0 in eight equal chunks, 11.0 in four; the whole batch in one
+    // launch is 8.9 ms of kernel; profiles/r03_x25519_ffi_shapes.txt)
+    const bool xtaper = n >= (1u << 19);
+    return ffi_pipeline(ctx, n, xtaper ? (((n / 2) + 1023) & ~(uint64_t)1023) : ffi_chunk_units(n, 1u << 17), in, 2, o, 2, [&](uint64_t lo, uint64_t m, hipStream_t st) -> int32_t {
+        int32_t rr = x25519_enqueue(ctx, st, d_k + lo * 32, d_u + lo * 32, m, (uint32_t *)ctx->scratch.p + lo * 32, (uint32_t *)ctx->prefix.p + lo * 12, d_out + lo * 32, nullptr);
+        if (rr || !contributory) return rr;
+        hipLaunchKernelGGL(k_nonzero32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, d_out + lo * 32, m, d_fl + lo);
+        HIPCHK(hipGetLastError());
+        return C25519_OK;
+    }, false, 0, xtaper);
 }
 EXPORT int32_t c25519_x25519_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out) { return x25519_host(ctx, k, u, n, out, nullptr); }
 EXPORT int32_t c25519_x25519_contributory_batch(c25519_ctx *ctx, const uint8_t *k, const uint8_t *u, uint64_t n, uint8_t *out, uint8_t *contributory) {
