@@ -1528,6 +1528,7 @@ struct msm_plan {
     msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
     uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs, *bad_ws, *bad_sticky = nullptr; long_item *items;
     hipStream_t sort_stream;
+    bool beside_lds_kernel = false;      // in: the sort runs beside a kernel that holds most of a compute unit's LDS (verify_batch: the decompression of R_i)
 };
 // md (may be null): merged layout -- d_scalars holds n_scalars scalars, the sort runs over md->K * md->ns digit-terms
 // n_carve (0 = n): the number of terms the workspace is carved for -- passes that CONTINUE each other's bucket sums (msm_record_enqueue)
@@ -1580,7 +1581,9 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC);
         uint32_t *bad_blk = (uint32_t *)(ws + oBB);           // one word per chunk (the bin bases of round 2's scan are not needed here)
         // counting block: as many waves (each with private counters) as fit LDS -- 48 / 56 / 84 us per 2^21 terms with 16 / 8 / 4
-        const int CT = ((size_t)16 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 1024 : ((size_t)8 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 512 : 256;
+        // (verify_batch sorts beside the decompression of R_i, two blocks per compute unit with 64 KB of LDS reserved each: only the
+        //  four-wave block, 35 KB, finds room there -- the pass's kernels span 2.78 ms instead of 2.93)
+        const int CT = pl.beside_lds_kernel ? 256 : ((size_t)16 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 1024 : ((size_t)8 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 512 : 256;
         const size_t ldsc = ((size_t)(CT / 64) * g.nwin * SL + 1) * 4, lds1 = ((size_t)2 * SWEEP_WAVES * SL + 3 * SL + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
@@ -1673,8 +1676,9 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     return C25519_OK;
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr) {
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr, bool beside_lds_kernel = false) {
     msm_plan pl;
+    pl.beside_lds_kernel = beside_lds_kernel;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
@@ -2213,7 +2217,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     HIPCHK(hipGetLastError());
     if (stage && d_pk_points && (r = prep_A())) return r;   // the keys' points come last: only the accumulation needs them
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
-    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc, true);
 }
 // Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
 // 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
