@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(1024) k_scatter(const uint16_t *__restrict__ D
 // offsets, all coalesced.  Intermediate entry: bucket_low8 << 24 | sign << 23 | term index (n <= 2^23).
 // ================================================================================================
 constexpr int PART_BPS_MAX = 256;        // buckets per slice: 2^g.bps_log2 <= this, chosen so that a bin holds ~16 K entries
-constexpr int PART_CAP = 18432;          // bin capacity of the LDS path of pass 2 (mean <= 16384; larger bins take the global path)
+constexpr int PART_CAP = 17408;          // bin capacity of the LDS path of pass 2 (mean <= 16384, sigma 128; larger bins take the global path)
 // terms per pass-1 block: the staging buffer (4 bytes per term) plus 18 counters per slice must leave room for two blocks
 // per CU (2 x 80 KB of the 160 KB LDS)
 static inline int part_chunk(int SL) { return SL <= 128 ? 16384 : 15360; }
@@ -505,13 +505,21 @@ __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ 
 // terms) and then read it twice, window-major (k_part_hist: slice counts per chunk; k_part1: the partition) -- 277 MB
 // and three launches before the first entry reaches its slice; and k_digits indexed its scalar words with a runtime
 // window position, i.e. through scratch (0.10 ms for 135 MB).  Here a block owns a CHUNK of terms for ALL windows: a lane
-// keeps SWEEP_TPT scalars (s' = s + addk, nine words each) in registers and treats each as a shift register -- the window
+// keeps SWEEP_TPT scalars (s' = s + addk, eight words each) in registers and treats each as a shift register -- the window
 // layout is contiguous (msm_layout: pos[k+1] = pos[k] + wid[k]), so window k is always the low wid[k] bits and the next
 // window arrives by a funnel shift with a wave-uniform amount: no dynamic register index, no digit matrix.
-//   k_sweep_count    slice counts of every (window, slice) for this chunk   (64 MB in; cc out)
-//   k_part_scan      unchanged
-//   k_sweep_scatter  per window: count per wave and slice, scan, stage the entries by slice in LDS, copy whole runs out
-//                    (the body of round 2's k_part1 inside the window loop; 64 MB in, 143 MB out)
+//
+// The partition is CHUNK-LOCAL (third form of round 3).  The first two forms gave every (window, slice, chunk) run its exact place
+// in a global (window, slice)-major array, which needs all chunks' counts before any chunk can write: a counting kernel over the
+// same scalars (k_sweep_count, 48 - 104 us), a scan of its 557 K counters (k_seg_scan), and a scatter kernel that fetched 128 run
+// offsets per window and copied 128 runs of ~256 bytes out (k_sweep_scatter, 136 - 173 us, 13 spilled registers).  Now
+//   k_sweep_local   per window: count per wave and slice, block-wide scan, stage the entries by slice in LDS -- and write the staging
+//                   buffer out AS IT IS, one contiguous block per (window, chunk), with its 129 slice starts     (97 us per 2^21 terms)
+//   k_bin_totals    entries per (window, slice) bin = its run lengths added over the chunks                      (6 us)
+//   k_part2g        pass 2 GATHERS a bin's runs from the chunks' blocks (one 256-byte segment per chunk)        (134 us; 105 - 112 with
+//                   contiguous bins)
+//   k_order_place   unchanged                                                                                     (26 us)
+// 263 us instead of 331 (363 at the start of the round, 560 in round 2), four launches instead of five.
 // Deterministic like the kernels they replace (offsets come from exact counts, not from atomics on a global cursor).
 constexpr int SWEEP_TPT = 8, SWEEP_THREADS = 1024, SWEEP_WAVES = SWEEP_THREADS / 64, SWEEP_CHUNK = SWEEP_THREADS * SWEEP_TPT;
 // (eight words per scalar: s' = s + addk < 2^256 whenever bit 255 of s is clear, and a scalar with bit 255 set fails the call
@@ -538,173 +546,44 @@ __device__ __forceinline__ u32 sweep_take(sweep_regs &R, int r, int wd) {
     R.s[r][7] >>= wd;
     return v;
 }
-// Counting: LDS atomics of many waves on ONE set of counters serialise badly (a 1024-thread block per chunk with shared
-// counters: 297 us per 2^21 terms), private counters per wave do not.  A chunk is counted by one block of CT / 64 waves, each
-// wave with its own [window][slice] counters: as many waves as LDS allows (16 x 17 x 128 x 4 B = 139 KB at c = 16: the grid is one
-// block per compute unit, so what matters is how many waves share the chunk: 84 / 56 / 48 us with 4 / 8 / 16).
-__device__ __forceinline__ u32 take8(u32 s[8], int wd) {
-    const u32 v = s[0] & ((1u << wd) - 1u);
-#pragma unroll
-    for (int i = 0; i < 7; i++) s[i] = __funnelshift_r(s[i], s[i + 1], (u32)wd);
-    s[7] >>= wd;
-    return v;
-}
-// zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket
-// counters) -- zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain
-// waits 30 - 180 us for a dispatch slot.  bad_blk[j] = 1 if a scalar of chunk j has bit 255 set (k_seg_scan ORs them into one
-// word, the bucket reduction ORs that into the result slot: the sort itself never touches the slot).
-template <int CT>                                            // threads per block: CT / 64 waves, each with its own counters
-__global__ void __launch_bounds__(CT) k_sweep_count(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, int nchunk, u32 *__restrict__ cc, u32 *__restrict__ bad_blk,
-                                                    u32 *__restrict__ zero_words, int nzero) {
-    C25519_PRIO_CHAIN();
-    constexpr int CW = CT / 64;
-    extern __shared__ u32 sm[];                               // [CW waves][nwin][SL] + 1
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += CT) zero_words[i] = 0;
-    const int j = blockIdx.x, NC = g.nwin * SL, w = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i <= CW * NC; i += CT) sm[i] = 0;
-    __syncthreads();
-    u32 *mine = sm + w * NC, *bad = sm + CW * NC;
-    const u64 lo = (u64)blockIdx.x * SWEEP_CHUNK;
-    constexpr int B = 8;                                      // scalars in flight per lane; SWEEP_CHUNK / CT per lane in all
-#pragma unroll 1
-    for (int r0 = 0; r0 < SWEEP_CHUNK / CT; r0 += B) {
-        u32 s[B][8];
-#pragma unroll
-        for (int r = 0; r < B; r++) {
-            const u64 t = lo + (u64)(r0 + r) * CT + threadIdx.x;
-            u32 wv[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (t < n) load8(scalars, t, wv);
-            if (wv[7] >> 31) *bad = 1u;
-            u32 carry = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { const u64 v = (u64)wv[i] + g.addk[i] + carry; s[r][i] = (u32)v; carry = (u32)(v >> 32); }
-        }
-#pragma unroll 1
-        for (int k = 0; k < g.nwin; k++) {
-            const int wd = g.wid[k];
-#pragma unroll
-            for (int r = 0; r < B; r++) {
-                u32 sl, e;
-                if (part_entry(take8(s[r], wd), k, g, 0u, sl, e)) atomicAdd(&mine[k * SL + sl], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < NC; i += CT) {             // i = k * SL + slice
-        u32 v = 0;
-#pragma unroll
-        for (int q = 0; q < CW; q++) v += sm[q * NC + i];
-        cc[(u64)i * nchunk + j] = v;
-    }
-    if (threadIdx.x == 0) bad_blk[j] = *bad;
-}
-// Segmented scan of the chunk counters: the M = SL x nchunk counters of a window are cut into SCAN_SEGS segments, one 256-thread
-// block each (the scan of a window no longer grows with the number of chunks, and every block fits the hole one retiring
-// k_accumulate block leaves); a block leaves the exclusive scan of ITS segment in place and the segment total in seg_tot.
-// Consumers add the totals of the segments before theirs (seg_offset): eight loads of words that stay in L2.
-constexpr int SCAN_SEGS = 8;
-__global__ void __launch_bounds__(256) k_seg_scan(u32 *__restrict__ cc, int M, u32 *__restrict__ seg_tot, const u32 *__restrict__ bad_blk, int nchunk, u32 *__restrict__ bad_ws, u32 *__restrict__ bad_sticky) {
-    C25519_PRIO_CHAIN();
-    if (blockIdx.x == 0 && blockIdx.y == 0) {                  // one word out of the chunks' bad-scalar flags (bad_sticky: ORed over the passes of a call)
-        u32 any = 0;
-        for (int i = threadIdx.x; i < nchunk; i += 256) any |= bad_blk[i];
-        any = __syncthreads_or((int)any);
-        if (threadIdx.x == 0) { *bad_ws = any ? 1u : 0u; if (any && bad_sticky) atomicOr(bad_sticky, 1u); }
-    }
-    __shared__ u32 tile[SCAN_TILE + SCAN_TILE / 32];
-    __shared__ u32 wsum[4];
-    const int gseg = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, seglen = M / SCAN_SEGS;
-    u32 *v = cc + (u64)k * M + (u64)gseg * seglen;
-    u32 carry = 0;
-#pragma unroll 1
-    for (int t0 = 0; t0 < seglen; t0 += SCAN_TILE) {
-#pragma unroll
-        for (int r = 0; r < SCAN_PER; r++) { const int a = r * 256 + tid, e = t0 + a; tile[a + (a >> 5)] = e < seglen ? v[e] : 0u; }
-        __syncthreads();
-        u32 x[SCAN_PER], sum = 0;
-#pragma unroll
-        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; x[q] = tile[a + (a >> 5)]; sum += x[q]; }
-        u32 inc = sum;
-        for (int off = 1; off < 64; off <<= 1) { const u32 y = __shfl_up(inc, off, 64); if (lane >= off) inc += y; }
-        if (lane == 63) wsum[w] = inc;
-        __syncthreads();
-        u32 wbase = 0, total = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { const u32 ws = wsum[i]; wbase += i < w ? ws : 0u; total += ws; }
-        u32 run = carry + wbase + inc - sum;
-#pragma unroll
-        for (int q = 0; q < SCAN_PER; q++) { const int a = tid * SCAN_PER + q; tile[a + (a >> 5)] = run; run += x[q]; }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < SCAN_PER; r++) { const int a = r * 256 + tid, e = t0 + a; if (e < seglen) v[e] = tile[a + (a >> 5)]; }
-        carry += total;
-        __syncthreads();
-    }
-    if (tid == 0) seg_tot[k * SCAN_SEGS + gseg] = carry;
-}
-// offset of counter idx of a window: its scanned value within its segment + the totals of the segments before it
-__device__ __forceinline__ u32 seg_offset(const u32 *__restrict__ cc_k, const u32 *__restrict__ seg_tot_k, u32 idx, u32 seglen) {
-    u32 v = cc_k[idx];
-    const u32 sg = idx / seglen;
-#pragma unroll
-    for (u32 q = 0; q < (u32)SCAN_SEGS; q++) v += q < sg ? seg_tot_k[q] : 0u;
-    return v;
-}
-__device__ __forceinline__ u32 seg_total(const u32 *__restrict__ seg_tot_k) {
-    u32 v = 0;
-#pragma unroll
-    for (int q = 0; q < SCAN_SEGS; q++) v += seg_tot_k[q];
-    return v;
-}
-// Block shape, measured in round 3 (2^24 terms, one box, profiles/r03_sort_block_shapes.txt): 1024 threads x 8 scalars (chunks of 8192
-// terms, runs of ~64 entries) 14.5 - 14.8 ms; 512 threads 14.6; 256 threads with a 256-thread k_part2 16.0.  Beside k_accumulate
-// (three waves of 168 VGPRs per SIMD = 504 of 512 registers) a block only starts in the holes retiring accumulate blocks leave, and
-// small blocks do start sooner -- but the work of a call is conserved, not hidden: what counts is how long the sort takes ALONE
-// (363 us per 2^21 terms in this form, 710 us in the 256-thread forms), so the shapes that are fastest alone are kept.
-// (verify_batch, where the sort runs beside the decompression of R_i -- capped at two waves per SIMD, so a 256-thread block does
-//  co-reside -- was tried with 256-thread sort kernels as well: the decompression stretched from 1.29 to 1.53 ms and the call from
-//  2.88 to 2.96 ms.  Same conclusion.)
-__global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, const u32 *__restrict__ cc, const u32 *__restrict__ seg_tot,
-                                                                 u32 *__restrict__ P1) {
+// k_sweep_local: the staging buffer of (window k, chunk j) -- the chunk's entries grouped by slice -- goes to
+// P1[k * wstride + j * SWEEP_CHUNK ..] and the slice starts to lsg[(k * (SL + 1) + s) * nchunk + j] (s = SL: the number of entries).
+// The (slice, wave) counters live in ONE flat array, slice-major: counter (s, w) at s * NW + (w ^ ((s >> 2) & (NW - 1))) -- the order of
+// the waves inside a slice does not matter, and this swizzle spreads a wave's counters of 64 consecutive slices over all 64 banks.
+// In that order the counters ARE the layout of the staging buffer, so the cursors are a plain block-wide exclusive scan by all
+// sixteen waves (first form: wave 0 walked all waves' counters of every slice -- 32 dependent LDS accesses per slice while fifteen
+// waves idled; a build with the scan disabled put it at 45 us of 150).  Four barriers per window; a software-pipelined form with
+// three (window k-1 staged while window k is counted) measured the same: the kernel's time is two LDS atomics per entry and
+// their latency, not barriers.  Per-wave counters because LDS atomics of many waves on one set of counters serialise (a counting
+// kernel with shared counters: 297 us against 48).
+// zero_words: the small counters of the kernels further down the chain (bucket-order histogram and cursors, long-bucket counters) --
+// zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain waits 30 - 180 us for
+// a dispatch slot.  bad_blk[j] = 1 if a scalar of chunk j has bit 255 set (k_bin_totals ORs them into one word, the bucket
+// reduction ORs that into the result slot: the sort itself never touches the slot).
+__global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_local(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, u32 *__restrict__ lsg, u32 *__restrict__ bad_blk,
+                                                               u32 *__restrict__ P1, u64 wstride, u32 *__restrict__ zero_words, int nzero) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     constexpr int NW = SWEEP_WAVES;
-    // per-(slice, wave) counters in ONE flat array, slice-major: counter (s, w) at s * NW + (w ^ ((s >> 2) & (NW - 1))) -- the order of
-    // the waves inside a slice does not matter, and this swizzle spreads a wave's counters of 64 consecutive slices over all 64 banks.
-    // In that order the counters ARE the layout of the staging buffer, so the cursors are simply the exclusive scan of the flat array.
-    u32 *cnt = sm;                         // [SL * NW]: counts of the current window (a wave only ever adds to its own counters)
-    u32 *cur = sm + NW * SL;               // [SL * NW]: cursors into the staging buffer
-    u32 *ls = sm + 2 * NW * SL;            // [SL]: start of each slice in the staging buffer
-    u32 *send = ls + SL;                   // [SL]: its end
-    u32 *gdst = send + SL;                 // [SL]: where this chunk's run of each slice goes in P1 (prefetched: a wave that fetched
-                                           //       the offset of each of its runs right before copying it paid a global-load latency per run)
-    u32 *stage = gdst + SL;                // [SWEEP_CHUNK]
+    u32 *cnt = sm;                         // [SL * NW], slice-major with the bank swizzle (above)
+    u32 *cur = sm + NW * SL;               // [SL * NW]
+    u32 *ls = sm + 2 * NW * SL;            // [SL + 1]: start of each slice in the staging buffer, then the number of entries
+    u32 *stage = ls + SL + 1;              // [SWEEP_CHUNK]
     __shared__ u32 wtot[NW];
+    __shared__ u32 sbad;
     const int j = blockIdx.x, nchunk = gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const u32 seglen = (u32)(SL * nchunk) / SCAN_SEGS;
-    const u64 lo = (u64)j * SWEEP_CHUNK;
-    sweep_regs R;
-    sweep_load(scalars, n, lo, g, R, nullptr);
-    const int total = NW * SL, ept = total >= SWEEP_THREADS ? total / SWEEP_THREADS : 1;      // 1, 2 or 4 counters per thread (SL <= 256)
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += SWEEP_THREADS) zero_words[i] = 0;
+    if (threadIdx.x == 0) sbad = 0;
+    const int total = NW * SL, ept = total >= SWEEP_THREADS ? total / SWEEP_THREADS : 1;
     const int base = (int)threadIdx.x * ept;
     for (int i = threadIdx.x; i < total; i += SWEEP_THREADS) cnt[i] = 0;
     __syncthreads();
-    // Four barriers per window.  (1) counts complete -> block-wide exclusive scan of the flat counter array by ALL threads (ept
-    // consecutive counters each, one wave scan by shuffles, wave totals through LDS: barrier 2) -> cursors, slice starts and ends
-    // (3) -> staging (4) -> copy-out.  Round 3's first form let wave 0 walk all sixteen waves' counters of every slice (32 dependent LDS
-    // accesses per slice while fifteen waves idled), the second let every wave do that for itself: 45 us of a 150 us kernel either
-    // way (a build with the phase disabled).  A software-pipelined form with three barriers per window -- window k-1 staged while
-    // window k is counted, copied out while the counters of window k are scanned -- measures the same as this one (144 / 137 us on
-    // two boxes): the kernel's time is LDS atomics (two per entry) and their latency, not barriers.  The counters are zeroed by
-    // the scan itself.  A barrier that every wave has passed
-    // also says that every wave has finished the previous window, so the copy-out of window k-1 needs no barrier of its own: nothing
-    // it reads (stage, ls, send, gdst) is written before barrier 1 of window k.
+    const u64 lo = (u64)j * SWEEP_CHUNK;
+    sweep_regs R;
+    sweep_load(scalars, n, lo, g, R, &sbad);
 #pragma unroll 1
     for (int k = 0; k < g.nwin; k++) {
         const int wd = g.wid[k];
-        u32 my_gofs = 0;                                                   // in flight during the counting (SL <= SWEEP_THREADS - 64: never a lane of wave 0)
-        if ((int)threadIdx.x >= SWEEP_THREADS - SL)
-            my_gofs = seg_offset(cc + (u64)k * SL * nchunk, seg_tot + k * SCAN_SEGS, (u32)(threadIdx.x - (SWEEP_THREADS - SL)) * (u32)nchunk + (u32)j, seglen);
         u32 ent[SWEEP_TPT], slc[SWEEP_TPT];
 #pragma unroll
         for (int r = 0; r < SWEEP_TPT; r++) {
@@ -717,7 +596,7 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *
                 atomicAdd(&cnt[slc[r]], 1u);
             }
         }
-        __syncthreads();                                                   // 1: the counts of this window are complete
+        __syncthreads();                                                   // 1: the counts of this window are complete (and the previous window has left the staging buffer)
         u32 v4[4], tsum = 0;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -738,22 +617,42 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_scatter(const uint8_t *
                 const int idx = base + e;
                 cur[idx] = run;
                 if ((idx & (NW - 1)) == 0) ls[idx / NW] = run;
-                if ((idx & (NW - 1)) == NW - 1) send[idx / NW] = run + v4[e];
+                if (idx == total - 1) ls[SL] = run + v4[e];
             }
             run += v4[e];
         }
-        if ((int)threadIdx.x >= SWEEP_THREADS - SL) gdst[threadIdx.x - (SWEEP_THREADS - SL)] = my_gofs;      // (the previous window's copy-out is over: barrier 1)
-        __syncthreads();                                                   // 3: cursors, slice starts and ends
+        __syncthreads();                                                   // 3: cursors and slice starts
 #pragma unroll
         for (int r = 0; r < SWEEP_TPT; r++)
             if (slc[r] != 0xffffffffu) stage[atomicAdd(&cur[slc[r]], 1u)] = ent[r];
         __syncthreads();                                                   // 4: the staging buffer holds the entries slice by slice
-        for (int sidx = w; sidx < SL; sidx += NW) {                       // each wave copies whole runs
-            const u32 src = ls[sidx], len = send[sidx] - src;
-            u32 *dst = P1 + (u64)k * n + gdst[sidx];
-            for (u32 i = lane; i < len; i += 64) dst[i] = stage[src + i];
-        }
+        const u32 tot = ls[SL];
+        u32 *dst = P1 + (u64)k * wstride + (u64)j * SWEEP_CHUNK;
+        for (u32 i = threadIdx.x; i < tot; i += SWEEP_THREADS) dst[i] = stage[i];
+        if ((int)threadIdx.x <= SL) lsg[((u64)k * (SL + 1) + threadIdx.x) * nchunk + j] = ls[threadIdx.x];
     }
+    if (threadIdx.x == 0) bad_blk[j] = sbad;
+}
+// entries of every (window, slice) bin: one wave per bin adds the run lengths over the chunks.  Block 0 also folds the chunks'
+// bad-scalar flags into one word (bad_sticky: ORed over the passes of a call).
+__global__ void __launch_bounds__(256) k_bin_totals(const u32 *__restrict__ lsg, int nchunk, int SL, int nbins, u32 *__restrict__ binm, const u32 *__restrict__ bad_blk,
+                                                    u32 *__restrict__ bad_ws, u32 *__restrict__ bad_sticky) {
+    C25519_PRIO_CHAIN();
+    if (blockIdx.x == 0) {
+        u32 any = 0;
+        for (int i = threadIdx.x; i < nchunk; i += 256) any |= bad_blk[i];
+        any = __syncthreads_or((int)any);
+        if (threadIdx.x == 0) { *bad_ws = any ? 1u : 0u; if (any && bad_sticky) atomicOr(bad_sticky, 1u); }
+    }
+    const int bin = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (bin >= nbins) return;
+    const int k = bin / SL, s = bin % SL;
+    const u32 *row0 = lsg + ((u64)k * (SL + 1) + s) * nchunk, *row1 = row0 + nchunk;
+    u32 sum = 0;
+    for (int j = lane; j < nchunk; j += 64) sum += row1[j] - row0[j];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) sum += (u32)__shfl_xor((int)sum, d, 64);
+    if (lane == 0) binm[bin] = sum;
 }
 
 // a long bucket's list is cut into segments of LONG_SEG entries: one work item each (k_long_segments)
@@ -784,7 +683,7 @@ constexpr int PART_R = PART_CAP / 1024;
 __global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 n, msm_geom g, int SL, const u32 *__restrict__ bin_base,
                                                 u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted,
                                                 u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items, u32 *__restrict__ counters,
-                                                u32 *__restrict__ long_gids, u32 *__restrict__ long_first, int nchunk, const u32 *__restrict__ seg_tot) {
+                                                u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX;
@@ -794,14 +693,7 @@ __global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 
     //  its successor's loads, a loop with barriers does not)
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x;
     u32 b0, m;
-    if (seg_tot) {                                             // segmented counters (k_seg_scan): bin_base = the chunk counters themselves
-        const u32 *cc_k = bin_base + (u64)k * SL * nchunk, *st_k = seg_tot + k * SCAN_SEGS;
-        const u32 seglen = (u32)(SL * nchunk) / SCAN_SEGS;
-        b0 = seg_offset(cc_k, st_k, (u32)sidx * (u32)nchunk, seglen);
-        const u32 b1 = sidx + 1 < SL ? seg_offset(cc_k, st_k, (u32)(sidx + 1) * (u32)nchunk, seglen) : seg_total(st_k);
-        m = b1 - b0;
-        if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b1;      // number of entries of the window
-    } else { b0 = bin_base[(u64)k * (SL + 1) + sidx]; m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0; }
+    b0 = bin_base[(u64)k * (SL + 1) + sidx]; m = bin_base[(u64)k * (SL + 1) + sidx + 1] - b0;
     const u32 *src = P1 + (u64)k * n + b0;
     u32 *dst = sorted + (u64)k * n + b0;
     const bool fits = m <= (u32)PART_CAP;
@@ -865,6 +757,144 @@ __global__ void __launch_bounds__(1024) k_part2(const u32 *__restrict__ P1, u64 
                 pos = atomicAdd(&cur[bk], 1u);
             }
             if (have) dst[pos] = (ev & 0x7fffffu) | ((ev & (1u << 23)) << 8);
+        }
+    }
+}
+
+
+// pass 2 of the chunk-local form: the bin's entries are gathered from the chunks' blocks.  Wave w takes chunks w, w + 16, ...; a run
+// of a chunk is read in pieces of 64 entries (one 256-byte segment); the pieces of a wave are listed in LDS once and walked twice --
+// to count, and (from L2 now) to place: 32 pieces in registers with static indices need more than the 64 VGPRs two 1024-thread
+// blocks per compute unit leave a lane (42 spilled).  A bin with more than P2G_ITER pieces per wave or more than PART_CAP entries --
+// heavily skewed digits -- walks its chunks without the list and places its entries straight into the sorted array.
+constexpr int P2G_ITER = 48;
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
+k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int nchunk, const u32 *__restrict__ lsg, const u32 *__restrict__ binm,
+         u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted,
+         u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items, u32 *__restrict__ counters,
+         u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
+    C25519_PRIO_CHAIN();
+    extern __shared__ u32 sm[];
+    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX, *wl = out + PART_CAP;      // wl[16][P2G_ITER]
+    __shared__ u32 red[16];
+    __shared__ u32 s_over;
+    const int PART_BPS = 1 << g.bps_log2;
+    const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // the bin's place in the window's sorted list = the entries of the bins before it (SL <= 256 <= the block)
+    {
+        u32 part = tid < sidx ? binm[(u64)k * SL + tid] : 0u;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) part += (u32)__shfl_xor((int)part, d, 64);
+        if (lane == 0) red[w] = part;
+    }
+    if (tid < PART_BPS) cnt[tid] = 0;
+    if (tid < 256) oh[tid] = 0;
+    if (tid == 0) s_over = 0;
+    __syncthreads();
+    u32 b0 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) b0 += red[q];
+    const u32 m = binm[(u64)k * SL + sidx];
+    if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b0 + m;      // number of entries of the window
+    const u32 *row0 = lsg + ((u64)k * (SL + 1) + sidx) * nchunk, *row1 = row0 + nchunk;
+    const u32 *src = P1 + (u64)k * wstride;
+    u32 *dst = sorted + (u64)k * n + b0;
+    // this wave's pieces: (offset in the window's P1 region) << 7 | entries in the piece
+    int nslots = 0;
+    for (int j0 = 0; j0 < nchunk; j0 += 16 * 64) {
+        const int j = j0 + w + 16 * lane;
+        u32 st = 0, len = 0;
+        if (j < nchunk) { st = row0[j]; len = row1[j] - st; }
+        const u32 np = (len + 63u) >> 6;
+        u32 inc = np;
+        for (int off = 1; off < 64; off <<= 1) { const u32 x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
+        const u32 first = (u32)nslots + inc - np;
+        for (u32 p = 0; p < np; p++)
+            if (first + p < (u32)P2G_ITER) wl[w * P2G_ITER + first + p] = (((u32)j * (u32)SWEEP_CHUNK + st + 64u * p) << 7) | (len - 64u * p < 64u ? len - 64u * p : 64u);
+        nslots += (int)__shfl(inc, 63, 64);
+    }
+    if (nslots > P2G_ITER && lane == 0) s_over = 1u;
+    __syncthreads();
+    const bool fits = m <= (u32)PART_CAP && !s_over;
+    if (fits) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < nslots; t0 += 8) {                         // eight pieces in flight
+            u32 ev[8];
+            bool ok[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const u32 d = t0 + q < nslots ? wl[w * P2G_ITER + t0 + q] : 0u;
+                ok[q] = (u32)lane < (d & 127u);
+                ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (ok[q]) atomicAdd(&cnt[ev[q] >> 24], 1u);
+        }
+    } else {
+        for (int j = w; j < nchunk; j += 16) {
+            const u32 st = row0[j], en = row1[j];
+            for (u32 o = st + lane; o < en; o += 64) atomicAdd(&cnt[src[(u64)j * SWEEP_CHUNK + o] >> 24], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {                                                    // exclusive scan of the bucket counts by one wave (4, 2 or 1 per lane)
+        const int per = PART_BPS >> 6;
+        u32 c4[4] = {0, 0, 0, 0}, sum = 0;
+        for (int q = 0; q < per; q++) { c4[q] = cnt[per * tid + q]; sum += c4[q]; }
+        u32 inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { u32 x = __shfl_up(inc, off, 64); if (tid >= off) inc += x; }
+        u32 run = inc - sum;
+        for (int q = 0; q < per; q++) { cur[per * tid + q] = run; run += c4[q]; }
+    }
+    __syncthreads();
+    if (tid < PART_BPS) {
+        const u64 b = (u64)sidx * PART_BPS + tid;
+        totals[(u64)k * g.half + b] = cnt[tid];
+        base[(u64)k * (g.half + 1) + b] = b0 + cur[tid];
+    }
+    __syncthreads();
+    if (tid < PART_BPS) order_note_bucket(cnt[tid], (u64)k * g.half + (u64)sidx * PART_BPS + tid, g, base, oh, max_items, items, counters, long_gids, long_first);
+    __syncthreads();
+    if (tid < 256 && oh[tid]) atomicAdd(&ord_hist[tid], oh[tid]);
+    if (fits) {
+#pragma unroll 1
+        for (int t0 = 0; t0 < nslots; t0 += 8) {
+            u32 ev[8];
+            bool ok[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const u32 d = t0 + q < nslots ? wl[w * P2G_ITER + t0 + q] : 0u;
+                ok[q] = (u32)lane < (d & 127u);
+                ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) if (ok[q]) out[atomicAdd(&cur[ev[q] >> 24], 1u)] = (ev[q] & 0x7fffffu) | ((ev[q] & (1u << 23)) << 8);
+        }
+        __syncthreads();
+        for (u32 i = tid; i < m; i += 1024) dst[i] = out[i];
+    } else {
+        // oversize bin = heavily skewed digits (e.g. one bucket holding most of the window).  Entries go straight to their final place;
+        // lanes of a wave that share the first lane's bucket take their slots with ONE atomic.
+        for (int j = w; j < nchunk; j += 16) {
+            const u32 st = row0[j], en = row1[j];
+            for (u32 o0 = st; o0 < en; o0 += 64) {
+                const u32 o = o0 + lane;
+                const bool have = o < en;
+                const u32 ev = have ? src[(u64)j * SWEEP_CHUNK + o] : 0u, bk = ev >> 24;
+                const u32 lead_bk = __shfl(bk, __ffsll((long long)__ballot(have)) - 1, 64);
+                const unsigned long long same = __ballot(have && bk == lead_bk);
+                u32 pos = 0;
+                if (have && bk == lead_bk) {
+                    const int leader = __ffsll((long long)same) - 1;
+                    u32 first = 0;
+                    if (lane == leader) first = atomicAdd(&cur[bk], (u32)__popcll(same));
+                    first = __shfl(first, leader, 64);
+                    pos = first + (u32)__popcll(same & ((1ull << lane) - 1ull));
+                } else if (have) {
+                    pos = atomicAdd(&cur[bk], 1u);
+                }
+                if (have) dst[pos] = (ev & 0x7fffffu) | ((ev & (1u << 23)) << 8);
+            }
         }
     }
 }
@@ -945,7 +975,7 @@ __global__ void __launch_bounds__(256) k_order_scan(u32 *__restrict__ ord_hist) 
     ord_hist[threadIdx.x] = p[threadIdx.x] - v;
 }
 // the same with the scan inside: every block scans the 256-bin histogram itself (read-only) and takes its slots from a
-// separate cursor array (zeroed by k_sweep_count) -- one launch less in the chain
+// separate cursor array (zeroed by k_sweep_local) -- one launch less in the chain
 __global__ void __launch_bounds__(256) k_order_place(const u32 *__restrict__ totals, u64 nb, const u32 *__restrict__ ord_hist, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
     C25519_PRIO_CHAIN();
     __shared__ u32 h[256], start[256], basep[256];
@@ -1528,7 +1558,6 @@ struct msm_plan {
     msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
     uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs, *bad_ws, *bad_sticky = nullptr; long_item *items;
     hipStream_t sort_stream;
-    bool beside_lds_kernel = false;      // in: the sort runs beside a kernel that holds most of a compute unit's LDS (verify_batch: the decompression of R_i)
 };
 // md (may be null): merged layout -- d_scalars holds n_scalars scalars, the sort runs over md->K * md->ns digit-terms
 // n_carve (0 = n): the number of terms the workspace is carved for -- passes that CONTINUE each other's bucket sums (msm_record_enqueue)
@@ -1558,19 +1587,20 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // two-pass partition sort (see k_part1): pass-1 output, coarse counts / offsets, bin bases
     const bool use_part = g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);
     // (the merged layout of the precomputed tables keeps round 2's digit-matrix kernels: its terms are (window, scalar) pairs)
-    const bool sweep = use_part && !md && (g.half >> g.bps_log2) <= 256 && (g.half >> g.bps_log2) >= SCAN_SEGS;      // (k_sweep_scatter: at most four counters per thread)
+    const bool sweep = use_part && !md && (g.half >> g.bps_log2) <= 256 && (g.half >> g.bps_log2) >= 8;      // (k_sweep_local: at most four counters per thread)
     const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = sweep ? SWEEP_CHUNK : part_chunk(SL), pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     size_t oP1 = 0, oCC = 0, oBB = 0;
-    if (use_part) { oP1 = carve((size_t)g.nwin * nc * 4); oCC = carve((size_t)g.nwin * SL * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
+    // (the chunk-local form of the sweep path: P1 holds whole chunk blocks, oCC the slice starts [window][SL + 1][chunk], oBB the bin totals and the chunks' flags)
+    const size_t p1_words = sweep ? (size_t)g.nwin * pchunks_c * SWEEP_CHUNK : (size_t)g.nwin * nc;
+    if (use_part) { oP1 = carve(p1_words * 4); oCC = carve((size_t)g.nwin * (SL + 1) * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
     if (r) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
     uint16_t *D = (uint16_t *)(ws + oD);
     uint32_t *counts = (uint32_t *)(ws + oC), *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     // small words of the chain (u32 index): [8..] long-bucket counters, [64..319] bucket-order histogram, [320..575] its cursors,
-    // [576] "a scalar has bit 255 set" (ORed into the result slot by the bucket reduction: the sort itself never touches the slot),
-    // [1024..] segment totals of the chunk-counter scan
-    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *ord_cursor = flags + 320, *bad_ws = flags + 576, *seg_tot = flags + 1024, *perm = (uint32_t *)(ws + oPerm);
+    // [576] "a scalar has bit 255 set" (ORed into the result slot by the bucket reduction: the sort itself never touches the slot)
+    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *ord_cursor = flags + 320, *bad_ws = flags + 576, *perm = (uint32_t *)(ws + oPerm);
     constexpr int ZERO_WORDS = 576;
     pl.g = g; pl.n = n; pl.nb = nb; pl.nseg = nseg; pl.max_items = max_items; pl.max_long = max_long;
     pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8; pl.bad_ws = bad_ws;
@@ -1578,24 +1608,14 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     if (sweep) {
-        uint32_t *P1 = (uint32_t *)(ws + oP1), *cc = (uint32_t *)(ws + oCC);
-        uint32_t *bad_blk = (uint32_t *)(ws + oBB);           // one word per chunk (the bin bases of round 2's scan are not needed here)
-        // counting block: as many waves (each with private counters) as fit LDS -- 48 / 56 / 84 us per 2^21 terms with 16 / 8 / 4
-        // (verify_batch sorts beside the decompression of R_i, two blocks per compute unit with 64 KB of LDS reserved each: only the
-        //  four-wave block, 35 KB, finds room there -- the pass's kernels span 2.78 ms instead of 2.93)
-        const int CT = pl.beside_lds_kernel ? 256 : ((size_t)16 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 1024 : ((size_t)8 * g.nwin * SL + 1) * 4 <= 144 * 1024 ? 512 : 256;
-        const size_t ldsc = ((size_t)(CT / 64) * g.nwin * SL + 1) * 4, lds1 = ((size_t)2 * SWEEP_WAVES * SL + 3 * SL + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_count<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsc));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        if (CT == 1024) hipLaunchKernelGGL(k_sweep_count<1024>, dim3(pchunks), dim3(1024), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
-        else if (CT == 512) hipLaunchKernelGGL(k_sweep_count<512>, dim3(pchunks), dim3(512), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
-        else hipLaunchKernelGGL(k_sweep_count<256>, dim3(pchunks), dim3(256), ldsc, st, d_scalars, n, g, SL, pchunks, cc, bad_blk, flags, ZERO_WORDS);
-        hipLaunchKernelGGL(k_seg_scan, dim3(SCAN_SEGS, g.nwin), dim3(256), 0, st, cc, SL * pchunks, seg_tot, bad_blk, pchunks, bad_ws, pl.bad_sticky);
-        hipLaunchKernelGGL(k_sweep_scatter, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, cc, seg_tot, P1);
-        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, cc, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst, pchunks, seg_tot);
+        uint32_t *P1 = (uint32_t *)(ws + oP1), *lsg = (uint32_t *)(ws + oCC), *binm = (uint32_t *)(ws + oBB), *bad_blk = binm + (size_t)g.nwin * (SL + 1);
+        const uint64_t wstride = (uint64_t)pchunks_c * SWEEP_CHUNK;
+        const size_t lds1 = ((size_t)2 * SWEEP_WAVES * SL + SL + 1 + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP + 16 * P2G_ITER) * 4;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_sweep_local, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+        hipLaunchKernelGGL(k_bin_totals, dim3((g.nwin * SL + 3) / 4), dim3(256), 0, st, lsg, pchunks, SL, g.nwin * SL, binm, bad_blk, bad_ws, pl.bad_sticky);
+        hipLaunchKernelGGL(k_part2g, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, wstride, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
         hipLaunchKernelGGL(k_order_place, dim3(div_up64(nb, 256)), dim3(256), 0, st, totals, nb, ord_hist, ord_cursor, perm);
         HIPCHK(hipGetLastError());
         return C25519_OK;
@@ -1611,7 +1631,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         hipLaunchKernelGGL(k_part_hist, dim3(g.nwin, pchunks), dim3(256), (size_t)4 * SL * 4, st, D, n, g, SL, PART_CHUNK, cc);
         hipLaunchKernelGGL(k_part_scan, dim3(g.nwin), dim3(256), 0, st, cc, SL, pchunks, g, bin_base, base);
         hipLaunchKernelGGL(k_part1, dim3(g.nwin, pchunks), dim3(1024), lds1, st, D, n, g, SL, PART_CHUNK, cc, P1);
-        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst, 0, (const uint32_t *)nullptr);
+        hipLaunchKernelGGL(k_part2, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, g, SL, bin_base, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     } else {
         size_t lds = (size_t)g.half * 4;
         // (window, chunk) grid order: blockIdx.x = window, so that the chunk blocks of one window share an XCD's L2
@@ -1676,9 +1696,8 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     return C25519_OK;
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr, bool beside_lds_kernel = false) {
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr) {
     msm_plan pl;
-    pl.beside_lds_kernel = beside_lds_kernel;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc);
@@ -2217,7 +2236,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     HIPCHK(hipGetLastError());
     if (stage && d_pk_points && (r = prep_A())) return r;   // the keys' points come last: only the accumulation needs them
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
-    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc, true);
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
 }
 // Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
 // 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
