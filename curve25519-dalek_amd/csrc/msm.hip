@@ -777,28 +777,17 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX, *wl = out + PART_CAP;      // wl[16][P2G_ITER]
     __shared__ u32 red[16];
-    __shared__ u32 s_over;
     const int PART_BPS = 1 << g.bps_log2;
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    // the bin's place in the window's sorted list = the entries of the bins before it (SL <= 256 <= the block)
-    {
-        u32 part = tid < sidx ? binm[(u64)k * SL + tid] : 0u;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += (u32)__shfl_xor((int)part, d, 64);
-        if (lane == 0) red[w] = part;
-    }
-    if (tid < PART_BPS) cnt[tid] = 0;
-    if (tid < 256) oh[tid] = 0;
-    if (tid == 0) s_over = 0;
-    __syncthreads();
-    u32 b0 = 0;
-#pragma unroll
-    for (int q = 0; q < 16; q++) b0 += red[q];
-    const u32 m = binm[(u64)k * SL + sidx];
-    if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b0 + m;      // number of entries of the window
+    // Everything the block needs from memory before the gather is requested together: the bin totals (the bin's place in the window's
+    // sorted list = the entries of the bins before it; SL <= 256 <= the block) and this wave's run starts -- the gather does not wait
+    // for the prefix sum.
     const u32 *row0 = lsg + ((u64)k * (SL + 1) + sidx) * nchunk, *row1 = row0 + nchunk;
     const u32 *src = P1 + (u64)k * wstride;
-    u32 *dst = sorted + (u64)k * n + b0;
+    u32 part = tid < sidx ? binm[(u64)k * SL + tid] : 0u;
+    const u32 m = binm[(u64)k * SL + sidx];
+    if (tid < PART_BPS) cnt[tid] = 0;
+    if (tid < 256) oh[tid] = 0;
     // this wave's pieces: (offset in the window's P1 region) << 7 | entries in the piece
     int nslots = 0;
     for (int j0 = 0; j0 < nchunk; j0 += 16 * 64) {
@@ -813,9 +802,15 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
             if (first + p < (u32)P2G_ITER) wl[w * P2G_ITER + first + p] = (((u32)j * (u32)SWEEP_CHUNK + st + 64u * p) << 7) | (len - 64u * p < 64u ? len - 64u * p : 64u);
         nslots += (int)__shfl(inc, 63, 64);
     }
-    if (nslots > P2G_ITER && lane == 0) s_over = 1u;
-    __syncthreads();
-    const bool fits = m <= (u32)PART_CAP && !s_over;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) part += (u32)__shfl_xor((int)part, d, 64);
+    if (lane == 0) red[w] = part;
+    const bool fits = !__syncthreads_or(nslots > P2G_ITER) && m <= (u32)PART_CAP;      // (the barrier: counters zeroed, wave sums of the prefix written)
+    u32 b0 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) b0 += red[q];
+    if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b0 + m;      // number of entries of the window
+    u32 *dst = sorted + (u64)k * n + b0;
     if (fits) {
 #pragma unroll 1
         for (int t0 = 0; t0 < nslots; t0 += 8) {                         // eight pieces in flight
