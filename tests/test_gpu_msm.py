@@ -316,3 +316,17 @@ def test_msm_and_verify_over_several_contexts_in_one_process(eng, orc):
         assert E.verify_batch_multi(engs, M, bad, P, z) == E.SCALAR_FORMAT
     for e in engs[1:]:
         e.close()
+
+
+def test_msm_long_runs_in_a_few_chunks(eng, orc):
+    """The first 8000 of 2^20 terms share the raw bits of window 3: their entries form ONE run of ~8000 in chunk 0 of a (window, slice)
+    bin that still fits LDS -- the pass-2 gather's "more pieces than a wave lists" branch (msm.hip k_part2g), and a long bucket."""
+    import torch
+    n = 1 << 20
+    g = torch.Generator(device="cuda"); g.manual_seed(90210)
+    dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dx[:, 31] &= 0x0F
+    dx[:8000, 6] = 0x55; dx[:8000, 7] = 0x05                     # bits 48 .. 63
+    draw = eng.mul_base_batch_t(dx, out_fmt=2)
+    st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
