@@ -361,8 +361,10 @@ def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling, clock_h
                              "traffic": traffic, "traffic_source": traffic_src,
                              "traffic_frac": (traffic / (dom_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if (traffic and dom_ms) else None,
                              "note": "`frac` prices the ALGORITHMIC bytes (what the caller hands over) against HBM: small, because the kernel is bound by "
-                                     "v_mad_u64_u32 issue.  `traffic` is what the kernel actually moves per launch (PMC; table / point gathers): "
-                                     "`traffic_frac` of HBM peak is the second roof these kernels sit under"}},
+                                     "v_mad_u64_u32 issue.  `traffic` is what the kernel's L2 requests from the fabric per launch (PMC FETCH_SIZE "
+                                     "x 2 + WRITE_SIZE; table / point gathers) -- the 256 MiB MALL serves part of it (the MSM sizes its passes so that "
+                                     "a pass's gather records stay there), so `traffic_frac` (traffic / duration / HBM peak) is an upper bound on the "
+                                     "HBM share: the second roof these kernels sit under"}},
         "cpu_baseline": cpu_baseline,
     }
     return res
