@@ -326,6 +326,11 @@ def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling, clock_h
     pk = {"msm": "k_accumulate", "verify": "k_prep_compressed" if kt.get("dominant_is_prep") else "k_accumulate",
           "fixed_base": "k_mul_base_comb" if w.variant == "comb" else ("k_mul_base<" if w.variant == "ct" else "k_mul_base_wide"), "x25519": "k_x25519"}[name]
     traffic, traffic_src = pmc_traffic(name if not w.variant else name + "_" + w.variant, pk)
+    if traffic and name == "msm":
+        # the PMC profile of the MSM is taken on ONE 2^21-term launch (tools/profile_all.sh: the counters of a 2^24-term call would be
+        # averaged over launches of different passes); a launch of the call measured here covers `upl` terms
+        traffic *= upl / float(1 << 21)
+        traffic_src += " (one 2^21-term launch, scaled to the %d terms of a launch of this call)" % int(upl)
     per_gpu = units / dt / world
     kmac = costs.mac(w.kernel_cost(cost))                                  # multiply-adds per unit inside the dominant kernel
     mac_achieved = (upl * kmac / (dom_ms * 1e-3)) if dom_ms else None       # MAC/s of the dominant kernel while it runs
