@@ -75,7 +75,7 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
         for (int c = 0; c < PTS_Q; c++) q[c] = my_rec[(c + lane) & 7u];
         const bool neg = (e >> 31) != 0, active = it < len;
         const u32 e_next = e1;
-        if (it + 2 < len) e1 = list[lo + it + 2];
+        if (it + 2 < len) e1 = list[lo + it + 2];          // (a non-temporal load here -- to keep the lists out of the MALL -- loses the line reuse of a lane's consecutive entries: k_accumulate 1.12 against 1.00 ms)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (it + 1 < wmax) { C25519_COOP_ISSUE(e_next) }
         // (the loop counter is wave-uniform here, so the first entry of a list could be CONVERTED -- 1 M instead of 7 M --
