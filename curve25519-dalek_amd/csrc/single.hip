@@ -319,6 +319,74 @@ int32_t mul_batch_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t 
 EXPORT int32_t c25519_mul_batch_dev(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok) {
     return mul_batch_impl(ctx, d_scalars, d_points, n, in_fmt, out_fmt, d_out, d_ok, !(ctx->flags & C25519_FLAG_VARTIME_TABLES));
 }
+// ---- order checks (edwards.rs:1405-1437) --------------------------------------------------------------------------------------
+namespace c25519 {
+// flags[i] = decodes | small_order << 1 (8 P = O); raw points always decode
+template <int FMT>
+__global__ void __launch_bounds__(256) k_small_order(const uint8_t *__restrict__ in, u64 n, uint8_t *__restrict__ flags) {
+    const u64 idx = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    ge_p3 P;
+    bool ok = true;
+    if (FMT == 0) { u32 w[8]; load8(in, idx, w); ok = ge_decompress(P, w); }
+    else P = raw160_load(in, idx);
+    const bool small = ge_is_identity(ge_mul_by_pow_2(P, 3));
+    flags[idx] = ok ? (uint8_t)(1u | (small ? 2u : 0u)) : (uint8_t)0;
+}
+// the group order l as a 32-byte scalar for every lane (edwards.rs:1436 BASEPOINT_ORDER)
+__global__ void __launch_bounds__(256) k_fill_order(u64 n, uint8_t *__restrict__ out) {
+    const u64 idx = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    u32 l[8];
+    sc28_l_words(l);
+    store8(out, idx, l);
+}
+// flags[i] |= 4 where the point decodes (ok[i]) and enc[i] is the identity's encoding (y = 1, sign 0)
+__global__ void __launch_bounds__(256) k_flag_identity_enc(const uint8_t *__restrict__ enc, const uint8_t *__restrict__ ok, u64 n, uint8_t *__restrict__ flags, int fresh) {
+    const u64 idx = (u64)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n) return;
+    u32 w[8];
+    load8(enc, idx, w);
+    const bool id = w[0] == 1u && (w[1] | w[2] | w[3] | w[4] | w[5] | w[6] | w[7]) == 0u;
+    const uint8_t prev = fresh ? (uint8_t)(ok[idx] ? 1 : 0) : flags[idx];
+    flags[idx] = ok[idx] ? (uint8_t)(prev | (id ? 4u : 0u)) : (uint8_t)0;
+}
+}  // namespace c25519
+EXPORT int32_t c25519_point_order_checks_batch_dev(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, int which, uint8_t *d_flags) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (in_fmt != C25519_FMT_EDWARDS_Y && in_fmt != C25519_FMT_RAW160) { ctx->err = "point_order_checks: in_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    if (!(which & (C25519_POINT_SMALL_ORDER | C25519_POINT_TORSION_FREE))) { ctx->err = "point_order_checks: nothing to check"; return -(int32_t)hipErrorInvalidValue; }
+    if (n == 0) return C25519_OK;
+    const bool small = (which & C25519_POINT_SMALL_ORDER) != 0;
+    if (small) {
+        if (in_fmt == C25519_FMT_EDWARDS_Y) hipLaunchKernelGGL(k_small_order<0>, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, d_points, n, d_flags);
+        else hipLaunchKernelGGL(k_small_order<2>, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, d_points, n, d_flags);
+        HIPCHK(hipGetLastError());
+    }
+    if (which & C25519_POINT_TORSION_FREE) {
+        int32_t r;
+        if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 65 + 64))) return r;
+        uint8_t *l = (uint8_t *)ctx->tmp_c2.p, *enc = l + n * 32, *ok = enc + n * 32;
+        hipLaunchKernelGGL(k_fill_order, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, n, l);
+        if ((r = mul_batch_impl(ctx, l, d_points, n, in_fmt, C25519_FMT_EDWARDS_Y, enc, ok, false))) return r;     // public points, public scalar: the fast tables
+        hipLaunchKernelGGL(k_flag_identity_enc, dim3(dup(n, 256)), dim3(256), 0, ctx->stream, enc, ok, n, d_flags, small ? 0 : 1);
+        HIPCHK(hipGetLastError());
+    }
+    return C25519_OK;
+}
+EXPORT int32_t c25519_point_order_checks_batch(c25519_ctx *ctx, const uint8_t *points, uint64_t n, int in_fmt, int which, uint8_t *flags) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (in_fmt != C25519_FMT_EDWARDS_Y && in_fmt != C25519_FMT_RAW160) { ctx->err = "point_order_checks: in_fmt must be 0 or 2"; return -(int32_t)hipErrorInvalidValue; }
+    const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * psz + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n + 16))) return r;
+    uint8_t *dp = (uint8_t *)ctx->tmp_a.p, *dfl = (uint8_t *)ctx->tmp_b.p;
+    const ffi_in in = {points, dp, psz};
+    const ffi_out o = {flags, dfl, 1};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), &in, 1, &o, 1, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return c25519_point_order_checks_batch_dev(ctx, dp + lo * psz, m, in_fmt, which, dfl + lo);
+    });
+}
 static int32_t mul_batch_host(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok, bool clamp) {
     HIPCHK(hipSetDevice(ctx->device));
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32, osz = out_fmt == C25519_FMT_RAW160 ? 160 : 32;

@@ -17,6 +17,7 @@ error behaviour), batched, on top of Engine.  Reference entry points mirrored:
   RistrettoBasepointTable::create             curve25519-dalek/src/ristretto.rs:1080-1110
   EdwardsPoint::mul_base_clamped / mul_clamped   curve25519-dalek/src/edwards.rs:948 / :932
   SharedSecret::was_contributory              x25519-dalek/src/x25519.rs:335
+  EdwardsPoint::is_small_order / is_torsion_free   curve25519-dalek/src/edwards.rs:1405 / :1435;  VerifyingKey::is_weak  ed25519-dalek/src/verifying.rs:192
 
 Values cross this layer as the reference's wire types: Scalar = 32 canonical LE bytes,
 CompressedEdwardsY / CompressedRistretto / MontgomeryPoint = 32 bytes.
@@ -95,6 +96,23 @@ class EdwardsPoint:
         eng = engine or default_engine()
         out, ok = eng.mul_clamped_batch(_cat(raw_bytes, 32), _cat(points, 32), _e.FMT_EDWARDS_Y, _e.FMT_EDWARDS_Y)
         return [out[i].tobytes() if ok[i] else None for i in range(out.shape[0])]
+
+
+def _order_flags(points, which, engine):
+    eng = engine or default_engine()
+    return eng.point_order_checks(_cat(points, 32), _e.FMT_EDWARDS_Y, which)
+
+
+def is_small_order(points, engine=None):
+    """[CompressedEdwardsY] -> [EdwardsPoint::is_small_order(), or None where the encoding does not decode] (edwards.rs:1405)"""
+    fl = _order_flags(points, _e.POINT_SMALL_ORDER, engine)
+    return [bool(f & _e.POINT_SMALL_ORDER) if f & _e.POINT_DECODES else None for f in fl]
+
+
+def is_torsion_free(points, engine=None):
+    """[CompressedEdwardsY] -> [EdwardsPoint::is_torsion_free(), or None] (edwards.rs:1435)"""
+    fl = _order_flags(points, _e.POINT_TORSION_FREE, engine)
+    return [bool(f & _e.POINT_TORSION_FREE) if f & _e.POINT_DECODES else None for f in fl]
 
 
 class EdwardsBasepointTable:
@@ -190,6 +208,13 @@ class VerifyingKey:
         if _token is not VerifyingKey._from_bytes_token:
             raise TypeError("VerifyingKey objects are built by VerifyingKey.from_bytes (verifying.rs:167-175)")
         self.compressed, self.point = bytes(compressed), bytes(point)
+
+    @staticmethod
+    def is_weak(keys, engine=None):
+        """VerifyingKey::is_weak (verifying.rs:192-194) for a list of VerifyingKey: the point has small order"""
+        eng = engine or default_engine()
+        fl = eng.point_order_checks(_cat([k.point for k in keys], 160), _e.FMT_RAW160, _e.POINT_SMALL_ORDER)
+        return [bool(f & _e.POINT_SMALL_ORDER) for f in fl]
 
     @staticmethod
     def from_bytes(keys, engine=None):

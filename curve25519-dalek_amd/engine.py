@@ -11,6 +11,7 @@ import numpy as np
 
 OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH = 0, 1, 2, 3, 4
 FMT_EDWARDS_Y, FMT_RISTRETTO, FMT_RAW160 = 0, 1, 2
+POINT_DECODES, POINT_SMALL_ORDER, POINT_TORSION_FREE = 1, 2, 4      # flags of c25519_point_order_checks_batch
 Z_TRANSCRIPT, Z_DEVICE = 0, 1
 FLAG_VARTIME_TABLES = 0x100      # c25519_ctx_create: fast secret-indexed tables for mul_base / mul_batch / sign / keygen (public scalars only)
 
@@ -65,6 +66,8 @@ def load_library():
         "c25519_x25519_contributory_batch": (i32, [vp, vp, vp, u64, vp, vp]),
         "c25519_mul_clamped_batch_dev": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_mul_clamped_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_point_order_checks_batch_dev": (i32, [vp, vp, u64, C.c_int, C.c_int, vp]),
+        "c25519_point_order_checks_batch": (i32, [vp, vp, u64, C.c_int, C.c_int, vp]),
         "c25519_host_alloc": (vp, [C.c_size_t]),
         "c25519_host_free": (None, [vp]),
         "c25519_last_ffi_ms": (C.c_double, [vp, vp, vp]),
@@ -129,6 +132,7 @@ ABI_SYMBOLS = [
     "c25519_ctx_create", "c25519_ctx_destroy", "c25519_ctx_set_stream", "c25519_ctx_synchronize", "c25519_last_error",
     "c25519_mul_base_clamped_batch_dev", "c25519_mul_base_clamped_batch", "c25519_basetable_create", "c25519_basetable_destroy", "c25519_mul_table_batch_dev",
     "c25519_mul_table_batch", "c25519_x25519_contributory_batch_dev", "c25519_x25519_contributory_batch", "c25519_mul_clamped_batch_dev", "c25519_mul_clamped_batch",
+    "c25519_point_order_checks_batch_dev", "c25519_point_order_checks_batch",
     "c25519_host_alloc", "c25519_host_free", "c25519_last_ffi_ms", "c25519_ctx_trim", "c25519_last_kernel_name",
     "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
@@ -429,6 +433,21 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.c25519_mul_clamped_batch(self.ctx, s.ctypes.data, p.ctypes.data, n, in_fmt, out_fmt, out.ctypes.data, ok.ctypes.data))
         return out, ok
+
+    def point_order_checks(self, points, in_fmt=FMT_EDWARDS_Y, which=POINT_SMALL_ORDER | POINT_TORSION_FREE):
+        """EdwardsPoint::is_small_order / is_torsion_free (edwards.rs:1405 / :1435) -> (n,) uint8 flags: POINT_DECODES | POINT_SMALL_ORDER | POINT_TORSION_FREE"""
+        p = _np8(points, _PT[in_fmt]); n = p.shape[0]
+        fl = np.empty((n,), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_point_order_checks_batch(self.ctx, p.ctypes.data, n, in_fmt, which, fl.ctypes.data))
+        return fl
+
+    def point_order_checks_t(self, points, in_fmt=FMT_EDWARDS_Y, which=POINT_SMALL_ORDER | POINT_TORSION_FREE):
+        n = self._t(points, _PT[in_fmt])
+        fl = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        self._chk(self.lib.c25519_point_order_checks_batch_dev(self.ctx, points.data_ptr(), n, in_fmt, which, fl.data_ptr()))
+        return fl
 
     # -- constant-time fixed-base tables for a caller's point (EdwardsBasepointTable::create / RistrettoBasepointTable::create)
     def basetable_create(self, point, in_fmt=FMT_EDWARDS_Y):

@@ -300,6 +300,19 @@ int32_t c25519_mul_batch(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t 
 int32_t c25519_mul_clamped_batch_dev(c25519_ctx *ctx, const uint8_t *d_bytes, const uint8_t *d_points, uint64_t n, int in_fmt, int out_fmt, uint8_t *d_out, uint8_t *d_ok);
 int32_t c25519_mul_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out, uint8_t *ok);
 
+/* ---- order checks: flags[i] of point i ----------------------------------------------------------------------
+ * replaces EdwardsPoint::is_small_order (edwards.rs:1405-1407: mul_by_cofactor().is_identity()), EdwardsPoint::is_torsion_free
+ * (edwards.rs:1435-1437: (self * BASEPOINT_ORDER).is_identity()) and, through them, VerifyingKey::is_weak
+ * (ed25519-dalek/src/verifying.rs:192-194), batched.  in_fmt: C25519_FMT_EDWARDS_Y or C25519_FMT_RAW160.
+ * flags[i]: C25519_POINT_DECODES (always set for raw points) | C25519_POINT_SMALL_ORDER | C25519_POINT_TORSION_FREE;
+ * a point that does not decode has flags[i] = 0.  `which` selects the checks to run (C25519_POINT_SMALL_ORDER, C25519_POINT_TORSION_FREE
+ * or both; the torsion check is a full variable-base multiplication by l).  Variable time: the points are public keys / signature parts. */
+#define C25519_POINT_DECODES 1
+#define C25519_POINT_SMALL_ORDER 2
+#define C25519_POINT_TORSION_FREE 4
+int32_t c25519_point_order_checks_batch_dev(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, int which, uint8_t *d_flags);
+int32_t c25519_point_order_checks_batch(c25519_ctx *ctx, const uint8_t *points, uint64_t n, int in_fmt, int which, uint8_t *flags);
+
 /* ---- double base: out[i] = a[i] * A[i] + b[i] * B ---------------------------------------------------------
  * replaces backend::vartime_double_base_mul (backend.rs:267 -> scalar_mul/vartime_double_base.rs:23-72;
  * EdwardsPoint::vartime_double_scalar_mul_basepoint, edwards.rs:1099-1106), the single-signature kernel,

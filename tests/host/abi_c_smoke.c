@@ -93,6 +93,11 @@ int main(void) {
     if (c25519_partial_record_pack(raw5, C25519_NONE, NULL, recs + C25519_PARTIAL_RECORD_BYTES) != C25519_OK) return 29;
     if (c25519_fold_partial_records(NULL, recs, 2, C25519_FMT_EDWARDS_Y, folded) != C25519_NONE) return 30;
     if (c25519_ctx_trim(ctx) != C25519_OK) return 31;
+    /* order checks: B is torsion-free and not of small order; the identity is both; y = 2 does not decode */
+    uint8_t chk[3][32], fl3[3];
+    memcpy(chk[0], bp, 32); memset(chk[1], 0, 32); chk[1][0] = 1; memset(chk[2], 0, 32); chk[2][0] = 2;
+    if (c25519_point_order_checks_batch(ctx, &chk[0][0], 3, C25519_FMT_EDWARDS_Y, C25519_POINT_SMALL_ORDER | C25519_POINT_TORSION_FREE, fl3) != C25519_OK) return 32;
+    if (fl3[0] != (C25519_POINT_DECODES | C25519_POINT_TORSION_FREE) || fl3[1] != (C25519_POINT_DECODES | C25519_POINT_SMALL_ORDER | C25519_POINT_TORSION_FREE) || fl3[2] != 0) { fprintf(stderr, "order checks: %d %d %d\n", fl3[0], fl3[1], fl3[2]); return 33; }
     c25519_ctx_destroy(ctx2);
     c25519_ctx_destroy(ctx);
     printf("abi_c_smoke ok\n");

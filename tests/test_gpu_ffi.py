@@ -335,3 +335,44 @@ def test_reference_named_front_end_round3(eng, orc):
     ss = dalek.diffie_hellman(raw, [orc.x25519(b, (9).to_bytes(32, "little")) for b in raw[:8]] + [bytes(32)], engine=eng)
     assert [x.was_contributory() for x in ss] == [True] * 8 + [False] and ss[8].as_bytes() == bytes(32)
     assert ss[0].as_bytes() == orc.x25519(raw[0], orc.x25519(raw[0], (9).to_bytes(32, "little")))
+
+
+def test_point_order_checks(eng, orc, golden):
+    """c25519_point_order_checks_batch[_dev]: EdwardsPoint::is_small_order / is_torsion_free (edwards.rs:1405 / :1435) and
+    VerifyingKey::is_weak on the eight torsion points (multiples of the reference's EIGHT_TORSION generator), prime-order points,
+    mixed-order points (P + T), the identity and an encoding that does not decode -- against the oracle; compressed and raw input;
+    device and host entry points agree."""
+    import torch
+    import curve25519_dalek_amd as pkg
+    from curve25519_dalek_amd import dalek
+    E = pkg.engine
+    t1 = orc.ed_decompress(golden.bytes("ed25519.rs", "EIGHT_TORSION_4"))          # a torsion point the reference's own tests hold
+    pts = [orc.ed_identity(), t1, orc.ed_double(t1), orc.ed_add(t1, orc.ed_double(t1))]   # and its multiples
+    prime = [orc.ed_mul_base(util.rand_scalars(70 + i, 1)[0].tobytes()) for i in range(5)]
+    pts += prime
+    pts += [orc.ed_add(p, t1) for p in prime[:3]]                                     # mixed order
+    pts += [orc.ed_add(prime[3], orc.ed_double(t1))]
+    enc = [orc.ed_compress(p) for p in pts] + [(2).to_bytes(32, "little")]            # y = 2 is not on the curve
+    want = []
+    for p in pts:
+        want.append(E.POINT_DECODES | (E.POINT_SMALL_ORDER if orc.ed_is_small_order(p) else 0) | (E.POINT_TORSION_FREE if orc.ed_is_torsion_free(p) else 0))
+    want.append(0)
+    got = eng.point_order_checks(np.frombuffer(b"".join(enc), np.uint8).reshape(-1, 32))
+    assert got.tolist() == want
+    assert want[1] & E.POINT_SMALL_ORDER and not want[1] & E.POINT_TORSION_FREE and want[0] == 7 and want[4] == (E.POINT_DECODES | E.POINT_TORSION_FREE)
+    assert want[9] == E.POINT_DECODES                                                 # P + T: neither small nor torsion-free
+    # single checks leave the other bit clear
+    so = eng.point_order_checks(np.frombuffer(b"".join(enc), np.uint8).reshape(-1, 32), which=E.POINT_SMALL_ORDER)
+    tf = eng.point_order_checks(np.frombuffer(b"".join(enc), np.uint8).reshape(-1, 32), which=E.POINT_TORSION_FREE)
+    assert so.tolist() == [w & ~E.POINT_TORSION_FREE for w in want] and tf.tolist() == [w & ~E.POINT_SMALL_ORDER for w in want]
+    # raw input, device entry point, a batch large enough for several blocks
+    raw = np.frombuffer(b"".join(pts), np.uint8).reshape(-1, 160)
+    reps = 300
+    d = torch.from_numpy(np.tile(raw, (reps, 1))).cuda()
+    gd = eng.point_order_checks_t(d, E.FMT_RAW160).cpu().numpy()
+    assert gd.tolist() == want[:-1] * reps
+    # the reference-named front end
+    assert dalek.is_small_order(enc) == [bool(w & E.POINT_SMALL_ORDER) if w else None for w in want]
+    assert dalek.is_torsion_free(enc) == [bool(w & E.POINT_TORSION_FREE) if w else None for w in want]
+    keys = dalek.VerifyingKey.from_bytes(enc[:-1], engine=eng)
+    assert dalek.VerifyingKey.is_weak(keys, engine=eng) == [bool(w & E.POINT_SMALL_ORDER) for w in want[:-1]]
