@@ -1222,7 +1222,7 @@ __global__ void __launch_bounds__(128) k_record_sum(u32 *__restrict__ rec, const
 // hram_i = SHA-512(R_i || A_i || M_i) (batch.rs:179-191): 64-byte digest out; flags[0] += non-canonical s,
 // flags[1] |= 1 if the message offsets are not monotone or run past msgs_len (that message is hashed as empty)
 __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len, const uint8_t *__restrict__ sigs,
-                                              const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags) {
+                                              const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags, uint8_t *__restrict__ hred = nullptr) {
     C25519_PRIO_CHAIN();
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1247,46 +1247,63 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     sha512_digest_words(st.h, w);
     uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
     for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+    if (hred) {                                              // h_i mod l, 32 bytes: what the device z-tree commits to (below)
+        u32 o[8];
+        sc28_to_words(sc28_from_wide(w), o);
+        store8(hred, i, o);
+    }
+}
+// the same reduction for hashes that were computed elsewhere
+__global__ void __launch_bounds__(256) k_hram_mod_l(const uint8_t *__restrict__ hram, u64 n, uint8_t *__restrict__ hred) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 *hw = reinterpret_cast<const u32 *>(hram) + 16 * i;
+    u32 w[16], o[8];
+    for (int j = 0; j < 16; j++) w[j] = hw[j];
+    sc28_to_words(sc28_from_wide(w), o);
+    store8(hred, i, o);
 }
 
 // device z-mode (C25519_Z_DEVICE; NOT the reference's derivation -- see include/c25519_hip.h).  The z_i must depend on
 // every input bit of the batch (a per-signature or per-subtree derivation allows a 2^64 meet-in-the-middle forgery), so
-// they are derived from the root of a hash tree over exactly the byte strings the reference's transcript absorbs
-// (batch.rs:191-199): the 64-byte hram_i = H(R_i || A_i || M_i) and the 32-byte s_i of every signature.
+// they are derived from the root of a hash tree over what the reference's transcript absorbs (batch.rs:191-199) -- hram_i =
+// H(R_i || A_i || M_i) and the 32-byte s_i of every signature -- with hram_i taken mod l (v4; 32 bytes instead of 64: the batch
+// equation only ever sees h_i mod l, batch.rs:213-217, so that is the value to bind; two blocks per four signatures instead of three).
 //   node = first 32 bytes of the SHA-512 chaining value after absorbing  TAG(level, inputs, n) || data , where TAG is one
 //   128-byte block (domain separation and shape binding: level, number of inputs of the level, batch size) whose
 //   compression is done once on the host (the per-level IVs below), and `data` has a fixed length per level, so no
 //   length padding is needed: a Merkle-Damgard chain over fixed-length inputs is collision resistant if the compression
 //   function is; 32-byte nodes give the 128-bit level of the z_i.
-//   level 0: data = hram_4j || s_4j || ... || hram_4j+3 || s_4j+3 (absent = zero bytes): 3 blocks per 4 signatures, one lane
-//            each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
-//            VGPRs -- a latency-bound kernel that did not fit beside the decompression; now 4096 waves).
+//   level 0: data = (hram_4j mod l) || s_4j || ... || (hram_4j+3 mod l) || s_4j+3 (absent = zero bytes): 2 blocks per 4 signatures,
+//            one lane each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
+//            VGPRs -- a latency-bound kernel that did not fit beside the decompression; v3: 3 blocks with 64-byte hram_i).
 //   level l: data = four children: ONE compression per node.  These levels are pure latency (one dependent SHA-512
 //            compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
 constexpr int ZTREE_MAX_LEVELS = 16;
 struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
-__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hred, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
     C25519_PRIO_CHAIN();
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 m_out = (n + 3) / 4;
     if (j >= m_out) return;
     u64 hs[8];
     for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
-    u64 rec[48];                                          // 4 records of 96 bytes = 3 blocks
+    u64 rec[32];                                          // 4 records of 64 bytes = 2 blocks
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const u64 c = 4 * j + r;
-        const u64 *h = reinterpret_cast<const u64 *>(hram) + 8 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
+        const u64 *h = reinterpret_cast<const u64 *>(hred) + 4 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
 #pragma unroll
-        for (int q = 0; q < 8; q++) rec[12 * r + q] = c < n ? bswap64(h[q]) : 0ull;
+        for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? bswap64(h[q]) : 0ull;
 #pragma unroll
-        for (int q = 0; q < 4; q++) rec[12 * r + 8 + q] = c < n ? bswap64(sg[q]) : 0ull;
+        for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? bswap64(sg[q]) : 0ull;
     }
 #pragma unroll 1
-    for (int blk = 0; blk < 3; blk++) {
+    for (int blk = 0; blk < 2; blk++) {
         u64 w[16];
 #pragma unroll
-        for (int q = 0; q < 16; q++) w[q] = blk == 0 ? rec[q] : blk == 1 ? rec[16 + q] : rec[32 + q];
+        for (int q = 0; q < 16; q++) w[q] = blk == 0 ? rec[q] : rec[16 + q];
         sha512_compress(hs, w);
     }
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
@@ -2121,7 +2138,7 @@ static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
     uint64_t count = n;                                  // inputs of level 0: signatures
     for (int l = 0; l < ZTREE_MAX_LEVELS; l++) {
         u64 w[16] = {0};
-        const char tag[] = "c25519-hip/verify_batch/z-tree/v3";
+        const char tag[] = "c25519-hip/verify_batch/z-tree/v4";
         static_assert(sizeof(tag) - 1 <= 64, "tag fits the first half of the block");
         uint8_t blk[128] = {0};
         memcpy(blk, tag, sizeof(tag) - 1);
@@ -2134,12 +2151,12 @@ static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
 }
 // the z_i of one pass (n signatures) by the device derivation; z16: room for 4 * ceil(n/4) entries.  t0 / t1: tree scratch
 // ((n/4 + 1) * 32 bytes each).  Enqueued on `sa`.
-static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hram, const uint8_t *d_sigs, uint64_t n, uint8_t *t0, uint8_t *t1, uint8_t *z16) {
+static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hred, const uint8_t *d_sigs, uint64_t n, uint8_t *t0, uint8_t *t1, uint8_t *z16) {
     ztree_ivs ivs;
     ztree_make_ivs(n, ivs);
     uint64_t mm = (n + 3) / 4; uint8_t *a = t0, *b = t1;
     uint32_t level = 1;
-    hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hram, d_sigs, n, ivs, a);
+    hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hred, d_sigs, n, ivs, a);
     while (mm > 1024) {
         uint64_t mo = (mm + 3) / 4;
         hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, ivs, b);
@@ -2174,9 +2191,10 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32), oP = carve((size_t)nblk * 40);
+    const size_t oHr = carve(d_z_pre ? 0 : n * 32);       // h_i mod l, for the device z-tree
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
-    uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1;
+    uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1, *hred = d_z_pre ? nullptr : ws + oHr;
     uint32_t *partial = (uint32_t *)(ws + oP);
     uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
     uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
@@ -2219,11 +2237,12 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     }
     // (A)
     const uint8_t *hr = d_hram_pre;
-    if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4); hr = hram; }
+    if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
+    else if (hred) hipLaunchKernelGGL(k_hram_mod_l, dim3(nblk), dim3(256), 0, sa, hr, n, hred);
     HIPCHK(hipGetLastError());
     const uint8_t *zz = d_z_pre;
     if (!zz) {
-        if ((r = zchain_enqueue(ctx, sa, hr, d_sigs, n, t0, t1, z16))) return r;
+        if ((r = zchain_enqueue(ctx, sa, hred, d_sigs, n, t0, t1, z16))) return r;
         zz = z16;
         // the sign of z_i goes onto the stored R_i (main stream, beside the sort on the second one)
         HIPCHK(hipEventRecord(ctx->ev_z, sa));
@@ -2472,6 +2491,7 @@ EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     size_t oM = carve(mlen + 64), oO = carve((n + 1) * 8), oS = carve(n * 64), oK = carve(n * 32), oH = carve(n * 64), oZ = carve((n + 4) * 16), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32);
+    const size_t oHr = carve(n * 32);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
     hipStream_t st = ctx->stream;
@@ -2482,7 +2502,8 @@ EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
     HIPCHK(launch_hram(ws + oM, (const uint64_t *)(ws + oO), mlen, ws + oS, ws + oK, n, ws + oH, (uint32_t *)ctx->d_flag, st));
     if (z_mode == C25519_Z_DEVICE) {
-        if ((r = zchain_enqueue(ctx, st, ws + oH, ws + oS, n, ws + oT0, ws + oT1, ws + oZ))) return r;
+        hipLaunchKernelGGL(k_hram_mod_l, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws + oH, n, ws + oHr);
+        if ((r = zchain_enqueue(ctx, st, ws + oHr, ws + oS, n, ws + oT0, ws + oT1, ws + oZ))) return r;
         HIPCHK(hipMemcpyAsync(out_z16, ws + oZ, n * 16, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     } else {

@@ -59,8 +59,9 @@ extern "C" {
  *   2-3 x 10^6 signatures/s; the curve arithmetic still runs on the GPU.
  * C25519_Z_DEVICE (1, explicit opt-in, NOT the reference's derivation and not a reviewed standard construction):
  *   z_i = a 16-byte quarter of SHA-512(root || LE64(i / 4)), read as sign-magnitude (uniform on the 2^128 - 1 integers
- *   -(2^127 - 1) .. 2^127 - 1), where root is the root of a hash tree over exactly what the reference's transcript
- *   absorbs: the 64-byte H(R_i || A_i || M_i) and the 32-byte s_i of every signature (level 0: 4 signatures per
+ *   -(2^127 - 1) .. 2^127 - 1), where root is the root of a hash tree over what the reference's transcript
+ *   absorbs: H(R_i || A_i || M_i) -- taken mod l, 32 bytes: the batch equation only sees that residue (batch.rs:213-217) --
+ *   and the 32-byte s_i of every signature (level 0: 4 signatures per
  *   node; upper levels 4-ary; node = first 32 bytes of the SHA-512 chaining value after a one-block domain tag
  *   (level, inputs of the level, batch size) and the fixed-length data).  Every z_i depends on every bit of the batch;
  *   honest batches give the same verdict in both modes; a batch containing an invalid signature passes with
