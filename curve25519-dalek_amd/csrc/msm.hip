@@ -1241,7 +1241,7 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
     if (!okoff) atomicOr(&flags[1], 1u);
     const uint8_t *m = msgs + o0;
     const u64 len = okoff ? o1 - o0 : 0;
-    for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
+    st.put_bytes(m, len);
     st.finish();
     u32 w[16];
     sha512_digest_words(st.h, w);

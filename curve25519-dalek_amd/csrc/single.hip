@@ -230,7 +230,7 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     const u64 o0 = msg_off[i], o1 = msg_off[i + 1];
     const u64 len = (o0 <= o1 && o1 <= msgs_len) ? o1 - o0 : 0;        // bad offsets: flagged by k_hram, nothing read out of bounds
     const uint8_t *m = msgs + o0;
-    for (u64 j = 0; j < len; j++) st.put_byte(m[j]);
+    st.put_bytes(m, len);
     st.finish();
     u32 d[16], r[8];
     sha512_digest_words(st.h, d);

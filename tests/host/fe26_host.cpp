@@ -101,6 +101,15 @@ void h_sha512(const uint8_t *m, size_t n, uint8_t *o) {
     st.finish();
     u32 w[16]; sha512_digest_words(st.h, w); memcpy(o, w, 64);
 }
+// the kernels' message path: `pre` bytes one by one (any block position), then put_bytes over the rest (word-wise where it can)
+void h_sha512_put_bytes(const uint8_t *m, size_t n, size_t pre, uint8_t *o) {
+    sha512_stream st; st.init();
+    size_t i = 0;
+    for (; i < pre && i < n; i++) st.put_byte(m[i]);
+    st.put_bytes(m + i, n - i);
+    st.finish();
+    u32 w[16]; sha512_digest_words(st.h, w); memcpy(o, w, 64);
+}
 void h_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint64_t n, uint8_t *zs) { c25519_transcript_zs(hrams, sigs, n, zs); }
 }
 

@@ -215,6 +215,14 @@ def test_scalar_sha_transcript_host_vs_oracle(host, orc):
     for n in [0, 1, 7, 8, 63, 64, 65, 95, 96, 111, 112, 113, 119, 120, 127, 128, 129, 200, 255, 256, 300]:
         m = bytes(rng.getrandbits(8) for _ in range(n))
         assert call(host, "h_sha512", m, C.c_size_t(n), out=64) == hashlib.sha512(m).digest(), n
+        # the kernels' message path (sha512_stream::put_bytes): every block position it can start at, aligned and unaligned sources
+        for pre in (0, 1, 3, 8, 13, 64, 121, 127):
+            for shift in (0, 1, 2):
+                buf = bytes(shift) + m                                           # move the message off its 4-byte alignment
+                src = (C.c_char * len(buf)).from_buffer_copy(buf)
+                out = C.create_string_buffer(64)
+                host.h_sha512_put_bytes(C.byref(src, shift), C.c_size_t(n), C.c_size_t(pre), out)
+                assert out.raw == hashlib.sha512(m).digest(), (n, pre, shift)
     for n in [1, 2, 7, 40]:
         hr = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
         sg = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
