@@ -814,7 +814,11 @@ hipError_t launch_decompress_ristretto(const uint8_t *in, u64 n, uint8_t *out_ra
 // instead of 380, verify_batch 3.38 against 3.08 ms).  A 64 KB LDS reservation caps it at two blocks per CU.
 hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, bool shared, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    const unsigned lds = shared ? 65536u : 0u;
+    // (shared: the call runs beside verify_batch's hash chain.  Rounds 2-3 reserved 64 KB of LDS there -- two blocks per compute unit,
+    //  so that the chain's kernels found room beside 164-VGPR waves: 3.08 against 3.38 ms then; with the chain shortened in round 3
+    //  (k_hram 307 -> 178 us, level 0 of the z-tree 333 -> 231) the cap costs more than it buys: 2.73 - 2.74 ms with it, 2.69 without)
+    (void)shared;
+    const unsigned lds = 0u;
     if (fmt == 0) hipLaunchKernelGGL(k_prep_compressed<0>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
     else hipLaunchKernelGGL(k_prep_compressed<1>, dim3(div_up(n, 256)), dim3(256), lds, st, in, stride_items, n, pts, dst0, bad_count);
     return hipGetLastError();
