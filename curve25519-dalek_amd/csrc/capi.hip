@@ -693,40 +693,3 @@ EXPORT int32_t c25519_to_montgomery_batch(c25519_ctx *ctx, const uint8_t *in, ui
                         [&](uint64_t lo, uint64_t m) -> int32_t { return c25519_to_montgomery_batch_dev(ctx, d_in + lo * 160, m, d_out + lo * 32); });
 }
 
-// ---- diagnostics -------------------------------------------------------------------------------------
-// field self-test: raw limbs (n x 10 u32, HOST pointers; b may be NULL for the unary ops) -> n x 32 canonical bytes
-EXPORT int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out) {
-    HIPCHK(hipSetDevice(ctx->device));
-    if (op < 0 || op > 11 || (chain != 0 && chain != 1)) { ctx->err = "selftest_field: bad op / chain"; return -(int32_t)hipErrorInvalidValue; }
-    if (n == 0) return C25519_OK;
-    int32_t r;
-    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * 40)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 32))) return r;
-    HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, a_limbs, n * 40, hipMemcpyHostToDevice, ctx->stream));
-    if (b_limbs) HIPCHK(hipMemcpyAsync(ctx->tmp_b.p, b_limbs, n * 40, hipMemcpyHostToDevice, ctx->stream));
-    const uint32_t *db = b_limbs ? (const uint32_t *)ctx->tmp_b.p : nullptr;
-    if (chain) HIPCHK(launch_selftest_c1(op, (const uint32_t *)ctx->tmp_a.p, db, n, (uint8_t *)ctx->tmp_c.p, ctx->stream));
-    else HIPCHK(launch_selftest_c0(op, (const uint32_t *)ctx->tmp_a.p, db, n, (uint8_t *)ctx->tmp_c.p, ctx->stream));
-    HIPCHK(hipMemcpyAsync(out, ctx->tmp_c.p, n * 32, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return C25519_OK;
-}
-
-EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
-    if (hipSetDevice(ctx->device) != hipSuccess) return -1.0;
-    if (ctx_reserve(ctx, ctx->tmp_a, 4096)) return -1.0;
-    hipMemsetAsync(ctx->tmp_a.p, 0x5a, 4096, ctx->stream);
-    unsigned grid = (unsigned)ctx->num_cus * 8;   // 8 blocks x 4 waves per CU = 8 waves per SIMD
-    if (which >= 200) { which -= 200; grid = (unsigned)ctx->num_cus * 3; }   // which + 200: THREE waves per SIMD (the occupancy of k_accumulate)
-    else if (which >= 100) { which -= 100; grid = (unsigned)ctx->num_cus; }   // which + 100: ONE wave per SIMD (latency, not throughput)
-    if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, 16, grid, ctx->stream) != hipSuccess) return -1.0;  // warm-up
-    hipEventRecord(ctx->ev0, ctx->stream);
-    if (launch_probe(which, (uint32_t *)ctx->tmp_a.p, iters, grid, ctx->stream) != hipSuccess) return -1.0;
-    hipEventRecord(ctx->ev1, ctx->stream);
-    float ms = c25519_last_kernel_ms(ctx);
-    if (ms <= 0) return -1.0;
-    // 6, 7: the mixed probes count their v_mad_u64_u32 only (8 per iteration), so the result reads as
-    // "MAC rate with R simple integer ops issued beside every MAC"
-    double per_lane = (which >= 40 && which <= 42) ? 3.0 * iters : (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
-    double total = per_lane * 256.0 * grid;
-    return total / (ms * 1e-3) / 1e9;
-}

@@ -41,6 +41,7 @@ struct c25519_ctx {
     bool owns_table = true;
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
     devbuf tmp_a, tmp_b, tmp_c, tmp_c2, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
+    const uint32_t *cont_buckets = nullptr;                    // where the latest MSM pass on this context keeps its bucket sums (checked by a continuing pass)
     devbuf pts_all;                                            // gather records of passes 1.. of a multi-pass MSM (prepared ahead in one launch)
     // names of the kernels the latest entry point launched: [0] its dominant kernel (k_mul_base*, k_x25519, k_var_base, k_accumulate),
     // [1] the decompression of R_i in a verify_batch pass -- what c25519_phase_ms phases 0 and 3 time

@@ -68,9 +68,16 @@ __device__ __forceinline__ feT fe48_load(const u32 *base, u64 idx) {
 }
 
 // raw 160-byte EdwardsPoint (fmt 2): {X,Y,Z,T} x 5 x u64 radix-2^51, limbs < 2^52
-__device__ __forceinline__ feT fe_from_limbs51(const u64 l[5]) {
+// EXACT for every u64 limb value: the element is sum_i l_i 2^(51 i) mod p (u64/field.rs:43-52), whatever the magnitudes -- the
+// reference's own operations keep limbs below 2^52 (its debug_assert!s, field.rs:162-166), but a caller that hands over sums it
+// never reduced is still given the value its limbs denote, not a truncation: bits 51..63 of limb i are a 13-bit carry into limb
+// i+1 (x19 from the top limb), taken before the 26/25 split.
+C25519_HD feT fe_from_limbs51(const u64 l[5]) {
     feW t;
-    for (int i = 0; i < 5; i++) { t.v[2 * i] = (u32)l[i] & M26; t.v[2 * i + 1] = (u32)(l[i] >> 26); }
+    u32 hi[5];
+    for (int i = 0; i < 5; i++) { t.v[2 * i] = (u32)l[i] & M26; t.v[2 * i + 1] = (u32)(l[i] >> 26) & M25; hi[i] = (u32)(l[i] >> 32) >> 19; }
+    t.v[0] += 19u * hi[4];
+    for (int i = 1; i < 5; i++) t.v[2 * i] += hi[i - 1];
     return fe_carry(t);
 }
 __device__ __forceinline__ void fe_to_limbs51(const feT &a, u64 l[5]) {

@@ -25,5 +25,6 @@ hipError_t launch_raw_to_p32(const uint8_t *in_raw, uint64_t n, uint32_t *scratc
 hipError_t launch_selftest_c0(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_selftest_c1(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipStream_t st);
+hipError_t launch_selftest_scalar(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint32_t *out, hipStream_t st);
 
 }  // namespace c25519

@@ -1490,9 +1490,9 @@ void host_raw160(const ge_p3 &p, uint8_t *out) {
 ge_p3 host_from_raw160(const uint8_t *in) {
     ge_p3 p; feT *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
     for (int c = 0; c < 4; c++) {
-        feW t;
-        for (int i = 0; i < 5; i++) { uint64_t v; memcpy(&v, in + 40 * c + 8 * i, 8); t.v[2 * i] = (u32)v & M26; t.v[2 * i + 1] = (u32)(v >> 26); }
-        *f[c] = fe_carry(t);
+        uint64_t l[5];
+        memcpy(l, in + 40 * c, 40);
+        *f[c] = fe_from_limbs51(l);                        // exact for every u64 limb (devio.h)
     }
     return p;
 }
@@ -1583,9 +1583,12 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
                          const msm_merged *md = nullptr, uint64_t n_carve = 0) {
     const uint64_t n = md ? (uint64_t)md->K * md->ns : n_scalars;
     const uint64_t nc = n_carve > n ? n_carve : n;
+    // every region BEFORE the buckets (oK) must be sized from nc, the number of terms the call's passes are carved for, never from
+    // this pass's own n: a shorter last pass that CONTINUES its predecessor's bucket sums has to find them at the same offset
+    // (round 3 derived nchunk from n: with C25519_MSM_PASS_LOG2 = 21 / 22 a last pass one chunk shorter moved oC .. oK)
     int nchunk = std::max(1, std::min(64, 512 / g.nwin));
-    while (nchunk > 1 && n / nchunk < 4096) nchunk /= 2;
-    if ((n + nchunk - 1) / nchunk > 65536) nchunk = (int)((n + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
+    while (nchunk > 1 && nc / nchunk < 4096) nchunk /= 2;
+    if ((nc + nchunk - 1) / nchunk > 65536) nchunk = (int)((nc + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
     uint64_t chunk = (n + nchunk - 1) / nchunk;
     const uint64_t nb = (uint64_t)g.nwin * g.half;
     const int nseg = (g.half + RED_SEG - 1) / RED_SEG;
@@ -1956,6 +1959,9 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
     if (serial_sort) { HIPCHK(hipEventRecord(ctx->ev_z, ctx->stream)); HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_z, 0)); }
     if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve))) return r;
+    // a continuing pass adds onto the bucket sums its predecessor on this stream set left: they must be where it left them
+    if (cont && pl.buckets != ctx->cont_buckets) { ctx->err = "msm: internal error (the workspace of a continuing pass moved its buckets)"; return -(int32_t)hipErrorInvalidValue; }
+    ctx->cont_buckets = pl.buckets;
     return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc, cont, reduce, d_bad_sticky);
 }
 // The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column

@@ -119,6 +119,7 @@ def load_library():
         "c25519_scalar_invert_batch": (i32, [vp, vp, u64, vp]),
         "c25519_microbench": (C.c_double, [vp, C.c_int, C.c_int]),
         "c25519_selftest_field": (i32, [vp, C.c_int, C.c_int, vp, vp, u64, vp]),
+        "c25519_selftest_scalar": (i32, [vp, C.c_int, vp, vp, u64, vp]),
         "c25519_msm_geometry": (i32, [u64, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -138,7 +139,7 @@ ABI_SYMBOLS = [
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "c25519_msm_partial_record_dev", "c25519_fold_partial_records", "c25519_partial_record_pack",
-    "ed25519_batch_hram_dev", "ed25519_batch_transcript_zs", "ed25519_verify_batch_record_dev", "ed25519_fold_verify_records", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_msm_geometry",
+    "ed25519_batch_hram_dev", "ed25519_batch_transcript_zs", "ed25519_verify_batch_record_dev", "ed25519_fold_verify_records", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_selftest_scalar", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
@@ -231,6 +232,16 @@ class Engine:
         out = np.empty((n, 32), dtype=np.uint8)
         self._bind_stream()
         self._chk(self.lib.c25519_selftest_field(self.ctx, op, chain, a.ctypes.data, b.ctypes.data if b is not None else None, n, out.ctypes.data))
+        return out
+
+    def selftest_scalar(self, op, a_words, b_words=None):
+        """one sc28.h operation per row on the GPU: (n, 16) uint32 per operand -> (n, 32) bytes (c25519_selftest_scalar)"""
+        a = np.ascontiguousarray(a_words, dtype=np.uint32).reshape(-1, 16); n = a.shape[0]
+        b = None if b_words is None else np.ascontiguousarray(b_words, dtype=np.uint32).reshape(-1, 16)
+        assert b is None or b.shape[0] == n
+        out = np.empty((n, 32), dtype=np.uint8)
+        self._bind_stream()
+        self._chk(self.lib.c25519_selftest_scalar(self.ctx, op, a.ctypes.data, b.ctypes.data if b is not None else None, n, out.ctypes.data))
         return out
 
     def microbench(self, which, iters=2000):

@@ -22,7 +22,10 @@
  *     ed25519-dalek/src/errors.rs:21-42 InternalError); negative = -(hipError_t) runtime failure.
  *   - point formats (`fmt`): 0 = 32-byte CompressedEdwardsY (edwards.rs:175),
  *     1 = 32-byte CompressedRistretto (ristretto.rs:223),
- *     2 = 160-byte raw EdwardsPoint {X,Y,Z,T} x 5 x u64 radix-2^51 limbs, every limb < 2^52
+ *     2 = 160-byte raw EdwardsPoint {X,Y,Z,T} x 5 x u64 radix-2^51 limbs (u64/field.rs:43-52).  The reference keeps
+ *         limbs below 2^52 (its debug_assert!s, field.rs:162-166); INPUT limbs here may be ANY u64 values -- the
+ *         element read is sum_i l_i 2^(51 i) mod p exactly (no truncation, no status: there is no limb pattern without a
+ *         meaning), so unreduced sums are accepted as what they denote; OUTPUT limbs are canonical (< 2^51, value < p).
  *         (edwards.rs:390-395 is not repr(C); the Rust shim copies limb-by-limb into this layout).
  *   - scalars: 32 bytes little-endian, < 2^255 (Scalar invariant #1, scalar.rs:197-205); they need
  *     NOT be reduced mod l for point multiplication (clamped integers are legal).
@@ -390,6 +393,15 @@ double c25519_microbench(c25519_ctx *ctx, int which, int iters);
  * 8 a*b and 9 b^2 out of one group of three products, 10 a*b and 11 b^2 out of one group of four.  Pins the device code
  * generation against big integers (field.rs:552-642). */
 int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t *a_limbs, const uint32_t *b_limbs, uint64_t n, uint8_t *out);
+/* The same for the device SCALAR arithmetic mod l (csrc/sc28.h: ten 28-bit limbs, reduction by folding with l = 2^252 + c),
+ * which replaces Scalar52 (u64/scalar.rs:66-320) inside the verify_batch / sign / per-signature-verify kernels.
+ * a_words / b_words: n x 16 u32 per operand (HOST pointers; b may be NULL for the unary ops); out: n x 32 bytes.
+ * op 0 from_bytes_mod_order_wide(a: 16 words) (scalar.rs:248, u64/scalar.rs:89-118); 1 a*b mod l, a = 5 and b = 10 raw 28-bit
+ * limbs with a*b < 2^393 (z_i * s_i, z_i * h_i: batch.rs:225-233); 2 a*b mod l, 10 x 10 raw limbs with a*b < 2^512 (u64/scalar.rs:302;
+ * signing.rs:899 k*a with the clamped a); 3 a+b and 4 -a on canonical operands (8 words each; u64/scalar.rs:161-207);
+ * 5 out[0] = (a < l), the word-wise test behind from_canonical_bytes (scalar.rs:259-263); 6 words -> limbs -> words of a < 2^256;
+ * 7 r + k*a as the signer chains them: k = a mod l (16 words), a = b[0..8] (unreduced, < 2^256), r = b[8..16] (canonical). */
+int32_t c25519_selftest_scalar(c25519_ctx *ctx, int op, const uint32_t *a_words, const uint32_t *b_words, uint64_t n, uint8_t *out);
 /* The window layout the MSM uses for n terms (host arithmetic, no GPU needed): window k covers bits
  * [pos[k], pos[k] + wid[k]) of s' = s + addk (addk as 8 little-endian 32-bit words); all windows but the last two are
  * signed (digit = slice - 2^(wid-1)).  pos / wid need room for 56 entries.  Used by the CPU tests to check that the

@@ -330,3 +330,30 @@ def test_msm_long_runs_in_a_few_chunks(eng, orc):
     draw = eng.mul_base_batch_t(dx, out_fmt=2)
     st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+
+
+@pytest.mark.parametrize("log2pass,n", [(21, 5898242), (22, 12386305)])
+def test_msm_continuing_last_pass_one_sort_chunk_shorter(orc, log2pass, n):
+    """ADVICE r3 (msm.hip workspace carve): with C25519_MSM_PASS_LOG2 = 21 / 22 the last of three passes is one sort chunk shorter
+    than the others (1 966 080 against 1 966 081 terms: 30 against 31 chunks; 4 128 767 against 4 128 769: 63 against 64) and CONTINUES
+    the bucket sums of pass 0 on its stream set -- which it must find at the same workspace offset.  Fresh process: the knob is read once."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_msm as T, curve25519_dalek_amd as pkg
+        from oracle import orc
+        eng = pkg.Engine(0)
+        n = %d
+        g = torch.Generator(device="cuda"); g.manual_seed(1234 + n)
+        dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        dx[:, 31] &= 0x0F
+        draw = eng.mul_base_batch_vartime_t(dx, out_fmt=2)
+        st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+        assert eng.last_call_phase_ms(0)[1] == 3, eng.last_call_phase_ms(0)
+        assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(T.i2b(T._sumsq_device(dx))))
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n)
+    e = dict(os.environ, C25519_MSM_PASS_LOG2=str(log2pass))
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
