@@ -394,7 +394,7 @@ int32_t mul_base_impl(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, int
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     HIPCHK(hipEventRecord(ring[0], ctx->stream));
-    ctx->kname[0] = secret ? "c25519::k_mul_base<5, 1024, OUT, true> (constant-time scan, radix-2^5 tables in LDS)"
+    ctx->kname[0] = secret ? mul_base_ct_kernel_name(n, ctx->num_cus)
                            : (ctx->w >= 10 ? "c25519::k_mul_base_wide<OUT> (radix-2^w tables in HBM)" : ctx->w == 9 ? "c25519::k_mul_base_comb" : "c25519::k_mul_base<W, BS, OUT, false>");
     auto mul = [&](uint32_t *scratch, uint8_t *out_raw) -> hipError_t {
         return secret ? launch_mul_base_ct(d_scalars, n, table_ct ? table_ct : ctx->d_table_ct, scratch, out_raw, ctx->num_cus, ctx->stream)

@@ -61,7 +61,15 @@ struct stream_wipe {
     hipStream_t st; void *p[6]; size_t n[6]; int cnt = 0;
     explicit stream_wipe(hipStream_t s) : st(s) {}
     stream_wipe(const stream_wipe &) = delete;
-    void add(void *q, size_t bytes) { if (q && bytes && cnt < 6) { p[cnt] = q; n[cnt++] = bytes; } }
+    // more buffers than slots: never dropped silently -- the extra one is wiped at once, in stream order before whatever the caller enqueues next
+    // (correct for a buffer that is still empty; a caller that needs more late wipes must raise the slot count -- asserted in debug builds)
+    void add(void *q, size_t bytes) {
+        if (!q || !bytes) return;
+        if (cnt < 6) { p[cnt] = q; n[cnt++] = bytes; return; }
+        overflowed = true;
+        (void)hipMemsetAsync(q, 0, bytes, st);
+    }
+    bool overflowed = false;
     ~stream_wipe() { for (int i = 0; i < cnt; i++) (void)hipMemsetAsync(p[i], 0, n[i], st); }
 };
 

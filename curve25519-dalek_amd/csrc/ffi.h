@@ -26,6 +26,18 @@ int32_t ffi_begin(c25519_ctx *ctx);
 // the context's stream continues after the downloads (for wipes of staged secrets); records the wall-clock of the call
 int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes);
 
+// Between ffi_begin and the point where ffi_pipeline (or an explicit ffi_end) takes over, an entry point queues whole-array uploads on
+// the copy stream; if one of those fails it returns at once.  The guard makes that early exit drain the copy streams too (ffi_end), so
+// that no queued copy is still reading the caller's memory after the call has returned its error, the figures of c25519_last_ffi_ms
+// are those of THIS call, and a stream_wipe declared before it (destroyed after it) enqueues its memsets behind completed copies.
+struct ffi_guard {
+    c25519_ctx *ctx; bool armed = true;
+    explicit ffi_guard(c25519_ctx *c) : ctx(c) {}
+    ffi_guard(const ffi_guard &) = delete;
+    void dismiss() { armed = false; }
+    ~ffi_guard() { if (armed) (void)ffi_end(ctx, 0, 0); }
+};
+
 // units per chunk: at most FFI_MAXCH chunks of at least min_units units, a multiple of 1024
 static inline uint64_t ffi_chunk_units(uint64_t n, uint64_t min_units) {
     if (n <= min_units) return n ? n : 1;

@@ -531,6 +531,14 @@ static hipError_t launch_ct_split(const uint8_t *scalars, u64 n, const uint32_t 
 #undef C25519_CT_SPLIT_LAUNCH
     return hipGetLastError();
 }
+// the kernel launch_mul_base_ct picks for n scalars (what the timing records attribute phase 0 to)
+const char *mul_base_ct_kernel_name(u64 n, int num_cus) {
+    const u64 per_cu = (n + (u64)num_cus - 1) / (u64)(num_cus > 0 ? num_cus : 1);
+    if (per_cu <= 128) return "c25519::k_mul_base_ct_split<256, OUT> (constant-time scan, two lanes per scalar)";
+    if (per_cu <= 256) return "c25519::k_mul_base_ct_split<512, OUT> (constant-time scan, two lanes per scalar)";
+    if (per_cu <= 512) return "c25519::k_mul_base_ct_split<1024, OUT> (constant-time scan, two lanes per scalar)";
+    return "c25519::k_mul_base<5, 1024, OUT, true> (constant-time scan, radix-2^5 tables in LDS)";
+}
 hipError_t launch_mul_base_ct(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
     if (n == 0) return hipSuccess;
     // small batches: two threads per scalar, one block per compute unit (k_mul_base_ct_split); the block grows with the batch

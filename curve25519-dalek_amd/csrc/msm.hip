@@ -2099,6 +2099,7 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16))) return r;
     uint8_t *d_s = (uint8_t *)ctx->tmp_a.p, *d_p = (uint8_t *)ctx->tmp_b.p;
     if ((r = ffi_begin(ctx))) return r;
+    ffi_guard guard(ctx);
     // The inputs go up pass by pass on the copy stream while the previous pass computes.  Raw points are 192 bytes per term:
     // the link (56 GB/s = 0.29 G terms/s) is slower than the kernels (1.1 G terms/s), so passes are small (2^19 terms)
     // and what remains after the last byte has arrived is one small pass; compressed points (64 bytes per term) are bound
@@ -2119,6 +2120,7 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     const uint64_t pass_terms = n >= (1ull << 20) ? (in_fmt == C25519_FMT_RAW160 ? (1ull << 19) : (1ull << 20)) : 0;
     r = msm_record_enqueue(ctx, d_s, d_p, n, in_fmt, drec(ctx), &fetch, pass_terms);
     if (!r) r = rec_collect(ctx);
+    guard.dismiss();
     const int32_t r2 = ffi_end(ctx, up, 0);
     if (r || (r = r2)) return r;
     if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
@@ -2445,6 +2447,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     uint8_t *d_msg = (uint8_t *)ctx->tmp_a.p, *d_sig = (uint8_t *)ctx->tmp_c.p, *d_pk = (uint8_t *)ctx->scratch.p, *d_pp = pk_points ? d_pk + n * 32 : nullptr;
     uint64_t *d_off = (uint64_t *)ctx->tmp_b.p;
     if ((r = ffi_begin(ctx))) return r;
+    ffi_guard guard(ctx);                                 // the early exits of the uploads below drain the copy stream as well
     uint64_t up = 0;
     if (z_mode == C25519_Z_TRANSCRIPT) {
         // the whole batch is hashed before anything else can start and the sequential host transcript dominates: upload everything
@@ -2477,6 +2480,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
         };
         r = verify_batch_impl(ctx, d_msg, d_off, mlen, d_sig, d_pk, d_pp, n, z_mode, &fetch);
     }
+    guard.dismiss();
     const int32_t r2 = ffi_end(ctx, up, 0);
     return (r < 0 || !r2) ? r : r2;
 }

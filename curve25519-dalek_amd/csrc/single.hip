@@ -508,10 +508,12 @@ EXPORT int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const u
     uint64_t *doff = (uint64_t *)ctx->tmp_b.p;
     // the message blob and the offsets go up whole (the kernels index the blob through the offsets); signatures and keys in chunks
     if ((r = ffi_begin(ctx))) return r;
+    ffi_guard guard(ctx);                                 // an early exit below still drains the copy stream
     if (mlen) HIPCHK(hipMemcpyAsync(dmsg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
     HIPCHK(hipMemcpyAsync(doff, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
     const ffi_in in[2] = {{sigs, dsig, 64}, {pks, dpk, 32}};
     const ffi_out o = {status, dst, 1};
+    guard.dismiss();                                      // ffi_pipeline calls ffi_end on every path
     return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), in, 2, &o, 1, [&](uint64_t lo, uint64_t m) -> int32_t {
         return ed25519_verify_each_dev(ctx, dmsg, doff + lo, mlen, dsig + lo * 64, dpk + lo * 32, m, strict, dst + lo);
     }, true, mlen + (n + 1) * 8);
@@ -585,10 +587,12 @@ EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const u
     stream_wipe wipe(ctx->stream);
     wipe.add(dseed, n * 32);                              // the staged secret keys, on every path
     if ((r = ffi_begin(ctx))) return r;
+    ffi_guard guard(ctx);                                 // destroyed before `wipe`: the memset of the staged secrets follows completed copies
     if (mlen) HIPCHK(hipMemcpyAsync(dmsg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
     HIPCHK(hipMemcpyAsync(doff, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
     const ffi_in in = {seeds, dseed, 32};
     const ffi_out o[2] = {{pks, dpk, 32}, {sigs, dsig, 64}};
+    guard.dismiss();
     // one chunk: ed25519_sign_batch_dev reads its error flag back (a synchronisation per call)
     return ffi_pipeline(ctx, n, n, &in, 1, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
         return ed25519_sign_batch_dev(ctx, dseed + lo * 32, dmsg, doff + lo, mlen, m, dpk + lo * 32, dsig + lo * 64);

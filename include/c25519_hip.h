@@ -69,7 +69,12 @@ extern "C" {
  *   (level, inputs of the level, batch size) and the fixed-length data).  Every z_i depends on every bit of the batch;
  *   honest batches give the same verdict in both modes; a batch containing an invalid signature passes with
  *   probability <= 2^-127.99 (reference: 2^-128) under the usual assumption that SHA-512's compression function is
- *   collision resistant and its output unpredictable.  Batches beyond ~1.5 x 2^20 signatures are checked as
+ *   collision resistant and its output unpredictable.  BINDING MARGIN of the tree leaves (v4): the z_i bind (R_i, A_i, M_i) only
+ *   through h_i mod l, a 252-bit value, where the reference's transcript absorbs the full 64-byte hash (batch.rs:191-199).  Two
+ *   different (R, A, M) triples with equal h mod l would produce identical z_i for two different batch equations; finding such a pair
+ *   is a birthday search on 252 bits, about 2^126 hash evaluations -- near, not at, the 128-bit level of the rest of the construction
+ *   (the same order as the cross-pass birthday bound this library refuses elsewhere by checking sub-batches independently).  Callers
+ *   that need the reference's full margin use C25519_Z_TRANSCRIPT.  Batches beyond ~1.5 x 2^20 signatures are checked as
  *   independent sub-batches (own tree, own z_i, own identity check).  The z_i VALUES differ from the reference's. */
 #define C25519_Z_TRANSCRIPT 0
 #define C25519_Z_DEVICE 1

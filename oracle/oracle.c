@@ -330,6 +330,42 @@ static void run_jobs(int kind, const uint8_t *a, const uint8_t *b, uint8_t *out,
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
     free(th); free(js);
 }
+/* "All host cores" legs of bench.py's cpu_baseline (one independent slice per thread).  The reference's MSM and
+   verify_batch are single-threaded calls; a caller with T cores would cut its terms / signatures into T slices, run the
+   reference's own call on each (pippenger.rs / batch.rs:146 unchanged) and add the partial sums / AND the verdicts. */
+typedef struct { const uint8_t *scalars; const uint64_t *points; size_t lo, hi; ge_p3 sum; } msm_job;
+static void *msm_job_run(void *arg) {
+    msm_job *j = arg; size_t n = j->hi - j->lo;
+    ge_p3 *pts = malloc((n ? n : 1) * sizeof(ge_p3));
+    for (size_t i = 0; i < n; i++) pts[i] = p3_load(j->points + 20 * (j->lo + i));
+    j->sum = ge_multiscalar_mul_vartime(j->scalars + 32 * j->lo, pts, n);
+    free(pts); return NULL;
+}
+EXPORT void orc_ed_msm_vartime_mt(const uint8_t *scalars, const uint64_t *points, size_t n, int threads, uint64_t out[20]) {
+    ensure_tables();
+    if (threads < 1) threads = 1;
+    pthread_t *th = malloc(threads * sizeof *th); msm_job *js = malloc(threads * sizeof *js);
+    for (int t = 0; t < threads; t++) { js[t] = (msm_job){scalars, points, n * t / threads, n * (t + 1) / threads, ge_identity()}; pthread_create(&th[t], NULL, msm_job_run, &js[t]); }
+    ge_p3 r = ge_identity();
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); r = ge_add(r, js[t].sum); }
+    p3_store(out, r); free(th); free(js);
+}
+typedef struct { const uint8_t *msgs; const uint64_t *off; const uint8_t *sigs, *pks; size_t lo, hi; int status; } vb_job;
+static void *vb_job_run(void *arg) {
+    vb_job *j = arg;
+    j->status = orc_ed25519_verify_batch_z(j->msgs, j->off + j->lo, j->sigs + 64 * j->lo, j->pks + 32 * j->lo, j->hi - j->lo, NULL);
+    return NULL;
+}
+/* worst slice verdict (every slice is its own verify_batch call with its own transcript); msg_off are absolute offsets into msgs */
+EXPORT int orc_ed25519_verify_batch_mt(const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, size_t n, int threads) {
+    ensure_tables();
+    if (threads < 1) threads = 1;
+    pthread_t *th = malloc(threads * sizeof *th); vb_job *js = malloc(threads * sizeof *js);
+    for (int t = 0; t < threads; t++) { js[t] = (vb_job){msgs, msg_off, sigs, pks, n * t / threads, n * (t + 1) / threads, 0}; pthread_create(&th[t], NULL, vb_job_run, &js[t]); }
+    int st = ST_OK;
+    for (int t = 0; t < threads; t++) { pthread_join(th[t], NULL); if (js[t].status != ST_OK && st == ST_OK) st = js[t].status; }
+    free(th); free(js); return st;
+}
 EXPORT void orc_mul_base_compress_batch(const uint8_t *scalars, size_t n, uint8_t *out, int threads) { run_jobs(0, scalars, NULL, out, n, threads); }
 EXPORT void orc_x25519_batch(const uint8_t *k, const uint8_t *u, size_t n, uint8_t *out, int threads) { run_jobs(1, k, u, out, n, threads); }
 EXPORT void orc_ed_decompress_ok_batch(const uint8_t *in, size_t n, uint8_t *ok, int threads) { run_jobs(2, in, NULL, ok, n, threads); }

@@ -295,3 +295,21 @@ def ed25519_keygen_sign_batch(seeds, msgs, threads=1):
     lib().orc_ed25519_keygen_sign_batch(sd.ctypes.data_as(C.c_void_p), m.ctypes.data_as(C.c_void_p), C.c_size_t(mlen), C.c_size_t(n),
                                         pks.ctypes.data_as(C.c_void_p), sigs.ctypes.data_as(C.c_void_p), C.c_int(threads))
     return pks, sigs
+
+
+def ed_msm_mt_np(scalars, points, threads=1):
+    """`threads` independent slices, each the reference's single-threaded MSM, partial sums added (bench.py cpu_baseline all_cores)"""
+    s = np.ascontiguousarray(scalars, dtype=np.uint8); p = np.ascontiguousarray(points, dtype=np.uint8)
+    assert s.ndim == 2 and s.shape[1] == 32 and p.shape == (s.shape[0], 160)
+    o = _pt()
+    lib().orc_ed_msm_vartime_mt(s.ctypes.data_as(C.c_char_p), p.ctypes.data_as(C.c_char_p), C.c_size_t(s.shape[0]), C.c_int(threads), o)
+    return o.raw
+
+
+def ed25519_verify_batch_mt_np(msgs, mlen, sigs, pks, threads=1):
+    """fixed-length messages as an (n, mlen) array; `threads` independent verify_batch calls over contiguous slices -> worst verdict"""
+    m = np.ascontiguousarray(msgs, dtype=np.uint8); sg = np.ascontiguousarray(sigs, dtype=np.uint8); pk = np.ascontiguousarray(pks, dtype=np.uint8)
+    n = sg.shape[0]
+    off = (np.arange(n + 1, dtype=np.uint64) * np.uint64(mlen))
+    return lib().orc_ed25519_verify_batch_mt(m.ctypes.data_as(C.c_char_p), off.ctypes.data_as(C.c_void_p), sg.ctypes.data_as(C.c_char_p),
+                                             pk.ctypes.data_as(C.c_char_p), C.c_size_t(n), C.c_int(threads))

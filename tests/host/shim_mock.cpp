@@ -1,0 +1,276 @@
+// A COMPILED stand-in for the Rust shim that INTEGRATION.md section 3 specifies (BackendKind::Hip; no Rust toolchain exists in this
+// image).  It does, in C++, exactly what the shim does on the reference's side of the C ABI:
+//   * the reference's in-memory types -- FieldElement51([u64; 5]) (u64/field.rs:43-52), EdwardsPoint{X, Y, Z, T} (edwards.rs:388-395,
+//     not repr(C)), Scalar{bytes: [u8; 32]} (scalar.rs:193-205) -- copied LIMB BY LIMB into / out of the 160-byte raw layout;
+//   * Option<EdwardsPoint> inputs (None -> None before any call) and the status -> Option / panic mapping of backend.rs:79-277;
+//   * the size-threshold dispatch of edwards.rs:1025 with one more arm: below HIP_THRESHOLD the "serial backend" (here the C
+//     restatement in oracle/ -- TEST INFRASTRUCTURE, standing in for serial::scalar_mul::{straus, pippenger}), at or above it the GPU;
+// and then runs the reference's OWN consistency shapes through those functions:
+//   edwards.rs:2276-2335  multiscalar_consistency_n_{100, 250, 500, 1000}      (constant-time, variable-time, mul_base(sum x_i^2))
+//   edwards.rs:2364-2411  vartime_precomputed_vs_nonprecomputed_multiscalar
+//   edwards.rs:2084-2129  mul_base_clamped vs mul_clamped, on B and on a random point with torsion through a basepoint table
+//   edwards.rs:2268-2274  scalarmult both ways (variable base against the table)
+// Exit code 0 = every assertion of those tests holds through the shim.  Built and run by tests/test_gpu_shim_mock.py.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <optional>
+#include <random>
+#include <vector>
+#include "../../include/c25519_hip.h"
+
+// ---- the "serial backend" and the scalar arithmetic of the test bodies: the C restatement (oracle/oracle.c exports) ---------------
+extern "C" {
+void orc_ed_msm_vartime(const uint8_t *scalars, const uint64_t *points, size_t n, int which, uint64_t out[20]);
+void orc_sc_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void orc_sc_add(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void orc_sc_from_bytes_mod_order_wide(const uint8_t in[64], uint8_t out[32]);
+}
+
+// ---- the reference's types ---------------------------------------------------------------------------------------------------------
+struct FieldElement51 { uint64_t l[5]; };
+struct EdwardsPoint { FieldElement51 X, Y, Z, T; };
+struct Scalar { uint8_t bytes[32]; };
+struct CompressedEdwardsY { uint8_t b[32]; bool operator==(const CompressedEdwardsY &o) const { return !memcmp(b, o.b, 32); } };
+
+#define CHECK(cond, ...) do { if (!(cond)) { fprintf(stderr, "shim_mock: " __VA_ARGS__); fprintf(stderr, " (%s:%d)\n", __FILE__, __LINE__); exit(1); } } while (0)
+
+namespace hip {
+static c25519_ctx *g_ctx = nullptr;
+// crossover of bench.py's small_n record: below it a GPU call costs more than the serial backend
+static size_t HIP_THRESHOLD = 32;
+static c25519_ctx *context() { if (!g_ctx) g_ctx = c25519_ctx_create(0, 0); return g_ctx; }
+[[noreturn]] static void backend_panic(const char *what, int32_t st) { fprintf(stderr, "hip backend error in %s: %d (%s)\n", what, st, c25519_last_error(context())); exit(3); }
+
+// edwards.rs:388-395 is not repr(C) and its fields are pub(crate): the shim copies limb by limb
+static void raw160(const EdwardsPoint &p, uint8_t *out) {
+    const FieldElement51 *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 5; i++) { const uint64_t v = f[c]->l[i]; for (int b = 0; b < 8; b++) out[40 * c + 8 * i + b] = (uint8_t)(v >> (8 * b)); }   // l.to_le_bytes()
+}
+static EdwardsPoint edwards_from_raw160(const uint8_t *in) {
+    EdwardsPoint p; FieldElement51 *f[4] = {&p.X, &p.Y, &p.Z, &p.T};
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 5; i++) { uint64_t v = 0; for (int b = 0; b < 8; b++) v |= (uint64_t)in[40 * c + 8 * i + b] << (8 * b); f[c]->l[i] = v; }
+    return p;
+}
+}  // namespace hip
+
+// ---- the reference's API over the seam -------------------------------------------------------------------------------------------
+// EdwardsPoint::optional_multiscalar_mul (edwards.rs:1002-1031) -> backend.rs:79 / :224 with the Hip arm
+static std::optional<EdwardsPoint> optional_multiscalar_mul(const std::vector<Scalar> &scalars, const std::vector<std::optional<EdwardsPoint>> &points) {
+    CHECK(scalars.size() == points.size(), "size hints differ (edwards.rs:1017-1019 asserts)");
+    const size_t n = scalars.size();
+    std::vector<uint8_t> s(n * 32 + 1), p(n * 160 + 1);
+    for (size_t i = 0; i < n; i++) {
+        if (!points[i]) return std::nullopt;                                      // `let pt = pt?;`
+        memcpy(&s[32 * i], scalars[i].bytes, 32);
+        hip::raw160(*points[i], &p[160 * i]);
+    }
+    uint8_t out[160];
+    if (n < hip::HIP_THRESHOLD) {                                                 // BackendKind::Serial: Straus below 190 terms, Pippenger above (edwards.rs:1025)
+        uint64_t o[20];
+        std::vector<uint64_t> pl(n * 20 + 1);
+        memcpy(pl.data(), p.data(), n * 160);
+        orc_ed_msm_vartime(s.data(), pl.data(), n, 0, o);
+        memcpy(out, o, 160);
+        return hip::edwards_from_raw160(out);
+    }
+    const int32_t st = c25519_msm_vartime(hip::context(), s.data(), p.data(), n, C25519_FMT_RAW160, C25519_FMT_RAW160, out);
+    if (st == C25519_OK) return hip::edwards_from_raw160(out);                    // limbs < 2^51: valid Mul input (u64/field.rs:125-166)
+    if (st == C25519_NONE) return std::nullopt;
+    hip::backend_panic("c25519_msm_vartime", st);
+}
+static EdwardsPoint vartime_multiscalar_mul(const std::vector<Scalar> &scalars, const std::vector<EdwardsPoint> &points) {   // traits.rs:249
+    std::vector<std::optional<EdwardsPoint>> o(points.begin(), points.end());
+    auto r = optional_multiscalar_mul(scalars, o);
+    CHECK(r.has_value(), "should return some point (traits.rs:262)");
+    return *r;
+}
+// EdwardsPoint::multiscalar_mul (constant time; backend.rs:196 straus_multiscalar_mul)
+static EdwardsPoint multiscalar_mul(const std::vector<Scalar> &scalars, const std::vector<EdwardsPoint> &points) {
+    const size_t n = scalars.size();
+    CHECK(n == points.size(), "sizes");
+    std::vector<uint8_t> s(n * 32 + 1), p(n * 160 + 1);
+    for (size_t i = 0; i < n; i++) { memcpy(&s[32 * i], scalars[i].bytes, 32); hip::raw160(points[i], &p[160 * i]); }
+    uint8_t out[160];
+    const int32_t st = c25519_msm_consttime(hip::context(), s.data(), p.data(), n, C25519_FMT_RAW160, C25519_FMT_RAW160, out);
+    if (st != C25519_OK) hip::backend_panic("c25519_msm_consttime", st);
+    return hip::edwards_from_raw160(out);
+}
+static EdwardsPoint mul_base(const Scalar &s) {                                   // edwards.rs:918
+    uint8_t out[160];
+    const int32_t st = c25519_mul_base_batch(hip::context(), s.bytes, 1, C25519_FMT_RAW160, out);
+    if (st != C25519_OK) hip::backend_panic("c25519_mul_base_batch", st);
+    return hip::edwards_from_raw160(out);
+}
+static std::vector<EdwardsPoint> mul_base_many(const std::vector<Scalar> &xs) {   // the batched front end a caller with many scalars uses
+    std::vector<uint8_t> s(xs.size() * 32 + 1), out(xs.size() * 160 + 1);
+    for (size_t i = 0; i < xs.size(); i++) memcpy(&s[32 * i], xs[i].bytes, 32);
+    const int32_t st = c25519_mul_base_batch(hip::context(), s.data(), xs.size(), C25519_FMT_RAW160, out.data());
+    if (st != C25519_OK) hip::backend_panic("c25519_mul_base_batch", st);
+    std::vector<EdwardsPoint> r;
+    for (size_t i = 0; i < xs.size(); i++) r.push_back(hip::edwards_from_raw160(&out[160 * i]));
+    return r;
+}
+static EdwardsPoint mul(const EdwardsPoint &P, const Scalar &s) {                 // &EdwardsPoint * &Scalar (backend.rs:253 variable_base_mul)
+    uint8_t p[160], out[160], ok = 0;
+    hip::raw160(P, p);
+    const int32_t st = c25519_mul_batch(hip::context(), s.bytes, p, 1, C25519_FMT_RAW160, C25519_FMT_RAW160, out, &ok);
+    if (st != C25519_OK || !ok) hip::backend_panic("c25519_mul_batch", st);
+    return hip::edwards_from_raw160(out);
+}
+static EdwardsPoint mul_base_clamped(const uint8_t bytes[32]) {                   // edwards.rs:948
+    uint8_t out[160];
+    const int32_t st = c25519_mul_base_clamped_batch(hip::context(), bytes, 1, C25519_FMT_RAW160, out);
+    if (st != C25519_OK) hip::backend_panic("c25519_mul_base_clamped_batch", st);
+    return hip::edwards_from_raw160(out);
+}
+static EdwardsPoint mul_clamped(const EdwardsPoint &P, const uint8_t bytes[32]) {  // edwards.rs:932
+    uint8_t p[160], out[160], ok = 0;
+    hip::raw160(P, p);
+    const int32_t st = c25519_mul_clamped_batch(hip::context(), bytes, p, 1, C25519_FMT_RAW160, C25519_FMT_RAW160, out, &ok);
+    if (st != C25519_OK || !ok) hip::backend_panic("c25519_mul_clamped_batch", st);
+    return hip::edwards_from_raw160(out);
+}
+static CompressedEdwardsY compress(const EdwardsPoint &P) {                        // edwards.rs:615
+    uint8_t p[160]; CompressedEdwardsY c;
+    hip::raw160(P, p);
+    const int32_t st = c25519_compress_batch(hip::context(), p, 1, C25519_FMT_EDWARDS_Y, c.b);
+    if (st != C25519_OK) hip::backend_panic("c25519_compress_batch", st);
+    return c;
+}
+static std::optional<EdwardsPoint> decompress(const CompressedEdwardsY &c) {       // edwards.rs:211
+    uint8_t out[160], ok = 0;
+    const int32_t st = c25519_decompress_batch(hip::context(), c.b, 1, C25519_FMT_EDWARDS_Y, out, &ok);
+    if (st == C25519_NONE || !ok) return std::nullopt;
+    if (st != C25519_OK) hip::backend_panic("c25519_decompress_batch", st);
+    return hip::edwards_from_raw160(out);
+}
+static bool eq(const EdwardsPoint &a, const EdwardsPoint &b) { return compress(a) == compress(b); }   // (ct_eq compares projectively, edwards.rs:455-467; the encoding decides the same)
+// EdwardsBasepointTable::create(&P) / mul_base_clamped on the table (edwards.rs:1131-1141)
+struct EdwardsBasepointTable {
+    c25519_basetable *t;
+    explicit EdwardsBasepointTable(const EdwardsPoint &P) { uint8_t p[160]; hip::raw160(P, p); t = c25519_basetable_create(hip::context(), p, C25519_FMT_RAW160); CHECK(t, "basetable_create: %s", c25519_last_error(hip::context())); }
+    ~EdwardsBasepointTable() { c25519_basetable_destroy(hip::context(), t); }
+    EdwardsPoint mul_base_clamped(const uint8_t bytes[32]) const {
+        uint8_t s[32], out[160];
+        memcpy(s, bytes, 32); s[0] &= 248; s[31] &= 127; s[31] |= 64;              // clamp_integer, scalar.rs:1407
+        const int32_t st = c25519_mul_table_batch(hip::context(), t, s, 1, C25519_FMT_RAW160, out);
+        if (st != C25519_OK) hip::backend_panic("c25519_mul_table_batch", st);
+        return hip::edwards_from_raw160(out);
+    }
+};
+// VartimeEdwardsPrecomputation (edwards.rs:1037-1076; backend.rs:100-192)
+struct VartimeEdwardsPrecomputation {
+    c25519_precomp *h;
+    explicit VartimeEdwardsPrecomputation(const std::vector<EdwardsPoint> &st) {
+        std::vector<uint8_t> p(st.size() * 160 + 1);
+        for (size_t i = 0; i < st.size(); i++) hip::raw160(st[i], &p[160 * i]);
+        h = c25519_precomp_create(hip::context(), p.data(), st.size(), C25519_FMT_RAW160);
+        CHECK(h, "precomp_create: %s", c25519_last_error(hip::context()));
+    }
+    ~VartimeEdwardsPrecomputation() { c25519_precomp_destroy(hip::context(), h); }
+    size_t len() const { return (size_t)c25519_precomp_len(h); }
+    bool is_empty() const { return len() == 0; }
+    EdwardsPoint vartime_mixed_multiscalar_mul(const std::vector<Scalar> &ss, const std::vector<Scalar> &ds, const std::vector<EdwardsPoint> &dp) const {
+        std::vector<uint8_t> a(ss.size() * 32 + 1), b(ds.size() * 32 + 1), p(dp.size() * 160 + 1);
+        for (size_t i = 0; i < ss.size(); i++) memcpy(&a[32 * i], ss[i].bytes, 32);
+        for (size_t i = 0; i < ds.size(); i++) { memcpy(&b[32 * i], ds[i].bytes, 32); hip::raw160(dp[i], &p[160 * i]); }
+        uint8_t out[160];
+        const int32_t st = c25519_precomp_msm_vartime(hip::context(), h, a.data(), ss.size(), b.data(), p.data(), ds.size(), C25519_FMT_RAW160, C25519_FMT_RAW160, out);
+        if (st != C25519_OK) hip::backend_panic("c25519_precomp_msm_vartime", st);
+        return hip::edwards_from_raw160(out);
+    }
+};
+
+// ---- the test bodies ---------------------------------------------------------------------------------------------------------------
+static std::mt19937_64 g_rng(0xC25519);
+static Scalar scalar_random() {                                                    // Scalar::random: 64 random bytes reduced (scalar.rs:590-596)
+    uint8_t w[64]; for (int i = 0; i < 64; i += 8) { const uint64_t v = g_rng(); memcpy(w + i, &v, 8); }
+    Scalar s; orc_sc_from_bytes_mod_order_wide(w, s.bytes); return s;
+}
+static Scalar sum_of_squares(const std::vector<Scalar> &xs) {
+    Scalar acc; memset(acc.bytes, 0, 32);
+    for (const Scalar &x : xs) { uint8_t sq[32]; orc_sc_mul(x.bytes, x.bytes, sq); orc_sc_add(acc.bytes, sq, acc.bytes); }
+    return acc;
+}
+static void multiscalar_consistency_iter(size_t n) {                               // edwards.rs:2276-2296
+    std::vector<Scalar> xs; for (size_t i = 0; i < n; i++) xs.push_back(scalar_random());
+    const Scalar check = sum_of_squares(xs);
+    const std::vector<EdwardsPoint> Gs = mul_base_many(xs);
+    const EdwardsPoint H1 = multiscalar_mul(xs, Gs), H2 = vartime_multiscalar_mul(xs, Gs), H3 = mul_base(check);
+    CHECK(eq(H1, H3), "multiscalar_consistency n = %zu: constant-time MSM differs from mul_base(sum x^2)", n);
+    CHECK(eq(H2, H3), "multiscalar_consistency n = %zu: variable-time MSM differs from mul_base(sum x^2)", n);
+    for (int c = 0; c < 4; c++) for (int i = 0; i < 5; i++) CHECK((&H2.X)[c].l[i] < (1ull << 51), "a returned limb is not below 2^51");
+}
+static void vartime_precomputed_vs_nonprecomputed_multiscalar() {                   // edwards.rs:2364-2411
+    std::vector<Scalar> ss, ds; for (int i = 0; i < 128; i++) { ss.push_back(scalar_random()); ds.push_back(scalar_random()); }
+    std::vector<Scalar> all(ss); all.insert(all.end(), ds.begin(), ds.end());
+    const Scalar check = sum_of_squares(all);
+    const std::vector<EdwardsPoint> sp = mul_base_many(ss), dp = mul_base_many(ds);
+    VartimeEdwardsPrecomputation pre(sp);
+    CHECK(pre.len() == 128 && !pre.is_empty(), "precomputation.len()");
+    const EdwardsPoint P = pre.vartime_mixed_multiscalar_mul(ss, ds, dp);
+    std::vector<EdwardsPoint> allp(sp); allp.insert(allp.end(), dp.begin(), dp.end());
+    const EdwardsPoint Q = vartime_multiscalar_mul(all, allp), R = mul_base(check);
+    CHECK(compress(P) == compress(R), "precomputed MSM differs from mul_base(check)");
+    CHECK(compress(Q) == compress(R), "plain MSM differs from mul_base(check)");
+}
+static void mul_base_clamped_test() {                                               // edwards.rs:2084-2129
+    uint8_t b[32]; for (int i = 0; i < 32; i += 8) { const uint64_t v = g_rng(); memcpy(b + i, &v, 8); }
+    // a random point with torsion: mul_base_clamped(b) + T8, T8 a point of order 8 (EIGHT_TORSION[1] up to the choice of generator)
+    CompressedEdwardsY t8c;
+    const char *hex = "26e8958fc2b227b045c3f489f2ef98f0d5dfac05d3c63339b13802886d53fc05";
+    for (int i = 0; i < 32; i++) { unsigned v; sscanf(hex + 2 * i, "%2x", &v); t8c.b[i] = (uint8_t)v; }
+    const auto T8 = decompress(t8c);
+    CHECK(T8.has_value(), "the order-8 point must decode");
+    uint8_t fl = 0;
+    CHECK(c25519_point_order_checks_batch(hip::context(), t8c.b, 1, C25519_FMT_EDWARDS_Y, 6, &fl) == C25519_OK && (fl & 2) && !(fl & 4), "T8 must be of small order and not torsion-free");
+    Scalar one; memset(one.bytes, 0, 32); one.bytes[0] = 1;
+    const EdwardsPoint random_point = vartime_multiscalar_mul({one, one}, {mul_base_clamped(b), *T8});      // P + T8
+    CHECK(c25519_point_order_checks_batch(hip::context(), compress(random_point).b, 1, C25519_FMT_EDWARDS_Y, 6, &fl) == C25519_OK && !(fl & 2) && !(fl & 4), "P + T8 carries torsion");
+    const EdwardsBasepointTable random_table(random_point);
+    const EdwardsPoint B = mul_base(one);
+    uint8_t a[32]; memset(a, 0xff, 32);
+    CHECK(eq(mul_base_clamped(a), mul_clamped(B, a)), "mul_base_clamped(ff..) != B.mul_clamped(ff..)");
+    CHECK(eq(random_table.mul_base_clamped(a), mul_clamped(random_point, a)), "table.mul_base_clamped(ff..) != P.mul_clamped(ff..)");
+    for (int it = 0; it < 100; it++) {
+        for (int i = 0; i < 32; i += 8) { const uint64_t v = g_rng(); memcpy(a + i, &v, 8); }
+        CHECK(eq(mul_base_clamped(a), mul_clamped(B, a)), "mul_base_clamped != B.mul_clamped (iteration %d)", it);
+        CHECK(eq(random_table.mul_base_clamped(a), mul_clamped(random_point, a)), "table.mul_base_clamped != P.mul_clamped (iteration %d)", it);
+    }
+}
+static void scalarmult_both_ways_and_none() {
+    const Scalar s = scalar_random();
+    Scalar one; memset(one.bytes, 0, 32); one.bytes[0] = 1;
+    const EdwardsPoint G = mul_base(one);
+    CHECK(eq(mul(G, s), mul_base(s)), "G * s != s * B (edwards.rs:2268-2274)");
+    // Option plumbing: a None among the points gives None without a call; sizes that differ are asserted by the reference
+    std::vector<std::optional<EdwardsPoint>> pts = {G, std::nullopt, G};
+    CHECK(!optional_multiscalar_mul({s, s, s}, pts).has_value(), "None in -> None out");
+    // unreduced limbs handed over by a caller (sums the reference never reduced): 2^51 added to limb 0 and taken from limb 1 of X
+    EdwardsPoint P = mul_base(s), Q = P;
+    if (Q.X.l[1] > 0) { Q.X.l[0] += 1ull << 51; Q.X.l[1] -= 1; }
+    std::vector<Scalar> xs; std::vector<EdwardsPoint> a, b;
+    for (int i = 0; i < 200; i++) { xs.push_back(scalar_random()); a.push_back(P); b.push_back(Q); }
+    CHECK(eq(vartime_multiscalar_mul(xs, a), vartime_multiscalar_mul(xs, b)), "limb representation changed an MSM result");
+}
+
+int main(int argc, char **argv) {
+    CHECK(hip::context() != nullptr, "no GPU context");
+    const int iters = argc > 1 ? atoi(argv[1]) : 3;
+    const size_t thresholds[2] = {0, hip::HIP_THRESHOLD};                          // everything on the GPU, then the shim's dispatch
+    for (size_t th : thresholds) {
+        hip::HIP_THRESHOLD = th;
+        for (size_t n : {(size_t)1, (size_t)31, (size_t)32, (size_t)100, (size_t)250, (size_t)500, (size_t)1000})
+            for (int it = 0; it < (n >= 100 ? iters : 1); it++) multiscalar_consistency_iter(n);
+    }
+    vartime_precomputed_vs_nonprecomputed_multiscalar();
+    mul_base_clamped_test();
+    scalarmult_both_ways_and_none();
+    c25519_ctx_destroy(hip::g_ctx);
+    printf("shim_mock ok\n");
+    return 0;
+}

@@ -159,6 +159,17 @@ def test_three_ranks_many_passes_gloo():
     _check(outs)
 
 
+@pytest.mark.parametrize("n,m", [(1003, 77), (5, 5)])
+def test_eight_ranks_on_one_gpu_real_engine_gloo(n, m):
+    """world_size 8 -- the size BASELINE configs[3] is quoted on -- with the real engine on every rank, all sharing cuda:0 over gloo:
+    the index arithmetic of multi.shard_range / gather_transcript_inputs / the record fold at eight ranks.  (1003, 77): tiny RAGGED shards
+    (125 / 126 terms, 9 / 10 signatures), the undecodable point on the last rank (NONE everywhere), seven EMPTY shards beside one full one;
+    (5, 5): more ranks than units -- ranks 5..7 hold nothing in the MSM, in both verify_batch z-modes and in the ONE transcript."""
+    outs = _launch(8, "gloo", False, {"TEST_N": str(n), "TEST_M": str(m)})
+    assert sorted(o["rank"] for o in outs) == list(range(8))
+    _check(outs)
+
+
 def test_rccl_collectives_execute_world_1():
     """backend nccl (= RCCL), world_size 1, force_collective: all_gather_into_tensor on the device records (uint8), on the
     shard sizes (int64) and all_reduce(MAX) on the verdict (int32) really run in RCCL."""
