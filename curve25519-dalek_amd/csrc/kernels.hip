@@ -81,8 +81,14 @@ __global__ void __launch_bounds__(BS) k_mul_base(const uint8_t *__restrict__ sca
 #pragma unroll
                 for (int i = 0; i < 24; i++) tw[i] = t2[i];
             }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(C25519_CT_LOCKSTEP)
+            // A/B arm: the seven products of the addition in lockstep (fe26x.h, the form k_accumulate uses), the sign by operand swap
+            if (CT) P = ge_madd_signed_p3_lockstep(P, aniels_from_words(tw), neg);
+            else { aniels_words_cneg(tw, neg); P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw))); }
+#else
             aniels_words_cneg(tw, neg);
             P = ge_p1p1_to_p3(ge_madd(P, aniels_from_words(tw)));
+#endif
             wtab += ENT * 6;
         }
         if (OUT == 1) raw160_store(out_raw, idx, P);
@@ -546,7 +552,10 @@ hipError_t launch_mul_base_ct(const uint8_t *scalars, u64 n, const uint32_t *tab
     if (per_cu <= 128) return launch_ct_split<256>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
     if (per_cu <= 256) return launch_ct_split<512>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
     if (per_cu <= 512) return launch_ct_split<1024>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
-    return launch_mul_base_w<C25519_CT_W, 1024, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+#ifndef C25519_CT_BS
+#define C25519_CT_BS 1024
+#endif
+    return launch_mul_base_w<C25519_CT_W, C25519_CT_BS, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
 }
 
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st) {

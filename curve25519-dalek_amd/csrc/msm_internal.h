@@ -20,6 +20,61 @@ struct msm_merged { int c, K; uint64_t ns; };
 constexpr u32 LONG_CAP_MIN = 192;  // msm_geom.long_cap = max(this, 2.5 x mean list length)
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 }
+// ---- what the translation units of the MSM share (msm.hip: driver, prep, long buckets, reduction, records; msm_sort.hip: the chunk-local
+//      sort; msm_sort_matrix.hip: the digit-matrix sort of the merged layout; small.hip: inputs below 2048 terms; verify.hip) -------------
+namespace c25519 {
+struct long_item;
+constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A of the bucket reduction
+// partial-result record = result slot: 56 column sums of 40 u32, then 16 words -- [0..7] counters, [8, 9] the term count the window layout
+// was derived from, [10] passes summed, [11] a magic word
+constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11;
+constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
+constexpr uint64_t MSM_SMALL_MAX = 2047;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5 and 6
+}
+static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
+static inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
+static inline uint32_t *slot_flags(uint32_t *slot) { return slot + c25519::MSM_MAX_WIN * 40; }
+static inline uint32_t *dslot(c25519_ctx *ctx, int i) { return ctx->d_slots + (size_t)i * C25519_SLOT_U32; }
+static inline const uint32_t *hslot(c25519_ctx *ctx, int i) { return (const uint32_t *)ctx->h_msm + (size_t)i * C25519_SLOT_U32; }
+// the context's own record (slot C25519_MAX_SLOTS of d_slots / h_msm): where a call that answers on the host sums its passes
+static inline uint32_t *drec(c25519_ctx *ctx) { return dslot(ctx, C25519_MAX_SLOTS); }
+// An MSM pass is enqueued in two halves so that a caller can put other work between them (msm.hip):
+//   msm_enqueue_sort  the counting sort of the term indices by bucket, bucket order, long-bucket work list -- needs only the SCALARS
+//   msm_enqueue_acc   accumulation (+ the long-bucket path on the second stream) and bucket reduction -- needs the POINTS (affine Niels records)
+struct msm_plan {
+    c25519::msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
+    uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs, *bad_ws, *bad_sticky = nullptr; c25519::long_item *items;
+    hipStream_t sort_stream;
+};
+void msm_sort_params(uint64_t n, c25519::msm_geom &g);
+int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
+                         const c25519::msm_merged *md = nullptr, uint64_t n_carve = 0);
+struct msm_matrix_sort_args {
+    const uint8_t *d_scalars; uint64_t n_scalars, n; int nchunk; bool use_part; int SL, PART_CHUNK, pchunks;
+    uint16_t *D; uint32_t *counts, *P1, *cc, *bin_base, *flags, *totals, *ord_hist;
+};
+int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const c25519::msm_geom &g, const c25519::msm_merged &md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st);
+int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont = false, bool reduce = true,
+                        const uint32_t *d_bad_sticky = nullptr);
+// sort + accumulate + reduce of one pass over prepared records; inputs of at most MSM_SMALL_MAX terms take the small path
+int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const c25519::msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr);
+// the whole MSM of at most MSM_SMALL_MAX terms in two launches, column sums of the layout g to d_slot (small.hip).  src_fmt: 0 = raw 160-byte points,
+// 1 = affine Niels records (128 bytes); flags: the slot's counters (bit 255 of a scalar is ORed into flags[0])
+int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t st);
+c25519::ge_p3 host_p40(const uint32_t *t);
+c25519::ge_p3 msm_horner(const uint32_t *cols, const c25519::msm_geom &g);
+int32_t slots_collect(c25519_ctx *ctx, int count);
+int32_t rec_collect(c25519_ctx *ctx);
+void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st);
+int32_t records_fold(const uint8_t *records, uint64_t count, c25519::ge_p3 &R, uint32_t flags[8], std::string *err);
+struct pass_set { c25519_ctx *c[4]; int lanes; };
+int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps);
+int32_t passes_join(c25519_ctx *ctx, pass_set &ps);
+hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind);
+void launch_merged_table(const uint8_t *in_raw, uint64_t ns, int c, int K, uint8_t *out_raw, hipStream_t st);
+void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
+void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);
 // bucket accumulation (accum.hip); returns the kernel's name for the timing records
 const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, int cont, hipStream_t st);
 void msm_layout(uint64_t n, c25519::msm_geom &g);

@@ -1,0 +1,175 @@
+// Small multiscalar multiplications -- up to MSM_SMALL_MAX = 2047 terms: the reference's own benchmark shapes (benches/dalek_benchmarks.rs:16
+// MULTISCALAR_SIZES 1 .. 1024; ed25519_benchmarks.rs:53 verify_batch of 4 .. 256 signatures = 9 .. 513 terms) and everything the reference
+// hands to Straus (edwards.rs:1025, below 190 terms).
+//
+// The bucket pipeline of msm.hip is built for millions of terms: fifteen launches (normalise, four sort kernels, bucket order, accumulate,
+// long buckets, two reduction levels, ...) whose fixed cost -- ~0.4 ms, most of it launch gaps and single-wave latency chains, the batched
+// inversion of the normaliser alone ~0.1 ms -- is all a 100-term call pays for.  What Straus does on a CPU (straus.rs:159-200: a small table
+// of multiples per point, then ONE shared doubling chain) becomes, on a machine with 250 000 lanes and a 0.5 us field multiplication
+// latency per lone wave, "no chain at all":
+//
+//   k_small_cols    a block owns 4 terms.  It builds their tables of multiples {1 .. 2^(c-1)} P in LDS by REPEATED COMPLETE ADDITION in c - 1
+//                   rounds (round r: E[2^r + j] = E[2^r] + E[j], j = 1 .. 2^r -- edwards.rs:795 is complete, so the same code doubles), straight
+//                   from the raw projective point: no normalisation, no inversion.  Then thread (window k, term i) looks its signed digit
+//                   up -- the SAME window layout as the bucket pipeline (msm_layout: c = 5 below 1024 terms, c = 6 below 2048), so the
+//                   column sums are a partial-result record like any other -- and the four terms of a window are added across the
+//                   lanes of a quad.  Chain: c - 1 + 2 additions.
+//   k_small_reduce  one block per window: the <= 512 block partials are added in a shuffle / LDS tree.  Chain: <= 10 additions.
+//
+// and the Horner fold over the windows stays where it always was (host, msm_horner).  Work is n (2^(c-1) + 2 nwin) additions instead of the
+// bucket method's n nwin / 2 -- irrelevant: below 2048 terms the GPU is latency-bound, not throughput-bound.  Variable time like the path it
+// replaces (digits index the table): vartime_multiscalar_mul and verify_batch only; the constant-time MSM is extra.hip's.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string>
+#include "../../include/c25519_hip.h"
+#include "devio.h"
+#include "ctx.h"
+#include "msm_internal.h"
+#include "msm_sort.h"
+
+using namespace c25519;
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+namespace c25519 {
+
+constexpr int SMALL_T = 4;                   // terms per block: thread = (window slot, term), the four terms of a window are one quad
+constexpr int SMALL_SLOTS = 64;              // window slots per block (>= MSM_MAX_WIN = 56 windows)
+constexpr int SMALL_THREADS = SMALL_T * SMALL_SLOTS;
+
+__device__ __forceinline__ void p3_to_lds(u32 *dst, const ge_p3 &p) {
+    for (int i = 0; i < 10; i++) { dst[i] = p.X.v[i]; dst[10 + i] = p.Y.v[i]; dst[20 + i] = p.Z.v[i]; dst[30 + i] = p.T.v[i]; }
+}
+__device__ __forceinline__ ge_p3 p3_from_lds(const u32 *src) {
+    ge_p3 p;
+    for (int i = 0; i < 10; i++) { p.X.v[i] = src[i]; p.Y.v[i] = src[10 + i]; p.Z.v[i] = src[20 + i]; p.T.v[i] = src[30 + i]; }
+    return p;
+}
+__device__ __forceinline__ ge_p3 p3_quad_xor(const ge_p3 &a, int d) {
+    ge_p3 o;
+    for (int i = 0; i < 10; i++) {
+        o.X.v[i] = __shfl_xor(a.X.v[i], d, 64); o.Y.v[i] = __shfl_xor(a.Y.v[i], d, 64);
+        o.Z.v[i] = __shfl_xor(a.Z.v[i], d, 64); o.T.v[i] = __shfl_xor(a.T.v[i], d, 64);
+    }
+    return o;
+}
+// (y+x, y-x, 2dxy) of an affine point -> the same point as (2x : 2y : 2 : 2xy): one multiplication by 1/d, no halving
+__device__ __forceinline__ ge_p3 p3_from_aniels(const ge_aniels &a) {
+    ge_p3 p;
+    p.X = fe_carry(fe_sub(a.ypx, a.ymx));
+    p.Y = fe_carry(fe_add(a.ypx, a.ymx));
+    p.Z = fe_small(2);
+    p.T = fe_mul(a.xy2d, fe_d_inv());
+    return p;
+}
+
+// grid: ceil(n / SMALL_T) blocks of SMALL_THREADS threads; dynamic LDS: SMALL_T * half * 160 bytes.
+// partial: [block][window] 160-byte sums (or, with a single block, the column sums themselves: `direct`)
+__global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__restrict__ scalars, const void *__restrict__ points, int src_fmt, u64 n, msm_geom g,
+                                                              u32 *__restrict__ partial, u32 *__restrict__ flags) {
+    extern __shared__ u32 tab[];                          // [SMALL_T][half][40]
+    const int tid = threadIdx.x, ti = tid & (SMALL_T - 1), slot = tid / SMALL_T;
+    const u64 t = (u64)blockIdx.x * SMALL_T + ti;
+    const int half = g.half;
+    // ---- tables: E[1] = P, then c - 1 rounds of complete additions -----------------------------------------------------------------
+    if (tid < SMALL_T) {
+        const u64 tt = (u64)blockIdx.x * SMALL_T + tid;
+        ge_p3 P = ge_identity();
+        if (tt < n) {
+            if (src_fmt == 0) {
+                // like the normaliser of the bucket pipeline, the small path reads X, Y, Z only: (XZ : YZ : Z^2 : XY) is the same point with a T
+                // that is consistent by construction, whatever the caller stored there
+                const uint8_t *in = (const uint8_t *)points;
+                const feT X = raw160_fe(in, tt, 0), Y = raw160_fe(in, tt, 1), Z = raw160_fe(in, tt, 2);
+                P.X = fe_mul(X, Z); P.Y = fe_mul(Y, Z); P.Z = fe_sq(Z); P.T = fe_mul(X, Y);
+            } else P = p3_from_aniels(pts_load((const u32 *)points, tt));
+        }
+        p3_to_lds(tab + ((size_t)tid * half + 0) * 40, P);
+    }
+    __syncthreads();
+    for (int span = 1; span < half; span <<= 1) {         // E[span + 1 + j] = E[span] + E[1 + j]  (entries are stored at index multiple - 1)
+        const int pairs = SMALL_T * span;
+        if (tid < pairs) {
+            const int i = tid / span, j = tid % span;
+            const u32 *row = tab + (size_t)i * half * 40;
+            const ge_p3 s = ge_add(p3_from_lds(row + (size_t)(span - 1) * 40), p3_from_lds(row + (size_t)j * 40));
+            p3_to_lds(tab + ((size_t)i * half + span + j) * 40, s);
+        }
+        __syncthreads();
+    }
+    // ---- digits of this thread's (window, term) -----------------------------------------------------------------------------------------
+    int d = 0;
+    if (slot < g.nwin && t < n) {
+        u32 s[9];
+        load8(scalars, t, s);
+        if ((s[7] >> 31) && slot == 0) atomicOr(flags, 1u);
+        u64 carry = 0;
+        for (int i = 0; i < 8; i++) { const u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = v >> 32; }
+        s[8] = (u32)carry;
+        const int bit = g.pos[slot], wi = bit >> 5, sh = bit & 31;
+        u32 lo = 0, hi = 0;
+        for (int i = 0; i < 9; i++) { lo = i == wi ? s[i] : lo; hi = i == wi + 1 ? s[i] : hi; }      // (no dynamic register index)
+        const u64 two = (u64)lo | ((u64)hi << 32);
+        d = digit_of((u32)(two >> sh) & ((1u << g.wid[slot]) - 1u), slot, g);
+    }
+    ge_p3 Q = ge_identity();
+    if (d != 0) {
+        Q = p3_from_lds(tab + ((size_t)ti * half + (d > 0 ? d : -d) - 1) * 40);
+        if (d < 0) Q = ge_neg(Q);
+    }
+    // the four terms of a window: lanes 4 slot .. 4 slot + 3
+    Q = ge_add(Q, p3_quad_xor(Q, 1));
+    Q = ge_add(Q, p3_quad_xor(Q, 2));
+    if (ti == 0 && slot < g.nwin) p40_store(partial, (u64)blockIdx.x * g.nwin + slot, Q);
+}
+
+// one block per window: col_k = sum over the blocks' partials
+__global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ partial, int nblocks, int nwin, u32 *__restrict__ cols) {
+    __shared__ u32 stage[4 * 40];
+    const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    ge_p3 acc = ge_identity();
+    bool any = false;
+    for (int b = tid; b < nblocks; b += 256) {
+        const ge_p3 v = p40_load(partial, (u64)b * nwin + k);
+        acc = any ? ge_add(acc, v) : v;
+        any = true;
+    }
+    // shuffle tree over the lanes that hold something (wave-uniform trip count)
+    const int active = nblocks < 256 ? nblocks : 256;
+    const int in_wave = active - 64 * w < 64 ? active - 64 * w : 64;
+    for (int dd = 1; dd < in_wave; dd <<= 1) {
+        const ge_p3 o = p3_quad_xor(acc, dd);                 // (lanes beyond `active` hold the identity)
+        acc = ge_add(acc, o);
+    }
+    if (active > 64) {
+        if (lane == 0 && w < 4) p3_to_lds(stage + w * 40, acc);
+        __syncthreads();
+        if (tid == 0) {
+            const int waves = (active + 63) / 64;
+            for (int q = 1; q < waves; q++) acc = ge_add(acc, p3_from_lds(stage + q * 40));
+        }
+    }
+    if (tid == 0) p40_store(cols, k, acc);
+}
+
+}  // namespace c25519
+
+int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, hipStream_t st) {
+    if (n == 0 || n > MSM_SMALL_MAX || g.half > 32 || g.nwin > SMALL_SLOTS) { ctx->err = "msm: internal error (small path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
+    const int nblocks = (int)((n + SMALL_T - 1) / SMALL_T);
+    const size_t lds = (size_t)SMALL_T * g.half * 160;
+    uint32_t *partial = d_slot;                                     // a single block writes the column sums themselves
+    if (nblocks > 1) {
+        int32_t r = ctx_reserve(ctx, ctx->tmp_d, (size_t)nblocks * g.nwin * 160 + 256);
+        if (r) return r;
+        partial = (uint32_t *)ctx->tmp_d.p;
+    }
+    hipLaunchKernelGGL(k_small_cols, dim3(nblocks), dim3(SMALL_THREADS), lds, st, d_scalars, d_points, src_fmt, n, g, partial, slot_flags(d_slot));
+    if (nblocks > 1) hipLaunchKernelGGL(k_small_reduce, dim3(g.nwin), dim3(256), 0, st, partial, nblocks, g.nwin, d_slot);
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}

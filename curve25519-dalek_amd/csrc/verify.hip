@@ -1,0 +1,671 @@
+// ed25519-dalek verify_batch (batch.rs:146-251) on the GPU: SHA-512(R || A || M) per signature, the z_i (the reference's transcript on the
+// host, or the device hash tree), the batch scalars mod l (sc28.h), and the 2n+1-term MSM through the Pippenger pipeline of msm.hip.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
+#include <string.h>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <functional>
+#include "../../include/c25519_hip.h"
+#include "devio.h"
+#include "sc_sha.h"
+#include "sc28.h"
+#include "kernels.h"
+#include "ctx.h"
+#include "msm_internal.h"
+#include "msm_sort.h"
+#include "ffi.h"
+
+using namespace c25519;
+#define EXPORT extern "C" __attribute__((visibility("default")))
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+namespace c25519 {
+
+// ================================================================================================
+// verify_batch kernels
+// ================================================================================================
+// hram_i = SHA-512(R_i || A_i || M_i) (batch.rs:179-191): 64-byte digest out; flags[0] += non-canonical s,
+// flags[1] |= 1 if the message offsets are not monotone or run past msgs_len (that message is hashed as empty)
+__global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len, const uint8_t *__restrict__ sigs,
+                                              const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags, uint8_t *__restrict__ hred = nullptr) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 r[8], a[8], s[8];
+    load8(sigs, 2 * i, r);
+    load8(sigs, 2 * i + 1, s);
+    load8(pks, i, a);
+    if (!sc28_words_canonical(s)) atomicAdd(&flags[0], 1u);     // signature.rs:89-94 check_scalar: s < l, a word-wise comparison
+    sha512_stream st;
+    st.init();
+    for (int j = 0; j < 4; j++) st.w[j] = bswap64((u64)r[2 * j] | ((u64)r[2 * j + 1] << 32));       // R || A fills the
+    for (int j = 0; j < 4; j++) st.w[4 + j] = bswap64((u64)a[2 * j] | ((u64)a[2 * j + 1] << 32));   // first 64 bytes
+    st.fill = 64; st.total = 64;
+    const u64 o0 = msg_off[i], o1 = msg_off[i + 1];
+    const bool okoff = o0 <= o1 && o1 <= msgs_len;
+    if (!okoff) atomicOr(&flags[1], 1u);
+    const uint8_t *m = msgs + o0;
+    const u64 len = okoff ? o1 - o0 : 0;
+    st.put_bytes(m, len);
+    st.finish();
+    u32 w[16];
+    sha512_digest_words(st.h, w);
+    uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
+    for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+    if (hred) {                                              // h_i mod l, 32 bytes: what the device z-tree commits to (below)
+        u32 o[8];
+        sc28_to_words(sc28_from_wide(w), o);
+        store8(hred, i, o);
+    }
+}
+// the same reduction for hashes that were computed elsewhere
+__global__ void __launch_bounds__(256) k_hram_mod_l(const uint8_t *__restrict__ hram, u64 n, uint8_t *__restrict__ hred) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 *hw = reinterpret_cast<const u32 *>(hram) + 16 * i;
+    u32 w[16], o[8];
+    for (int j = 0; j < 16; j++) w[j] = hw[j];
+    sc28_to_words(sc28_from_wide(w), o);
+    store8(hred, i, o);
+}
+
+// device z-mode (C25519_Z_DEVICE; NOT the reference's derivation -- see include/c25519_hip.h).  The z_i must depend on
+// every input bit of the batch (a per-signature or per-subtree derivation allows a 2^64 meet-in-the-middle forgery), so
+// they are derived from the root of a hash tree over what the reference's transcript absorbs (batch.rs:191-199) -- hram_i =
+// H(R_i || A_i || M_i) and the 32-byte s_i of every signature -- with hram_i taken mod l (v4; 32 bytes instead of 64: the batch
+// equation only ever sees h_i mod l, batch.rs:213-217, so that is the value to bind; two blocks per four signatures instead of three).
+//   node = first 32 bytes of the SHA-512 chaining value after absorbing  TAG(level, inputs, n) || data , where TAG is one
+//   128-byte block (domain separation and shape binding: level, number of inputs of the level, batch size) whose
+//   compression is done once on the host (the per-level IVs below), and `data` has a fixed length per level, so no
+//   length padding is needed: a Merkle-Damgard chain over fixed-length inputs is collision resistant if the compression
+//   function is; 32-byte nodes give the 128-bit level of the z_i.
+//   level 0: data = (hram_4j mod l) || s_4j || ... || (hram_4j+3 mod l) || s_4j+3 (absent = zero bytes): 2 blocks per 4 signatures,
+//            one lane each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
+//            VGPRs -- a latency-bound kernel that did not fit beside the decompression; v3: 3 blocks with 64-byte hram_i).
+//   level l: data = four children: ONE compression per node.  These levels are pure latency (one dependent SHA-512
+//            compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
+constexpr int ZTREE_MAX_LEVELS = 16;
+struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
+__global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hred, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
+    C25519_PRIO_CHAIN();
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 m_out = (n + 3) / 4;
+    if (j >= m_out) return;
+    u64 hs[8];
+    for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
+    u64 rec[32];                                          // 4 records of 64 bytes = 2 blocks
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const u64 c = 4 * j + r;
+        const u64 *h = reinterpret_cast<const u64 *>(hred) + 4 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? bswap64(h[q]) : 0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? bswap64(sg[q]) : 0ull;
+    }
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {
+        u64 w[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) w[q] = blk == 0 ? rec[q] : rec[16 + q];
+        sha512_compress(hs, w);
+    }
+    u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
+    for (int q = 0; q < 4; q++) o[q] = hs[q];
+}
+// one 4-ary level: out[j] = F_level(in[4j] || in[4j+1] || in[4j+2] || in[4j+3])[0..32]
+__device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, const u64 iv[8], u64 *out4) {
+    u64 hs[8], w[16];
+    for (int q = 0; q < 8; q++) hs[q] = iv[q];
+#pragma unroll
+    for (int ch = 0; ch < 4; ch++) {
+        const u64 c = 4 * j + ch;
+#pragma unroll
+        for (int q = 0; q < 4; q++) w[4 * ch + q] = c < m_in ? in[4 * c + q] : 0ull;
+    }
+    sha512_compress(hs, w);
+    for (int q = 0; q < 4; q++) out4[q] = hs[q];
+}
+__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out) {
+    C25519_PRIO_CHAIN();
+    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (m_in + 3) / 4) return;
+    u64 r[4];
+    ztree_node4(reinterpret_cast<const u64 *>(in), m_in, j, ivs.iv[level], r);
+    u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
+    for (int q = 0; q < 4; q++) o[q] = r[q];
+}
+// the last levels (m_in <= 1024 nodes) in ONE block: no launch gaps between levels that hold a handful of nodes
+__global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ root) {
+    C25519_PRIO_CHAIN();
+    __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
+    for (u64 i = threadIdx.x; i < m_in * 4; i += 256) buf0[i] = reinterpret_cast<const u64 *>(in)[i];
+    __syncthreads();
+    u64 *cur = buf0, *nxt = buf1;
+    u64 m = m_in;
+    while (m > 1) {
+        const u64 mo = (m + 3) / 4;                                  // <= 256 = blockDim
+        if (threadIdx.x < mo) {
+            u64 r[4];
+            ztree_node4(cur, m, threadIdx.x, ivs.iv[level], r);
+            for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = r[q];
+        }
+        __syncthreads();
+        u64 *t = cur; cur = nxt; nxt = t;
+        m = mo; level++;
+    }
+    if (threadIdx.x < 4) reinterpret_cast<u64 *>(root)[threadIdx.x] = cur[threadIdx.x];
+}
+// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)) (standard, padded); n4 = ceil(n/4)
+// lanes, z16 has room for 4*n4 entries.  A quarter is read as SIGN-MAGNITUDE: bit 127 = sign, bits 0..126 = |z_i|, i.e.
+// z_i is uniform on {-(2^127-1) .. 2^127-1} (2^128 - 1 values; a forged batch passes with probability <= 2^-127.99
+// against the reference's 2^-128).  Why signed: the MSM recodes scalars into signed windows, and a magnitude below 2^127
+// never carries out of its eighth 16-bit window, so the R_i terms stay out of windows 8..15; an unsigned 128-bit z_i
+// (C25519_Z_TRANSCRIPT) puts the carry digit +1 of about half of all R_i into ONE bucket of window 8 (the long-bucket
+// path takes it).  The sign is applied to the stored point (k_apply_sign), the MSM scalar is |z_i|.
+__global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ root, u64 n4, uint8_t *__restrict__ z16) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const u64 *h = reinterpret_cast<const u64 *>(root);
+    u64 hs[8], w[16];   // 40-byte message: one block
+    sha512_init(hs);
+    for (int q = 0; q < 4; q++) w[q] = h[q];           // the root is kept as big-endian words of the chaining value
+    w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
+    for (int q = 6; q < 15; q++) w[q] = 0;
+    w[15] = 40 * 8;
+    sha512_compress(hs, w);
+    u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
+    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
+}
+// R_i <- -R_i where z_i is negative (device z-mode): swap y+x / y-x, negate 2dxy of the stored affine Niels record
+__global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 dst0, const uint8_t *__restrict__ z16, u64 n) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (!(reinterpret_cast<const u32 *>(z16)[4 * i + 3] >> 31)) return;
+    ge_aniels A = pts_load(pts, dst0 + i);
+    feT t = fe_carry(fe_neg(A.xy2d));
+    u32 w[32];
+    for (int q = 0; q < 10; q++) { w[q] = A.ymx.v[q]; w[10 + q] = A.ypx.v[q]; w[20 + q] = t.v[q]; }
+    w[30] = 0; w[31] = 0;
+    uint4 *q4 = reinterpret_cast<uint4 *>(pts) + PTS_Q * (dst0 + i);
+    for (int q = 0; q < PTS_Q; q++) q4[q] = make_uint4(w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]);
+}
+// scalars of the batch equation (batch.rs:213-233): msm_scalars[1+i] = |z_i|, [1+n+i] = z_i*h_i;
+// per-block partial sums of z_i*s_i (mod l) to `partial` (ten 28-bit limbs each).  signed_z: z16 is sign-magnitude (device z-mode).
+// Arithmetic: sc28.h -- radix 2^28, folding with l = 2^252 + c; per signature one 512-bit reduction (95 multiplier instructions)
+// and two 5 x 10 limb products with their reductions (95 each), against ~1200 in the 5 x 52 Montgomery form of rounds 1-2.
+__global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ z16,
+                                                       u64 n, int signed_z, uint8_t *__restrict__ msm_scalars, u32 *__restrict__ partial) {
+    C25519_PRIO_CHAIN();
+    __shared__ u32 red[256][10];
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    sc28 zs = sc28_zero();
+    if (i < n) {
+        const u32 *hw = reinterpret_cast<const u32 *>(hram) + 16 * i;
+        u32 h16[16];
+        for (int j = 0; j < 16; j++) h16[j] = hw[j];
+        const u32 *zw = reinterpret_cast<const u32 *>(z16) + 4 * i;
+        const bool neg = signed_z && (zw[3] >> 31);
+        u32 zwords[8] = {zw[0], zw[1], zw[2], signed_z ? (zw[3] & 0x7fffffffu) : zw[3], 0, 0, 0, 0};
+        u32 s[8], zl[5];
+        load8(sigs, 2 * i + 1, s);
+        sc28_limbs_from_words<4, 5>(zwords, zl);
+        const sc28 h = sc28_from_wide(h16);
+        zs = sc28_mul_5x10(zl, sc28_from_words(s).v);        // |z| s   (s < 2^256: a non-canonical s is reduced here and fails the batch through the flag)
+        sc28 hz = sc28_mul_5x10(zl, h.v);                    // |z| h
+        if (neg) { zs = sc28_neg(zs); hz = sc28_neg(hz); }   // z = -|z|
+        u32 out[8];
+        sc28_to_words(hz, out);
+        store8(msm_scalars, 1 + n + i, out);
+        store8(msm_scalars, 1 + i, zwords);
+    }
+    for (int j = 0; j < 10; j++) red[threadIdx.x][j] = zs.v[j];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sc28 a, b;
+            for (int j = 0; j < 10; j++) { a.v[j] = red[threadIdx.x][j]; b.v[j] = red[threadIdx.x + off][j]; }
+            a = sc28_add(a, b);
+            for (int j = 0; j < 10; j++) red[threadIdx.x][j] = a.v[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) for (int j = 0; j < 10; j++) partial[(u64)blockIdx.x * 10 + j] = red[0][j];
+}
+
+// msm_scalars[0] = -(sum of the per-block partial sums) mod l: one block, strided sums then a tree
+__global__ void __launch_bounds__(256) k_bsum_finish(const u32 *__restrict__ partial, u32 nblk, uint8_t *__restrict__ msm_scalars) {
+    C25519_PRIO_CHAIN();
+    __shared__ u32 red[256][10];
+    sc28 acc = sc28_zero();
+    for (u32 b = threadIdx.x; b < nblk; b += 256) {
+        sc28 p;
+        for (int j = 0; j < 10; j++) p.v[j] = partial[(u64)b * 10 + j];
+        acc = sc28_add(acc, p);
+    }
+    for (int j = 0; j < 10; j++) red[threadIdx.x][j] = acc.v[j];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            sc28 a, b;
+            for (int j = 0; j < 10; j++) { a.v[j] = red[threadIdx.x][j]; b.v[j] = red[threadIdx.x + off][j]; }
+            a = sc28_add(a, b);
+            for (int j = 0; j < 10; j++) red[threadIdx.x][j] = a.v[j];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sc28 t;
+        for (int j = 0; j < 10; j++) t.v[j] = red[0][j];
+        u32 w[8];
+        sc28_to_words(sc28_neg(t), w);
+        store8(msm_scalars, 0, w);
+    }
+}
+
+hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msgs, msg_off, msgs_len, sigs, pks, n, hram, flags);
+    return hipGetLastError();
+}
+
+
+}  // namespace c25519
+
+
+// ---- verify_batch ---------------------------------------------------------------------------------------
+#include "transcript_host.h"
+
+// IVs of the z tree: iv[l] = SHA-512 chaining value after the one-block tag of level l (see k_ztree_first)
+static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
+    uint64_t count = n;                                  // inputs of level 0: signatures
+    for (int l = 0; l < ZTREE_MAX_LEVELS; l++) {
+        u64 w[16] = {0};
+        const char tag[] = "c25519-hip/verify_batch/z-tree/v4";
+        static_assert(sizeof(tag) - 1 <= 64, "tag fits the first half of the block");
+        uint8_t blk[128] = {0};
+        memcpy(blk, tag, sizeof(tag) - 1);
+        for (int q = 0; q < 16; q++) { u64 v = 0; for (int b = 0; b < 8; b++) v = (v << 8) | blk[8 * q + b]; w[q] = v; }
+        w[13] = (u64)l; w[14] = count; w[15] = n;        // level, number of inputs of this level, batch size
+        sha512_init(ivs.iv[l]);
+        sha512_compress(ivs.iv[l], w);
+        count = (count + 3) / 4;
+    }
+}
+// the z_i of one pass (n signatures) by the device derivation; z16: room for 4 * ceil(n/4) entries.  t0 / t1: tree scratch
+// ((n/4 + 1) * 32 bytes each).  Enqueued on `sa`.
+static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hred, const uint8_t *d_sigs, uint64_t n, uint8_t *t0, uint8_t *t1, uint8_t *z16) {
+    ztree_ivs ivs;
+    ztree_make_ivs(n, ivs);
+    uint64_t mm = (n + 3) / 4; uint8_t *a = t0, *b = t1;
+    uint32_t level = 1;
+    hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hred, d_sigs, n, ivs, a);
+    while (mm > 1024) {
+        uint64_t mo = (mm + 3) / 4;
+        hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, ivs, b);
+        mm = mo; level++; std::swap(a, b);
+    }
+    hipLaunchKernelGGL(k_ztree_tail, dim3(1), dim3(256), 0, sa, a, mm, level, ivs, b);      // leaves the 32-byte root at b
+    hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, b, (n + 3) / 4, z16);
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+
+// One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms), enqueued on
+// context ctx (the caller's or its peer); column sums and counters go to d_slot, nothing waits for the host.
+// d_pk_points (may be NULL): the keys' decompressed points, n x 160 raw -- what VerifyingKey carries beside its bytes
+// (verifying.rs:64-71), so that, like the reference (batch.rs:236), the batch does not decompress A_i again.
+// d_hram_pre / d_z_pre (transcript z-mode): H(R||A||M) and the z_i of these signatures, computed over the whole batch.
+// stage (host-pointer calls, may be null): called right before the first kernels that need an input array are enqueued, in the
+// order 0 = signatures, 1 = key bytes, 2 = messages + offsets, 3 = the keys' points (only if given); it starts the upload of
+// that array's slice for THIS pass on the copy stream and returns the event to wait for.  So R_i is being decompressed
+// while the keys and messages travel, and the hash chain runs while the (five times larger) key points travel.
+typedef std::function<int32_t(int what, hipEvent_t *ready)> verify_stage;
+static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                   const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
+                                   const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc,
+                                   const verify_stage *stage = nullptr) {
+    hipStream_t st = ctx->stream;
+    const uint64_t m = 2 * n + 1;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
+    // tmp_f: hram (64n) | z16 (16n) | msm scalars (32m) | tree scratch | partial sums
+    const unsigned nblk = div_up64(n, 256);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32), oP = carve((size_t)nblk * 40);
+    const size_t oHr = carve(d_z_pre ? 0 : n * 32);       // h_i mod l, for the device z-tree
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
+    uint8_t *hram = ws + oH, *z16 = ws + oZ, *msc = ws + oSc, *t0 = ws + oT0, *t1 = ws + oT1, *hred = d_z_pre ? nullptr : ws + oHr;
+    uint32_t *partial = (uint32_t *)(ws + oP);
+    uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p;
+    uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
+    hipEvent_t *ring = pass_ring(owner, ctx, 2);
+    HIPCHK(hipEventRecord(ring[3], st));
+    slot_init(d_slot, terms, d_pre_flags, st);
+    // Two independent chains: (S) decompress R_i and A_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
+    // partly latency-bound (the tree levels).  They run on two streams and join before the accumulation.
+    hipStream_t sa = ctx->aux;
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
+    hipEvent_t ev_sig = nullptr, ev_pk = nullptr, ev_msg = nullptr, ev_pts = nullptr;
+    // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
+    launch_prep_basepoint(d_pts, 0, st);
+    auto prep_A = [&]() -> int32_t {
+        if (d_pk_points) {
+            if (stage) { int32_t q = (*stage)(3, &ev_pts); if (q) return q; HIPCHK(hipStreamWaitEvent(st, ev_pts, 0)); }
+            return prep_points(ctx, d_pk_points, n, C25519_FMT_RAW160, d_pts, n + 1, d_cnt + 2);
+        }
+        HIPCHK(launch_prep_compressed(0, d_pks, 1, n, d_pts, n + 1, d_cnt + 2, true, st));
+        return C25519_OK;
+    };
+    auto prep_R = [&]() -> int32_t {   // R_i = the first half of every 64-byte signature (stride 2)
+        HIPCHK(hipEventRecord(ring[4], st));
+        ctx->kname[1] = "c25519::k_prep_compressed<0> (decompression of R_i)";
+        HIPCHK(launch_prep_compressed(0, d_sigs, 2, n, d_pts, 1, d_cnt + 3, true, st));
+        HIPCHK(hipEventRecord(ring[5], st));
+        return C25519_OK;
+    };
+    if (stage) {
+        // host-pointer call: in the order the inputs arrive -- signatures, then R_i decompresses while keys and messages travel
+        if ((r = (*stage)(0, &ev_sig))) return r;
+        HIPCHK(hipStreamWaitEvent(st, ev_sig, 0));
+        if ((r = prep_R())) return r;
+        if ((r = (*stage)(1, &ev_pk)) || (r = (*stage)(2, &ev_msg))) return r;
+        HIPCHK(hipStreamWaitEvent(sa, ev_sig, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_pk, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_msg, 0));
+        if (!d_pk_points) { HIPCHK(hipStreamWaitEvent(st, ev_pk, 0)); if ((r = prep_A())) return r; }
+    } else {
+        if ((r = prep_A()) || (r = prep_R())) return r;
+    }
+    // (A)
+    const uint8_t *hr = d_hram_pre;
+    if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
+    else if (hred) hipLaunchKernelGGL(k_hram_mod_l, dim3(nblk), dim3(256), 0, sa, hr, n, hred);
+    HIPCHK(hipGetLastError());
+    const uint8_t *zz = d_z_pre;
+    if (!zz) {
+        if ((r = zchain_enqueue(ctx, sa, hred, d_sigs, n, t0, t1, z16))) return r;
+        zz = z16;
+        // the sign of z_i goes onto the stored R_i (main stream, beside the sort on the second one)
+        HIPCHK(hipEventRecord(ctx->ev_z, sa));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_z, 0));
+        hipLaunchKernelGGL(k_apply_sign, dim3(nblk), dim3(256), 0, st, d_pts, (uint64_t)1, zz, n);
+    }
+    hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hr, d_sigs, zz, n, z_mode == C25519_Z_DEVICE ? 1 : 0, msc, partial);
+    // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block
+    hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
+    HIPCHK(hipGetLastError());
+    if (stage && d_pk_points && (r = prep_A())) return r;   // the keys' points come last: only the accumulation needs them
+    // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
+    return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
+}
+// Batches beyond ~1.5 * 2^20 signatures are checked as several independent random linear combinations of about
+// 2^20 signatures each (same reason as MSM_PASS_MAX; in the device z-mode every pass derives its own z_i from its own
+// tree; in the transcript z-mode the z_i come from ONE transcript over the whole batch, exactly the reference's).  Every
+// pass keeps its own identity check.  All passes run even after a failure so that the reference's precedence -- key
+// decoding, then ScalarFormat for ANY non-canonical s (batch.rs:208-211), then Verify -- does not depend on where the
+// batch was cut.
+static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 21 ? 21 : v); }();   // A/B knob
+static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
+// flags of a folded verify_batch record + its point -> the reference's verdict (precedence: key decoding, then ScalarFormat
+// for ANY non-canonical s, batch.rs:208-211, then Verify, :244-250)
+static int32_t verify_record_verdict(c25519_ctx *ctx, const ge_p3 &R, const uint32_t flags[8]) {
+    if (flags[5]) { if (ctx) ctx->err = "verify_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
+    if (flags[0]) { if (ctx) ctx->err = "verify_batch: internal error (batch scalar with bit 255 set)"; return -(int32_t)hipErrorInvalidValue; }
+    if (flags[2]) return C25519_NONE;                       // a key that VerifyingKey::from_bytes rejects
+    if (flags[4]) return C25519_SCALAR_FORMAT;
+    if (flags[3]) return C25519_VERIFY;                     // batch.rs:244 (an R that fails to decompress)
+    return ge_is_identity(R) ? C25519_OK : C25519_VERIFY;   // batch.rs:246-250
+}
+// Every pass of a batch whose z_i are GIVEN (transcript z-mode: d_hram = H(R||A||M) of these n signatures followed by a
+// 64-byte trailer of counters -- [0] non-canonical s, [1] bad offsets -- as ed25519_batch_hram_dev leaves them; d_z16 = their
+// z_i), summed into ONE record at d_record: the reference's single equation (batch.rs:235-250) whatever the pass split.
+static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
+                                     uint64_t n, uint32_t *d_record) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
+    const uint32_t *d_pre = (const uint32_t *)(d_hram + n * 64);
+    if (n == 0) { ctx->last_passes.clear(); slot_init(d_record, 0, d_pre, ctx->stream); HIPCHK(hipGetLastError()); return C25519_OK; }
+    const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
+    msm_geom g;
+    msm_layout(2 * per + 1, g);
+    int32_t r;
+    pass_set ps;
+    if ((r = passes_begin(ctx, passes, ps))) return r;
+    hipEvent_t prev_acc = nullptr;
+    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
+        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        if (p0 && ps.lanes > 1) {
+            HIPCHK(hipEventRecord(ctx->ev_in, ctx->stream));
+            for (int l = 1; l < ps.lanes; l++) HIPCHK(hipStreamWaitEvent(ps.c[l]->stream, ctx->ev_in, 0));
+        }
+        for (int i = 0; i < cnt; i++) {
+            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
+            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);
+            r = verify_pass_enqueue(ctx, c, nullptr, nullptr, 0, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, C25519_Z_TRANSCRIPT,
+                                    d_hram + lo * 64, d_z16 + lo * 16, (p0 + i == 0) ? d_pre : nullptr, g, 2 * per + 1, slot, prev_acc);
+            if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
+            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
+        }
+        if ((r = passes_join(ctx, ps))) return r;
+        if (passes > 1) launch_record_sum(d_record, ctx->d_slots, cnt, g.nwin, p0 == 0 ? 1 : 0, ctx->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return C25519_OK;
+}
+// H(R_i || A_i || M_i) of n signatures to d_hram (n x 64 bytes) followed by a 64-byte trailer of counters ([0] signatures
+// with a non-canonical s, [1] bad message offsets): the per-signature half of the transcript z-mode, enqueue only.
+static int32_t batch_hram_enqueue(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint8_t *d_hram) {
+    HIPCHK(hipSetDevice(ctx->device));
+    uint32_t *fl = (uint32_t *)(d_hram + n * 64);
+    HIPCHK(hipMemsetAsync(fl, 0, 64, ctx->stream));
+    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram, fl, ctx->stream));
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_batch_hram_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n,
+                                      uint8_t *d_hram) {
+    return batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram);
+}
+// the reference's z_i from the bytes its transcript absorbs (batch.rs:168-222): host arithmetic, no context, sequential
+EXPORT int32_t ed25519_batch_transcript_zs(const uint8_t *hram, const uint8_t *sigs, uint64_t n, uint8_t *z16) {
+    c25519_transcript_zs(hram, sigs, n, z16);
+    return C25519_OK;
+}
+EXPORT int32_t ed25519_verify_batch_record_dev(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
+                                               uint64_t n, uint8_t *d_record) {
+    return verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram, d_z16, n, (uint32_t *)d_record);
+}
+EXPORT int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *records, uint64_t count) {
+    ge_p3 R;
+    uint32_t flags[8];
+    int32_t r = records_fold(records, count, R, flags, ctx ? &ctx->err : nullptr);
+    if (r) return r;
+    return verify_record_verdict(ctx, R, flags);
+}
+
+// pass_stage (host-pointer calls, device z-mode; may be null): (first signature of the pass, its length, which array, event out)
+typedef std::function<int32_t(uint64_t lo, uint64_t m, int what, hipEvent_t *ready)> verify_fetch;
+static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                 const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode, const verify_fetch *fetch) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
+    if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
+    if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    int32_t r;
+    if (z_mode == C25519_Z_TRANSCRIPT) {
+        // the reference's sequential Merlin transcript (batch.rs:168-222) over the WHOLE batch, on one host core; then ONE
+        // equation over the whole batch (the passes' column sums are added on the device), exactly batch.rs:235-250
+        try {
+            if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 128))) return r;
+            uint8_t *d_hram_all = (uint8_t *)ctx->tmp_c2.p, *d_z_all = d_hram_all + n * 64 + 64;
+            if ((r = batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all))) return r;
+            std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
+            HIPCHK(hipMemcpyAsync(hh.data(), d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));
+            c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
+            HIPCHK(hipMemcpyAsync(d_z_all, hz.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));      // hz is a local buffer
+            if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx)))) return r;
+        } catch (const std::exception &e) { ctx->err = std::string("verify_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
+        if ((r = rec_collect(ctx))) return r;
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        ge_p3 R;
+        uint32_t flags[8];
+        if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+        return verify_record_verdict(ctx, R, flags);
+    }
+    // device z-mode: every pass derives its own z_i from its own tree and is its own random linear combination (summing
+    // passes with independent z_i would open a 2^126 birthday attack across passes); all passes run even after a failure so
+    // that the precedence does not depend on where the batch was cut
+    const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
+    msm_geom g;
+    msm_layout(2 * per + 1, g);
+    pass_set ps;
+    if ((r = passes_begin(ctx, passes, ps))) return r;
+    bool seen[5] = {false, false, false, false, false}, bad_off = false, bad_scalar = false;
+    hipEvent_t prev_acc = nullptr;
+    for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
+        const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
+        for (int i = 0; i < cnt; i++) {
+            const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
+            c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
+            const verify_stage stage = [&](int what, hipEvent_t *ready) -> int32_t { return (*fetch)(lo, m, what, ready); };
+            r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
+                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr);
+            if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
+            prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
+        }
+        if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
+        for (int i = 0; i < cnt; i++) {
+            const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
+            if (f[0]) bad_scalar = true;
+            if (f[5]) bad_off = true;
+            uint32_t fl[8] = {0, 0, f[2], f[3], f[4], 0, 0, 0};
+            const bool clean = !(f[2] | f[3] | f[4]);
+            seen[verify_record_verdict(nullptr, clean ? msm_horner(s, g) : ge_identity(), fl)] = true;
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (bad_off) { ctx->err = "verify_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
+    if (bad_scalar) { ctx->err = "verify_batch: internal error (batch scalar with bit 255 set)"; return -(int32_t)hipErrorInvalidValue; }
+    return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;
+}
+
+EXPORT int32_t ed25519_verify_batch_keys_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                             const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode) {
+    return verify_batch_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, d_pk_points, n, z_mode, nullptr);
+}
+EXPORT int32_t ed25519_verify_batch_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                        const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, uint32_t z_mode) {
+    return ed25519_verify_batch_keys_dev(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, nullptr, n, z_mode);
+}
+// host-side check of the offsets array (the _dev entry points check on the device, inside k_hram)
+static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
+    for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) return false;
+    return true;
+}
+EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                         const uint8_t *pk_points, uint64_t n, uint32_t z_mode) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
+    if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t mlen = msg_off[n];
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||
+        (r = ctx_reserve(ctx, ctx->scratch, n * 32 + (pk_points ? n * 160 : 0) + 16)))
+        return r;
+    uint8_t *d_msg = (uint8_t *)ctx->tmp_a.p, *d_sig = (uint8_t *)ctx->tmp_c.p, *d_pk = (uint8_t *)ctx->scratch.p, *d_pp = pk_points ? d_pk + n * 32 : nullptr;
+    uint64_t *d_off = (uint64_t *)ctx->tmp_b.p;
+    if ((r = ffi_begin(ctx))) return r;
+    ffi_guard guard(ctx);                                 // the early exits of the uploads below drain the copy stream as well
+    uint64_t up = 0;
+    if (z_mode == C25519_Z_TRANSCRIPT) {
+        // the whole batch is hashed before anything else can start and the sequential host transcript dominates: upload everything
+        if (mlen) HIPCHK(hipMemcpyAsync(d_msg, msgs, mlen, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_off, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_sig, sigs, n * 64, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipMemcpyAsync(d_pk, pks, n * 32, hipMemcpyHostToDevice, ctx->s_h2d));
+        if (pk_points) HIPCHK(hipMemcpyAsync(d_pp, pk_points, n * 160, hipMemcpyHostToDevice, ctx->s_h2d));
+        HIPCHK(hipEventRecord(ctx->ev_up[0], ctx->s_h2d));
+        HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_up[0], 0));
+        up = mlen + (n + 1) * 8 + n * 96 + (pk_points ? n * 160 : 0);
+        r = verify_batch_impl(ctx, d_msg, d_off, mlen, d_sig, d_pk, d_pp, n, z_mode, nullptr);
+    } else {
+        // device z-mode: every array goes up right before the first kernels that need it (verify_pass_enqueue), pass by pass
+        int slot = 0;
+        const verify_fetch fetch = [&](uint64_t lo, uint64_t m, int what, hipEvent_t *ready) -> int32_t {
+            if (what == 0) { HIPCHK(hipMemcpyAsync(d_sig + lo * 64, sigs + lo * 64, m * 64, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 64; }
+            else if (what == 1) { HIPCHK(hipMemcpyAsync(d_pk + lo * 32, pks + lo * 32, m * 32, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 32; }
+            else if (what == 2) {
+                // the kernels index the blob through ABSOLUTE offsets: this pass's offsets and the bytes they span, in place
+                const uint64_t b0 = msg_off[lo], b1 = msg_off[lo + m];
+                if (b1 > b0) HIPCHK(hipMemcpyAsync(d_msg + b0, msgs + b0, b1 - b0, hipMemcpyHostToDevice, ctx->s_h2d));
+                HIPCHK(hipMemcpyAsync(d_off + lo, msg_off + lo, (m + 1) * 8, hipMemcpyHostToDevice, ctx->s_h2d));
+                up += (b1 - b0) + (m + 1) * 8;
+            } else { HIPCHK(hipMemcpyAsync(d_pp + lo * 160, pk_points + lo * 160, m * 160, hipMemcpyHostToDevice, ctx->s_h2d)); up += m * 160; }
+            HIPCHK(hipEventRecord(ctx->ev_up[slot], ctx->s_h2d));
+            *ready = ctx->ev_up[slot];
+            slot = (slot + 1) % c25519_ctx::FFI_MAXCH;
+            return C25519_OK;
+        };
+        r = verify_batch_impl(ctx, d_msg, d_off, mlen, d_sig, d_pk, d_pp, n, z_mode, &fetch);
+    }
+    guard.dismiss();
+    const int32_t r2 = ffi_end(ctx, up, 0);
+    return (r < 0 || !r2) ? r : r2;
+}
+EXPORT int32_t ed25519_verify_batch(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
+                                    uint64_t n, uint32_t z_mode) {
+    return ed25519_verify_batch_keys(ctx, msgs, msg_off, sigs, pks, nullptr, n, z_mode);
+}
+
+// diagnostics: the z_i a batch of n <= VERIFY_PASS_MAX signatures gets (16 bytes each to the HOST buffer out_z16;
+// device z-mode: sign-magnitude, see k_zderive).  For the tests that pin the derivation's dependence on every input.
+EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n,
+                                     uint32_t z_mode, uint8_t *out_z16) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n == 0) return C25519_OK;
+    if (n > VERIFY_PASS_MAX || z_mode > 1 || !offsets_ok(msg_off, n)) { ctx->err = "debug_batch_zs: bad arguments"; return -(int32_t)hipErrorInvalidValue; }
+    const uint64_t mlen = msg_off[n];
+    int32_t r;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    size_t oM = carve(mlen + 64), oO = carve((n + 1) * 8), oS = carve(n * 64), oK = carve(n * 32), oH = carve(n * 64), oZ = carve((n + 4) * 16), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32);
+    const size_t oHr = carve(n * 32);
+    if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
+    hipStream_t st = ctx->stream;
+    if (mlen) HIPCHK(hipMemcpyAsync(ws + oM, msgs, mlen, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oO, msg_off, (n + 1) * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oS, sigs, n * 64, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ws + oK, pks, n * 32, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
+    HIPCHK(launch_hram(ws + oM, (const uint64_t *)(ws + oO), mlen, ws + oS, ws + oK, n, ws + oH, (uint32_t *)ctx->d_flag, st));
+    if (z_mode == C25519_Z_DEVICE) {
+        hipLaunchKernelGGL(k_hram_mod_l, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, ws + oH, n, ws + oHr);
+        if ((r = zchain_enqueue(ctx, st, ws + oHr, ws + oS, n, ws + oT0, ws + oT1, ws + oZ))) return r;
+        HIPCHK(hipMemcpyAsync(out_z16, ws + oZ, n * 16, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    } else {
+        std::vector<uint8_t> hh(n * 64);
+        HIPCHK(hipMemcpyAsync(hh.data(), ws + oH, n * 64, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        c25519_transcript_zs(hh.data(), sigs, n, out_z16);
+    }
+    return C25519_OK;
+}

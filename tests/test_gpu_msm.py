@@ -357,3 +357,60 @@ def test_msm_continuing_last_pass_one_sort_chunk_shorter(orc, log2pass, n):
     e = dict(os.environ, C25519_MSM_PASS_LOG2=str(log2pass))
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
+    """The reference's benchmark shapes (dalek_benchmarks.rs:16 MULTISCALAR_SIZES = 1 .. 1024) and everything it hands to Straus
+    (edwards.rs:1025): EVERY n in 1 .. 1024 through the small path (small.hip: tables by repeated addition, one lane per (window, term)),
+    then both sides of its boundary at 2047 / 2048 terms and the window-width steps of the chunk-local sort below 2^16 terms (c = 7 .. 12,
+    1 / 2 / 4 / 8 slices per window).  Expected: (sum_{i < n} x_i^2) B for every prefix, from ONE fixed-base batch over the prefix sums."""
+    nmax = 1024
+    x = util.rand_scalars(7001, nmax)
+    pts = eng.mul_base_batch(x, out_fmt=2)
+    enc = eng.compress_batch(pts)
+    ris = eng.compress_batch(pts, out_fmt=1)
+    acc, pref = 0, []
+    for i in range(nmax):
+        acc = (acc + int.from_bytes(x[i].tobytes(), "little") ** 2) % L
+        pref.append(acc)
+    want = eng.mul_base_batch(np.frombuffer(b"".join(i2b(v) for v in pref), np.uint8).reshape(-1, 32))
+    for n in range(1, nmax + 1):
+        st, got = eng.msm_vartime(x[:n], pts[:n], in_fmt=2, out_fmt=0)
+        assert st == 0 and got == want[n - 1].tobytes(), n
+    for n in list(range(1, 70)) + [127, 128, 129, 255, 256, 511, 512, 513, 1023, 1024]:          # compressed input: decompression, then the same path
+        st, got = eng.msm_vartime(x[:n], enc[:n], in_fmt=0, out_fmt=0)
+        assert st == 0 and got == want[n - 1].tobytes(), n
+    for n in (1, 5, 64, 190, 1000):                                                                # Ristretto in and out
+        st, got = eng.msm_vartime(x[:n], ris[:n], in_fmt=1, out_fmt=1)
+        assert st == 0 and got == orc.ris_compress(orc.ed_decompress(want[n - 1].tobytes())), n
+    # against the oracle's own Straus / Pippenger on points OUTSIDE the prime-order subgroup (decompressed random encodings) with edge scalars
+    rnd = util.rand_bytes(7002, 4000)
+    rnd = rnd[orc.ed_decompress_ok_batch(rnd) == 1][:1500]
+    s = util.rand_scalars(7003, rnd.shape[0])
+    edge = util.edge_scalars()
+    edge = edge[[int.from_bytes(e.tobytes(), "little") < 2**255 for e in edge]]
+    s[:edge.shape[0]] = edge
+    opts = [orc.ed_decompress(e) for e in rows(rnd)]
+    raw = np.frombuffer(b"".join(opts), np.uint8).reshape(-1, 160)
+    for n in (1, 2, 3, 4, 5, 7, 8, 9, 31, 33, 100, 189, 190, 191, 257, 1023, 1024, 1025, 1500):
+        w = orc.ed_compress(orc.ed_msm(rows(s[:n]), opts[:n]))
+        assert eng.msm_vartime(s[:n], raw[:n], in_fmt=2, out_fmt=0) == (0, w), n
+        assert eng.msm_vartime(s[:n], rnd[:n], in_fmt=0, out_fmt=0) == (0, w), n
+    # an undecodable point and a scalar with bit 255 set, on the small path
+    bad = enc[:100].copy(); bad[57] = np.frombuffer(i2b(2), np.uint8)
+    assert eng.msm_vartime(x[:100], bad, in_fmt=0, out_fmt=0)[0] == 1
+    hi = x[:100].copy(); hi[3, 31] |= 0x80
+    import curve25519_dalek_amd as pkg
+    with pytest.raises(pkg.engine.EngineError):
+        eng.msm_vartime(hi, pts[:100], in_fmt=2, out_fmt=0)
+    # the boundary of the small path and the narrow windows of the sort
+    import torch
+    for n in (2047, 2048, 2049, 3000, 4095, 4096, 8191, 8192, 16383, 16384, 32767, 32768, 50001):
+        g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
+        dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        dx[:, 31] &= 0x0F
+        draw = eng.mul_base_batch_vartime_t(dx, out_fmt=2)
+        st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+        assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx)))), n
+        st, got = eng.msm_vartime_t(dx, eng.compress_batch_t(draw), in_fmt=0, out_fmt=0)
+        assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx)))), n
