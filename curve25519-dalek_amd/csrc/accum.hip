@@ -33,7 +33,10 @@ namespace c25519 {
 // then reads its own record back.  Piece c of record r sits at position (c + r) mod 8 of the record's 128 bytes,
 // so that the read-back of a piece touches all 32 banks once per 8 lanes.  The records of addition i+1 are in
 // flight during addition i; the wave's own vmcnt(0) orders DMA -> ds_read, lgkmcnt(0) orders ds_read -> next DMA.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
+#ifndef C25519_ACC_WAVES
+#define C25519_ACC_WAVES 3       // A/B arm (profiles/r04_ab_accumulate_occupancy.txt): 2 leaves a third of every SIMD's registers to other kernels
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C25519_ACC_WAVES, C25519_ACC_WAVES)))
 k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
              const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets, int cont) {
     const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;

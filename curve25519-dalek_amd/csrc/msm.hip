@@ -495,7 +495,11 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
     // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
     HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));
-    if (reduce) {
+    static const int coop_reduce = env_int("C25519_REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
+    if (reduce && coop_reduce) {
+        launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux);
+        HIPCHK(hipGetLastError());
+    } else if (reduce) {
         hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, ctx->aux, pl.buckets, g.half, pl.nseg, pl.SW, d_slot, pl.nseg == 1 ? 1 : 0, d_bad_sticky ? d_bad_sticky : pl.bad_ws);
         if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, ctx->aux, pl.SW, pl.nseg, d_slot);
         HIPCHK(hipGetLastError());
@@ -694,6 +698,15 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
         r = ctx_reserve(ctx, ctx->prefix, (size_t)blocks * wpb * CH * 3 * 64 * 16);
         if (r) return r;
+        // A/B proxy (profiles/r04_ab_prep_two_waves.txt): what the normaliser's memory system does with TWO waves per compute unit -- the occupancy
+        // an LDS-resident inversion tree (prefix products of 16 points per lane kept in LDS: 40 KB per wave) would leave it
+        static const int two_waves = env_int("C25519_PREP_TWO_WAVES", 0);
+        if (two_waves && CH == 16) {
+            const unsigned b2 = (unsigned)div_up64((n + CH - 1) / CH, 64 * 2);
+            if ((r = ctx_reserve(ctx, ctx->prefix, (size_t)b2 * 2 * CH * 3 * 64 * 16))) return r;
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_raw2<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
+            hipLaunchKernelGGL((k_prep_raw2<16, 2>), dim3(b2), dim3(128), 100 * 1024, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        } else
         if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
         else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
         else hipLaunchKernelGGL((k_prep_raw2<16, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);

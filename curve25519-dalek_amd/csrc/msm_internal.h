@@ -73,6 +73,8 @@ int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps);
 int32_t passes_join(c25519_ctx *ctx, pass_set &ps);
 hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind);
 void launch_merged_table(const uint8_t *in_raw, uint64_t ns, int c, int K, uint8_t *out_raw, hipStream_t st);
+// bucket reduction with four waves per point operation (reduce.hip)
+void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st);
 void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
 void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);
 // bucket accumulation (accum.hip); returns the kernel's name for the timing records
