@@ -55,10 +55,11 @@ namespace c25519 {
 //  anyway (bad_scalar); a term beyond n is loaded as s = 0, whose digits are all zero: s' = addk puts 2^(wid-1) into every signed
 //  window and 0 into the unsigned ones -- it is skipped like any zero digit)
 struct sweep_regs { u32 s[SWEEP_TPT][8]; };
+template <int THREADS>
 __device__ __forceinline__ void sweep_load(const uint8_t *__restrict__ scalars, u64 n, u64 lo, const msm_geom &g, sweep_regs &R, u32 *__restrict__ bad_scalar) {
 #pragma unroll
     for (int r = 0; r < SWEEP_TPT; r++) {
-        const u64 t = lo + (u64)r * SWEEP_THREADS + threadIdx.x;
+        const u64 t = lo + (u64)r * THREADS + threadIdx.x;
         u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (t < n) load8(scalars, t, w);
         if (bad_scalar && (w[7] >> 31)) atomicOr(bad_scalar, 1u);
@@ -89,11 +90,14 @@ __device__ __forceinline__ u32 sweep_take(sweep_regs &R, int r, int wd) {
 // zeroed here by block 0 instead of a memset of their own: beside k_accumulate every extra launch of the chain waits 30 - 180 us for
 // a dispatch slot.  bad_blk[j] = 1 if a scalar of chunk j has bit 255 set (k_bin_totals ORs them into one word, the bucket
 // reduction ORs that into the result slot: the sort itself never touches the slot).
-__global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_local(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, u32 *__restrict__ lsg, u32 *__restrict__ bad_blk,
+// THREADS: 1024 (a chunk of 8192 terms per block: the shape that is fastest ALONE) or 256 (2048 terms: one wave per SIMD and 13 KB of LDS,
+// the shape that FITS beside a k_accumulate held at two waves per SIMD -- profiles/r04_ab_sort_beside_accumulate.txt)
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS) k_sweep_local(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, u32 *__restrict__ lsg, u32 *__restrict__ bad_blk,
                                                                u32 *__restrict__ P1, u64 wstride, u32 *__restrict__ zero_words, int nzero) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
-    constexpr int NW = SWEEP_WAVES;
+    constexpr int NW = THREADS / 64, CHUNK = THREADS * SWEEP_TPT;
     u32 *cnt = sm;                         // [SL * NW], slice-major with the bank swizzle (above)
     u32 *cur = sm + NW * SL;               // [SL * NW]
     u32 *ls = sm + 2 * NW * SL;            // [SL + 1]: start of each slice in the staging buffer, then the number of entries
@@ -101,15 +105,15 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_local(const uint8_t *__
     __shared__ u32 wtot[NW];
     __shared__ u32 sbad;
     const int j = blockIdx.x, nchunk = gridDim.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += SWEEP_THREADS) zero_words[i] = 0;
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += THREADS) zero_words[i] = 0;
     if (threadIdx.x == 0) sbad = 0;
-    const int total = NW * SL, ept = total >= SWEEP_THREADS ? total / SWEEP_THREADS : 1;
+    const int total = NW * SL, ept = total >= THREADS ? total / THREADS : 1;
     const int base = (int)threadIdx.x * ept;
-    for (int i = threadIdx.x; i < total; i += SWEEP_THREADS) cnt[i] = 0;
+    for (int i = threadIdx.x; i < total; i += THREADS) cnt[i] = 0;
     __syncthreads();
-    const u64 lo = (u64)j * SWEEP_CHUNK;
+    const u64 lo = (u64)j * CHUNK;
     sweep_regs R;
-    sweep_load(scalars, n, lo, g, R, &sbad);
+    sweep_load<THREADS>(scalars, n, lo, g, R, &sbad);
 #pragma unroll 1
     for (int k = 0; k < g.nwin; k++) {
         const int wd = g.wid[k];
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_local(const uint8_t *__
             const u32 v = sweep_take(R, r, wd);
             slc[r] = 0xffffffffu;
             u32 sl, e;
-            if (part_entry(v, k, g, (u32)lo + (u32)r * SWEEP_THREADS + threadIdx.x, sl, e)) {
+            if (part_entry(v, k, g, (u32)lo + (u32)r * THREADS + threadIdx.x, sl, e)) {
                 slc[r] = sl * NW + ((u32)w ^ ((sl >> 2) & (NW - 1)));
                 ent[r] = e;
                 atomicAdd(&cnt[slc[r]], 1u);
@@ -156,9 +160,9 @@ __global__ void __launch_bounds__(SWEEP_THREADS) k_sweep_local(const uint8_t *__
             if (slc[r] != 0xffffffffu) stage[atomicAdd(&cur[slc[r]], 1u)] = ent[r];
         __syncthreads();                                                   // 4: the staging buffer holds the entries slice by slice
         const u32 tot = ls[SL];
-        u32 *dst = P1 + (u64)k * wstride + (u64)j * SWEEP_CHUNK;
-        for (u32 i = threadIdx.x; i < tot; i += SWEEP_THREADS) dst[i] = stage[i];
-        if ((int)threadIdx.x <= SL) lsg[((u64)k * (SL + 1) + threadIdx.x) * nchunk + j] = ls[threadIdx.x];
+        u32 *dst = P1 + (u64)k * wstride + (u64)j * CHUNK;
+        for (u32 i = threadIdx.x; i < tot; i += THREADS) dst[i] = stage[i];
+        for (int i = threadIdx.x; i <= SL; i += THREADS) lsg[((u64)k * (SL + 1) + i) * nchunk + j] = ls[i];      // (SL can be 256 = THREADS of the small shape)
     }
     if (threadIdx.x == 0) bad_blk[j] = sbad;
 }
@@ -190,15 +194,18 @@ __global__ void __launch_bounds__(256) k_bin_totals(const u32 *__restrict__ lsg,
 // to count, and (from L2 now) to place: 32 pieces in registers with static indices need more than the 64 VGPRs two 1024-thread
 // blocks per compute unit leave a lane (42 spilled).  A bin with more than P2G_ITER pieces per wave or more than PART_CAP entries --
 // heavily skewed digits -- walks its chunks without the list and places its entries straight into the sorted array.
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
-k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int nchunk, const u32 *__restrict__ lsg, const u32 *__restrict__ binm,
+// NW waves per block (16: two blocks per CU; 8: 512 threads, two waves per SIMD at 56 VGPRs -- fits beside k_accumulate at two waves per SIMD), ITER:
+// pieces a wave lists; chunk: terms per chunk of the partition that produced P1 (SWEEP_TPT x its block size)
+template <int NW, int ITER>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2)))
+k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, int SL, int nchunk, const u32 *__restrict__ lsg, const u32 *__restrict__ binm,
          u32 *__restrict__ totals, u32 *__restrict__ base, u32 *__restrict__ sorted,
          u32 *__restrict__ ord_hist, u32 max_items, long_item *__restrict__ items, u32 *__restrict__ counters,
          u32 *__restrict__ long_gids, u32 *__restrict__ long_first) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
-    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX, *wl = out + PART_CAP;      // wl[16][P2G_ITER]
-    __shared__ u32 red[16];
+    u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX, *wl = out + PART_CAP;      // wl[NW][ITER]
+    __shared__ u32 red[NW];
     const int PART_BPS = 1 << g.bps_log2;
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // Everything the block needs from memory before the gather is requested together: the bin totals (the bin's place in the window's
@@ -212,8 +219,8 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
     if (tid < 256) oh[tid] = 0;
     // this wave's pieces: (offset in the window's P1 region) << 7 | entries in the piece
     int nslots = 0;
-    for (int j0 = 0; j0 < nchunk; j0 += 16 * 64) {
-        const int j = j0 + w + 16 * lane;
+    for (int j0 = 0; j0 < nchunk; j0 += NW * 64) {
+        const int j = j0 + w + NW * lane;
         u32 st = 0, len = 0;
         if (j < nchunk) { st = row0[j]; len = row1[j] - st; }
         const u32 np = (len + 63u) >> 6;
@@ -221,16 +228,16 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
         for (int off = 1; off < 64; off <<= 1) { const u32 x = __shfl_up(inc, off, 64); if (lane >= off) inc += x; }
         const u32 first = (u32)nslots + inc - np;
         for (u32 p = 0; p < np; p++)
-            if (first + p < (u32)P2G_ITER) wl[w * P2G_ITER + first + p] = (((u32)j * (u32)SWEEP_CHUNK + st + 64u * p) << 7) | (len - 64u * p < 64u ? len - 64u * p : 64u);
+            if (first + p < (u32)ITER) wl[w * ITER + first + p] = (((u32)j * chunk + st + 64u * p) << 7) | (len - 64u * p < 64u ? len - 64u * p : 64u);
         nslots += (int)__shfl(inc, 63, 64);
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) part += (u32)__shfl_xor((int)part, d, 64);
     if (lane == 0) red[w] = part;
-    const bool fits = !__syncthreads_or(nslots > P2G_ITER) && m <= (u32)PART_CAP;      // (the barrier: counters zeroed, wave sums of the prefix written)
+    const bool fits = !__syncthreads_or(nslots > ITER) && m <= (u32)PART_CAP;      // (the barrier: counters zeroed, wave sums of the prefix written)
     u32 b0 = 0;
 #pragma unroll
-    for (int q = 0; q < 16; q++) b0 += red[q];
+    for (int q = 0; q < NW; q++) b0 += red[q];
     if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b0 + m;      // number of entries of the window
     u32 *dst = sorted + (u64)k * n + b0;
     if (fits) {
@@ -240,7 +247,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
             bool ok[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const u32 d = t0 + q < nslots ? wl[w * P2G_ITER + t0 + q] : 0u;
+                const u32 d = t0 + q < nslots ? wl[w * ITER + t0 + q] : 0u;
                 ok[q] = (u32)lane < (d & 127u);
                 ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
             }
@@ -248,9 +255,9 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
             for (int q = 0; q < 8; q++) if (ok[q]) atomicAdd(&cnt[ev[q] >> 24], 1u);
         }
     } else {
-        for (int j = w; j < nchunk; j += 16) {
+        for (int j = w; j < nchunk; j += NW) {
             const u32 st = row0[j], en = row1[j];
-            for (u32 o = st + lane; o < en; o += 64) atomicAdd(&cnt[src[(u64)j * SWEEP_CHUNK + o] >> 24], 1u);
+            for (u32 o = st + lane; o < en; o += 64) atomicAdd(&cnt[src[(u64)j * chunk + o] >> 24], 1u);
         }
     }
     __syncthreads();
@@ -280,7 +287,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
             bool ok[8];
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                const u32 d = t0 + q < nslots ? wl[w * P2G_ITER + t0 + q] : 0u;
+                const u32 d = t0 + q < nslots ? wl[w * ITER + t0 + q] : 0u;
                 ok[q] = (u32)lane < (d & 127u);
                 ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
             }
@@ -288,16 +295,16 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, msm_geom g, int SL, int
             for (int q = 0; q < 8; q++) if (ok[q]) out[atomicAdd(&cur[ev[q] >> 24], 1u)] = (ev[q] & 0x7fffffu) | ((ev[q] & (1u << 23)) << 8);
         }
         __syncthreads();
-        for (u32 i = tid; i < m; i += 1024) dst[i] = out[i];
+        for (u32 i = tid; i < m; i += 64 * NW) dst[i] = out[i];
     } else {
         // oversize bin = heavily skewed digits (e.g. one bucket holding most of the window).  Entries go straight to their final place;
         // lanes of a wave that share the first lane's bucket take their slots with ONE atomic.
-        for (int j = w; j < nchunk; j += 16) {
+        for (int j = w; j < nchunk; j += NW) {
             const u32 st = row0[j], en = row1[j];
             for (u32 o0 = st; o0 < en; o0 += 64) {
                 const u32 o = o0 + lane;
                 const bool have = o < en;
-                const u32 ev = have ? src[(u64)j * SWEEP_CHUNK + o] : 0u, bk = ev >> 24;
+                const u32 ev = have ? src[(u64)j * chunk + o] : 0u, bk = ev >> 24;
                 const u32 lead_bk = __shfl(bk, __ffsll((long long)__ballot(have)) - 1, 64);
                 const unsigned long long same = __ballot(have && bk == lead_bk);
                 u32 pos = 0;
@@ -395,9 +402,13 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     const size_t oLS = carve((size_t)max_items * 160);
     const bool use_part = md && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);          // the two-pass partition of the digit-matrix sort
-    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = md ? part_chunk(SL) : SWEEP_CHUNK, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
+    // block shapes of the chunk-local sort: the large ones are the fastest alone; the small ones fit beside a k_accumulate held at two waves
+    // per SIMD (one wave per SIMD at 128 VGPRs / two at 56; profiles/r04_ab_sort_beside_accumulate.txt).  Read once per process.
+    static const int small_blocks = env_int("C25519_SORT_SMALL", 0);
+    const int sweep_chunk = (small_blocks ? 256 : SWEEP_THREADS) * SWEEP_TPT;
+    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = md ? part_chunk(SL) : sweep_chunk, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     // chunk-local form: P1 holds whole chunk blocks, oCC the slice starts [window][SL + 1][chunk], oBB the bin totals and the chunks' flags
-    const size_t p1_words = md ? (size_t)g.nwin * nc : (size_t)g.nwin * pchunks_c * SWEEP_CHUNK;
+    const size_t p1_words = md ? (size_t)g.nwin * nc : (size_t)g.nwin * pchunks_c * sweep_chunk;
     size_t oP1 = 0, oCC = 0, oBB = 0;
     if (!md || use_part) { oP1 = carve(p1_words * 4); oCC = carve((size_t)g.nwin * (SL + 1) * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
@@ -421,13 +432,23 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         return msm_matrix_sort_enqueue(ctx, g, *md, pl, a, st);
     }
     uint32_t *P1 = (uint32_t *)(ws + oP1), *lsg = (uint32_t *)(ws + oCC), *binm = (uint32_t *)(ws + oBB), *bad_blk = binm + (size_t)g.nwin * (SL + 1);
-    const uint64_t wstride = (uint64_t)pchunks_c * SWEEP_CHUNK;
-    const size_t lds1 = ((size_t)2 * SWEEP_WAVES * SL + SL + 1 + SWEEP_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP + 16 * P2G_ITER) * 4;
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    hipLaunchKernelGGL(k_sweep_local, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+    const uint64_t wstride = (uint64_t)pchunks_c * sweep_chunk;
+    constexpr int ITER_SMALL = 160;                                          // pieces per wave: up to 1024 chunks of 2048 terms over 8 waves
+    const int nw1 = sweep_chunk / SWEEP_TPT / 64;
+    const size_t lds1 = ((size_t)2 * nw1 * SL + SL + 1 + sweep_chunk) * 4;
+    const size_t lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP + (small_blocks ? 8 * ITER_SMALL : 16 * P2G_ITER)) * 4;
+    if (small_blocks) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<8, ITER_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_sweep_local<256>, dim3(pchunks), dim3(256), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+    } else {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<SWEEP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<16, P2G_ITER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_sweep_local<SWEEP_THREADS>, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+    }
     hipLaunchKernelGGL(k_bin_totals, dim3((g.nwin * SL + 3) / 4), dim3(256), 0, st, lsg, pchunks, SL, g.nwin * SL, binm, bad_blk, bad_ws, pl.bad_sticky);
-    hipLaunchKernelGGL(k_part2g, dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, wstride, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
+    if (small_blocks) hipLaunchKernelGGL((k_part2g<8, ITER_SMALL>), dim3(g.nwin, SL), dim3(512), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
+    else hipLaunchKernelGGL((k_part2g<16, P2G_ITER>), dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     hipLaunchKernelGGL(k_order_place<1024>, dim3(div_up64(nb, 1024)), dim3(1024), 0, st, totals, nb, ord_hist, ord_cursor, perm);
     HIPCHK(hipGetLastError());
     return C25519_OK;

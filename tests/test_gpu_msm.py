@@ -206,7 +206,9 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
 
 
 @pytest.mark.parametrize("env", [{}, {"C25519_MSM_PASS_LOG2": "16"}, {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "1"},
-                                 {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
+                                 {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"},
+                                 {"C25519_SORT_SMALL": "1"}, {"C25519_SORT_SMALL": "1", "C25519_MSM_PASS_LOG2": "16"},      # the A/B arms of round 4 stay bit-exact
+                                 {"C25519_REDUCE_COOP": "0"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
@@ -330,6 +332,29 @@ def test_msm_long_runs_in_a_few_chunks(eng, orc):
     draw = eng.mul_base_batch_t(dx, out_fmt=2)
     st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+
+
+def test_msm_small_sort_blocks_256_slices(orc):
+    """C25519_SORT_SMALL=1 (round 4's A/B arm: 256-thread partition blocks) at a pass size whose windows have 256 slices -- as many as the block
+    has threads (the slice-start copy-out must loop); fresh process: the knob is read once."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import sys, torch
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import test_gpu_msm as T, curve25519_dalek_amd as pkg
+        from oracle import orc
+        eng = pkg.Engine(0)
+        for n in (2200001, 2625000):
+            g = torch.Generator(device="cuda"); g.manual_seed(4321 + n)
+            dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+            dx[:, 31] &= 0x0F
+            draw = eng.mul_base_batch_vartime_t(dx, out_fmt=2)
+            st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+            assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(T.i2b(T._sumsq_device(dx)))), n
+        print("ok")
+    """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, C25519_SORT_SMALL="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
 
 
 @pytest.mark.parametrize("log2pass,n", [(21, 5898242), (22, 12386305)])

@@ -3,7 +3,7 @@
 # Raw output under gpurun_out/prof_rNN/, summaries under gpurun_out/profiles_rNN/ (copy those to profiles/).
 #   bash tools/profile_all.sh r03 [nopmc]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$R/gpurun_out/profiles_$TAG
 RAW=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT $RAW
