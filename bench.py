@@ -742,9 +742,27 @@ def main():
         for k in list(res):
             if k not in ("sub", "scale_model", "roofline", "cpu_baseline"):
                 ordered[k] = res.pop(k)
-        for k in ("sub", "scale_model", "roofline", "cpu_baseline"):
+        for k in ("sub", "roofline", "cpu_baseline", "scale_model"):
             if k in res:
                 ordered[k] = res.pop(k)
+        # the LAST object of the line: the headline numbers of everything above in < 2 KB (the driver keeps the last 2 000 characters of stdout verbatim;
+        # the full records stay earlier in the same line)
+        if "sub" in ordered:
+            sm = {"what": "[ms per step, units/s, dominant-kernel fraction of the measured v_mad_u64_u32 peak, of the theoretical 39.3 TMAC/s, whole-call fraction of theoretical]"}
+            sm["msm_2p24"] = [ordered["ms_per_step"], ordered["value"], ordered["roofline"]["frac"], ordered["roofline"]["frac_of_theoretical"], ordered["roofline"]["whole_call"]["frac_of_theoretical"]]
+            for k, v in ordered["sub"].items():
+                sm[k] = [v["ms_per_step"], v["value"], v["roofline"]["frac"], v["roofline"]["frac_of_theoretical"], v["roofline"]["whole_call"]["frac_of_theoretical"]]
+            sm["verify_strict_transcript_2p20_per_s"] = ordered["sub"]["verify_batch_2p20"]["strict_transcript_z_mode"]["2^20"]["verifies_per_s"]
+            sm["cpu_port_single_thread_and_all_cores_per_s"] = {k: [v["cpu_baseline"]["single_thread"], v["cpu_baseline"]["all_cores"]] for k, v in
+                                                                 [("msm_2p24", ordered)] + list(ordered["sub"].items()) if v.get("cpu_baseline")}
+            pr = ordered["scale_model"]["per_rank"]
+            sm["scale_model_predicted_step_ms_N1_2_4_8"] = [pr["N=%d" % n]["predicted_step_ms"] for n in (1, 2, 4, 8)]
+            sm["scale_model_predicted_efficiency_N2_4_8"] = [pr["N=%d" % n]["predicted_efficiency"] for n in (2, 4, 8)]
+            sn = ordered["small_n"]
+            sm["small_n_us_at_sizes"] = {"msm_sizes": sn["msm_vartime"]["sizes"], "msm_gpu": sn["msm_vartime"]["gpu_us"], "msm_cpu": sn["msm_vartime"]["cpu_port_us"], "msm_crossover_n": sn["msm_vartime"]["crossover_n"],
+                                         "verify_sizes": sn["verify_batch_strict_transcript"]["sizes"], "verify_strict_gpu": sn["verify_batch_strict_transcript"]["gpu_us"],
+                                         "verify_cpu": sn["verify_batch_strict_transcript"].get("cpu_port_us"), "verify_crossover_n": sn["verify_batch_strict_transcript"].get("crossover_n")}
+            ordered["summary"] = compact(sm, 3)
         res = compact(ordered)
 
     if rank == 0:

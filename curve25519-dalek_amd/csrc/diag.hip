@@ -179,6 +179,35 @@ C25519_PROBE32(k_probe_or, "v_or_b32_e32 %0, %1, %0")
 C25519_PROBE32(k_probe_xor, "v_xor_b32_e32 %0, %1, %0")
 C25519_PROBE32(k_probe_cndmask, "v_cndmask_b32_e32 %0, %1, %0, vcc")
 C25519_PROBE32(k_probe_mov, "v_mov_b32_e32 %0, %1")
+// the select as k_accumulate / the constant-time scan issue it (VOP3, condition in an SGPR pair), and the arithmetic alternative for a conditional
+// swap (xor / and / xor on a lane mask: three full-rate instructions for the two selects of a pair)
+__global__ void __launch_bounds__(256) k_probe_cndmask_e64(u32 *out, int iters, u32 seed) {
+    u32 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    u32 b = seed | 1u;
+    const unsigned long long m = __ballot((threadIdx.x & 3u) != 0u);
+    for (int i = 0; i < iters; i++) {
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a0) : "v"(b), "s"(m)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a1) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a2) : "v"(b), "s"(m)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a3) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a4) : "v"(b), "s"(m)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a5) : "v"(b), "s"(m));
+        asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a6) : "v"(b), "s"(m)); asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(a7) : "v"(b), "s"(m));
+    }
+    u32 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345678u) out[0] = r;
+}
+// the e32 form again, but with VCC written once before the loop by a real compare (the generic probe leaves VCC as the prologue left it)
+__global__ void __launch_bounds__(256) k_probe_cndmask_vcc(u32 *out, int iters, u32 seed) {
+    u32 a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    u32 b = seed | 1u;
+    asm volatile("v_cmp_ne_u32_e32 vcc, 0, %0" :: "v"(threadIdx.x & 3u) : "vcc");
+    for (int i = 0; i < iters; i++) {
+        asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a0) : "v"(b)); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a1) : "v"(b));
+        asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a2) : "v"(b)); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a3) : "v"(b));
+        asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a4) : "v"(b)); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a5) : "v"(b));
+        asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a6) : "v"(b)); asm volatile("v_cndmask_b32_e32 %0, %0, %1, vcc" : "+v"(a7) : "v"(b));
+    }
+    u32 r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345678u) out[0] = r;
+}
 C25519_PROBE32(k_probe_perm, "v_perm_b32 %0, %0, %1, %1")
 C25519_PROBE32(k_probe_add_sdwa, "v_add_u32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1")
 C25519_PROBE32(k_probe_lshlor, "v_lshl_or_b32 %0, %0, 6, %1")
@@ -326,6 +355,8 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 29: hipLaunchKernelGGL(k_probe_perm, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 30: hipLaunchKernelGGL(k_probe_add_sdwa, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 31: hipLaunchKernelGGL(k_probe_lshlor, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 36: hipLaunchKernelGGL(k_probe_cndmask_e64, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 37: hipLaunchKernelGGL(k_probe_cndmask_vcc, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 32: hipLaunchKernelGGL(k_probe_addco, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 40: hipLaunchKernelGGL(k_probe_femul3<0>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 41: hipLaunchKernelGGL(k_probe_femul3<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;

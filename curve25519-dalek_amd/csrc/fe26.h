@@ -390,30 +390,36 @@ C25519_HD bool fe_eq(const feW &a, const feW &b) {
     return acc == 0;
 }
 
-// branch-free selects (per-lane data-dependent choice, v_cndmask)
-C25519_HD feT fe_select(const feT &a, const feT &b, bool choose_b) {
-    feT r; for (int i = 0; i < 10; i++) r.v[i] = choose_b ? b.v[i] : a.v[i];
-    return r;
-}
-C25519_HD feL fe_select(const feL &a, const feL &b, bool choose_b) {
-    feL r; for (int i = 0; i < 10; i++) r.v[i] = choose_b ? b.v[i] : a.v[i];
-    return r;
-}
-C25519_HD feW fe_select(const feW &a, const feW &b, bool choose_b) {
-    feW r; for (int i = 0; i < 10; i++) r.v[i] = choose_b ? b.v[i] : a.v[i];
-    return r;
-}
-C25519_HD void fe_cswap(feT &a, feT &b, u32 swap) {  // montgomery.rs:199 conditional_swap
+// branch-free selects (per-lane data-dependent choice): the condition becomes a 64-bit lane mask ONCE (lane_mask: a ballot, i.e. an SGPR pair)
+// and every select is written as v_cndmask_b32_e64 with that pair, so the instruction form does not depend on where LLVM happens to keep a
+// compare result.  Why this exists: the one-instruction probe of the VOP2 form (condition in VCC) reads 22.5 cycles per wave against 4.5 for
+// the VOP3 form (profiles/r04_instruction_rates.txt) -- a penalty of BACK-TO-BACK VCC readers, as it turned out: with the ladder's 60 selects
+// per step, the fixed-base recoding and the normaliser all moved to this form, k_x25519, k_mul_base<5, CT>, verify_batch and the MSM measure
+// the same as before within 0.2 % (profiles/r04_ab_select_forms.txt).  Kept because it is never the slower form; not a speed-up.
+// Constant time as before: a select executes identically whatever its mask holds.
 #if defined(__HIP_DEVICE_COMPILE__)
-    // two v_cndmask per limb (a select executes identically whatever the condition: constant-time on the GPU) instead of
-    // the four mask operations of the host form: -40 issue slots per ladder step
-    const bool s = swap != 0;
-    for (int i = 0; i < 10; i++) { const u32 x = a.v[i], y = b.v[i]; a.v[i] = s ? y : x; b.v[i] = s ? x : y; }
-#else
-    u32 m = 0u - swap;
-    for (int i = 0; i < 10; i++) { u32 t = m & (a.v[i] ^ b.v[i]); a.v[i] ^= t; b.v[i] ^= t; }
-#endif
+typedef unsigned long long lanemask;
+__device__ __forceinline__ lanemask lane_mask(bool c) { return __ballot(c); }
+__device__ __forceinline__ u32 sel_u32(u32 a, u32 b, lanemask m) {       // lane's bit of m set -> b
+    u32 r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
 }
+#else
+typedef bool lanemask;
+C25519_HD lanemask lane_mask(bool c) { return c; }
+C25519_HD u32 sel_u32(u32 a, u32 b, lanemask m) { return m ? b : a; }
+#endif
+C25519_HD feT fe_select_m(const feT &a, const feT &b, lanemask m) { feT r; for (int i = 0; i < 10; i++) r.v[i] = sel_u32(a.v[i], b.v[i], m); return r; }
+C25519_HD feL fe_select_m(const feL &a, const feL &b, lanemask m) { feL r; for (int i = 0; i < 10; i++) r.v[i] = sel_u32(a.v[i], b.v[i], m); return r; }
+C25519_HD feW fe_select_m(const feW &a, const feW &b, lanemask m) { feW r; for (int i = 0; i < 10; i++) r.v[i] = sel_u32(a.v[i], b.v[i], m); return r; }
+C25519_HD feT fe_select(const feT &a, const feT &b, bool choose_b) { return fe_select_m(a, b, lane_mask(choose_b)); }
+C25519_HD feL fe_select(const feL &a, const feL &b, bool choose_b) { return fe_select_m(a, b, lane_mask(choose_b)); }
+C25519_HD feW fe_select(const feW &a, const feW &b, bool choose_b) { return fe_select_m(a, b, lane_mask(choose_b)); }
+C25519_HD void fe_cswap_m(feT &a, feT &b, lanemask m) {
+    for (int i = 0; i < 10; i++) { const u32 x = a.v[i], y = b.v[i]; a.v[i] = sel_u32(x, y, m); b.v[i] = sel_u32(y, x, m); }
+}
+C25519_HD void fe_cswap(feT &a, feT &b, u32 swap) { fe_cswap_m(a, b, lane_mask(swap != 0)); }  // montgomery.rs:199 conditional_swap
 C25519_HD feT fe_cneg(const feT &a, bool neg) { return fe_select(a, fe_carry(fe_neg(a)), neg); }
 
 // ---- fixed addition chains (field.rs:176-306) --------------------------------------------------

@@ -81,8 +81,9 @@ __device__ __forceinline__ feT fe_mul_cols_g(const feW &f, const feL &g) {
 __device__ __forceinline__ ge_p3 ge_madd_signed_p3_lockstep(const ge_p3 &p, const ge_aniels &q, bool neg) {
     feW f3[3]; feL g3[3]; feT r3[3];
     f3[0] = fe_add(p.Y, p.X); f3[1] = fe_sub(p.Y, p.X); f3[2] = p.T;
+    const lanemask nm = lane_mask(neg);
 #pragma unroll
-    for (int i = 0; i < 10; i++) { g3[0].v[i] = neg ? q.ymx.v[i] : q.ypx.v[i]; g3[1].v[i] = neg ? q.ypx.v[i] : q.ymx.v[i]; }
+    for (int i = 0; i < 10; i++) { g3[0].v[i] = sel_u32(q.ypx.v[i], q.ymx.v[i], nm); g3[1].v[i] = sel_u32(q.ymx.v[i], q.ypx.v[i], nm); }
     g3[2] = q.xy2d;
     fe_mul_chain_n<3>(r3, f3, g3);
     const feT &PP = r3[0], &MM = r3[1], &TT = r3[2];
@@ -92,7 +93,7 @@ __device__ __forceinline__ ge_p3 ge_madd_signed_p3_lockstep(const ge_p3 &p, cons
     feW zm = fe_sub_w(Z2, TT);
     feW f4[4]; feL g4[4]; feT r4[4];
 #pragma unroll
-    for (int i = 0; i < 10; i++) { f4[0].v[i] = neg ? zp.v[i] : zm.v[i]; f4[1].v[i] = neg ? zm.v[i] : zp.v[i]; }
+    for (int i = 0; i < 10; i++) { f4[0].v[i] = sel_u32(zm.v[i], zp.v[i], nm); f4[1].v[i] = sel_u32(zp.v[i], zm.v[i], nm); }
     f4[2] = zm; f4[3] = X;
     g4[0] = X; g4[1] = Y; g4[2] = zp; g4[3] = Y;
     fe_mul_chain_n<4>(r4, f4, g4);

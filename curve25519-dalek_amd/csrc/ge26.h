@@ -106,7 +106,8 @@ C25519_HD ge_p1p1 ge_madd(const ge_p3 &p, const ge_aniels &q) {
 // conditional subtraction p - v and the three unpackings.  7 M like ge_madd + ge_p1p1_to_p3.
 C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) {
     feT qa, qb;
-    for (int i = 0; i < 10; i++) { qa.v[i] = neg ? q.ymx.v[i] : q.ypx.v[i]; qb.v[i] = neg ? q.ypx.v[i] : q.ymx.v[i]; }
+    const lanemask nm = lane_mask(neg);
+    for (int i = 0; i < 10; i++) { qa.v[i] = sel_u32(q.ypx.v[i], q.ymx.v[i], nm); qb.v[i] = sel_u32(q.ymx.v[i], q.ypx.v[i], nm); }
     feL YpX = fe_add(p.Y, p.X), YmX = fe_sub(p.Y, p.X);
     feT PP = fe_mul(YpX, qa), MM = fe_mul(YmX, qb);
     feT TT = fe_mul(p.T, q.xy2d);
@@ -115,7 +116,7 @@ C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) 
     feL zp = fe_add_lt(Z2, TT);            // Z of the completed point for +Q, T for -Q   (loose)
     feW zm = fe_sub_w(Z2, TT);             // T of the completed point for +Q, Z for -Q   (wide)
     feW fx, fy;                            // the factor of X (the completed T) and of Y (the completed Z)
-    for (int i = 0; i < 10; i++) { fx.v[i] = neg ? zp.v[i] : zm.v[i]; fy.v[i] = neg ? zm.v[i] : zp.v[i]; }
+    for (int i = 0; i < 10; i++) { fx.v[i] = sel_u32(zm.v[i], zp.v[i], nm); fy.v[i] = sel_u32(zp.v[i], zm.v[i], nm); }
     ge_p3 r;
     r.X = fe_mul(fx, X);
     r.Y = fe_mul(fy, Y);
@@ -130,28 +131,30 @@ C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) 
 // and negates T.
 C25519_HD ge_p3 ge_from_aniels_signed(const ge_aniels &q, bool neg) {
     feT qa, qb;
-    for (int i = 0; i < 10; i++) { qa.v[i] = neg ? q.ymx.v[i] : q.ypx.v[i]; qb.v[i] = neg ? q.ypx.v[i] : q.ymx.v[i]; }
+    const lanemask nm = lane_mask(neg);
+    for (int i = 0; i < 10; i++) { qa.v[i] = sel_u32(q.ypx.v[i], q.ymx.v[i], nm); qb.v[i] = sel_u32(q.ymx.v[i], q.ypx.v[i], nm); }
     feT t = fe_mul(q.xy2d, fe_d_inv());
     feT tn = fe_carry(fe_neg(t));
     ge_p3 r;
     r.X = fe_carry(fe_sub(qa, qb));
     r.Y = fe_carry(fe_add(qa, qb));
     r.Z = fe_small(2);
-    for (int i = 0; i < 10; i++) r.T.v[i] = neg ? tn.v[i] : t.v[i];
+    for (int i = 0; i < 10; i++) r.T.v[i] = sel_u32(t.v[i], tn.v[i], nm);
     return r;
 }
 
 // w[0..7] = y+x, w[8..15] = y-x, w[16..23] = 2dxy as canonical 255-bit words.  neg: swap the first
 // two and replace the third by p - v (v = 0 gives p, a non-canonical but valid representative of 0).
 C25519_HD void aniels_words_cneg(u32 w[24], bool neg) {
-    for (int i = 0; i < 8; i++) { u32 a = w[i], b = w[8 + i]; w[i] = neg ? b : a; w[8 + i] = neg ? a : b; }
+    const lanemask nm = lane_mask(neg);
+    for (int i = 0; i < 8; i++) { u32 a = w[i], b = w[8 + i]; w[i] = sel_u32(a, b, nm); w[8 + i] = sel_u32(b, a, nm); }
     const u32 P0 = 0xffffffedu, PM = 0xffffffffu, P7 = 0x7fffffffu;
     u64 borrow = 0;
     for (int i = 0; i < 8; i++) {
         u64 pi = (i == 0) ? P0 : (i == 7 ? P7 : PM);
         u64 d = pi - (u64)w[16 + i] - borrow;
         borrow = (d >> 63) & 1;
-        w[16 + i] = neg ? (u32)d : w[16 + i];
+        w[16 + i] = sel_u32(w[16 + i], (u32)d, nm);
     }
 }
 C25519_HD ge_aniels aniels_from_words(const u32 w[24]) {

@@ -93,13 +93,19 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
     const u64 last4 = n * 10 - 1;
     int nj = 0;
     while (nj < CH && w0 + (u64)nj * T < n) nj++;            // steps with at least one point of this wave in range
+    // (the clamp of the last, partial block is decided per WAVE, not as twenty per-lane selects per step)
 #define C25519_PREP_ISSUE(j)                                                                                                   \
     {                                                                                                                          \
         const u64 b4 = (w0 + (u64)(j) * T) * 10;                                                                               \
-        _Pragma("unroll") for (int i = 0; i < 10; i++) {                                                                      \
-            u64 a = b4 + (u64)(i * 64) + lane;                                                                                 \
-            a = a > last4 ? last4 : a;                                                                                         \
-            __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + a), (lds_void *)(sin + i * 64), 16, 0, 0);                     \
+        if (b4 + 639 <= last4) {                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 10; i++)                                                                    \
+                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + b4 + (u64)(i * 64) + lane), (lds_void *)(sin + i * 64), 16, 0, 0); \
+        } else {                                                                                                               \
+            _Pragma("unroll") for (int i = 0; i < 10; i++) {                                                                  \
+                u64 a = b4 + (u64)(i * 64) + lane;                                                                             \
+                a = a > last4 ? last4 : a;                                                                                     \
+                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + a), (lds_void *)(sin + i * 64), 16, 0, 0);                 \
+            }                                                                                                                  \
         }                                                                                                                      \
     }
     const uint4 *my4 = sin + lane * 10;
@@ -115,17 +121,20 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
         const uint2 z2 = my2[14];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (j + 1 < nj) C25519_PREP_ISSUE(j + 1)
-        if (t + (u64)j * T < n) {
+        {
+            // (a lane whose point of this step is out of range works on the clamped block: its prefix slot is its own, its running product is
+            //  kept by an explicit select)
+            const bool in = t + (u64)j * T < n;
             const u64 l[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
-            affine = affine && (l[0] == 1) && ((l[1] | l[2] | l[3] | l[4]) == 0);
+            affine = affine && (!in || ((l[0] == 1) && ((l[1] | l[2] | l[3] | l[4]) == 0)));
             pre4[(j * 3 + 0) * 64] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
             pre4[(j * 3 + 1) * 64] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
             pre4[(j * 3 + 2) * 64] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
-            acc = fe_mul(acc, fe_from_limbs51(l));
+            acc = fe_select_m(acc, fe_mul(acc, fe_from_limbs51(l)), lane_mask(in));
         }
     }
     feT inv = fe_one();
-    if (!affine) inv = fe_invert(acc);
+    if (__ballot(!affine) != 0ull) inv = fe_select_m(inv, fe_invert(acc), lane_mask(!affine));      // (wave-uniform branch, explicit select)
     const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa;     // prefix product of the step about to be unwound
     if (nj > 0) { pa = pre4[((nj - 1) * 3 + 0) * 64]; pb = pre4[((nj - 1) * 3 + 1) * 64]; pc = pre4[((nj - 1) * 3 + 2) * 64]; }
@@ -144,19 +153,21 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
         const u64 lx[5] = {x0.x | (u64)x0.y << 32, x0.z | (u64)x0.w << 32, x1.x | (u64)x1.y << 32, x1.z | (u64)x1.w << 32, x2.x | (u64)x2.y << 32};
         const u64 ly[5] = {y0.x | (u64)y0.y << 32, y1.x | (u64)y1.y << 32, y1.z | (u64)y1.w << 32, y2.x | (u64)y2.y << 32, y2.z | (u64)y2.w << 32};
         const u64 lz[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
+        // (no zero-filling and no merging of per-lane branches here: lanes whose point is out of range compute on the clamped block and are
+        //  masked at the store; the per-lane choices are explicit selects on lane masks, fe26.h)
         uint4 q[PTS_Q];
-        for (int i = 0; i < PTS_Q; i++) q[i] = make_uint4(0, 0, 0, 0);
-        if (t + (u64)j * T < n) {
-            if (affine) pts_pieces(fe_from_limbs51(lx), fe_from_limbs51(ly), q);
-            else {
-                feT pre;
-                pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
-                pre.v[8] = c.x; pre.v[9] = c.y;
-                const feT zi = fe_mul(inv, pre);
-                inv = fe_mul(inv, fe_from_limbs51(lz));
-                pts_pieces(fe_mul(fe_from_limbs51(lx), zi), fe_mul(fe_from_limbs51(ly), zi), q);
-            }
+        const bool in = t + (u64)j * T < n;
+        feT x = fe_from_limbs51(lx), y = fe_from_limbs51(ly);
+        if (__ballot(!affine) != 0ull) {                    // wave-uniform: a wave of VerifyingKey points (Z = 1 throughout) skips the unwinding
+            feT pre;
+            pre.v[0] = a.x; pre.v[1] = a.y; pre.v[2] = a.z; pre.v[3] = a.w; pre.v[4] = b.x; pre.v[5] = b.y; pre.v[6] = b.z; pre.v[7] = b.w;
+            pre.v[8] = c.x; pre.v[9] = c.y;
+            const feT zi = fe_mul(inv, pre);
+            const lanemask proj = lane_mask(in && !affine);
+            inv = fe_select_m(inv, fe_mul(inv, fe_from_limbs51(lz)), proj);
+            x = fe_select_m(x, fe_mul(x, zi), proj); y = fe_select_m(y, fe_mul(y, zi), proj);
         }
+        pts_pieces(x, y, q);
 #pragma unroll
         for (int i = 0; i < PTS_Q; i++) sout[lane * 8 + ((i + lane) & 7u)] = q[i];
         uint4 *dst = reinterpret_cast<uint4 *>(pts) + PTS_Q * (dst0 + w0 + (u64)j * T);

@@ -109,11 +109,12 @@ C25519_HD sc28 sc28_finish(const u32 x[10]) {
         carry = acc >> 28;
     }
     const bool neg = carry < 0;              // lo - c * hi in (-2^127, 2^252): negative -> add l once
+    const lanemask nm = lane_mask(neg);      // (explicit lane-mask selects: fe26.h sel_u32)
     sc28 r;
     u32 cy = 0;
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-        const u32 add = (neg && k < 5) ? c[k] : 0u;
+        const u32 add = k < 5 ? sel_u32(0u, c[k], nm) : 0u;
         const u32 s = t[k] + add + cy;
         r.v[k] = s & SC28_MASK;
         cy = s >> 28;
@@ -186,8 +187,9 @@ C25519_HD sc28 sc28_add(const sc28 &a, const sc28 &b) {
     }
     const bool keep = carry < 0;             // a + b < l
     sc28 r;
+    const lanemask km = lane_mask(keep);
 #pragma unroll
-    for (int k = 0; k < 10; k++) r.v[k] = keep ? s[k] : d[k];
+    for (int k = 0; k < 10; k++) r.v[k] = sel_u32(d[k], s[k], km);
     return r;
 }
 C25519_HD sc28 sc28_neg(const sc28 &a) {
@@ -197,11 +199,12 @@ C25519_HD sc28 sc28_neg(const sc28 &a) {
 #pragma unroll
     for (int k = 0; k < 10; k++) any |= a.v[k];
     sc28 r;
+    const lanemask am = lane_mask(any != 0);
     long long carry = 0;
 #pragma unroll
     for (int k = 0; k < 10; k++) {
         long long acc = carry + (long long)(k < 5 ? c[k] : 0u) + (k == 9 ? 1 : 0) - (long long)a.v[k];
-        r.v[k] = any ? (u32)((u64)acc & SC28_MASK) : 0u;
+        r.v[k] = sel_u32(0u, (u32)((u64)acc & SC28_MASK), am);
         carry = acc >> 28;
     }
     return r;

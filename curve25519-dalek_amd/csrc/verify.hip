@@ -90,8 +90,8 @@ __global__ void __launch_bounds__(256) k_hram_mod_l(const uint8_t *__restrict__ 
 //   level 0: data = (hram_4j mod l) || s_4j || ... || (hram_4j+3 mod l) || s_4j+3 (absent = zero bytes): 2 blocks per 4 signatures,
 //            one lane each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
 //            VGPRs -- a latency-bound kernel that did not fit beside the decompression; v3: 3 blocks with 64-byte hram_i).
-//   level l: data = four children: ONE compression per node.  These levels are pure latency (one dependent SHA-512
-//            compression is ~30 us for a single wave), so the last ones (<= 1024 nodes) run inside one block.
+//   level l: data = four children: ONE compression per node (out[j] = F_level(in[4j] || .. || in[4j+3])[0..32]).  These levels are pure latency
+//            (one dependent SHA-512 compression is ~20 us for a single wave): five of them run inside one block (k_ztree_block).
 constexpr int ZTREE_MAX_LEVELS = 16;
 struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hred, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
@@ -121,48 +121,40 @@ __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
     for (int q = 0; q < 4; q++) o[q] = hs[q];
 }
-// one 4-ary level: out[j] = F_level(in[4j] || in[4j+1] || in[4j+2] || in[4j+3])[0..32]
-__device__ __forceinline__ void ztree_node4(const u64 *in, u64 m_in, u64 j, const u64 iv[8], u64 *out4) {
-    u64 hs[8], w[16];
-    for (int q = 0; q < 8; q++) hs[q] = iv[q];
-#pragma unroll
-    for (int ch = 0; ch < 4; ch++) {
-        const u64 c = 4 * j + ch;
-#pragma unroll
-        for (int q = 0; q < 4; q++) w[4 * ch + q] = c < m_in ? in[4 * c + q] : 0ull;
-    }
-    sha512_compress(hs, w);
-    for (int q = 0; q < 4; q++) out4[q] = hs[q];
-}
-__global__ void __launch_bounds__(256) k_ztree(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out) {
-    C25519_PRIO_CHAIN();
-    u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= (m_in + 3) / 4) return;
-    u64 r[4];
-    ztree_node4(reinterpret_cast<const u64 *>(in), m_in, j, ivs.iv[level], r);
-    u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
-    for (int q = 0; q < 4; q++) o[q] = r[q];
-}
-// the last levels (m_in <= 1024 nodes) in ONE block: no launch gaps between levels that hold a handful of nodes
-__global__ void __launch_bounds__(256) k_ztree_tail(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ root) {
+// FIVE levels per launch: a block owns 1024 consecutive nodes of level `level` - 1 and reduces them to ONE node of level `level` + 4 through LDS
+// (4^5 = 1024: the partition is aligned, so every node is the same function of the same children, with the same per-level tag, as when each level
+// was a launch of its own -- rounds 2-3: four launches of one level each and a single-block tail, 317 us of launch gaps and single-wave
+// compressions on the critical chain of verify_batch; now one launch of 256 blocks and the tail: ~200).  nlev: levels to do (5), or "until one
+// node is left" for the tail (m_in <= 1024, one block).  The global node counts decide which children exist, exactly as in ztree_node4.
+__global__ void __launch_bounds__(256) k_ztree_block(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out, int nlev) {
     C25519_PRIO_CHAIN();
     __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
-    for (u64 i = threadIdx.x; i < m_in * 4; i += 256) buf0[i] = reinterpret_cast<const u64 *>(in)[i];
+    const u64 base = (u64)blockIdx.x * 1024;
+    for (u32 i = threadIdx.x; i < 1024 * 4; i += 256) buf0[i] = base + i / 4 < m_in ? reinterpret_cast<const u64 *>(in)[base * 4 + i] : 0ull;
     __syncthreads();
     u64 *cur = buf0, *nxt = buf1;
-    u64 m = m_in;
-    while (m > 1) {
-        const u64 mo = (m + 3) / 4;                                  // <= 256 = blockDim
-        if (threadIdx.x < mo) {
-            u64 r[4];
-            ztree_node4(cur, m, threadIdx.x, ivs.iv[level], r);
-            for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = r[q];
+    u64 m = m_in, gbase = base;                                        // nodes of the current level (global), global index of this block's first one
+    u32 cnt = 1024;                                                    // nodes of the current level held by this block
+    for (int lv = 0; lv < nlev && m > 1; lv++) {
+        const u64 mo = (m + 3) / 4, gb = gbase / 4;
+        const u32 co = cnt / 4;
+        if (threadIdx.x < co && gb + threadIdx.x < mo) {
+            u64 hs[8], w[16];
+            for (int q = 0; q < 8; q++) hs[q] = ivs.iv[level][q];
+#pragma unroll
+            for (int ch = 0; ch < 4; ch++) {
+                const u32 c = 4 * threadIdx.x + ch;
+#pragma unroll
+                for (int q = 0; q < 4; q++) w[4 * ch + q] = gbase + c < m ? cur[4 * c + q] : 0ull;
+            }
+            sha512_compress(hs, w);
+            for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = hs[q];
         }
         __syncthreads();
         u64 *t = cur; cur = nxt; nxt = t;
-        m = mo; level++;
+        m = mo; gbase = gb; cnt = co; level++;
     }
-    if (threadIdx.x < 4) reinterpret_cast<u64 *>(root)[threadIdx.x] = cur[threadIdx.x];
+    if (threadIdx.x < 4) reinterpret_cast<u64 *>(out)[(u64)blockIdx.x * 4 + threadIdx.x] = cur[threadIdx.x];
 }
 // step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)) (standard, padded); n4 = ceil(n/4)
 // lanes, z16 has room for 4*n4 entries.  A quarter is read as SIGN-MAGNITUDE: bit 127 = sign, bits 0..126 = |z_i|, i.e.
@@ -310,12 +302,12 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
     uint64_t mm = (n + 3) / 4; uint8_t *a = t0, *b = t1;
     uint32_t level = 1;
     hipLaunchKernelGGL(k_ztree_first, dim3(div_up64(mm, 256)), dim3(256), 0, sa, hred, d_sigs, n, ivs, a);
-    while (mm > 1024) {
-        uint64_t mo = (mm + 3) / 4;
-        hipLaunchKernelGGL(k_ztree, dim3(div_up64(mo, 256)), dim3(256), 0, sa, a, mm, level, ivs, b);
-        mm = mo; level++; std::swap(a, b);
+    while (mm > 1024) {                                   // five levels per launch (4^5 = 1024 nodes per block)
+        const uint64_t mo = (mm + 1023) / 1024;
+        hipLaunchKernelGGL(k_ztree_block, dim3((unsigned)mo), dim3(256), 0, sa, a, mm, level, ivs, b, 5);
+        mm = mo; level += 5; std::swap(a, b);
     }
-    hipLaunchKernelGGL(k_ztree_tail, dim3(1), dim3(256), 0, sa, a, mm, level, ivs, b);      // leaves the 32-byte root at b
+    hipLaunchKernelGGL(k_ztree_block, dim3(1), dim3(256), 0, sa, a, mm, level, ivs, b, 64);      // the last <= 1024 nodes: leaves the 32-byte root at b
     hipLaunchKernelGGL(k_zderive, dim3(div_up64((n + 3) / 4, 256)), dim3(256), 0, sa, b, (n + 3) / 4, z16);
     HIPCHK(hipGetLastError());
     return C25519_OK;

@@ -10,7 +10,7 @@ e = pkg.Engine(0)
 names = {0: "v_mad_u64_u32 (8 independent chains)", 22: "v_mad_u64_u32 (ONE dependent chain)", 5: "v_mul_lo_u32", 18: "v_mul_hi_u32", 16: "v_mul_u32_u24 (VOP2)",
          17: "v_mad_u32_u24", 4: "v_xad_u32 / add+xor pair", 8: "v_add_u32 (VOP2)", 13: "v_and_b32 (VOP2)", 14: "v_lshlrev_b32 (VOP2)", 12: "v_alignbit_b32",
          15: "v_and_or_b32", 19: "v_add3_u32", 20: "v_bfe_u32", 21: "v_lshl_add_u32", 10: "v_lshrrev_b64", 11: "v_lshl_add_u64",
-         23: "v_lshrrev_b32 (VOP2)", 24: "v_sub_u32 (VOP2)", 25: "v_or_b32 (VOP2)", 26: "v_xor_b32 (VOP2)", 27: "v_cndmask_b32 (VOP2)", 28: "v_mov_b32",
+         23: "v_lshrrev_b32 (VOP2)", 24: "v_sub_u32 (VOP2)", 25: "v_or_b32 (VOP2)", 26: "v_xor_b32 (VOP2)", 27: "v_cndmask_b32 (VOP2)", 28: "v_mov_b32", 36: "v_cndmask_b32_e64 (condition in an SGPR pair)", 37: "v_cndmask_b32_e32 (VCC written by a compare)",
          29: "v_perm_b32", 30: "v_add_u32_sdwa (src1 WORD_1)", 31: "v_lshl_or_b32", 32: "v_add_co_u32 + v_addc_co_u32 (pair = 1)",
          6: "v_mad_u64_u32 with 1 v_xad_u32 beside each", 7: "v_mad_u64_u32 with 2 v_xad_u32 beside each",
          33: "v_mad_u64_u32 with 1 v_add_u32 beside each", 34: "v_mad_u64_u32 with 2 v_add_u32 beside each", 35: "v_mad_u64_u32 with 3 v_add_u32 beside each",
