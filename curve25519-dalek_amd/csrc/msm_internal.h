@@ -21,7 +21,7 @@ constexpr u32 LONG_CAP_MIN = 192;  // msm_geom.long_cap = max(this, 2.5 x mean l
 constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per lane)
 }
 // ---- what the translation units of the MSM share (msm.hip: driver, prep, long buckets, reduction, records; msm_sort.hip: the chunk-local
-//      sort; msm_sort_matrix.hip: the digit-matrix sort of the merged layout; small.hip: inputs below 2048 terms; verify.hip) -------------
+//      sort; msm_sort_matrix.hip: the digit-matrix sort (merged layout, passes below 2^16 terms); small.hip: inputs below 4096 terms; verify.hip) -------------
 namespace c25519 {
 struct long_item;
 constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A of the bucket reduction
@@ -29,7 +29,7 @@ constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per 
 // was derived from, [10] passes summed, [11] a magic word
 constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11;
 constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
-constexpr uint64_t MSM_SMALL_MAX = 2047;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5 and 6
+constexpr uint64_t MSM_SMALL_MAX = 4095;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5, 6 and 7
 }
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 static inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
@@ -53,7 +53,7 @@ struct msm_matrix_sort_args {
     const uint8_t *d_scalars; uint64_t n_scalars, n; int nchunk; bool use_part; int SL, PART_CHUNK, pchunks;
     uint16_t *D; uint32_t *counts, *P1, *cc, *bin_base, *flags, *totals, *ord_hist;
 };
-int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const c25519::msm_geom &g, const c25519::msm_merged &md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st);
+int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const c25519::msm_geom &g, const c25519::msm_merged *md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st);
 int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont = false, bool reduce = true,
                         const uint32_t *d_bad_sticky = nullptr);
 // sort + accumulate + reduce of one pass over prepared records; inputs of at most MSM_SMALL_MAX terms take the small path

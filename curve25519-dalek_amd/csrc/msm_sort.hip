@@ -379,8 +379,12 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const uint64_t n = md ? (uint64_t)md->K * md->ns : n_scalars;
     const uint64_t nc = n_carve > n ? n_carve : n;
     // The chunk-local sort serves every plain MSM pass: its per-bin counting sort scans 2^bps_log2 >= 64 buckets per wave, i.e. windows of
-    // c >= 7 bits (n >= 2048 terms: smaller inputs never get here, msm_small_enqueue), and its entries keep a 23-bit term index.
+    // c >= 7 bits (n >= 2048 terms; inputs below 4096 terms never get here, msm_small_enqueue), and its entries keep a 23-bit term index.
     if (!md && (g.half < 64 || n > (1ull << 23))) { ctx->err = "msm: internal error (a pass outside the range of the chunk-local sort)"; return -(int32_t)hipErrorInvalidValue; }
+    // which sort: the digit-matrix sort for the merged layout and for plain passes below 2^16 terms (the chunk-local partition wants hundreds of
+    // chunks: msm_sort_matrix.hip has the numbers); C25519_SORT_CHUNK_LOCAL_MIN lowers the boundary (tests run the chunk-local sort from 2 048 terms)
+    static const uint64_t chunk_local_min = (uint64_t)env_int("C25519_SORT_CHUNK_LOCAL_MIN", 1 << 16);
+    const bool matrix = md != nullptr || nc < chunk_local_min;
     // every region BEFORE the buckets (oK) must be sized from nc, the number of terms the call's passes are carved for, never from
     // this pass's own n: a shorter last pass that CONTINUES its predecessor's bucket sums has to find them at the same offset
     // (round 3 derived nchunk from n: with C25519_MSM_PASS_LOG2 = 21 / 22 a last pass one chunk shorter moved oC .. oK)
@@ -392,7 +396,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // workspace carve-up (tmp_d): [digit matrix | counts] (merged layout only) | base | sorted | buckets | segment pairs | flags | perm | long-bucket lists | sort scratch
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t oD = carve(md ? (size_t)g.nwin * nc * 2 : 0), oC = carve(md ? (size_t)g.nwin * nchunk * g.half * 4 : 0), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
+    const size_t oD = carve(matrix ? (size_t)g.nwin * nc * 2 : 0), oC = carve(matrix ? (size_t)g.nwin * nchunk * g.half * 4 : 0), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
     const size_t oS = carve((size_t)g.nwin * nc * 4), oK = carve(nb * 160), oT = carve(nb * 4);
     const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(8192), oPerm = carve(nb * 4);
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
@@ -401,16 +405,16 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
     const size_t oLI = carve((size_t)max_items * sizeof(long_item)), oLG = carve((size_t)max_long * 4), oLF = carve((size_t)max_long * 4);
     const size_t oLS = carve((size_t)max_items * 160);
-    const bool use_part = md && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);          // the two-pass partition of the digit-matrix sort
+    const bool use_part = matrix && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);          // the two-pass partition of the digit-matrix sort
     // block shapes of the chunk-local sort: the large ones are the fastest alone; the small ones fit beside a k_accumulate held at two waves
     // per SIMD (one wave per SIMD at 128 VGPRs / two at 56; profiles/r04_ab_sort_beside_accumulate.txt).  Read once per process.
     static const int small_blocks = env_int("C25519_SORT_SMALL", 0);
     const int sweep_chunk = (small_blocks ? 256 : SWEEP_THREADS) * SWEEP_TPT;
-    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = md ? part_chunk(SL) : sweep_chunk, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
+    const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = matrix ? part_chunk(SL) : sweep_chunk, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     // chunk-local form: P1 holds whole chunk blocks, oCC the slice starts [window][SL + 1][chunk], oBB the bin totals and the chunks' flags
-    const size_t p1_words = md ? (size_t)g.nwin * nc : (size_t)g.nwin * pchunks_c * sweep_chunk;
+    const size_t p1_words = matrix ? (size_t)g.nwin * nc : (size_t)g.nwin * pchunks_c * sweep_chunk;
     size_t oP1 = 0, oCC = 0, oBB = 0;
-    if (!md || use_part) { oP1 = carve(p1_words * 4); oCC = carve((size_t)g.nwin * (SL + 1) * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
+    if (!matrix || use_part) { oP1 = carve(p1_words * 4); oCC = carve((size_t)g.nwin * (SL + 1) * pchunks_c * 4); oBB = carve((size_t)g.nwin * (SL + 1) * 4 + (size_t)pchunks_c * 4); }
     int32_t r = ctx_reserve(ctx, ctx->tmp_d, off);
     if (r) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
@@ -424,12 +428,12 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     pl.items = (long_item *)(ws + oLI); pl.lgids = (uint32_t *)(ws + oLG); pl.lfirst = (uint32_t *)(ws + oLF); pl.segs = (uint32_t *)(ws + oLS);
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
-    if (md) {
+    if (matrix) {
         msm_matrix_sort_args a;
         a.d_scalars = d_scalars; a.n_scalars = n_scalars; a.n = n; a.nchunk = nchunk; a.use_part = use_part; a.SL = SL; a.PART_CHUNK = PART_CHUNK; a.pchunks = pchunks;
         a.D = (uint16_t *)(ws + oD); a.counts = (uint32_t *)(ws + oC); a.P1 = (uint32_t *)(ws + oP1); a.cc = (uint32_t *)(ws + oCC); a.bin_base = (uint32_t *)(ws + oBB);
         a.flags = flags; a.totals = totals; a.ord_hist = ord_hist;
-        return msm_matrix_sort_enqueue(ctx, g, *md, pl, a, st);
+        return msm_matrix_sort_enqueue(ctx, g, md, pl, a, st);
     }
     uint32_t *P1 = (uint32_t *)(ws + oP1), *lsg = (uint32_t *)(ws + oCC), *binm = (uint32_t *)(ws + oBB), *bad_blk = binm + (size_t)g.nwin * (SL + 1);
     const uint64_t wstride = (uint64_t)pchunks_c * sweep_chunk;

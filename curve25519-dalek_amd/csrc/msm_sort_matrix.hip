@@ -1,7 +1,10 @@
-// Round 2's digit-matrix sort (u16 digit matrix D[window][term], histogram / scan / scatter or the two-pass partition through LDS):
-// serves ONLY the merged layout of the precomputed static tables (extra.hip c25519_precomp_*: its terms are (window, scalar) pairs with
-// up to 2^24 ids, beyond the 23-bit term index of the chunk-local sort's entries).  Every plain MSM and verify_batch goes through
-// msm_sort.hip (>= 2048 terms) or small.hip (below).
+// Round 2's digit-matrix sort (u16 digit matrix D[window][term], histogram / scan / scatter or the two-pass partition through LDS).  It serves
+//   * the merged layout of the precomputed static tables (extra.hip c25519_precomp_*: its terms are (window, scalar) pairs with up to 2^24 ids,
+//     beyond the 23-bit term index of the chunk-local sort's entries), and
+//   * plain MSM / verify_batch passes of 4 096 .. 65 535 terms.  Round 4 first routed those through the chunk-local sort as well (msm_sort.hip
+//     runs correctly from 2 048 terms on, tested) -- and measured why not: its partition wants hundreds of 8 192-term chunks, and below 2^16
+//     terms there are 1 - 8 of them (one block walks all ~36 windows of a 4 096-term input): 0.79 ms per call at 4 096 terms against 0.59 here,
+//     0.92 against 0.66 at 16 384, 1.24 against 0.92 at 65 535 (profiles/r04_msm_midrange.txt).  Below 4 096 terms: small.hip.
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <stdlib.h>
@@ -43,6 +46,26 @@ namespace c25519 {
 //   addk = sum over signed windows of 2^(pos[k] + wid[k] - 1).
 // (struct msm_geom: msm_internal.h)
 
+// D[k][t] = window k of s' = s + addk  (u16); flags bit 255 of any scalar
+__global__ void __launch_bounds__(256) k_digits(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
+    C25519_PRIO_CHAIN();
+    // (two terms per thread and one 32-bit store per window instead of two 2-byte stores: 0.24 ms against 0.11; the block's
+    //  17 x 256 digits through LDS and out as 16-byte stores: 0.29 ms)
+    u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    u32 s[9];
+    load8(scalars, t, s);
+    if (s[7] >> 31) atomicOr(bad_scalar, 1u);
+    u64 carry = 0;
+    for (int i = 0; i < 8; i++) { u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = v >> 32; }
+    s[8] = (u32)carry;
+    for (int k = 0; k < g.nwin; k++) {
+        int bit = g.pos[k], wi = bit >> 5, sh = bit & 31;
+        u64 two = (u64)s[wi] | ((u64)(wi + 1 <= 8 ? s[wi + 1] : 0u) << 32);
+        u32 v = (u32)(two >> sh) & ((1u << g.wid[k]) - 1u);
+        D[(u64)k * n + t] = (uint16_t)v;
+    }
+}
 // merged layout (precomputed static points): D[k * ns + t] = d + 2^(c-1), d = signed digit k of scalar t in [-2^(c-1), 2^(c-1))
 // (windows 0 .. K-2 signed through s' = s + sum_k 2^(c k + c - 1), window K-1 unsigned); t >= n: digit 0
 __global__ void __launch_bounds__(256) k_digits_merged(const uint8_t *__restrict__ scalars, u64 n, u64 ns, int c, int K, uint16_t *__restrict__ D, u32 *__restrict__ bad_scalar) {
@@ -482,14 +505,15 @@ __global__ void __launch_bounds__(256) k_order_scatter(const u32 *__restrict__ t
 using namespace c25519;
 
 // the launches of the digit-matrix sort over the workspace msm_enqueue_sort carved (merged layout only)
-int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const msm_geom &g, const msm_merged &md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st) {
+int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const msm_geom &g, const msm_merged *md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st) {
     const uint64_t n = a.n, nb = pl.nb;
     const int nchunk = a.nchunk, SL = a.SL, PART_CHUNK = a.PART_CHUNK, pchunks = a.pchunks;
     const uint64_t chunk = (n + nchunk - 1) / nchunk;
     uint16_t *D = a.D;
     uint32_t *counts = a.counts, *flags = a.flags, *totals = a.totals, *ord_hist = a.ord_hist, *base = pl.base, *sorted = pl.sorted, *perm = pl.perm;
     HIPCHK(hipMemsetAsync(flags, 0, 4096, st));
-    hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md.ns, 256)), dim3(256), 0, st, a.d_scalars, a.n_scalars, md.ns, md.c, md.K, D, pl.bad_ws);
+    if (md) hipLaunchKernelGGL(k_digits_merged, dim3(div_up64(md->ns, 256)), dim3(256), 0, st, a.d_scalars, a.n_scalars, md->ns, md->c, md->K, D, pl.bad_ws);
+    else hipLaunchKernelGGL(k_digits, dim3(div_up64(n, 256)), dim3(256), 0, st, a.d_scalars, n, g, D, pl.bad_sticky ? pl.bad_sticky : pl.bad_ws);
     if (a.use_part) {
         uint32_t *P1 = a.P1, *cc = a.cc, *bin_base = a.bin_base;
         const size_t lds1 = ((size_t)16 * SL + 2 * SL + 1 + PART_CHUNK) * 4, lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP) * 4;

@@ -208,7 +208,8 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
 @pytest.mark.parametrize("env", [{}, {"C25519_MSM_PASS_LOG2": "16"}, {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "1"},
                                  {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"},
                                  {"C25519_SORT_SMALL": "1"}, {"C25519_SORT_SMALL": "1", "C25519_MSM_PASS_LOG2": "16"},      # the A/B arms of round 4 stay bit-exact
-                                 {"C25519_REDUCE_COOP": "0"}])
+                                 {"C25519_REDUCE_COOP": "0"},
+                                 {"C25519_SORT_CHUNK_LOCAL_MIN": "2048"}])                  # the chunk-local sort at its smallest sizes (one to a few chunks per window)
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
@@ -387,8 +388,8 @@ def test_msm_continuing_last_pass_one_sort_chunk_shorter(orc, log2pass, n):
 def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
     """The reference's benchmark shapes (dalek_benchmarks.rs:16 MULTISCALAR_SIZES = 1 .. 1024) and everything it hands to Straus
     (edwards.rs:1025): EVERY n in 1 .. 1024 through the small path (small.hip: tables by repeated addition, one lane per (window, term)),
-    then both sides of its boundary at 2047 / 2048 terms and the window-width steps of the chunk-local sort below 2^16 terms (c = 7 .. 12,
-    1 / 2 / 4 / 8 slices per window).  Expected: (sum_{i < n} x_i^2) B for every prefix, from ONE fixed-base batch over the prefix sums."""
+    then its upper sizes (c = 6 from 1024 terms, c = 7 from 2048), both sides of its boundary at 4095 / 4096 terms and the window-width steps of the
+    digit-matrix sort below 2^16 terms (c = 8 .. 12).  Expected: (sum_{i < n} x_i^2) B for every prefix, from ONE fixed-base batch over the prefix sums."""
     nmax = 1024
     x = util.rand_scalars(7001, nmax)
     pts = eng.mul_base_batch(x, out_fmt=2)
@@ -430,7 +431,7 @@ def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
         eng.msm_vartime(hi, pts[:100], in_fmt=2, out_fmt=0)
     # the boundary of the small path and the narrow windows of the sort
     import torch
-    for n in (2047, 2048, 2049, 3000, 4095, 4096, 8191, 8192, 16383, 16384, 32767, 32768, 50001):
+    for n in (2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 16383, 16384, 32767, 32768, 50001):
         g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
         dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
         dx[:, 31] &= 0x0F
