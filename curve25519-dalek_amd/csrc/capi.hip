@@ -42,6 +42,15 @@ int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes) {
     b.cap = want;
     return 0;
 }
+int32_t ctx_host_stage(c25519_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->h_stage_cap) return C25519_OK;
+    if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_cap = 0; }
+    const size_t cap = bytes + bytes / 8 + 4096;
+    hipError_t e = hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault);
+    if (e != hipSuccess) return c25519_fail(ctx, e, "hipHostMalloc(host staging)");
+    ctx->h_stage_cap = cap;
+    return C25519_OK;
+}
 
 // ---- fixed-base table, built by the `create` logic of edwards.rs:1131-1141 -----------------------
 // entry j (1..HALF) of window i = j * 2^(W i) * P (P = B for the context's own tables), as canonical (y+x, y-x, 2dxy); entry 0 = identity.
@@ -259,6 +268,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     for (int i = 0; i < c25519_ctx::FFI_MAXCH; i++) { if (ctx->ev_up[i]) hipEventDestroy(ctx->ev_up[i]); if (ctx->ev_kd[i]) hipEventDestroy(ctx->ev_kd[i]); }
     if (ctx->ev_ffi) hipEventDestroy(ctx->ev_ffi);
     if (ctx->h_msm) hipHostFree(ctx->h_msm);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
     if (ctx->d_slots) hipFree(ctx->d_slots);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) if (ctx->ring[i][j]) hipEventDestroy(ctx->ring[i][j]);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -33,6 +33,7 @@ struct c25519_ctx {
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr, ev_pts = nullptr;
     void *h_msm = nullptr;                               // pinned: C25519_MAX_SLOTS result slots
+    void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned, grown on demand: hram / s / z of the strict z-mode of verify_batch (ctx_host_stage)
     uint32_t *d_slots = nullptr;                         // device: C25519_MAX_SLOTS result slots (written by this context and its peer)
     // a second set of streams / workspaces on the same device (shares the fixed-base tables): multi-pass MSM and
     // verify_batch enqueue alternate passes on it, so that the low-VALU phases of one pass (normalise, sort, reduce)
@@ -75,6 +76,8 @@ struct stream_wipe {
 
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);
 int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
+// page-locked host staging of at least `bytes` bytes, kept by the context (fresh pageable buffers pay first-touch faults at ~5 GB/s inside a copy)
+int32_t ctx_host_stage(c25519_ctx *ctx, size_t bytes);
 c25519_ctx *ctx_peer(c25519_ctx *ctx);      // nullptr if it cannot be created
 // out[i] = scalars[i] * B.  secret: constant-time table scan (k_mul_base<5, CT>) and wiped scratch; otherwise the context's
 // fast tables (the radix-2^16 HBM tables by default), whose addresses depend on the scalar.

@@ -32,15 +32,30 @@ static inline uint64_t rotl(uint64_t x, unsigned n) { return n ? (x << n) | (x >
         a15 = b15 ^ (~b16 & b17); a16 = b16 ^ (~b17 & b18); a17 = b17 ^ (~b18 & b19); a18 = b18 ^ (~b19 & b15); a19 = b19 ^ (~b15 & b16);         \
         a20 = b20 ^ (~b21 & b22); a21 = b21 ^ (~b22 & b23); a22 = b22 ^ (~b23 & b24); a23 = b23 ^ (~b24 & b20); a24 = b24 ^ (~b20 & b21);         \
     }
-static inline void keccak_f(uint64_t a[25]) {
-    static const uint64_t RC[24] = C25519_KECCAK_RC;
-    uint64_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8], a9 = a[9], a10 = a[10], a11 = a[11],
-             a12 = a[12], a13 = a[13], a14 = a[14], a15 = a[15], a16 = a[16], a17 = a[17], a18 = a[18], a19 = a[19], a20 = a[20], a21 = a[21],
-             a22 = a[22], a23 = a[23], a24 = a[24];
-    for (int rnd = 0; rnd < 24; rnd += 2) { C25519_K_ROUND(RC[rnd]) C25519_K_ROUND(RC[rnd + 1]) }
-    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4; a[5] = a5; a[6] = a6; a[7] = a7; a[8] = a8; a[9] = a9; a[10] = a10; a[11] = a11; a[12] = a12;
+#define C25519_KECCAK_BODY                                                                                                                            \
+    static const uint64_t RC[24] = C25519_KECCAK_RC;                                                                                                  \
+    uint64_t a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7], a8 = a[8], a9 = a[9], a10 = a[10], a11 = a[11],  \
+             a12 = a[12], a13 = a[13], a14 = a[14], a15 = a[15], a16 = a[16], a17 = a[17], a18 = a[18], a19 = a[19], a20 = a[20], a21 = a[21],        \
+             a22 = a[22], a23 = a[23], a24 = a[24];                                                                                                    \
+    for (int rnd = 0; rnd < 24; rnd += 2) { C25519_K_ROUND(RC[rnd]) C25519_K_ROUND(RC[rnd + 1]) }                                                     \
+    a[0] = a0; a[1] = a1; a[2] = a2; a[3] = a3; a[4] = a4; a[5] = a5; a[6] = a6; a[7] = a7; a[8] = a8; a[9] = a9; a[10] = a10; a[11] = a11; a[12] = a12; \
     a[13] = a13; a[14] = a14; a[15] = a15; a[16] = a16; a[17] = a17; a[18] = a18; a[19] = a19; a[20] = a20; a[21] = a21; a[22] = a22; a[23] = a23; a[24] = a24;
-}
+static void keccak_f_generic(uint64_t a[25]) { C25519_KECCAK_BODY }
+// (r4) The strict z-mode of verify_batch is ONE sequential sponge on one host core (batch.rs:195-222: ~1.7 permutations per signature), so the
+// permutation IS the reference-exact mode's throughput.  The library is built for a generic x86-64; the same source compiled for BMI / BMI2 turns
+// every chi term (~b & c) into one ANDN and every rotation into one RORX without a flags dependency.  Chosen once per process from CPUID; the
+// bytes are the same (tests/test_oracle_kat.py pins them against the independent STROBE of tests/pyref.py on whichever path the host takes).
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+__attribute__((target("bmi,bmi2"))) static void keccak_f_bmi2(uint64_t a[25]) { C25519_KECCAK_BODY }
+typedef void (*keccak_fn)(uint64_t *);
+static inline keccak_fn keccak_pick() { __builtin_cpu_init(); return (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) ? keccak_f_bmi2 : keccak_f_generic; }
+static inline void keccak_f(uint64_t a[25]) { static const keccak_fn f = keccak_pick(); f(a); }
+static inline const char *keccak_impl() { return keccak_pick() == keccak_f_bmi2 ? "bmi2" : "generic"; }
+#else
+static inline void keccak_f(uint64_t a[25]) { keccak_f_generic(a); }
+static inline const char *keccak_impl() { return "generic"; }
+#endif
+#undef C25519_KECCAK_BODY
 #undef C25519_K_ROUND
 
 struct strobe {

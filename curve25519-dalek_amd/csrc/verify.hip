@@ -504,13 +504,16 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 128))) return r;
             uint8_t *d_hram_all = (uint8_t *)ctx->tmp_c2.p, *d_z_all = d_hram_all + n * 64 + 64;
             if ((r = batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all))) return r;
-            std::vector<uint8_t> hh(n * 64), hs(n * 64), hz(n * 16);
-            HIPCHK(hipMemcpyAsync(hh.data(), d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(hipMemcpyAsync(hs.data(), d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            // (r4) the host copies live in a page-locked buffer the context keeps instead of three fresh std::vectors per call (144 MB at 2^20
+            // signatures).  Measured neutral (468 ms per 2^20 signatures either way): the call IS the sponge -- ~410 ns per signature inside the
+            // library on the GPU box's host (1.73 permutations of ~185 ns + framing), tools/keccak_bench.cpp, tools/strict_rate.py
+            if ((r = ctx_host_stage(ctx, n * 144 + 64))) return r;
+            uint8_t *hh = (uint8_t *)ctx->h_stage, *hs = hh + n * 64, *hz = hs + n * 64;
+            HIPCHK(hipMemcpyAsync(hh, d_hram_all, n * 64, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(hipMemcpyAsync(hs, d_sigs, n * 64, hipMemcpyDeviceToHost, ctx->stream));
             HIPCHK(hipStreamSynchronize(ctx->stream));
-            c25519_transcript_zs(hh.data(), hs.data(), n, hz.data());
-            HIPCHK(hipMemcpyAsync(d_z_all, hz.data(), n * 16, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));      // hz is a local buffer
+            c25519_transcript_zs(hh, hs, n, hz);
+            HIPCHK(hipMemcpyAsync(d_z_all, hz, n * 16, hipMemcpyHostToDevice, ctx->stream));
             if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx)))) return r;
         } catch (const std::exception &e) { ctx->err = std::string("verify_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
         if ((r = rec_collect(ctx))) return r;
