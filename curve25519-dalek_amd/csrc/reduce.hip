@@ -1,9 +1,10 @@
 // Bucket reduction col_k = sum_b (b + 1) B_b (pippenger.rs:146-151) with FOUR WAVES PER POINT OPERATION.
 //
 // The reduction is a latency chain, not a throughput problem: 1.1 M complete additions per 2^21-term pass are 35 us of multiplier time
-// on this GPU, but as a running sum they are ~50 dependent point operations, and a lone wave issues one v_mad_u64_u32 per 11.7 cycles --
-// 9 M x 100 products per addition make 4.4 us per link of the chain, 0.25 ms for rounds 2-3's k_reduce_a / k_reduce_b (one lane per
-// point, msm.hip).  Nothing hides beside it: it is the tail of every call (and of every verify_batch).
+// on this GPU, but as a running sum they are ~50 dependent point operations, and a lone wave issues a v_mad_u64_u32 every 6.4 cycles when it is
+// independent of its predecessors and every 14 when it is not (profiles/r04_instruction_rates.txt) -- 9 M x 100 products per addition make
+// ~4.4 us per link of the chain, 0.25 ms for rounds 2-3's k_reduce_a / k_reduce_b (one lane per point, msm.hip).  Nothing hides beside it: it
+// is the tail of every call (and of every verify_batch).
 //
 // The reference's own answer to "one addition is too slow" is its parallel formulas (docs/parallel-formulas.md:106-213, the AVX2 backend:
 // the four products of each half of an addition are independent).  Here the four lanes are four WAVES of a block: the 64 lanes of a wave
