@@ -540,7 +540,7 @@ static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const v
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                     hipStream_t sort_stream, hipEvent_t wait_acc) {
-    if (n <= MSM_SMALL_MAX) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);
+    if (n <= MSM_SMALL_MAX && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
@@ -702,8 +702,10 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
     else if (in_fmt == C25519_FMT_RAW160) {
         int32_t r;
         // points per lane and inversion: 64 when the launch still has >= 2048 waves (the records of the later passes of a
-        // multi-pass call), 16 for one pass of 2^21 points (2^24 terms: 15.8 ms with 16 everywhere, 15.3 with 64)
-        const int CH = n >= (1ull << 23) ? 64 : n >= (1ull << 22) ? 32 : 16;
+        // multi-pass call; 2^24 terms: 15.8 ms with 16 everywhere, 15.3 with 64), 32 from 2^20 points (profiles/r04_ab_prep_points_per_lane.txt:
+        // 2^20 terms 1.10 against 1.18 ms, 2^21 the same either way), 16 below (2^19: 0.76 against 0.81 ms; 8 and 4 buy nothing down to 2^16)
+        static const int ch_knob = env_int("C25519_PREP_CH", 0);             // A/B knob: 4 / 8 / 16 / 32 / 64
+        const int CH = ch_knob ? ch_knob : (n >= (1ull << 23) ? 64 : n >= (1ull << 20) ? 32 : 16);
         constexpr int wpb = 4;
         const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
         // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
@@ -720,6 +722,8 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         } else
         if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
         else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        else if (CH == 8) hipLaunchKernelGGL((k_prep_raw2<8, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        else if (CH == 4) hipLaunchKernelGGL((k_prep_raw2<4, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
         else hipLaunchKernelGGL((k_prep_raw2<16, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
     } else { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipGetLastError());

@@ -44,7 +44,7 @@ static void keccak_f_generic(uint64_t a[25]) { C25519_KECCAK_BODY }
 // (r4) The strict z-mode of verify_batch is ONE sequential sponge on one host core (batch.rs:195-222: ~1.7 permutations per signature), so the
 // permutation IS the reference-exact mode's throughput.  The library is built for a generic x86-64; the same source compiled for BMI / BMI2 turns
 // every chi term (~b & c) into one ANDN and every rotation into one RORX without a flags dependency.  Chosen once per process from CPUID; the
-// bytes are the same (tests/test_oracle_kat.py pins them against the independent STROBE of tests/pyref.py on whichever path the host takes).
+// bytes are the same (the known-answer tests under tests/ pin them against the independent STROBE of tests/pyref.py on whichever path the host takes).
 #if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
 __attribute__((target("bmi,bmi2"))) static void keccak_f_bmi2(uint64_t a[25]) { C25519_KECCAK_BODY }
 typedef void (*keccak_fn)(uint64_t *);

@@ -35,5 +35,10 @@ for r in range(reps):
     st = eng.verify_batch_t(msgs.reshape(-1), off, sigs, pks, E.Z_DEVICE); assert st == 0, st
     check("x", bytes(eng.x25519_batch_t(xs[:4096], msgs[:4096]).cpu().numpy().tobytes()))
     check("fb", bytes(eng.mul_base_batch_t(xs[:4096]).cpu().numpy().tobytes()))
+    # (r4) the small path (tables + lane-per-(window, term), small.hip), the digit-matrix range and small verify_batch calls
+    for m in (1, 3, 100, 1024, 2049, 4095, 4096, 30000):
+        st, out = eng.msm_vartime_t(xs[:m], pts[:m], E.FMT_RAW160, E.FMT_EDWARDS_Y); assert st == 0; check("msm_small_%d" % m, bytes(out))
+    for m in (4, 256, 2047):
+        st = eng.verify_batch_t(msgs.reshape(-1)[:32 * m], off[:m + 1], sigs[:m], pks[:m], E.Z_DEVICE); assert st == 0, st
 torch.cuda.synchronize()
 print("soak ok: %d repetitions, %.1f s" % (reps, time.time() - t0))
