@@ -179,6 +179,7 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_pts, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_lists[0], hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_lists[1], hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
     // C25519_MAX_SLOTS pass slots + the context's own record (msm.hip drec)
     if (hipMalloc((void **)&ctx->d_slots, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4) != hipSuccess) return false;
@@ -263,6 +264,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
     if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
     if (ctx->ev_pts) hipEventDestroy(ctx->ev_pts);
+    for (int q = 0; q < 2; q++) if (ctx->ev_lists[q]) hipEventDestroy(ctx->ev_lists[q]);
     if (ctx->s_h2d) { hipStreamSynchronize(ctx->s_h2d); hipStreamDestroy(ctx->s_h2d); }
     if (ctx->s_d2h) { hipStreamSynchronize(ctx->s_d2h); hipStreamDestroy(ctx->s_d2h); }
     for (int i = 0; i < c25519_ctx::FFI_MAXCH; i++) { if (ctx->ev_up[i]) hipEventDestroy(ctx->ev_up[i]); if (ctx->ev_kd[i]) hipEventDestroy(ctx->ev_kd[i]); }

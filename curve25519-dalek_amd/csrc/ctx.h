@@ -32,6 +32,7 @@ struct c25519_ctx {
     void *d_flag = nullptr;        // 256 bytes of device flags / small results
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr, ev_pts = nullptr;
+    hipEvent_t ev_lists[2] = {nullptr, nullptr};        // multi-pass MSM: [q] = recorded when the pass with list parity q was enqueued (the accumulation before it has finished)
     void *h_msm = nullptr;                               // pinned: C25519_MAX_SLOTS result slots
     void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned, grown on demand: hram / s / z of the strict z-mode of verify_batch (ctx_host_stage)
     uint32_t *d_slots = nullptr;                         // device: C25519_MAX_SLOTS result slots (written by this context and its peer)

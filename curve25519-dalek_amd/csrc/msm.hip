@@ -505,7 +505,7 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // main stream its few small blocks had normal priority: once the sort of the next pass stopped being late (round 3) the next
     // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
     // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
-    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));
+    if (reduce) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));      // (without a reduction nothing on the second stream needs the accumulated buckets)
     static const int coop_reduce = env_int("C25519_REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
     if (reduce && coop_reduce) {
         launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux);
@@ -785,7 +785,7 @@ hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind) {
 struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
                                 hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr,
-                                bool cont = false, bool reduce = true, uint64_t n_carve = 0, uint32_t *d_bad_sticky = nullptr) {
+                                bool cont = false, bool reduce = true, uint64_t n_carve = 0, uint32_t *d_bad_sticky = nullptr, int parity = -1) {
     int32_t r;
     uint32_t *d_pts;
     if (wait_in) HIPCHK(hipStreamWaitEvent(ctx->stream, wait_in, 0));      // host-pointer calls: this pass's inputs are still on their way up
@@ -796,7 +796,24 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     hipEvent_t *ring = pass_ring(owner, ctx, 1);
     HIPCHK(hipEventRecord(ring[3], ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));     // the sort does not touch the slot: it need not wait for k_slot_init's dispatch
-    HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+    // A continuing pass on device-resident inputs does not wait for its predecessor on this stream set with the first half of its SORT
+    // (k_sweep_local, k_bin_totals: scalars in, sort scratch out -- consumed by kernels that precede it on the second stream); only the
+    // second half (k_part2g on) overwrites the lists the predecessor's accumulation reads and waits for it -- or not even that, when the lists
+    // exist twice (parity).  Before, the whole sort waited: its 1024-thread blocks found no room beside the OTHER set's accumulation, ended in
+    // that kernel's tail, and every second accumulation started ~0.4 ms late (profiles/r04_msm_2p24_last_call_timeline.txt: gaps of
+    // 35 / 420 us alternating; with the partition ahead 30 - 190 us, profiles/r04_msm_2p24_sort_ahead_timeline.txt).
+    // C25519_SWEEP_EARLY: 0 = round 3's order, 1 (default) = only the partition half (k_sweep_local, k_bin_totals: sort scratch only) runs ahead,
+    // 2 = all of it.  profiles/r04_ab_sort_ahead.txt: 13.39 - 13.51 ms against 13.69 - 13.71 on one box, 13.93 - 14.00 against 13.93 - 14.11 on
+    // another; 1 and 2 measure the same (the accumulation beside a sort stretches by what the sort no longer costs afterwards), so the
+    // default is the one without a second copy of the lists.
+    static const int sweep_early = env_int("C25519_SWEEP_EARLY", 1);
+    const bool early = sweep_early && cont && !wait_in && terms > MSM_SMALL_MAX && parity >= 0;
+    hipEvent_t lists_free = nullptr;
+    if (parity >= 0) {
+        HIPCHK(hipEventRecord(ctx->ev_lists[parity & 1], ctx->stream));                 // the accumulation before this pass (list copy parity ^ 1) is behind this point
+        if (early) lists_free = sweep_early >= 2 ? ctx->ev_lists[(parity & 1) ^ 1] : ctx->ev_fork;   // (copy `parity` was last read two passes ago: implied by the stream order, stated anyway)
+    }
+    if (!early) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream);            // (a continuing pass adds its counters to the slot of its stream set)
     if (terms <= MSM_SMALL_MAX && !cont && reduce && !ahead) {
         // the small path (small.hip): raw points as they are (projective: no normalisation, no inversion); compressed ones through the
@@ -815,7 +832,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
     if (serial_sort) { HIPCHK(hipEventRecord(ctx->ev_z, ctx->stream)); HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_z, 0)); }
-    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve))) return r;
+    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve, lists_free, sweep_early >= 2 ? parity : -1))) return r;
     // a continuing pass adds onto the bucket sums its predecessor on this stream set left: they must be where it left them
     if (cont && pl.buckets != ctx->cont_buckets) { ctx->err = "msm: internal error (the workspace of a continuing pass moved its buckets)"; return -(int32_t)hipErrorInvalidValue; }
     ctx->cont_buckets = pl.buckets;
@@ -872,7 +889,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         hipEvent_t in_ev = nullptr;
         if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
         if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p >= 1) ? &ah : nullptr, in_ev,
-                                  !first, last, per, sticky))) {
+                                  !first, last, per, sticky, passes > (uint64_t)L ? (int)((p / L) & 1) : -1))) {
             if (ctx->err.empty()) ctx->err = c->err;
             return r;
         }

@@ -48,7 +48,7 @@ struct msm_plan {
 };
 void msm_sort_params(uint64_t n, c25519::msm_geom &g);
 int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
-                         const c25519::msm_merged *md = nullptr, uint64_t n_carve = 0);
+                         const c25519::msm_merged *md = nullptr, uint64_t n_carve = 0, hipEvent_t lists_free = nullptr, int parity = -1);
 struct msm_matrix_sort_args {
     const uint8_t *d_scalars; uint64_t n_scalars, n; int nchunk; bool use_part; int SL, PART_CHUNK, pchunks;
     uint16_t *D; uint32_t *counts, *P1, *cc, *bin_base, *flags, *totals, *ord_hist;

@@ -374,7 +374,7 @@ void msm_sort_params(uint64_t n, msm_geom &g) {
 // n_carve (0 = n): the number of terms the workspace is carved for -- passes that CONTINUE each other's bucket sums (msm_record_enqueue)
 // must find the buckets at the same address although the last pass is shorter
 int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
-                         const msm_merged *md, uint64_t n_carve) {
+                         const msm_merged *md, uint64_t n_carve, hipEvent_t lists_free, int parity) {
     (void)d_slot;
     const uint64_t n = md ? (uint64_t)md->K * md->ns : n_scalars;
     const uint64_t nc = n_carve > n ? n_carve : n;
@@ -396,9 +396,13 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // workspace carve-up (tmp_d): [digit matrix | counts] (merged layout only) | base | sorted | buckets | segment pairs | flags | perm | long-bucket lists | sort scratch
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t oD = carve(matrix ? (size_t)g.nwin * nc * 2 : 0), oC = carve(matrix ? (size_t)g.nwin * nchunk * g.half * 4 : 0), oB = carve((size_t)g.nwin * (g.half + 1) * 4);
-    const size_t oS = carve((size_t)g.nwin * nc * 4), oK = carve(nb * 160), oT = carve(nb * 4);
-    const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(8192), oPerm = carve(nb * 4);
+    // parity >= 0 (the passes of a multi-pass call): what the accumulation READS of the sort -- bucket bases, gather lists, bucket order -- exists
+    // twice, and the pass uses copy `parity`: the sort of the next pass on this workspace can then run beside this pass's accumulation
+    const int copies = parity >= 0 ? 2 : 1, cp = parity >= 0 ? (parity & 1) : 0;
+    const size_t szB = ((size_t)g.nwin * (g.half + 1) * 4 + 255) & ~(size_t)255, szS = ((size_t)g.nwin * nc * 4 + 255) & ~(size_t)255, szPerm = (nb * 4 + 255) & ~(size_t)255;
+    const size_t oD = carve(matrix ? (size_t)g.nwin * nc * 2 : 0), oC = carve(matrix ? (size_t)g.nwin * nchunk * g.half * 4 : 0), oB = carve(szB * copies) + szB * cp;
+    const size_t oS = carve(szS * copies) + szS * cp, oK = carve(nb * 160), oT = carve(nb * 4);
+    const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(8192), oPerm = carve(szPerm * copies) + szPerm * cp;
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * nc;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
@@ -429,6 +433,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     pl.sort_stream = sort_stream;
     hipStream_t st = sort_stream ? sort_stream : ctx->stream;
     if (matrix) {
+        if (lists_free) HIPCHK(hipStreamWaitEvent(st, lists_free, 0));     // (the digit-matrix sort is not split: all of it waits)
         msm_matrix_sort_args a;
         a.d_scalars = d_scalars; a.n_scalars = n_scalars; a.n = n; a.nchunk = nchunk; a.use_part = use_part; a.SL = SL; a.PART_CHUNK = PART_CHUNK; a.pchunks = pchunks;
         a.D = (uint16_t *)(ws + oD); a.counts = (uint32_t *)(ws + oC); a.P1 = (uint32_t *)(ws + oP1); a.cc = (uint32_t *)(ws + oCC); a.bin_base = (uint32_t *)(ws + oBB);
@@ -451,6 +456,10 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         hipLaunchKernelGGL(k_sweep_local<SWEEP_THREADS>, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
     }
     hipLaunchKernelGGL(k_bin_totals, dim3((g.nwin * SL + 3) / 4), dim3(256), 0, st, lsg, pchunks, SL, g.nwin * SL, binm, bad_blk, bad_ws, pl.bad_sticky);
+    // lists_free: the partition above writes only the sort's own scratch (chunk blocks, slice starts, bin totals, the small counters of the chain);
+    // the gather lists, bucket bases, totals and the bucket order -- what the accumulation of the PREVIOUS pass on this workspace still reads --
+    // are written from here on
+    if (lists_free) HIPCHK(hipStreamWaitEvent(st, lists_free, 0));
     if (small_blocks) hipLaunchKernelGGL((k_part2g<8, ITER_SMALL>), dim3(g.nwin, SL), dim3(512), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     else hipLaunchKernelGGL((k_part2g<16, P2G_ITER>), dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     hipLaunchKernelGGL(k_order_place<1024>, dim3(div_up64(nb, 1024)), dim3(1024), 0, st, totals, nb, ord_hist, ord_cursor, perm);

@@ -209,7 +209,13 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"},
                                  {"C25519_SORT_SMALL": "1"}, {"C25519_SORT_SMALL": "1", "C25519_MSM_PASS_LOG2": "16"},      # the A/B arms of round 4 stay bit-exact
                                  {"C25519_REDUCE_COOP": "0"},
-                                 {"C25519_SORT_CHUNK_LOCAL_MIN": "2048"}])                  # the chunk-local sort at its smallest sizes (one to a few chunks per window)
+                                 {"C25519_SORT_CHUNK_LOCAL_MIN": "2048"},                   # the chunk-local sort at its smallest sizes (one to a few chunks per window)
+                                 # how far the sort of a continuing pass runs ahead of its predecessor's accumulation (0 = not at all, 1 = the partition
+                                 # half, 2 = all of it on a second copy of the lists), with the chunk-local sort on many short passes
+                                 {"C25519_SWEEP_EARLY": "0", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
+                                 {"C25519_SWEEP_EARLY": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
+                                 {"C25519_SWEEP_EARLY": "2", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
+                                 {"C25519_SWEEP_EARLY": "2", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
