@@ -239,6 +239,10 @@ class Workload:
         passes = max(1, self.kt["passes_per_step"]) if hasattr(self, "kt") else 1
         per = -(-self.n // passes)
         terms = per if self.name == "msm" else 2 * per + 1
+        if self.name == "msm" and passes > 2 and per >= (1 << 20):
+            terms = max(terms, 1 << 21)              # msm_record_enqueue: passes that continue each other's buckets share the layout of a 2^21-term pass
+        if self.name != "msm":
+            terms = min(terms, (1 << 21) - 1)        # verify_batch keeps 16-bit windows (verify.hip: msm_layout(.., 16)); same window count as any larger 16-bit layout
         lib.c25519_msm_geometry(terms, C.byref(c), C.byref(nwin), pos, wid, addk)
         half = 1 << (c.value - 1)
         self._nwin = nwin.value

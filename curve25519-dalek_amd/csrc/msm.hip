@@ -302,36 +302,36 @@ __device__ __forceinline__ void wave_weighted_sum(ge_p3 &S, ge_p3 &W, int shift,
 }
 // level A: block (one wave) = segment `seg` of window k.  direct: the window has a single segment, write col_k itself.
 // bad_ws (may be null): the sort's "a scalar has bit 255 set" word, ORed into the slot's flag 0 (the sort does not touch the slot)
-__global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
+__global__ void __launch_bounds__(64) k_reduce_a(const u32 *__restrict__ buckets, int half, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
                                                  const u32 *__restrict__ bad_ws) {
     C25519_PRIO_SIDE();
     const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg, lane = threadIdx.x;
     if (bad_ws && blockIdx.x == 0 && lane == 0 && *bad_ws) atomicOr(cols + MSM_MAX_WIN * 40, 1u);
-    const int b0 = seg * RED_SEG + lane * RED_LB;
+    const int LB = 1 << lb, b0 = (seg * 64 + lane) * LB;
     const u32 *B = buckets + (u64)k * half * 40;
     const ge_p3 id = ge_identity();
-    ge_p3 run = (b0 + RED_LB - 1 < half) ? p40_load(B, b0 + RED_LB - 1) : id;
+    ge_p3 run = (b0 + LB - 1 < half) ? p40_load(B, b0 + LB - 1) : id;
     ge_p3 acc = run;
 #pragma unroll 1
-    for (int j = RED_LB - 2; j >= 1; j--) {
+    for (int j = LB - 2; j >= 1; j--) {
         run = ge_add(run, (b0 + j < half) ? p40_load(B, b0 + j) : id);
         acc = ge_add(acc, run);
     }
     run = ge_add(run, (b0 < half) ? p40_load(B, b0) : id);
-    wave_weighted_sum(run, acc, 3, lane);                // run (lane 0) = S_seg, acc = W_seg = sum (b - seg base) B_b
+    wave_weighted_sum(run, acc, lb, lane);                // run (lane 0) = S_seg, acc = W_seg = sum (b - seg base) B_b
     if (lane == 0) {
         if (direct) p40_store(cols, k, ge_add(acc, run));
         else { p40_store(SW, 2 * (u64)blockIdx.x, run); p40_store(SW, 2 * (u64)blockIdx.x + 1, acc); }
     }
 }
 // level B: one wave per window over its nseg <= 64 segment pairs
-__global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int nseg, u32 *__restrict__ cols) {
+__global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols) {
     C25519_PRIO_SIDE();
     const int k = blockIdx.x, lane = threadIdx.x;
     const ge_p3 id = ge_identity();
     ge_p3 S = lane < nseg ? p40_load(SW, 2 * ((u64)k * nseg + lane)) : id;
     ge_p3 W = lane < nseg ? p40_load(SW, 2 * ((u64)k * nseg + lane) + 1) : id;
-    wave_weighted_sum(S, W, 9, lane);                    // 512 = RED_SEG buckets per segment
+    wave_weighted_sum(S, W, lb + 6, lane);                    // 64 x 2^lb buckets per segment
     if (lane == 0) p40_store(cols, k, ge_add(W, S));
 }
 
@@ -349,7 +349,7 @@ __global__ void __launch_bounds__(64) k_reduce_b(const u32 *__restrict__ SW, int
 // ================================================================================================
 // zero a slot and write its header; pre (may be null): counters a caller computed beforehand (whole-batch hashing in the
 // transcript z-mode: [0] non-canonical s, [1] bad message offsets), merged into flags [4] and [5]
-__global__ void __launch_bounds__(256) k_slot_init(u32 *__restrict__ slot, u32 terms_lo, u32 terms_hi, u32 passes, const u32 *__restrict__ pre) {
+__global__ void __launch_bounds__(256) k_slot_init(u32 *__restrict__ slot, u32 terms_lo, u32 terms_hi, u32 passes, u32 c, const u32 *__restrict__ pre) {
     for (int i = threadIdx.x; i < C25519_SLOT_U32; i += 256) {
         u32 v = 0;
         const int f = i - MSM_MAX_WIN * 40;
@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(256) k_slot_init(u32 *__restrict__ slot, u32 t
         else if (f == REC_TERMS_HI) v = terms_hi;
         else if (f == REC_PASSES) v = passes;
         else if (f == REC_MAGIC) v = REC_MAGIC_VALUE;
+        else if (f == REC_C) v = c;
         else if (f == 4 && pre) v = pre[0];
         else if (f == 5 && pre) v = pre[1];
         slot[i] = v;
@@ -420,18 +421,24 @@ void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
     memcpy(out, w, 32);
 }
 
-static int pick_window(uint64_t n) {
+// window width for n terms: c = log2(n) - 4 balances n additions per window against 2 x 2^(c-1) for its bucket reduction; at most cmax --
+// 17 for the plain layout (2^16 buckets per window: 512-bucket slices in the sort, 1024-bucket segments in the reduction), 16 for the merged
+// layout (u16 digit matrix)
+static int pick_window(uint64_t n, int cmax) {
     int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
     int c = lg - 4;
     if (c < 5) c = 5;
-    if (c > 16) c = 16;
+    if (c > cmax) c = cmax;
     return c;
 }
 
-// window layout for n terms (see msm_geom): signed windows share 253 - (c-1) bits evenly, then the unsigned (c-1)-bit
-// window, then bits 253..255
-void msm_layout(uint64_t n, msm_geom &g) {
-    g.c = pick_window(n);
+// window layout for n terms (see msm_geom): signed windows share the low 254 - c bits evenly, then an unsigned window of c - 2 bits up to
+// bit 251, then the overflow window, bits 252..255 (a canonical scalar leaves at most the recoding carry there).  (Rounds 1-3: unsigned
+// window of c - 1 bits up to bit 252, overflow window 253..255 -- the same signed windows; bit 252 of a canonical scalar is clear, so that
+// unsigned window used only the lower half of its buckets, cf. msm_slice_params.)
+void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
+    static const int cmax_env = std::min(17, std::max(12, env_int("C25519_MSM_CMAX", 17)));      // A/B knob: 16 = rounds 1-3 (profiles/r04_ab_window_17.txt)
+    g.c = c_exact ? c_exact : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
     uint32_t a[9] = {0};
@@ -441,12 +448,13 @@ void msm_layout(uint64_t n, msm_geom &g) {
         bit += g.wid[k];
         a[(bit - 1) >> 5] |= 1u << ((bit - 1) & 31);
     }
-    g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 1);          // bit == 253 - (c-1)
-    g.pos[nsig + 1] = 253; g.wid[nsig + 1] = 3;
+    g.pos[nsig] = (unsigned char)bit; g.wid[nsig] = (unsigned char)(g.c - 2);          // bit == 254 - c
+    g.pos[nsig + 1] = 252; g.wid[nsig + 1] = 4;
     g.nwin = nsig + 2;
     g.first_unsigned = nsig;
     msm_sort_params(n, g);
     for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
+    msm_slice_params(g);
     for (int i = 0; i < 8; i++) g.addk[i] = a[i];
 }
 // diagnostics (host only, no GPU needed): the layout the MSM would use for n terms
@@ -456,6 +464,23 @@ EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_
     *c = g.c; *nwin = g.nwin;
     for (int k = 0; k < g.nwin; k++) { pos[k] = g.pos[k]; wid[k] = g.wid[k]; }
     for (int i = 0; i < 8; i++) addk[i] = g.addk[i];
+    return C25519_OK;
+}
+
+// diagnostics: the sort of one pass alone (scalars on the device; layout as for `layout_terms` terms), `reps` times back to back on the context's
+// stream -- for kernel traces of the sort without an accumulation beside it (tools/sort_only.py)
+EXPORT int32_t c25519_debug_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, uint64_t layout_terms, int32_t reps) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (n <= MSM_SMALL_MAX || n > (1ull << 22)) { ctx->err = "debug_sort: n outside the range of a bucket-method pass"; return -(int32_t)hipErrorInvalidValue; }
+    msm_geom g;
+    msm_layout(layout_terms ? layout_terms : n, g);
+    for (int i = 0; i < reps; i++) {
+        msm_plan pl;
+        pl.bad_sticky = nullptr;
+        int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, dslot(ctx, 0), nullptr, pl);
+        if (r) return r;
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
     return C25519_OK;
 }
 
@@ -511,8 +536,8 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
         launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux);
         HIPCHK(hipGetLastError());
     } else if (reduce) {
-        hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, ctx->aux, pl.buckets, g.half, pl.nseg, pl.SW, d_slot, pl.nseg == 1 ? 1 : 0, d_bad_sticky ? d_bad_sticky : pl.bad_ws);
-        if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, ctx->aux, pl.SW, pl.nseg, d_slot);
+        hipLaunchKernelGGL(k_reduce_a, dim3((unsigned)(g.nwin * pl.nseg)), dim3(64), 0, ctx->aux, pl.buckets, g.half, pl.nseg, red_lb_log2(g.half), pl.SW, d_slot, pl.nseg == 1 ? 1 : 0, d_bad_sticky ? d_bad_sticky : pl.bad_ws);
+        if (pl.nseg > 1) hipLaunchKernelGGL(k_reduce_b, dim3((unsigned)g.nwin), dim3(64), 0, ctx->aux, pl.SW, pl.nseg, red_lb_log2(g.half), d_slot);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));
@@ -569,8 +594,8 @@ int32_t rec_collect(c25519_ctx *ctx) {
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return C25519_OK;
 }
-void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st) {
-    hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(256), 0, st, d_slot, (uint32_t)terms, (uint32_t)(terms >> 32), terms ? 1u : 0u, d_pre);
+void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st, int c) {
+    hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(256), 0, st, d_slot, (uint32_t)terms, (uint32_t)(terms >> 32), terms ? 1u : 0u, (uint32_t)c, d_pre);
 }
 static_assert(C25519_PARTIAL_RECORD_BYTES == C25519_SLOT_U32 * 4, "record = slot");
 
@@ -582,20 +607,22 @@ int32_t records_fold(const uint8_t *records, uint64_t count, ge_p3 &R, uint32_t 
     for (int j = 0; j < 8; j++) flags[j] = 0;
     bool same = true;
     uint64_t terms0 = 0;
+    uint32_t c0 = 0;
     for (uint64_t i = 0; i < count; i++) {
         uint32_t f[16];
         memcpy(f, records + i * C25519_PARTIAL_RECORD_BYTES + (size_t)MSM_MAX_WIN * 160, sizeof f);
         if (f[REC_MAGIC] != REC_MAGIC_VALUE) { if (err) *err = "fold: not a partial-result record (bad magic)"; return -(int32_t)hipErrorInvalidValue; }
         for (int j = 0; j < 8; j++) flags[j] += f[j];
         const uint64_t terms = (uint64_t)f[REC_TERMS_LO] | ((uint64_t)f[REC_TERMS_HI] << 32);
-        if (i == 0) terms0 = terms; else if (terms != terms0) same = false;
+        if (f[REC_C] != 0 && (f[REC_C] < 5 || f[REC_C] > 17)) { if (err) *err = "fold: bad window width in a record header"; return -(int32_t)hipErrorInvalidValue; }
+        if (i == 0) { terms0 = terms; c0 = f[REC_C]; } else if (terms != terms0 || f[REC_C] != c0) same = false;
     }
     if (count == 0) return C25519_OK;
     std::vector<uint32_t> cols((size_t)MSM_MAX_WIN * 40);
     if (same) {
         if (terms0 == 0) return C25519_OK;                  // empty shards only
         msm_geom g;
-        msm_layout(terms0, g);
+        msm_layout(terms0, g, 0, (int)c0);
         // columns of equal layouts add window by window (host51.h arithmetic), then ONE Horner fold
         std::vector<hp3> hc((size_t)g.nwin);
         for (uint64_t i = 0; i < count; i++) {
@@ -619,7 +646,7 @@ int32_t records_fold(const uint8_t *records, uint64_t count, ge_p3 &R, uint32_t 
         const uint64_t terms = (uint64_t)f[REC_TERMS_LO] | ((uint64_t)f[REC_TERMS_HI] << 32);
         if (terms == 0) continue;
         msm_geom g;
-        msm_layout(terms, g);
+        msm_layout(terms, g, 0, (int)f[REC_C]);
         memcpy(cols.data(), c, (size_t)g.nwin * 160);        // (records are only 4-byte aligned in general)
         R = ge_add(R, msm_horner(cols.data(), g));
     }
@@ -657,7 +684,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
 void msm_merged_layout(uint64_t ns, msm_merged &m) {
     // window width from the number of digit-terms (as pick_window does for plain terms): c = clamp(log2(17 ns) - 4, 5, 16)
     m.ns = ns;
-    m.c = pick_window(std::max<uint64_t>(1, ns) * 17);
+    m.c = pick_window(std::max<uint64_t>(1, ns) * 17, 16);
     m.K = (257 + m.c - 1) / m.c;                          // c (K - 1) + (c - 1) >= 256: the unsigned top window cannot overflow its buckets
     while (m.c * (m.K - 1) + m.c - 1 < 256) m.K++;
 }
@@ -682,6 +709,7 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     msm_sort_params((uint64_t)m.K * m.ns, g);
     g.pos[0] = 0; g.wid[0] = (unsigned char)m.c;
     for (int k = 1; k < MSM_MAX_WIN; k++) g.wid[k] = 1;
+    msm_slice_params(g);
     HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, dslot(ctx, 0), nullptr, pl, &m);
@@ -814,7 +842,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
         if (early) lists_free = sweep_early >= 2 ? ctx->ev_lists[(parity & 1) ^ 1] : ctx->ev_fork;   // (copy `parity` was last read two passes ago: implied by the stream order, stated anyway)
     }
     if (!early) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream);            // (a continuing pass adds its counters to the slot of its stream set)
+    if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream, g.c);            // (a continuing pass adds its counters to the slot of its stream set)
     if (terms <= MSM_SMALL_MAX && !cont && reduce && !ahead) {
         // the small path (small.hip): raw points as they are (projective: no normalisation, no inversion); compressed ones through the
         // decompression into records first
@@ -853,7 +881,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     if (n == 0) {                                           // the identity: an empty record (records_fold skips it)
         ctx->last_passes.clear();
-        slot_init(d_record, 0, nullptr, ctx->stream);
+        slot_init(d_record, 0, nullptr, ctx->stream, 0);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         return C25519_OK;
@@ -862,12 +890,17 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     const uint64_t passes = n <= PTMAX ? 1 : (n + PT - 1) / PT, per = (n + passes - 1) / passes;
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     msm_geom g;
-    msm_layout(per, g);                                   // one layout for every pass: their column sums add up window by window
     pass_set ps;
     int32_t r;
     uint32_t *sticky = (uint32_t *)ctx->d_flag + 40;      // "a scalar has bit 255 set", ORed over the passes of the call
     HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
     if ((r = passes_begin(ctx, passes, ps))) return r;
+    // One layout for every pass: their column sums add up window by window.  It is derived from the terms of a pass -- or, when stream sets
+    // get more than one pass each, from at least 2^21: their passes continue each other's bucket sums, ONE reduction serves all of them, and
+    // the wider window (17 bits: 15 additions per term instead of 16) costs what a single pass of 2^21 terms pays for it.  The record header
+    // carries the number the layout was derived from (records_fold re-derives it from there).
+    const uint64_t layout_terms = (passes > (uint64_t)ps.lanes && per >= (1ull << 20)) ? std::max<uint64_t>(per, 1ull << 21) : per;
+    msm_layout(layout_terms, g);
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
@@ -888,7 +921,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         uint32_t *slot = passes == 1 ? d_record : dslot(ctx, l);         // a single pass writes the record itself
         hipEvent_t in_ev = nullptr;
         if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
-        if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, per, slot, prev_acc, (ahead && p >= 1) ? &ah : nullptr, in_ev,
+        if ((r = msm_pass_enqueue(ctx, c, d_scalars + lo * 32, d_points + lo * psz, m, in_fmt, g, layout_terms, slot, prev_acc, (ahead && p >= 1) ? &ah : nullptr, in_ev,
                                   !first, last, per, sticky, passes > (uint64_t)L ? (int)((p / L) & 1) : -1))) {
             if (ctx->err.empty()) ctx->err = c->err;
             return r;
@@ -945,7 +978,7 @@ EXPORT int32_t c25519_partial_record_pack(const uint8_t *point160, int32_t statu
     uint32_t *f = rec.data() + (size_t)MSM_MAX_WIN * 40;
     if (counters8) for (int j = 0; j < 8; j++) f[j] = counters8[j];
     if (status == C25519_NONE) f[1] += 1;
-    f[REC_TERMS_LO] = 1; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE;
+    f[REC_TERMS_LO] = 1; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = (uint32_t)g.c;
     memcpy(record, rec.data(), C25519_PARTIAL_RECORD_BYTES);
     return C25519_OK;
 }

@@ -12,7 +12,10 @@ constexpr int MSM_MAX_WIN = 56;
 // first_unsigned: windows k >= first_unsigned hold unsigned digits (msm_layout: the top two), the others signed ones
 // bps_log2: log2 of the buckets per slice of the two-pass sort (a (window, slice) bin must fit the LDS of k_part2);
 // long_cap: bucket lists longer than this go to the wave-cooperative path (> mean + 8 sigma of a balanced bucket)
-struct msm_geom { int c, nwin, half, first_unsigned, bps_log2; u32 long_cap; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN]; };
+// bps[k]: log2 of the buckets per slice of window k in the chunk-local sort -- bps_log2 for a window that uses all `half` buckets, less for the
+//   narrower ones (a signed window of c - 1 bits, the unsigned windows), so that every window spreads its entries over all half >> bps_log2
+//   slices (msm_slice_params)
+struct msm_geom { int c, nwin, half, first_unsigned, bps_log2; u32 long_cap; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN], bps[MSM_MAX_WIN]; };
 // Precomputed-static MSM: ONE bucket set for all windows.  The table holds T[k][i] = 2^(c k) P_i for every window k, so
 // digit k of scalar i is a term of its own, (k, i) -> point k * ns + i, and all K * ns terms fall into the same 2^(c-1)
 // buckets: one accumulation, one bucket reduction, no Horner fold.
@@ -24,10 +27,13 @@ constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per 
 //      sort; msm_sort_matrix.hip: the digit-matrix sort (merged layout, passes below 2^16 terms); small.hip: inputs below 4096 terms; verify.hip) -------------
 namespace c25519 {
 struct long_item;
-constexpr int RED_LB = 8, RED_SEG = 64 * RED_LB;      // buckets per lane / per wave of level A of the bucket reduction
+// bucket reduction, level A: a wave takes a SEGMENT of 64 x 2^lb buckets (2^lb consecutive ones per lane); level B: one wave (block) per window over
+// its <= 64 segments.  lb = 3 up to 2^15 buckets per window (c <= 16), 4 for 2^16 (c = 17)
+static inline int red_lb_log2(int half) { return half > (1 << 15) ? 4 : 3; }
+static inline int red_nseg(int half) { const int seg = 64 << red_lb_log2(half); return (half + seg - 1) / seg; }
 // partial-result record = result slot: 56 column sums of 40 u32, then 16 words -- [0..7] counters, [8, 9] the term count the window layout
 // was derived from, [10] passes summed, [11] a magic word
-constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11;
+constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11, REC_C = 12;      // REC_C: the window width of the layout (0 in records of rounds 1-3: derived from the terms alone)
 constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
 constexpr uint64_t MSM_SMALL_MAX = 4095;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5, 6 and 7
 }
@@ -47,6 +53,7 @@ struct msm_plan {
     hipStream_t sort_stream;
 };
 void msm_sort_params(uint64_t n, c25519::msm_geom &g);
+void msm_slice_params(c25519::msm_geom &g);
 int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_scalars, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t sort_stream, msm_plan &pl,
                          const c25519::msm_merged *md = nullptr, uint64_t n_carve = 0, hipEvent_t lists_free = nullptr, int parity = -1);
 struct msm_matrix_sort_args {
@@ -66,7 +73,7 @@ c25519::ge_p3 host_p40(const uint32_t *t);
 c25519::ge_p3 msm_horner(const uint32_t *cols, const c25519::msm_geom &g);
 int32_t slots_collect(c25519_ctx *ctx, int count);
 int32_t rec_collect(c25519_ctx *ctx);
-void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st);
+void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st, int c);
 int32_t records_fold(const uint8_t *records, uint64_t count, c25519::ge_p3 &R, uint32_t flags[8], std::string *err);
 struct pass_set { c25519_ctx *c[4]; int lanes; };
 int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps);
@@ -79,7 +86,9 @@ void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
 void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);
 // bucket accumulation (accum.hip); returns the kernel's name for the timing records
 const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, int cont, hipStream_t st);
-void msm_layout(uint64_t n, c25519::msm_geom &g);
+// cmax (0 = the default, 17): upper limit of the window width -- verify_batch asks for 16 (its z_i are 128-bit: eight 16-bit windows exactly);
+// c_exact (0 = choose): the width itself (records_fold re-derives a record's layout from its header)
+void msm_layout(uint64_t n, c25519::msm_geom &g, int cmax = 0, int c_exact = 0);
 // sum_i scalars[i] * pts[i] over packed affine Niels points already on the device (enqueue, one read-back, host fold)
 int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, c25519::ge_p3 &R);
 // window width / count of the merged layout for ns static points; sum_i s_i P_i over the table (first n scalars), result to R

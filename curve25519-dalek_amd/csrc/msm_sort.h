@@ -35,20 +35,30 @@ __device__ __forceinline__ int digit_of(u32 v, int k, const msm_geom &g) {
     return (k >= g.first_unsigned) ? (v <= (u32)g.half ? (int)v : 0) : (int)v - (1 << (g.wid[k] - 1));     // msm_layout: the top two windows are unsigned
 }
 
-constexpr int PART_BPS_MAX = 256;        // buckets per slice: 2^g.bps_log2 <= this, chosen so that a bin holds ~16 K entries
-constexpr int PART_CAP = 17408;          // bin capacity of the LDS path of pass 2 (mean <= 16384, sigma 128; larger bins take the global path)
+constexpr int PART_BPS_MAX = 512;        // buckets per slice: 2^g.bps_log2 <= this, chosen so that a bin holds ~16 K entries (512: windows of 17 bits)
+#ifndef C25519_PART_CAP
+#define C25519_PART_CAP 17408
+#endif
+constexpr int PART_CAP = C25519_PART_CAP;          // bin capacity of the LDS path of pass 2 (mean <= 16384, sigma 128; larger bins take the global path)
 // terms per pass-1 block: the staging buffer (4 bytes per term) plus 18 counters per slice must leave room for two blocks
 // per CU (2 x 80 KB of the 160 KB LDS)
 static inline int part_chunk(int SL) { return SL <= 128 ? 16384 : 15360; }
 
-__device__ __forceinline__ bool part_entry(u32 v, int k, const msm_geom &g, u32 t, u32 &slice, u32 &entry) {
+// intermediate entry of the two-level sorts: bucket within the slice << sh | sign << (sh - 1) | term index, sh = 24 for slices of up to 256 buckets
+// (23-bit term index) and 23 for 512 (22-bit index: passes of at most 2^22 terms, msm_sort_params)
+__host__ __device__ __forceinline__ int part_entry_shift(const msm_geom &g) { return g.bps_log2 > 8 ? 32 - g.bps_log2 : 24; }
+// bps: log2 of the buckets per slice of THIS window (g.bps[k] in the chunk-local sort, g.bps_log2 in the digit-matrix sort)
+__device__ __forceinline__ bool part_entry(u32 v, int k, const msm_geom &g, int bps, u32 t, u32 &slice, u32 &entry) {
     int d = digit_of(v, k, g);
     if (d == 0) return false;
     u32 b = (u32)((d > 0 ? d : -d) - 1);
-    slice = b >> g.bps_log2;
-    entry = ((b & ((1u << g.bps_log2) - 1u)) << 24) | (d < 0 ? (1u << 23) : 0u) | t;
+    const int sh = part_entry_shift(g);
+    slice = b >> bps;
+    entry = ((b & ((1u << bps) - 1u)) << sh) | (d < 0 ? (1u << (sh - 1)) : 0u) | t;
     return true;
 }
+// sorted-list entry (what k_accumulate reads): term index | sign << 31
+__device__ __forceinline__ u32 part_entry_final(u32 ev, int sh) { return (ev & ((1u << (sh - 1)) - 1u)) | ((ev >> (sh - 1)) << 31); }
 
 constexpr int SWEEP_TPT = 8, SWEEP_THREADS = 1024, SWEEP_WAVES = SWEEP_THREADS / 64, SWEEP_CHUNK = SWEEP_THREADS * SWEEP_TPT;
 constexpr int P2G_ITER = 48;

@@ -116,14 +116,14 @@ __global__ void __launch_bounds__(THREADS) k_sweep_local(const uint8_t *__restri
     sweep_load<THREADS>(scalars, n, lo, g, R, &sbad);
 #pragma unroll 1
     for (int k = 0; k < g.nwin; k++) {
-        const int wd = g.wid[k];
+        const int wd = g.wid[k], bps = g.bps[k];
         u32 ent[SWEEP_TPT], slc[SWEEP_TPT];
 #pragma unroll
         for (int r = 0; r < SWEEP_TPT; r++) {
             const u32 v = sweep_take(R, r, wd);
             slc[r] = 0xffffffffu;
             u32 sl, e;
-            if (part_entry(v, k, g, (u32)lo + (u32)r * THREADS + threadIdx.x, sl, e)) {
+            if (part_entry(v, k, g, bps, (u32)lo + (u32)r * THREADS + threadIdx.x, sl, e)) {
                 slc[r] = sl * NW + ((u32)w ^ ((sl >> 2) & (NW - 1)));
                 ent[r] = e;
                 atomicAdd(&cnt[slc[r]], 1u);
@@ -205,15 +205,16 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     u32 *cnt = sm, *cur = sm + PART_BPS_MAX, *oh = sm + 2 * PART_BPS_MAX, *out = sm + 3 * PART_BPS_MAX, *wl = out + PART_CAP;      // wl[NW][ITER]
-    __shared__ u32 red[NW];
-    const int PART_BPS = 1 << g.bps_log2;
+    __shared__ u32 red[NW], red_all[NW];
     const int k = blockIdx.x, sidx = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int PART_BPS = 1 << g.bps[k], sh = part_entry_shift(g);
     // Everything the block needs from memory before the gather is requested together: the bin totals (the bin's place in the window's
     // sorted list = the entries of the bins before it; SL <= 256 <= the block) and this wave's run starts -- the gather does not wait
     // for the prefix sum.
     const u32 *row0 = lsg + ((u64)k * (SL + 1) + sidx) * nchunk, *row1 = row0 + nchunk;
     const u32 *src = P1 + (u64)k * wstride;
-    u32 part = tid < sidx ? binm[(u64)k * SL + tid] : 0u;
+    const u32 mine = tid < SL ? binm[(u64)k * SL + tid] : 0u;
+    u32 part = tid < sidx ? mine : 0u, all = mine;        // entries of the bins before this one / of the whole window
     const u32 m = binm[(u64)k * SL + sidx];
     if (tid < PART_BPS) cnt[tid] = 0;
     if (tid < 256) oh[tid] = 0;
@@ -232,13 +233,19 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
         nslots += (int)__shfl(inc, 63, 64);
     }
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) part += (u32)__shfl_xor((int)part, d, 64);
-    if (lane == 0) red[w] = part;
+    for (int d = 32; d > 0; d >>= 1) { part += (u32)__shfl_xor((int)part, d, 64); all += (u32)__shfl_xor((int)all, d, 64); }
+    if (lane == 0) { red[w] = part; red_all[w] = all; }
     const bool fits = !__syncthreads_or(nslots > ITER) && m <= (u32)PART_CAP;      // (the barrier: counters zeroed, wave sums of the prefix written)
-    u32 b0 = 0;
+    u32 b0 = 0, wtot = 0;
 #pragma unroll
-    for (int q = 0; q < NW; q++) b0 += red[q];
-    if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = b0 + m;      // number of entries of the window
+    for (int q = 0; q < NW; q++) { b0 += red[q]; wtot += red_all[q]; }
+    if (sidx == SL - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = wtot;      // number of entries of the window
+    {   // a window narrower than c bits leaves the buckets from SL << bps[k] on unused: empty lists at the end of the window's entries, this
+        // block's share of them (the bucket order and the accumulation walk ALL half buckets of every window)
+        const int per = (1 << g.bps_log2) - PART_BPS, first = (SL << g.bps[k]) + sidx * per;
+        for (int i = tid; i < per; i += 64 * NW) { totals[(u64)k * g.half + first + i] = 0; base[(u64)k * (g.half + 1) + first + i] = wtot; }
+        if (per > 0 && tid == 0) atomicAdd(&ord_hist[255], (u32)per);                  // (length class of an empty list)
+    }
     u32 *dst = sorted + (u64)k * n + b0;
     if (fits) {
 #pragma unroll 1
@@ -252,18 +259,18 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
                 ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) if (ok[q]) atomicAdd(&cnt[ev[q] >> 24], 1u);
+            for (int q = 0; q < 8; q++) if (ok[q]) atomicAdd(&cnt[ev[q] >> sh], 1u);
         }
     } else {
         for (int j = w; j < nchunk; j += NW) {
             const u32 st = row0[j], en = row1[j];
-            for (u32 o = st + lane; o < en; o += 64) atomicAdd(&cnt[src[(u64)j * chunk + o] >> 24], 1u);
+            for (u32 o = st + lane; o < en; o += 64) atomicAdd(&cnt[src[(u64)j * chunk + o] >> sh], 1u);
         }
     }
     __syncthreads();
-    if (tid < 64) {                                                    // exclusive scan of the bucket counts by one wave (4, 2 or 1 per lane)
+    if (tid < 64) {                                                    // exclusive scan of the bucket counts by one wave (8, 4, 2 or 1 per lane)
         const int per = PART_BPS >> 6;
-        u32 c4[4] = {0, 0, 0, 0}, sum = 0;
+        u32 c4[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sum = 0;
         for (int q = 0; q < per; q++) { c4[q] = cnt[per * tid + q]; sum += c4[q]; }
         u32 inc = sum;
         for (int off = 1; off < 64; off <<= 1) { u32 x = __shfl_up(inc, off, 64); if (tid >= off) inc += x; }
@@ -292,7 +299,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
                 ev[q] = ok[q] ? src[(d >> 7) + lane] : 0u;
             }
 #pragma unroll
-            for (int q = 0; q < 8; q++) if (ok[q]) out[atomicAdd(&cur[ev[q] >> 24], 1u)] = (ev[q] & 0x7fffffu) | ((ev[q] & (1u << 23)) << 8);
+            for (int q = 0; q < 8; q++) if (ok[q]) out[atomicAdd(&cur[ev[q] >> sh], 1u)] = part_entry_final(ev[q], sh);
         }
         __syncthreads();
         for (u32 i = tid; i < m; i += 64 * NW) dst[i] = out[i];
@@ -304,7 +311,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
             for (u32 o0 = st; o0 < en; o0 += 64) {
                 const u32 o = o0 + lane;
                 const bool have = o < en;
-                const u32 ev = have ? src[(u64)j * chunk + o] : 0u, bk = ev >> 24;
+                const u32 ev = have ? src[(u64)j * chunk + o] : 0u, bk = ev >> sh;
                 const u32 lead_bk = __shfl(bk, __ffsll((long long)__ballot(have)) - 1, 64);
                 const unsigned long long same = __ballot(have && bk == lead_bk);
                 u32 pos = 0;
@@ -317,7 +324,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
                 } else if (have) {
                     pos = atomicAdd(&cur[bk], 1u);
                 }
-                if (have) dst[pos] = (ev & 0x7fffffu) | ((ev & (1u << 23)) << 8);
+                if (have) dst[pos] = part_entry_final(ev, sh);
             }
         }
     }
@@ -361,9 +368,26 @@ using namespace c25519;
 // host side: workspace carve-up and the launches of the sort
 // ================================================================================================
 // sort / long-bucket parameters that depend on the number of terms per window (n) and buckets per window (g.half)
+// slices per window of the chunk-local sort: SL = half >> bps_log2 for every window, of 2^bps[k] buckets each.  A signed window of w bits has
+// digits in [-2^(w-1), 2^(w-1)): 2^(w-1) buckets; an unsigned one of w bits 2^w - 1.  With one slice width for all windows (rounds 2-3) the
+// windows one bit narrower than c -- up to two signed ones and the unsigned one below the overflow window -- filled only the lower half of
+// their slices with twice the entries: 128 - 192 bins per pass beyond the LDS capacity of k_part2g, whose global-memory path was a third
+// (16-bit windows) to more than half (17-bit) of that kernel's time (profiles/r04_sort_alone.txt).
+void msm_slice_params(msm_geom &g) {
+    int lsl = 0; while ((g.half >> g.bps_log2) > (1 << lsl)) lsl++;          // log2(SL)
+    for (int k = 0; k < MSM_MAX_WIN; k++) {
+        const int bits = k < g.nwin ? (k < g.first_unsigned ? g.wid[k] - 1 : g.wid[k]) : 0;     // log2 of the window's bucket range (rounded up)
+        int b = bits - lsl;
+        if (b < 6) b = 6;                                  // k_part2g scans its bucket counts with one wave: at least 64 buckets per slice
+        if (b > g.bps_log2) b = g.bps_log2;
+        g.bps[k] = (unsigned char)b;
+    }
+}
 void msm_sort_params(uint64_t n, msm_geom &g) {
     // slices of 2^bps_log2 buckets such that a (window, slice) bin holds at most ~16 K entries (PART_CAP with 12 % headroom)
-    g.bps_log2 = 8;
+    // (17-bit windows: 512 buckets per slice keep the 128 slices per window -- and with them the partition's LDS footprint and the number of
+    //  per-bin blocks -- of the 16-bit layout; the 22-bit term index that leaves is enough for a pass)
+    g.bps_log2 = (g.half > (1 << 15) && n <= (1ull << 22)) ? 9 : 8;
     while (g.bps_log2 > 6 && (n << g.bps_log2) / (uint64_t)g.half > 16500) g.bps_log2--;
     if ((1 << g.bps_log2) > g.half) { g.bps_log2 = 0; while ((2 << g.bps_log2) <= g.half) g.bps_log2++; }
     const uint64_t mean = n / (uint64_t)g.half + 1;
@@ -380,7 +404,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const uint64_t nc = n_carve > n ? n_carve : n;
     // The chunk-local sort serves every plain MSM pass: its per-bin counting sort scans 2^bps_log2 >= 64 buckets per wave, i.e. windows of
     // c >= 7 bits (n >= 2048 terms; inputs below 4096 terms never get here, msm_small_enqueue), and its entries keep a 23-bit term index.
-    if (!md && (g.half < 64 || n > (1ull << 23))) { ctx->err = "msm: internal error (a pass outside the range of the chunk-local sort)"; return -(int32_t)hipErrorInvalidValue; }
+    if (!md && (g.half < 64 || n > (1ull << (part_entry_shift(g) - 1)))) { ctx->err = "msm: internal error (a pass outside the range of the chunk-local sort)"; return -(int32_t)hipErrorInvalidValue; }
     // which sort: the digit-matrix sort for the merged layout and for plain passes below 2^16 terms (the chunk-local partition wants hundreds of
     // chunks: msm_sort_matrix.hip has the numbers); C25519_SORT_CHUNK_LOCAL_MIN lowers the boundary (tests run the chunk-local sort from 2 048 terms)
     static const uint64_t chunk_local_min = (uint64_t)env_int("C25519_SORT_CHUNK_LOCAL_MIN", 1 << 16);
@@ -392,7 +416,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     while (nchunk > 1 && nc / nchunk < 4096) nchunk /= 2;
     if ((nc + nchunk - 1) / nchunk > 65536) nchunk = (int)((nc + 65535) / 65536);   // a chunk's digits must fit LDS (k_scatter_sliced)
     const uint64_t nb = (uint64_t)g.nwin * g.half;
-    const int nseg = (g.half + RED_SEG - 1) / RED_SEG;
+    const int nseg = red_nseg(g.half);
     // workspace carve-up (tmp_d): [digit matrix | counts] (merged layout only) | base | sorted | buckets | segment pairs | flags | perm | long-bucket lists | sort scratch
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
@@ -413,7 +437,11 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     // block shapes of the chunk-local sort: the large ones are the fastest alone; the small ones fit beside a k_accumulate held at two waves
     // per SIMD (one wave per SIMD at 128 VGPRs / two at 56; profiles/r04_ab_sort_beside_accumulate.txt).  Read once per process.
     static const int small_blocks = env_int("C25519_SORT_SMALL", 0);
-    const int sweep_chunk = (small_blocks ? 256 : SWEEP_THREADS) * SWEEP_TPT;
+    // C25519_SWEEP_THREADS=512: the partition in 512-thread blocks (chunks of 4096 terms: two waves per SIMD at 64 VGPRs and 25 KB of LDS) with the
+    // per-bin sort in its large shape (four waves per SIMD at 32 VGPRs, 76 KB) -- the pairing that fits beside a two-wave k_accumulate without
+    // the 16-entry runs of the all-small arm
+    static const int sweep_threads = small_blocks ? 256 : (env_int("C25519_SWEEP_THREADS", SWEEP_THREADS) == 512 ? 512 : SWEEP_THREADS);
+    const int sweep_chunk = sweep_threads * SWEEP_TPT;
     const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = matrix ? part_chunk(SL) : sweep_chunk, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     // chunk-local form: P1 holds whole chunk blocks, oCC the slice starts [window][SL + 1][chunk], oBB the bin totals and the chunks' flags
     const size_t p1_words = matrix ? (size_t)g.nwin * nc : (size_t)g.nwin * pchunks_c * sweep_chunk;
@@ -450,6 +478,9 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<8, ITER_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
         hipLaunchKernelGGL(k_sweep_local<256>, dim3(pchunks), dim3(256), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+    } else if (sweep_threads == 512) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<16, P2G_ITER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(k_sweep_local<512>, dim3(pchunks), dim3(512), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
     } else {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<SWEEP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<16, P2G_ITER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));

@@ -208,13 +208,13 @@ __global__ void __launch_bounds__(256) k_part_hist(const uint16_t *__restrict__ 
 #pragma unroll
             for (int h = 0; h < 8; h++) {
                 u32 sl, e;
-                if (part_entry((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
+                if (part_entry((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g, g.bps_log2, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
             }
         }
     } else {
         for (u64 t = lo + threadIdx.x; t < hi; t += 256) {
             u32 sl, e;
-            if (part_entry(Dk[t], k, g, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
+            if (part_entry(Dk[t], k, g, g.bps_log2, 0u, sl, e)) atomicAdd(&sm[w * SL + sl], 1u);
         }
     }
     __syncthreads();
@@ -290,7 +290,7 @@ __global__ void __launch_bounds__(1024, 8) k_part1(const uint16_t *__restrict__ 
         slc[r] = 0xffffffffu;
         if (t < hi) {
             u32 sl, e;
-            if (part_entry(D[(u64)k * n + t], k, g, (u32)t, sl, e)) { slc[r] = sl; ent[r] = e; atomicAdd(&cnt[w * SL + sl], 1u); }
+            if (part_entry(D[(u64)k * n + t], k, g, g.bps_log2, (u32)t, sl, e)) { slc[r] = sl; ent[r] = e; atomicAdd(&cnt[w * SL + sl], 1u); }
         }
     }
     __syncthreads();

@@ -137,8 +137,8 @@ __device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 
 }
 __device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i = 0; i < 10; i++) r.v[i] = tot[c * 10 + i]; return r; }
 
-// level A: block = segment `seg` (RED_SEG = 512 buckets, 8 per logical lane) of window k.  direct: the window has a single segment, write col_k itself.
-__global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ buckets, int half, int nseg, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
+// level A: block = segment `seg` (64 x 2^lb buckets, 2^lb per logical lane: 512 / 8, or 1024 / 16 for 17-bit windows) of window k.  direct: the window has a single segment, write col_k itself.
+__global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ buckets, int half, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
                                                    const u32 *__restrict__ bad_ws) {
     C25519_PRIO_SIDE();
     __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
@@ -146,21 +146,21 @@ __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ bucke
     const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x) & 3), lane = threadIdx.x & 63;
     const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg;
     if (bad_ws && blockIdx.x == 0 && threadIdx.x == 0 && *bad_ws) atomicOr(cols + MSM_MAX_WIN * 40, 1u);
-    const int b0 = seg * RED_SEG + lane * RED_LB;
+    const int LB = 1 << lb, b0 = (seg * 64 + lane) * LB;
     const u32 *B = buckets + (u64)k * half * 40;
     auto bucket = [&](int b) { return [=](int c) { return b < half ? rc_global(B, (u64)b, c) : rc_ident(c); }; };
     {   // run = acc = B[b0 + 7]
         const int mc = rc_coord(role);
-        const feT v = bucket(b0 + RED_LB - 1)(mc);
+        const feT v = bucket(b0 + LB - 1)(mc);
         rc_put(S, lane, mc, v); rc_put(W, lane, mc, v);
     }
     __syncthreads();
 #pragma unroll 1
-    for (int j = RED_LB - 2; j >= 0; j--) {
+    for (int j = LB - 2; j >= 0; j--) {
         rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, bucket(b0 + j), scratch, S, lane);                                          // run += B_j
         if (j > 0) rc_add(role, lane, [&](int c) { return rc_get(W, lane, c); }, [&](int c) { return rc_get(S, lane, c); }, scratch, W, lane);   // acc += run
     }
-    rc_weighted_sum(role, lane, S, W, tot, scratch, 3);       // tot = S_seg, S[0] = W_seg = sum (b - segment base) B_b
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);       // tot = S_seg, S[0] = W_seg = sum (b - segment base) B_b
     const int mc = rc_coord(role);
     if (direct) {
         rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
@@ -170,8 +170,8 @@ __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ bucke
         rc_global_put(SW, 2 * (u64)blockIdx.x + 1, mc, rc_get(S, 0, mc));
     }
 }
-// level B: one block per window over its nseg <= 64 segment pairs (weight RED_SEG = 2^9 per segment)
-__global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, u32 *__restrict__ cols) {
+// level B: one block per window over its nseg <= 64 segment pairs (weight 2^(lb + 6) per segment)
+__global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols) {
     C25519_PRIO_SIDE();
     __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-    rc_weighted_sum(role, lane, S, W, tot, scratch, 9);
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb + 6);
     rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
     if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
 }
@@ -188,6 +188,6 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
 
 // the bucket reduction of a pass (level A over the segments, level B over the windows) on stream st
 void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, SW, d_slot, nseg == 1 ? 1 : 0, bad_ws);
-    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, nseg, d_slot);
+    hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, d_slot, nseg == 1 ? 1 : 0, bad_ws);
+    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, nseg, red_lb_log2(g.half), d_slot);
 }

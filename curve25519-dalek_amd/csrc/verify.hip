@@ -345,7 +345,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     uint32_t *d_cnt = slot_flags(d_slot);             // [2] bad A, [3] bad R, [4] bad s, [5] bad offsets
     hipEvent_t *ring = pass_ring(owner, ctx, 2);
     HIPCHK(hipEventRecord(ring[3], st));
-    slot_init(d_slot, terms, d_pre_flags, st);
+    slot_init(d_slot, terms, d_pre_flags, st, g.c);
     // Two independent chains: (S) decompress R_i and A_i -- VALU-bound; (A) hash, derive z_i, batch scalars, sort --
     // partly latency-bound (the tree levels).  They run on two streams and join before the accumulation.
     hipStream_t sa = ctx->aux;
@@ -428,10 +428,10 @@ static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, con
     HIPCHK(hipSetDevice(ctx->device));
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
     const uint32_t *d_pre = (const uint32_t *)(d_hram + n * 64);
-    if (n == 0) { ctx->last_passes.clear(); slot_init(d_record, 0, d_pre, ctx->stream); HIPCHK(hipGetLastError()); return C25519_OK; }
+    if (n == 0) { ctx->last_passes.clear(); slot_init(d_record, 0, d_pre, ctx->stream, 0); HIPCHK(hipGetLastError()); return C25519_OK; }
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
     msm_geom g;
-    msm_layout(2 * per + 1, g);
+    msm_layout(2 * per + 1, g, 16);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
     int32_t r;
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
@@ -528,7 +528,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     // that the precedence does not depend on where the batch was cut
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
     msm_geom g;
-    msm_layout(2 * per + 1, g);
+    msm_layout(2 * per + 1, g, 16);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
     bool seen[5] = {false, false, false, false, false}, bad_off = false, bad_scalar = false;

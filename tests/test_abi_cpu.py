@@ -59,9 +59,9 @@ def test_msm_window_layout_recomposes_every_scalar():
             continue
         seen_c.add(c.value)
         nw, half = nwin.value, 1 << (c.value - 1)
-        assert 5 <= c.value <= 16 and nw <= 56
+        assert 5 <= c.value <= 17 and nw <= 56
         assert pos[0] == 0 and all(pos[k] + wid[k] == pos[k + 1] for k in range(nw - 1)) and pos[nw - 1] + wid[nw - 1] == 256
-        assert pos[nw - 1] == 253 and wid[nw - 2] == c.value - 1 and max(wid[:nw]) == c.value
+        assert pos[nw - 1] == 252 and wid[nw - 2] == c.value - 2 and max(wid[:nw]) == c.value
         add = sum(int(addk[i]) << (32 * i) for i in range(8))
         assert add == sum(1 << (pos[k] + wid[k] - 1) for k in range(nw - 2))
         samples = [0, 1, L - 1, 2**252 - 1, 2**253 - 1, 2**255 - 1, 2**255 - 19, (1 << 254) + 12345] + [rng.randrange(L) for _ in range(300)]
@@ -74,8 +74,10 @@ def test_msm_window_layout_recomposes_every_scalar():
                 v = (sp >> pos[k]) & ((1 << wid[k]) - 1)
                 d = v if k >= nw - 2 else v - (1 << (wid[k] - 1))
                 assert abs(d) <= half                      # bucket index |d| - 1 < half
-                if s < 2**253 and k == nw - 1:
-                    assert d <= 1                          # the overflow window only ever sees the carry of a reduced scalar
+                if s < 2**252 and k == nw - 1:
+                    assert d <= 1                          # the overflow window only ever sees the carry of a scalar below 2^252 (bit 252 of l itself: 2 at most for a canonical one)
+                if k < nw - 2:
+                    assert abs(d) <= 1 << (wid[k] - 1)     # a signed window of w bits uses 2^(w-1) buckets (msm_slice_params relies on it)
                 total += d << pos[k]
             assert total == s
-    assert seen_c == set(range(5, 17))
+    assert seen_c == set(range(5, 18))
