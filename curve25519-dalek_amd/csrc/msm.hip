@@ -770,7 +770,9 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 // them 16 times -- 1.75 M terms = 224 MB (2^21 terms = 268 MB spill: k_accumulate 0.61 - 0.62 ns per term against 0.59 - 0.60, the
 // 2^24-term call 14.32 - 14.54 ms in 8 passes against 14.10 - 14.18 in 10, profiles/r03_ab_pass_size.txt; with the bucket
 // continuation a pass more costs a sort's fixed part, not a reduction).  C25519_MSM_PASS_LOG2 (tests: many small passes) overrides.
-static const uint64_t MSM_PASS = []() -> uint64_t { const char *e = getenv("C25519_MSM_PASS_LOG2"); if (!e) return (uint64_t)1750000; int v = atoi(e); return 1ull << (v < 16 ? 16 : (v > 22 ? 22 : v)); }();
+static const uint64_t MSM_PASS = []() -> uint64_t {
+    if (const char *t = getenv("C25519_MSM_PASS_TERMS")) { const long long v = atoll(t); if (v >= 65536 && v <= (1ll << 22)) return (uint64_t)v; }      // A/B knob
+    const char *e = getenv("C25519_MSM_PASS_LOG2"); if (!e) return (uint64_t)1750000; int v = atoi(e); return 1ull << (v < 16 ? 16 : (v > 22 ? 22 : v)); }();
 static const uint64_t MSM_PASS_MAX = MSM_PASS + MSM_PASS / 2;
 static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
 
@@ -905,7 +907,8 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
     // (not with a fetch: the later passes' points are not on the device yet)
-    const bool ahead = passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160 && !fetch;
+    static const int prep_ahead = env_int("C25519_PREP_AHEAD", 1);      // A/B knob: 0 = every pass normalises its own points (on its main stream, ahead of its accumulation)
+    const bool ahead = prep_ahead && passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160 && !fetch;
     if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
     // ONE bucket reduction per stream set, not one per pass: the passes dealt to a stream set run one after the other anyway, so
     // each continues from the bucket sums its predecessor left (k_accumulate `cont`) and only the last one reduces them into the
