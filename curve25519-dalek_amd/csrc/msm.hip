@@ -421,12 +421,17 @@ void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
     memcpy(out, w, 32);
 }
 
-// window width for n terms: c = log2(n) - 4 balances n additions per window against 2 x 2^(c-1) for its bucket reduction; at most cmax --
-// 17 for the plain layout (2^16 buckets per window: 512-bucket slices in the sort, 1024-bucket segments in the reduction), 16 for the merged
-// layout (u16 digit matrix)
+// window width for n terms.  c = log2(n) - 4 balances n additions per window against 2 x 2^(c-1) for its bucket reduction: the choice for
+// THROUGHPUT, from 2^20 terms.  Below that a call is a chain of latencies, and the longest link is k_accumulate's serial walk over a bucket's
+// list (2^(5) = 32 dependent additions at c = log2 n - 4, whatever n): wider windows shorten the lists faster than they lengthen the reduction
+// -- 2^16 terms 0.65 -> 0.45 ms, 2^14 0.55 -> 0.41 (profiles/r04_ab_midrange_windows.txt: +3 bits from 2^13 to 2^16 terms, +2 at 2^12 and 2^17,
+// +1 at 2^18 and 2^19).  At most cmax -- 17 for the plain layout (2^16 buckets per window: 512-bucket slices in the sort, 1024-bucket segments
+// in the reduction), 16 for the merged layout (u16 digit matrix) and verify_batch.
 static int pick_window(uint64_t n, int cmax) {
     int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
+    static const int mid = env_int("C25519_MSM_MIDRANGE_WINDOWS", 1);      // A/B knob: 0 = c = log2 n - 4 throughout (rounds 1-3)
     int c = lg - 4;
+    if (mid && lg >= 12 && lg <= 19) c += lg <= 12 ? 2 : lg <= 16 ? 3 : lg == 17 ? 2 : 1;
     if (c < 5) c = 5;
     if (c > cmax) c = cmax;
     return c;
