@@ -738,7 +738,9 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         // multi-pass call; 2^24 terms: 15.8 ms with 16 everywhere, 15.3 with 64), 32 from 2^20 points (profiles/r04_ab_prep_points_per_lane.txt:
         // 2^20 terms 1.10 against 1.18 ms, 2^21 the same either way), 16 below (2^19: 0.76 against 0.81 ms; 8 and 4 buy nothing down to 2^16)
         static const int ch_knob = env_int("C25519_PREP_CH", 0);             // A/B knob: 4 / 8 / 16 / 32 / 64
-        const int CH = ch_knob ? ch_knob : (n >= (1ull << 23) ? 64 : n >= (1ull << 20) ? 32 : 16);
+        // below 2^18 points the kernel is a latency chain (the lane's prefix products, ONE inversion, the unwinding): 4 points per lane shorten it
+        // (2^13 terms 0.48 -> 0.40 ms, 2^16 0.54 -> 0.51)
+        const int CH = ch_knob ? ch_knob : (n >= (1ull << 23) ? 64 : n >= (1ull << 20) ? 32 : n >= (1ull << 18) ? 16 : 4);
         constexpr int wpb = 4;
         const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
         // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
