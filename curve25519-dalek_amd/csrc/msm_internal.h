@@ -28,8 +28,17 @@ constexpr u32 LONG_SEG = 1024;     // entries per wave in the long path (16 per 
 namespace c25519 {
 struct long_item;
 // bucket reduction, level A: a wave takes a SEGMENT of 64 x 2^lb buckets (2^lb consecutive ones per lane); level B: one wave (block) per window over
-// its <= 64 segments.  lb = 3 up to 2^15 buckets per window (c <= 16), 4 for 2^16 (c = 17)
-static inline int red_lb_log2(int half) { return half > (1 << 15) ? 4 : 3; }
+// its <= 64 segments.  lb = 3 for 2^15 buckets per window (c = 16), 4 for 2^16 (c = 17), less below
+// (the fewest buckets per lane that leave level B its <= 64 segments: below 2^15 buckets per window a call is latency-bound and level A's serial
+//  part -- two dependent additions per bucket of a lane -- is the longest link of the reduction; at least 2 per lane: the kernels start from
+//  the lane's last bucket)
+static inline int red_lb_log2(int half) {
+    static const int lb_min = [] { const char *e = getenv("C25519_RED_LB_MIN"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 3 ? 3 : v); }();   // A/B knob: 3 = rounds 2-3
+    if (half <= 512) return 3;                      // a single segment per window: level A writes the column sums itself, no level B
+    int lb = lb_min;
+    while ((half >> (lb + 6)) > 64) lb++;
+    return lb;
+}
 static inline int red_nseg(int half) { const int seg = 64 << red_lb_log2(half); return (half + seg - 1) / seg; }
 // partial-result record = result slot: 56 column sums of 40 u32, then 16 words -- [0..7] counters, [8, 9] the term count the window layout
 // was derived from, [10] passes summed, [11] a magic word
