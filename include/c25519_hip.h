@@ -215,7 +215,7 @@ int32_t c25519_fold_partials(c25519_ctx *ctx, const uint8_t *partials160, uint64
  * process per GPU): c25519_msm_partial_record_dev only ENQUEUES on the context's stream and leaves a fixed-size RECORD in
  * device memory -- the window column sums of this rank's terms (the reference's `columns`, pippenger.rs:146-151, before
  * the Horner fold :159), its counters (a point that does not decode, a scalar with bit 255 set) and the number of terms
- * the window layout was derived from.  The exchange step is ONE all_gather of C25519_PARTIAL_RECORD_BYTES per rank
+ * and the window width the window layout was derived from.  The exchange step is ONE all_gather of C25519_PARTIAL_RECORD_BYTES per rank
  * (RCCL, device to device), one copy to the host, and c25519_fold_partial_records: records with the same layout are
  * added column by column and folded once; the others are folded one by one (host arithmetic over count x <= 56 points;
  * ctx may be NULL).  Returns C25519_NONE iff any rank saw a point that does not decode.  The result is bit-identical to
