@@ -144,6 +144,22 @@ def test_msm_full_size_2p21(eng, orc):
     print("MSM 2^21 compressed-in: last call %.3f ms (accumulate %.3f ms)" % (eng.last_kernel_ms(), eng.phase_ms(0, 0)))
 
 
+@pytest.mark.parametrize("n", [(1 << 21) + 5, 300001, 20000])
+def test_msm_scalars_up_to_2p255(eng, orc, n):
+    """Scalars anywhere below 2^255 (Scalar invariant #1 is all the MSM may assume, scalar.rs:199-225): bits 252 .. 254 fill the overflow
+    window (digits up to 7 plus the recoding carry) and the unsigned window below it to its last bucket -- the 17-bit layout, the latency-oriented
+    mid-range layout and the digit-matrix sort.  Sum-of-squares identity (x_i B is the same point for x_i and x_i mod l)."""
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(255 + n)
+    dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+    dx[:, 31] &= 0x7F
+    dx[::7, 31] |= 0x70                                      # every seventh scalar: bits 252 .. 254 all set
+    dx[1::11, :] = 0xFF; dx[1::11, 31] = 0x7F                # and some 2^255 - 1
+    draw = eng.mul_base_batch_t(dx, out_fmt=2)
+    st, got = eng.msm_vartime_t(dx, draw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
+
+
 def _sumsq_device(dx):
     """sum x_i^2 mod l for an (n, 32) uint8 CUDA tensor: exact 16-bit-limb Gram matrix on the device
     (every entry < 2^24 * 2^32), recombined with Python integers."""
@@ -255,10 +271,10 @@ def test_msm_two_passes_odd_size(eng, orc):
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
 
 
-@pytest.mark.parametrize("log2n", [13, 17, 20])
+@pytest.mark.parametrize("log2n", [13, 17, 20, 21])
 def test_msm_maximally_skewed_digits(eng, orc, log2n):
     """Every term carries the SAME scalar, so each window has one bucket holding all n entries: the oversize-bin branch
-    of the partition sort, the long-bucket path and the one-pass sort of small inputs.  Points are distinct
+    of the partition sort, the long-bucket path and the one-pass sort of small inputs (2^21: the 17-bit layout).  Points are distinct
     (P_i = y_i B); expected = s * (sum y_i) * B.  A second batch repeats one point n times (n * s * P)."""
     import torch
     n = 1 << log2n
