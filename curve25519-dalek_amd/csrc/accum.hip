@@ -82,7 +82,9 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (it + 1 < wmax) { C25519_COOP_ISSUE(e_next) }
         // (the loop counter is wave-uniform here, so the first entry of a list could be CONVERTED -- 1 M instead of 7 M --
-        //  behind a uniform branch: 76 scratch accesses in the addition at the 168-register budget)
+        //  behind a uniform branch: 76 scratch accesses in the addition at the 168-register budget.  Round 4 PEELED it in front of the loop
+        //  instead (kernel-uniform on `cont`; 168 VGPRs, no scratch): level from 2^12 to 2^20 terms and at 2^24, 1.978 against 1.907 ms at 2^21
+        //  (k_accumulate 1.21 against 1.12 ms), profiles/r04_ab_first_entry.txt -- not adopted)
         if (active) acc = ge_madd_acc(acc, pts_from_q(q), neg);
         e = e_next;
     }
