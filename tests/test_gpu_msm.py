@@ -231,7 +231,12 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_SWEEP_EARLY": "0", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
                                  {"C25519_SWEEP_EARLY": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
                                  {"C25519_SWEEP_EARLY": "2", "C25519_MSM_PASS_LOG2": "16", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
-                                 {"C25519_SWEEP_EARLY": "2", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
+                                 {"C25519_SWEEP_EARLY": "2", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"},
+                                 # the layouts of rounds 1-3 (window width log2 n - 4 throughout, at most 16 bits; 8 buckets per lane in the reduction)
+                                 {"C25519_MSM_MIDRANGE_WINDOWS": "0", "C25519_MSM_CMAX": "16", "C25519_RED_LB_MIN": "3"},
+                                 {"C25519_MSM_MIDRANGE_WINDOWS": "0", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
+                                 # every pass normalises its own points; the 512-thread partition
+                                 {"C25519_PREP_AHEAD": "0", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_SWEEP_THREADS": "512", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
