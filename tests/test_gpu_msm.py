@@ -160,6 +160,24 @@ def test_msm_scalars_up_to_2p255(eng, orc, n):
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx))))
 
 
+def test_msm_random_sizes_and_formats(eng, orc):
+    """Seeded sweep over sizes drawn log-uniformly from 1 to 2^21 (every path: small tables, digit-matrix sort, chunk-local sort with 16- and 17-bit
+    windows, the mid-range layouts in between) in all three input encodings: sum-of-squares identity against the oracle's fixed-base multiplication."""
+    import torch
+    rng = np.random.default_rng(20260924)
+    sizes = sorted(set(int(2 ** rng.uniform(0, 21)) for _ in range(48)) | {4095, 4096, 8191, 8192, 131071, 1 << 19, (1 << 20) + 1})
+    for i, n in enumerate(sizes):
+        g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
+        dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
+        dx[:, 31] &= 0x0F
+        fmt = i % 3
+        dpts = eng.mul_base_batch_t(dx, out_fmt=fmt)
+        # (a Ristretto encoding decodes to a representative of its coset: the sum is compared as a Ristretto element)
+        st, got = eng.msm_vartime_t(dx, dpts, in_fmt=fmt, out_fmt=1 if fmt == 1 else 0)
+        want = orc.ed_mul_base(i2b(_sumsq_device(dx)))
+        assert st == 0 and got == (orc.ris_compress(want) if fmt == 1 else orc.ed_compress(want)), (n, fmt)
+
+
 def _sumsq_device(dx):
     """sum x_i^2 mod l for an (n, 32) uint8 CUDA tensor: exact 16-bit-limb Gram matrix on the device
     (every entry < 2^24 * 2^32), recombined with Python integers."""
