@@ -195,7 +195,8 @@ def test_verify_batch_with_cached_key_points(eng, orc):
     assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts) == VERIFY
 
 
-@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4097, 16385, 16400])
+@pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4097, 16385, 16400,
+                               2047, 2048, 8191, 32769, 65536, 131073, 262144, 524291])      # (r4) either side of the small path and through the mid-range window layouts of its 2 n + 1 terms
 def test_verify_batch_tree_boundaries(eng, orc, n):
     """Batch sizes around the shapes of the z-derivation tree (16 signatures per first-level node, 4-ary upper levels,
     <= 1024 nodes handled by the single-block tail) and of the block-wise scalar sums: honest batch Ok, one flipped bit
