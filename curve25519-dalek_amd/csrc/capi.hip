@@ -361,6 +361,25 @@ int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
     if (e2 != hipSuccess) return c25519_fail(ctx, e2, "hipStreamSynchronize(h2d)");
     return C25519_OK;
 }
+// SMALL host-pointer calls (a few hundred KB at most): the pieces of the input are staged into ONE page-locked buffer and go up with ONE asynchronous
+// copy on the COMPUTE stream -- no copy stream, no events, no second synchronisation.  The chunked path above costs such a call a dozen runtime
+// calls and two pageable copies (each staged by the runtime on its own): ~45 us of a 185 us MSM of 256 terms.  d[i]: where piece i landed
+// (256-byte aligned, in ctx->tmp_a).  The caller synchronises ctx->stream before it returns (the staging buffer is reused by the next call).
+int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d) {
+    HIPCHK(hipSetDevice(ctx->device));
+    ctx->ffi_t0 = wall_ms();
+    size_t off[8], total = 0;
+    if (pieces > 8) { ctx->err = "ffi_small_upload: too many pieces"; return -(int32_t)hipErrorInvalidValue; }
+    for (int i = 0; i < pieces; i++) { off[i] = total; total += (bytes[i] + 255) & ~(size_t)255; }
+    int32_t r;
+    if ((r = ctx_host_stage(ctx, total + 256)) || (r = ctx_reserve(ctx, ctx->tmp_a, total + 256))) return r;
+    for (int i = 0; i < pieces; i++) { if (bytes[i]) memcpy((uint8_t *)ctx->h_stage + off[i], src[i], bytes[i]); d[i] = (uint8_t *)ctx->tmp_a.p + off[i]; }
+    if (total) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
+    return C25519_OK;
+}
+void ffi_small_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
+    ctx->ffi_ms = wall_ms() - ctx->ffi_t0; ctx->ffi_h2d = h2d_bytes; ctx->ffi_d2h = d2h_bytes;
+}
 // wall-clock milliseconds and bytes moved each way by the latest host-pointer call of this context (-1 if none)
 EXPORT double c25519_last_ffi_ms(const c25519_ctx *ctx, uint64_t *h2d_bytes, uint64_t *d2h_bytes) {
     if (h2d_bytes) *h2d_bytes = ctx->ffi_h2d;

@@ -26,6 +26,10 @@ int32_t ffi_begin(c25519_ctx *ctx);
 // the context's stream continues after the downloads (for wipes of staged secrets); records the wall-clock of the call
 int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes);
 
+// small calls: all input pieces through one page-locked buffer and one copy on the compute stream (capi.hip)
+int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d);
+void ffi_small_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes);
+
 // Between ffi_begin and the point where ffi_pipeline (or an explicit ffi_end) takes over, an entry point queues whole-array uploads on
 // the copy stream; if one of those fails it returns at once.  The guard makes that early exit drain the copy streams too (ffi_end), so
 // that no queued copy is still reading the caller's memory after the call has returned its error, the figures of c25519_last_ffi_ms

@@ -1013,6 +1013,24 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     if (out_fmt < 0 || out_fmt > 2 || in_fmt < 0 || in_fmt > 2) { ctx->err = "msm: bad format"; return -(int32_t)hipErrorInvalidValue; }
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
+    if (n <= MSM_SMALL_MAX) {
+        // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: one staged copy up, the kernels, one copy down
+        const void *src[2] = {scalars, points};
+        const size_t bytes[2] = {(size_t)n * 32, (size_t)n * psz};
+        uint8_t *d[2];
+        if ((r = ffi_small_upload(ctx, 2, src, bytes, d))) return r;
+        ge_p3 R;
+        uint32_t flags[8];
+        r = msm_record_enqueue(ctx, d[0], d[1], n, in_fmt, drec(ctx));
+        if (!r) r = rec_collect(ctx);
+        else (void)hipStreamSynchronize(ctx->stream);          // (the upload may still be reading the staging buffer)
+        ffi_small_end(ctx, n * (32 + psz), 0);
+        if (r) return r;
+        if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+        if ((r = msm_record_status(ctx, flags))) return r;
+        host_encode(R, out_fmt, out);
+        return C25519_OK;
+    }
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16))) return r;
     uint8_t *d_s = (uint8_t *)ctx->tmp_a.p, *d_p = (uint8_t *)ctx->tmp_b.p;
     if ((r = ffi_begin(ctx))) return r;

@@ -581,6 +581,18 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
     const uint64_t mlen = msg_off[n];
     int32_t r;
+    if (2 * n + 1 <= MSM_SMALL_MAX && mlen <= (1u << 20)) {
+        // the reference's own benchmark sizes (ed25519_benchmarks.rs:53: 4 .. 256 signatures) and everything else whose MSM takes the small path:
+        // all five arrays through one staged copy on the compute stream (capi.hip ffi_small_upload)
+        const void *src[5] = {msgs, msg_off, sigs, pks, pk_points};
+        const size_t bytes[5] = {(size_t)mlen, (size_t)(n + 1) * 8, (size_t)n * 64, (size_t)n * 32, pk_points ? (size_t)n * 160 : 0};
+        uint8_t *d[5];
+        if ((r = ffi_small_upload(ctx, 5, src, bytes, d))) return r;
+        r = verify_batch_impl(ctx, d[0], (const uint64_t *)d[1], mlen, d[2], d[3], pk_points ? d[4] : nullptr, n, z_mode, nullptr);
+        if (r < 0) (void)hipStreamSynchronize(ctx->stream);      // (an error before the call's own synchronisation: the upload may still be reading the staging buffer)
+        ffi_small_end(ctx, mlen + (n + 1) * 8 + n * 96 + (pk_points ? n * 160 : 0), 0);
+        return r;
+    }
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||
         (r = ctx_reserve(ctx, ctx->scratch, n * 32 + (pk_points ? n * 160 : 0) + 16)))
         return r;
