@@ -69,7 +69,9 @@ namespace c25519 {
 // ONE batched inversion over the lane totals, unwind: -68 % field operations, 0.083 + 0.107 + 0.192 ms -- the two
 // memory passes run at 3.6 - 5.2 TB/s and then contend with the sort on the second stream: no gain end to end), and
 // wave-coalesced record I/O transposed through LDS (8x fewer cache-line requests per instruction, but 40 + 30 + 32 LDS
-// dword accesses and four barriers per point: 0.47 ms).
+// dword accesses and four barriers per point: 0.47 ms).  Round 4: the way up fetching only Z (the three 16-byte pieces 5 .. 7 of every record,
+// 3 DMA instructions into a compact layout instead of 10): level at every size (2^24 terms 13.09 - 13.20 against 13.14 - 13.15 ms, 2^21
+// 1.88 - 1.90 against 1.89 - 1.93) -- a record's Z shares its 128-byte lines with X and Y; profiles/r04_ab_prep_z_only.txt.
 // WAVE-COALESCED memory accesses.  Lane t owns points t, t + T, ...: the 64 lanes of a wave own 64 CONSECUTIVE points at
 // every step; if each lane fetched its own 40-byte coordinates and stored its own 128-byte record (round 1's k_prep_raw),
 // every memory instruction would look up 64 different cache lines -- 1664 look-ups per point and wave, on
