@@ -365,14 +365,16 @@ int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
 // copy on the COMPUTE stream -- no copy stream, no events, no second synchronisation.  The chunked path above costs such a call a dozen runtime
 // calls and two pageable copies (each staged by the runtime on its own): ~45 us of a 185 us MSM of 256 terms.  d[i]: where piece i landed
 // (256-byte aligned, in ctx->tmp_a).  The caller synchronises ctx->stream before it returns (the staging buffer is reused by the next call).
-int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d) {
+int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d, size_t min_stage) {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ffi_t0 = wall_ms();
     size_t off[8], total = 0;
     if (pieces > 8) { ctx->err = "ffi_small_upload: too many pieces"; return -(int32_t)hipErrorInvalidValue; }
     for (int i = 0; i < pieces; i++) { off[i] = total; total += (bytes[i] + 255) & ~(size_t)255; }
     int32_t r;
-    if ((r = ctx_host_stage(ctx, total + 256)) || (r = ctx_reserve(ctx, ctx->tmp_a, total + 256))) return r;
+    // min_stage: what the rest of the call will ask of the staging buffer (the strict z-mode of verify_batch keeps its host copies there): it must not
+    // be re-allocated while the upload below is still reading it
+    if ((r = ctx_host_stage(ctx, std::max(total + 256, min_stage))) || (r = ctx_reserve(ctx, ctx->tmp_a, total + 256))) return r;
     for (int i = 0; i < pieces; i++) { if (bytes[i]) memcpy((uint8_t *)ctx->h_stage + off[i], src[i], bytes[i]); d[i] = (uint8_t *)ctx->tmp_a.p + off[i]; }
     if (total) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
     return C25519_OK;

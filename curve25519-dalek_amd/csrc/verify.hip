@@ -587,7 +587,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
         const void *src[5] = {msgs, msg_off, sigs, pks, pk_points};
         const size_t bytes[5] = {(size_t)mlen, (size_t)(n + 1) * 8, (size_t)n * 64, (size_t)n * 32, pk_points ? (size_t)n * 160 : 0};
         uint8_t *d[5];
-        if ((r = ffi_small_upload(ctx, 5, src, bytes, d))) return r;
+        if ((r = ffi_small_upload(ctx, 5, src, bytes, d, (size_t)n * 144 + 64))) return r;
         r = verify_batch_impl(ctx, d[0], (const uint64_t *)d[1], mlen, d[2], d[3], pk_points ? d[4] : nullptr, n, z_mode, nullptr);
         if (r < 0) (void)hipStreamSynchronize(ctx->stream);      // (an error before the call's own synchronisation: the upload may still be reading the staging buffer)
         ffi_small_end(ctx, mlen + (n + 1) * 8 + n * 96 + (pk_points ? n * 160 : 0), 0);

@@ -328,3 +328,26 @@ def test_verify_batch_rejects_bad_offsets(eng, orc):
     assert eng.verify_batch_t(dm, doff, ds, dp, 1) == OK                        # the context is still usable
     with pytest.raises(ValueError):
         eng.verify_batch([b"m"], [b"\0" * 63], [b"\0" * 32], 1)                # a 63-byte signature must not silently misalign the batch
+
+
+def test_verify_batch_small_host_call_on_a_fresh_context_with_empty_messages(orc):
+    """The small host-pointer path stages all five input arrays in ONE page-locked buffer (capi.hip ffi_small_upload); the strict z-mode then
+    keeps its host copies (144 bytes per signature) in the SAME buffer.  With empty messages the upload is smaller than that: the buffer must
+    be sized for the whole call up front, not re-allocated under the pending upload.  Fresh context (nothing allocated yet), both z-modes,
+    then one bad signature."""
+    import curve25519_dalek_amd as pkg
+    import torch
+    n = 2047
+    e0 = pkg.Engine(0)
+    seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
+    dm = torch.zeros((1,), dtype=torch.uint8, device="cuda"); doff = torch.zeros((n + 1,), dtype=torch.int64, device="cuda")
+    dpk, dsg = e0.sign_batch_t(seeds, dm, doff)
+    P = dpk.cpu().numpy(); S = dsg.cpu().numpy()
+    msgs = [b""] * n; sigs = [S[i].tobytes() for i in range(n)]; pks = [P[i].tobytes() for i in range(n)]
+    assert orc.ed25519_verify(pks[5], b"", sigs[5]) == 0
+    for z_mode in (0, 1):
+        fresh = pkg.Engine(0)
+        assert fresh.verify_batch(msgs, sigs, pks, z_mode) == OK
+        bad = list(sigs); b = bytearray(bad[n - 1]); b[3] ^= 4; bad[n - 1] = bytes(b)
+        assert fresh.verify_batch(msgs, bad, pks, z_mode) == VERIFY
+        assert fresh.verify_batch(msgs[:3], sigs[:3], pks[:3], z_mode) == OK
