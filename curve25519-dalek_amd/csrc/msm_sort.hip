@@ -49,7 +49,8 @@ namespace c25519 {
 //   k_part2g        pass 2 GATHERS a bin's runs from the chunks' blocks (one 256-byte segment per chunk)        (134 us; 105 - 112 with
 //                   contiguous bins)
 //   k_order_place   1024-thread blocks: a quarter of the per-(block, length class) global atomics               (11 us; 26 with 256)
-// 250 us instead of 331 (363 at the start of the round, 560 in round 2), four launches instead of five.
+// 250 us instead of 331 (363 at the start of the round, 560 in round 2), four launches instead of five.  (Round 4: 86 + 5 + 73 + 18 us per
+// 1.68 M terms with 17-bit windows once every window has its own slice width and no bin is oversize -- msm_slice_params.)
 // Deterministic like the kernels they replace (offsets come from exact counts, not from atomics on a global cursor).
 // (eight words per scalar: s' = s + addk < 2^256 whenever bit 255 of s is clear, and a scalar with bit 255 set fails the call
 //  anyway (bad_scalar); a term beyond n is loaded as s = 0, whose digits are all zero: s' = addk puts 2^(wid-1) into every signed
