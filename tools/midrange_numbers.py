@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""c25519_msm_vartime (host pointers, raw points) across the path boundaries: small path (<= 2047 terms), chunk-local sort with 1 .. 8 slices
-per window (2048 .. 65535), the full pipeline above; device-resident calls beside them.   python tools/midrange_numbers.py > profiles/rNN_msm_midrange.txt"""
+"""c25519_msm_vartime (host pointers, raw points) across the path boundaries: small path (<= 4095 terms), digit-matrix sort (4096 .. 65535; the
+chunk-local sort there with C25519_SORT_CHUNK_LOCAL_MIN=4096), the full pipeline above; device-resident calls beside them.   python tools/midrange_numbers.py > profiles/rNN_msm_midrange.txt"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
