@@ -48,7 +48,6 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
     const u32 *list = sorted + (u64)k * n;
     // cont: the bucket sums of the previous pass on this stream set are the starting point (one bucket reduction per call
     // instead of one per pass: msm.hip msm_record_enqueue)
-    ge_p3 acc = (cont && mine) ? p40_load(buckets, gid) : ge_identity();
     __shared__ uint4 stage[(256 / 64) * 8 * 64];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
@@ -60,6 +59,10 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
     u32 wmax = len;
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) { u32 o = (u32)__shfl_xor((int)wmax, d, 64); wmax = o > wmax ? o : wmax; }
+    // a wave whose lists are all empty leaves continued bucket sums where they are (the buckets a narrow window never uses -- a fifth of a
+    // 17-bit layout -- and whatever a short pass did not touch): no 160-byte load and store per lane
+    if (cont && wmax == 0) return;
+    ge_p3 acc = (cont && mine) ? p40_load(buckets, gid) : ge_identity();
     u32 e = 0, e1 = 0;                                   // entries of iterations it and it + 1 (a finished lane keeps a valid index)
     if (len > 0) e = list[lo];
     if (len > 1) e1 = list[lo + 1];
