@@ -445,7 +445,8 @@ static int pick_window(uint64_t n, int cmax) {
 // unsigned window used only the lower half of its buckets, cf. msm_slice_params.)
 void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
     static const int cmax_env = std::min(17, std::max(12, env_int("C25519_MSM_CMAX", 17)));      // A/B knob: 16 = rounds 1-3 (profiles/r04_ab_window_17.txt)
-    g.c = c_exact ? c_exact : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
+    static const int cforce = env_int("C25519_MSM_CFORCE", 0);       // A/B knob: this width for every plain layout of the process (0 = choose)
+    g.c = c_exact ? c_exact : (cforce >= 5 && cforce <= 17 && !cmax_call) ? cforce : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
     uint32_t a[9] = {0};
