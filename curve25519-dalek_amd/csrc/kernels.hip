@@ -449,10 +449,32 @@ __global__ void __launch_bounds__(256) C25519_PREPC_ATTR k_prep_compressed(const
     if (!ok) atomicAdd(bad_count, 1u);
 }
 
+// verify_batch, small batches: the keys A_i (n x 32 bytes -> records n + 1 ..) and the R_i (first half of every 64-byte signature -> records 1 ..)
+// in ONE launch.  A decompression is a chain of ~280 dependent field operations, ~70 us for a lone wave however few points there are: two
+// launches one after the other are two of those chains.  bad_count[0] counts the keys, bad_count[1] the R_i that do not decode.
+__global__ void __launch_bounds__(256) k_prep_compressed_keys_and_r(const uint8_t *__restrict__ pks, const uint8_t *__restrict__ sigs, u64 n, u32 *__restrict__ pts,
+                                                                    u32 *__restrict__ bad_count) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n) return;
+    const bool is_r = i >= n;
+    const u64 j = is_r ? i - n : i;
+    u32 w[8];
+    load8(is_r ? sigs : pks, is_r ? 2 * j : j, w);
+    ge_p3 P;
+    const bool ok = ge_decompress(P, w);
+    pts_store(pts, (is_r ? 1 : n + 1) + j, P.X, P.Y);
+    if (!ok) atomicAdd(bad_count + (is_r ? 1 : 0), 1u);
+}
+
 // ================================================================================================
 // launchers
 // ================================================================================================
 static inline unsigned div_up(u64 a, u64 b) { return (unsigned)((a + b - 1) / b); }
+hipError_t launch_prep_compressed_keys_and_r(const uint8_t *pks, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad_count, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_compressed_keys_and_r, dim3(div_up(2 * n, 256)), dim3(256), 0, st, pks, sigs, n, pts, bad_count);
+    return hipGetLastError();
+}
 
 template <int W, int BS, bool CT = false>
 static hipError_t launch_mul_base_w(const uint8_t *scalars, u64 n, const uint32_t *tab, uint32_t *scratch, uint8_t *out_raw,

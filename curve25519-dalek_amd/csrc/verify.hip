@@ -377,6 +377,12 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         if ((r = (*stage)(1, &ev_pk)) || (r = (*stage)(2, &ev_msg))) return r;
         HIPCHK(hipStreamWaitEvent(sa, ev_sig, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_pk, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_msg, 0));
         if (!d_pk_points) { HIPCHK(hipStreamWaitEvent(st, ev_pk, 0)); if ((r = prep_A())) return r; }
+    } else if (!d_pk_points && n <= 4096) {
+        // small batches of key BYTES: both decompressions in one launch (one latency chain instead of two; d_cnt[2] = bad A, d_cnt[3] = bad R)
+        HIPCHK(hipEventRecord(ring[4], st));
+        ctx->kname[1] = "c25519::k_prep_compressed_keys_and_r (decompression of A_i and R_i)";
+        HIPCHK(launch_prep_compressed_keys_and_r(d_pks, d_sigs, n, d_pts, d_cnt + 2, st));
+        HIPCHK(hipEventRecord(ring[5], st));
     } else {
         if ((r = prep_A()) || (r = prep_R())) return r;
     }
