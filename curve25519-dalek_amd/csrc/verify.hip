@@ -323,10 +323,17 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
 // that array's slice for THIS pass on the copy stream and returns the event to wait for.  So R_i is being decompressed
 // while the keys and messages travel, and the hash chain runs while the (five times larger) key points travel.
 typedef std::function<int32_t(int what, hipEvent_t *ready)> verify_stage;
+// pre (small batches of the transcript z-mode, may be null): the records of A_i and R_i are ALREADY at their place in the context's record buffer
+// (or will be once `ready` has fired) -- decompressed on the second stream while the hashes went to the host and the z_i came back -- with
+// cnt[0] keys and cnt[1] R_i that do not decode
+struct verify_pre { hipEvent_t ready; const uint32_t *cnt; };
+__global__ void k_add_point_counters(u32 *__restrict__ d_cnt, const u32 *__restrict__ cnt) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { d_cnt[2] += cnt[0]; d_cnt[3] += cnt[1]; }
+}
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
                                    const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc,
-                                   const verify_stage *stage = nullptr) {
+                                   const verify_stage *stage = nullptr, const verify_pre *pre = nullptr) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
@@ -377,6 +384,10 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         if ((r = (*stage)(1, &ev_pk)) || (r = (*stage)(2, &ev_msg))) return r;
         HIPCHK(hipStreamWaitEvent(sa, ev_sig, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_pk, 0)); HIPCHK(hipStreamWaitEvent(sa, ev_msg, 0));
         if (!d_pk_points) { HIPCHK(hipStreamWaitEvent(st, ev_pk, 0)); if ((r = prep_A())) return r; }
+    } else if (pre) {
+        HIPCHK(hipStreamWaitEvent(st, pre->ready, 0));
+        hipLaunchKernelGGL(k_add_point_counters, dim3(1), dim3(64), 0, st, d_cnt, pre->cnt);
+        HIPCHK(hipEventRecord(ring[4], st)); HIPCHK(hipEventRecord(ring[5], st));
     } else if (!d_pk_points && n <= 4096) {
         // small batches of key BYTES: both decompressions in one launch (one latency chain instead of two; d_cnt[2] = bad A, d_cnt[3] = bad R)
         HIPCHK(hipEventRecord(ring[4], st));
@@ -430,7 +441,7 @@ static int32_t verify_record_verdict(c25519_ctx *ctx, const ge_p3 &R, const uint
 // 64-byte trailer of counters -- [0] non-canonical s, [1] bad offsets -- as ed25519_batch_hram_dev leaves them; d_z16 = their
 // z_i), summed into ONE record at d_record: the reference's single equation (batch.rs:235-250) whatever the pass split.
 static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, const uint8_t *d_hram, const uint8_t *d_z16,
-                                     uint64_t n, uint32_t *d_record) {
+                                     uint64_t n, uint32_t *d_record, const verify_pre *pre = nullptr) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
     const uint32_t *d_pre = (const uint32_t *)(d_hram + n * 64);
@@ -453,7 +464,7 @@ static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, con
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             uint32_t *slot = passes == 1 ? d_record : dslot(ctx, i);
             r = verify_pass_enqueue(ctx, c, nullptr, nullptr, 0, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, C25519_Z_TRANSCRIPT,
-                                    d_hram + lo * 64, d_z16 + lo * 16, (p0 + i == 0) ? d_pre : nullptr, g, 2 * per + 1, slot, prev_acc);
+                                    d_hram + lo * 64, d_z16 + lo * 16, (p0 + i == 0) ? d_pre : nullptr, g, 2 * per + 1, slot, prev_acc, nullptr, passes == 1 ? pre : nullptr);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
         }
@@ -509,6 +520,19 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
         try {
             if ((r = ctx_reserve(ctx, ctx->tmp_c2, n * 80 + 128))) return r;
             uint8_t *d_hram_all = (uint8_t *)ctx->tmp_c2.p, *d_z_all = d_hram_all + n * 64 + 64;
+            // small batches of key bytes: A_i and R_i are decompressed on the second stream NOW -- a ~70 us latency chain that needs none of what follows --
+            // while the hashes go to the host, the transcript runs and the z_i come back (about as long at these sizes); the pass then finds its records ready
+            verify_pre pre_pts = {nullptr, nullptr};
+            if (!d_pk_points && n <= 4096) {
+                if ((r = ctx_reserve(ctx, ctx->tmp_e, (2 * n + 1) * PTS_BYTES + 256))) return r;
+                uint32_t *cnt = (uint32_t *)ctx->d_flag + 44;
+                HIPCHK(hipEventRecord(ctx->ev_fork, ctx->stream));                 // (the inputs are on the device once the main stream gets here)
+                HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
+                HIPCHK(hipMemsetAsync(cnt, 0, 8, ctx->aux));
+                HIPCHK(launch_prep_compressed_keys_and_r(d_pks, d_sigs, n, (uint32_t *)ctx->tmp_e.p, cnt, ctx->aux));
+                HIPCHK(hipEventRecord(ctx->ev_pts, ctx->aux));
+                pre_pts.ready = ctx->ev_pts; pre_pts.cnt = cnt;
+            }
             if ((r = batch_hram_enqueue(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, d_hram_all))) return r;
             // (r4) the host copies live in a page-locked buffer the context keeps instead of three fresh std::vectors per call (144 MB at 2^20
             // signatures).  Measured neutral (468 ms per 2^20 signatures either way): the call IS the sponge -- ~410 ns per signature inside the
@@ -520,7 +544,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             HIPCHK(hipStreamSynchronize(ctx->stream));
             c25519_transcript_zs(hh, hs, n, hz);
             HIPCHK(hipMemcpyAsync(d_z_all, hz, n * 16, hipMemcpyHostToDevice, ctx->stream));
-            if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx)))) return r;
+            if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx), pre_pts.ready ? &pre_pts : nullptr))) return r;
         } catch (const std::exception &e) { ctx->err = std::string("verify_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
         if ((r = rec_collect(ctx))) return r;
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
