@@ -53,6 +53,7 @@ def load_library():
         "c25519_phase_ms": (C.c_float, [vp, C.c_uint32, C.c_int]),
         "c25519_last_call_phase_ms": (C.c_float, [vp, C.c_int, vp]),
         "c25519_debug_batch_zs": (i32, [vp, vp, vp, vp, vp, u64, C.c_uint32, vp]),
+        "c25519_debug_sort": (i32, [vp, vp, u64, u64, C.c_int32]),
         "c25519_mul_base_batch_dev": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_mul_base_batch": (i32, [vp, vp, u64, C.c_int, vp]),
         "c25519_mul_base_batch_vartime_dev": (i32, [vp, vp, u64, C.c_int, vp]),
@@ -135,7 +136,7 @@ ABI_SYMBOLS = [
     "c25519_mul_table_batch", "c25519_x25519_contributory_batch_dev", "c25519_x25519_contributory_batch", "c25519_mul_clamped_batch_dev", "c25519_mul_clamped_batch",
     "c25519_point_order_checks_batch_dev", "c25519_point_order_checks_batch",
     "c25519_host_alloc", "c25519_host_free", "c25519_last_ffi_ms", "c25519_ctx_trim", "c25519_last_kernel_name",
-    "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
+    "c25519_last_kernel_ms", "c25519_phase_ms", "c25519_last_call_phase_ms", "c25519_debug_batch_zs", "c25519_debug_sort", "c25519_mul_base_batch_dev", "c25519_mul_base_batch_vartime_dev", "c25519_mul_base_batch", "c25519_x25519_batch_dev",
     "c25519_x25519_batch", "c25519_x25519_base_batch_dev", "c25519_x25519_base_batch", "c25519_decompress_batch_dev", "c25519_decompress_batch", "c25519_compress_batch_dev",
     "c25519_compress_batch", "c25519_msm_vartime_dev", "c25519_msm_vartime", "c25519_msm_partial_dev",
     "c25519_fold_partials", "c25519_msm_partial_record_dev", "c25519_fold_partial_records", "c25519_partial_record_pack",

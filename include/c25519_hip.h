@@ -297,6 +297,11 @@ int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *records, uin
 int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n,
                               uint32_t z_mode, uint8_t *out_z16);
 
+/* diagnostics for kernel traces: the SORT of one MSM pass alone (n scalars on the device, 4096 <= n <= 2^22; the window layout of
+ * `layout_terms` terms, 0 = of n), `reps` times back to back on the context's stream, then a synchronisation.  No result:
+ * tools/sort_only.py runs it under rocprofv3 to time the sort kernels without an accumulation beside them. */
+int32_t c25519_debug_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, uint64_t layout_terms, int32_t reps);
+
 /* ---- variable base: out[i] = scalars[i] * points[i] ------------------------------------------------
  * replaces backend::variable_base_mul (backend.rs:253 -> scalar_mul/variable_base.rs:11-47;
  * `&EdwardsPoint * &Scalar`, edwards.rs:890-911), radix-16 fixed windows, one pair per lane.

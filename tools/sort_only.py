@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The sort of one MSM pass alone, N times (c25519_debug_sort), for a kernel trace without an accumulation beside it:
     rocprofv3 --kernel-trace --stats -d out -o s -- python tools/sort_only.py <terms> <layout_terms> [reps]"""
-import ctypes as C, os, sys
+import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 import curve25519_dalek_amd as pkg
@@ -12,10 +12,7 @@ eng = pkg.Engine(0)
 g = torch.Generator(device="cuda"); g.manual_seed(7)
 x = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
 x[:, 31] &= 0x0F
-f = eng.lib.c25519_debug_sort
-f.restype = C.c_int32
-f.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32]
 torch.cuda.synchronize()
-st = f(eng.ctx, x.data_ptr(), n, layout, reps)
+st = eng.lib.c25519_debug_sort(eng.ctx, x.data_ptr(), n, layout, reps)
 assert st == 0, st
 print("ok", n, layout, reps)
