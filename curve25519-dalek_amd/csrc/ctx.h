@@ -60,19 +60,12 @@ struct c25519_ctx {
 // Zeroes device buffers on the given stream when it goes out of scope: secret-derived scratch is wiped on EVERY exit path of an
 // entry point (also the early returns of a failed launch), after whatever the entry point enqueued before.
 struct stream_wipe {
-    hipStream_t st; void *p[6]; size_t n[6]; int cnt = 0;
+    hipStream_t st;
+    std::vector<std::pair<void *, size_t>> bufs;          // (a vector: no registration is ever dropped, however many an entry point adds)
     explicit stream_wipe(hipStream_t s) : st(s) {}
     stream_wipe(const stream_wipe &) = delete;
-    // more buffers than slots: never dropped silently -- the extra one is wiped at once, in stream order before whatever the caller enqueues next
-    // (correct for a buffer that is still empty; a caller that needs more late wipes must raise the slot count -- asserted in debug builds)
-    void add(void *q, size_t bytes) {
-        if (!q || !bytes) return;
-        if (cnt < 6) { p[cnt] = q; n[cnt++] = bytes; return; }
-        overflowed = true;
-        (void)hipMemsetAsync(q, 0, bytes, st);
-    }
-    bool overflowed = false;
-    ~stream_wipe() { for (int i = 0; i < cnt; i++) (void)hipMemsetAsync(p[i], 0, n[i], st); }
+    void add(void *q, size_t bytes) { if (q && bytes) bufs.emplace_back(q, bytes); }
+    ~stream_wipe() { for (auto &b : bufs) (void)hipMemsetAsync(b.first, 0, b.second, st); }
 };
 
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);

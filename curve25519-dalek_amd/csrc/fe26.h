@@ -398,6 +398,10 @@ C25519_HD bool fe_eq(const feW &a, const feW &b) {
 // the same as before within 0.2 % (profiles/r04_ab_select_forms.txt).  Kept because it is never the slower form; not a speed-up.
 // Constant time as before: a select executes identically whatever its mask holds.
 #if defined(__HIP_DEVICE_COMPILE__)
+// (the mask is a 64-bit ballot handed to v_cndmask_b32_e64 as an SGPR PAIR: wave64 only -- gfx950 / CDNA; a wave32 target must not build this)
+#if !defined(__GFX9__)
+#error "fe26.h lane masks are 64-bit SGPR pairs: wave64 targets (the GFX9 / CDNA family, gfx950) only"
+#endif
 typedef unsigned long long lanemask;
 __device__ __forceinline__ lanemask lane_mask(bool c) { return __ballot(c); }
 __device__ __forceinline__ u32 sel_u32(u32 a, u32 b, lanemask m) {       // lane's bit of m set -> b

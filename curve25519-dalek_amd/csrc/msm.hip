@@ -431,7 +431,7 @@ void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
 // in the reduction), 16 for the merged layout (u16 digit matrix) and verify_batch.
 static int pick_window(uint64_t n, int cmax) {
     int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
-    static const int mid = env_int("C25519_MSM_MIDRANGE_WINDOWS", 1);      // A/B knob: 0 = c = log2 n - 4 throughout (rounds 1-3)
+    static const int mid = C25519_KNOB("MSM_MIDRANGE_WINDOWS", 1);      // A/B knob: 0 = c = log2 n - 4 throughout (rounds 1-3)
     int c = lg - 4;
     if (mid && lg >= 12 && lg <= 19) c += lg <= 12 ? 2 : lg <= 16 ? 3 : lg == 17 ? 2 : 1;
     if (c < 5) c = 5;
@@ -444,9 +444,12 @@ static int pick_window(uint64_t n, int cmax) {
 // window of c - 1 bits up to bit 252, overflow window 253..255 -- the same signed windows; bit 252 of a canonical scalar is clear, so that
 // unsigned window used only the lower half of its buckets, cf. msm_slice_params.)
 void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
-    static const int cmax_env = std::min(17, std::max(12, env_int("C25519_MSM_CMAX", 17)));      // A/B knob: 16 = rounds 1-3 (profiles/r04_ab_window_17.txt)
-    static const int cforce = env_int("C25519_MSM_CFORCE", 0);       // A/B knob: this width for every plain layout of the process (0 = choose)
-    g.c = c_exact ? c_exact : (cforce >= 5 && cforce <= 17 && !cmax_call) ? cforce : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
+    static const int cmax_env = std::min(17, std::max(12, C25519_KNOB("MSM_CMAX", 17)));      // A/B knob: 16 = rounds 1-3 (profiles/r04_ab_window_17.txt)
+    static const int cforce = C25519_KNOB("MSM_CFORCE", 0);       // A/B knob: this width for every plain layout of the process (0 = choose)
+    // (a forced width only where the kernels behind it were built for it: the small path's tables hold windows of 5 .. 7 bits, the chunk-local and
+    //  digit-matrix sorts scan at least 64 buckets per slice, i.e. windows of >= 7 bits)
+    const bool force_ok = cforce >= 5 && cforce <= 17 && !cmax_call && (n <= MSM_SMALL_MAX ? cforce <= 7 : cforce >= 7);
+    g.c = c_exact ? c_exact : force_ok ? cforce : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
     uint32_t a[9] = {0};
@@ -539,7 +542,7 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
     // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
     if (reduce) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));      // (without a reduction nothing on the second stream needs the accumulated buckets)
-    static const int coop_reduce = env_int("C25519_REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
+    static const int coop_reduce = C25519_KNOB("REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
     if (reduce && coop_reduce) {
         launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux);
         HIPCHK(hipGetLastError());
@@ -622,6 +625,9 @@ int32_t records_fold(const uint8_t *records, uint64_t count, ge_p3 &R, uint32_t 
         if (f[REC_MAGIC] != REC_MAGIC_VALUE) { if (err) *err = "fold: not a partial-result record (bad magic)"; return -(int32_t)hipErrorInvalidValue; }
         for (int j = 0; j < 8; j++) flags[j] += f[j];
         const uint64_t terms = (uint64_t)f[REC_TERMS_LO] | ((uint64_t)f[REC_TERMS_HI] << 32);
+        // (a record without its window width in the header -- the format before the width stopped being a function of the term count -- would be
+        //  folded with the wrong window positions: an explicit version error, never a silently different point)
+        if (terms != 0 && f[REC_C] == 0) { if (err) *err = "fold: a partial-result record without a window width in its header (made by an older library version)"; return -(int32_t)hipErrorInvalidValue; }
         if (f[REC_C] != 0 && (f[REC_C] < 5 || f[REC_C] > 17)) { if (err) *err = "fold: bad window width in a record header"; return -(int32_t)hipErrorInvalidValue; }
         if (i == 0) { terms0 = terms; c0 = f[REC_C]; } else if (terms != terms0 || f[REC_C] != c0) same = false;
     }
@@ -740,7 +746,7 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         // points per lane and inversion: 64 when the launch still has >= 2048 waves (the records of the later passes of a
         // multi-pass call; 2^24 terms: 15.8 ms with 16 everywhere, 15.3 with 64), 32 from 2^20 points (profiles/r04_ab_prep_points_per_lane.txt:
         // 2^20 terms 1.10 against 1.18 ms, 2^21 the same either way), 16 below (2^19: 0.76 against 0.81 ms; 8 and 4 buy nothing down to 2^16)
-        static const int ch_knob = env_int("C25519_PREP_CH", 0);             // A/B knob: 4 / 8 / 16 / 32 / 64
+        static const int ch_knob = C25519_KNOB("PREP_CH", 0);             // A/B knob: 4 / 8 / 16 / 32 / 64
         // below 2^18 points the kernel is a latency chain (the lane's prefix products, ONE inversion, the unwinding): 4 points per lane shorten it
         // (2^13 terms 0.48 -> 0.40 ms, 2^16 0.54 -> 0.51)
         const int CH = ch_knob ? ch_knob : (n >= (1ull << 23) ? 64 : n >= (1ull << 20) ? 32 : n >= (1ull << 18) ? 16 : 4);
@@ -751,7 +757,7 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         if (r) return r;
         // A/B proxy (profiles/r04_ab_prep_two_waves.txt): what the normaliser's memory system does with TWO waves per compute unit -- the occupancy
         // an LDS-resident inversion tree (prefix products of 16 points per lane kept in LDS: 40 KB per wave) would leave it
-        static const int two_waves = env_int("C25519_PREP_TWO_WAVES", 0);
+        static const int two_waves = C25519_KNOB("PREP_TWO_WAVES", 0);
         if (two_waves && CH == 16) {
             const unsigned b2 = (unsigned)div_up64((n + CH - 1) / CH, 64 * 2);
             if ((r = ctx_reserve(ctx, ctx->prefix, (size_t)b2 * 2 * CH * 3 * 64 * 16))) return r;
@@ -781,10 +787,10 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
 // 2^24-term call 14.32 - 14.54 ms in 8 passes against 14.10 - 14.18 in 10, profiles/r03_ab_pass_size.txt; with the bucket
 // continuation a pass more costs a sort's fixed part, not a reduction).  C25519_MSM_PASS_LOG2 (tests: many small passes) overrides.
 static const uint64_t MSM_PASS = []() -> uint64_t {
-    if (const char *t = getenv("C25519_MSM_PASS_TERMS")) { const long long v = atoll(t); if (v >= 65536 && v <= (1ll << 22)) return (uint64_t)v; }      // A/B knob
-    const char *e = getenv("C25519_MSM_PASS_LOG2"); if (!e) return (uint64_t)1750000; int v = atoi(e); return 1ull << (v < 16 ? 16 : (v > 22 ? 22 : v)); }();
+    { const long long v = C25519_KNOB_LL("MSM_PASS_TERMS", 0); if (v >= 65536 && v <= (1ll << 22)) return (uint64_t)v; }      // A/B knob
+    const int v = C25519_KNOB("MSM_PASS_LOG2", 0); if (!v) return (uint64_t)1750000; return 1ull << (v < 16 ? 16 : (v > 22 ? 22 : v)); }();
 static const uint64_t MSM_PASS_MAX = MSM_PASS + MSM_PASS / 2;
-static int pass_lanes() { static const int v = [] { int x = env_int("C25519_PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
+static int pass_lanes() { static const int v = [] { int x = C25519_KNOB("PASS_LANES", 2); return x < 1 ? 1 : (x > 4 ? 4 : x); }(); return v; }   // A/B knob: stream sets (2, 3, 4 measure the same within 3 %: the GPU is saturated)
 
 // the peers' streams start after everything already enqueued on the caller's stream (the inputs are complete)
 int32_t passes_begin(c25519_ctx *ctx, uint64_t passes, pass_set &ps) {
@@ -846,7 +852,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     // 2 = all of it.  profiles/r04_ab_sort_ahead.txt: 13.39 - 13.51 ms against 13.69 - 13.71 on one box, 13.93 - 14.00 against 13.93 - 14.11 on
     // another; 1 and 2 measure the same (the accumulation beside a sort stretches by what the sort no longer costs afterwards), so the
     // default is the one without a second copy of the lists.
-    static const int sweep_early = env_int("C25519_SWEEP_EARLY", 1);
+    static const int sweep_early = C25519_KNOB("SWEEP_EARLY", 1);
     const bool early = sweep_early && cont && !wait_in && terms > MSM_SMALL_MAX && parity >= 0;
     hipEvent_t lists_free = nullptr;
     if (parity >= 0) {
@@ -855,7 +861,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     }
     if (!early) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream, g.c);            // (a continuing pass adds its counters to the slot of its stream set)
-    if (terms <= MSM_SMALL_MAX && !cont && reduce && !ahead) {
+    if (terms <= MSM_SMALL_MAX && g.half <= 64 && g.nwin <= 64 && !cont && reduce && !ahead) {      // (g: a forced width may not be the small path's -- then the bucket pipeline serves)
         // the small path (small.hip): raw points as they are (projective: no normalisation, no inversion); compressed ones through the
         // decompression into records first
         if (in_fmt == C25519_FMT_RAW160) return msm_small_pass(ctx, d_scalars, d_points, 0, n, g, d_slot, ring, nullptr, wait_acc);
@@ -865,7 +871,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     msm_plan pl;
     pl.bad_sticky = d_bad_sticky;
     // (normalisation first, then the sort on the second stream: 2.26 against 2.34 ms at 2^21 terms the other way round)
-    static const int serial_sort = env_int("C25519_PROFILE_SERIAL_SORT", 0);     // profiling: the sort only starts after the normaliser, so that its kernels can be timed alone
+    static const int serial_sort = C25519_KNOB("PROFILE_SERIAL_SORT", 0);     // profiling: the sort only starts after the normaliser, so that its kernels can be timed alone
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
     else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
@@ -917,7 +923,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
     // (not with a fetch: the later passes' points are not on the device yet)
-    static const int prep_ahead = env_int("C25519_PREP_AHEAD", 1);      // A/B knob: 0 = every pass normalises its own points (on its main stream, ahead of its accumulation)
+    static const int prep_ahead = C25519_KNOB("PREP_AHEAD", 1);      // A/B knob: 0 = every pass normalises its own points (on its main stream, ahead of its accumulation)
     const bool ahead = prep_ahead && passes > 1 && ps.lanes > 1 && in_fmt == C25519_FMT_RAW160 && !fetch;
     if (ahead && (r = ctx_reserve(ctx, ctx->pts_all, (n - per) * PTS_BYTES + 256))) return r;
     // ONE bucket reduction per stream set, not one per pass: the passes dealt to a stream set run one after the other anyway, so

@@ -2,9 +2,24 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "ge26.h"
 #include "ctx.h"
 
+// ---- tuning knobs ------------------------------------------------------------------------------------------------------------
+// The RELEASE library (lib/libc25519hip.so) reads NOTHING from the environment: C25519_KNOB(name, default) is the default, a compile-time
+// constant, and no "C25519_..." string is left in the binary (tests/test_abi_cpu.py asserts it on the built file).  The A/B arms, the profiling
+// switches and the pass-size overrides the tests use to run many small passes exist only in the TUNING build (make tune ->
+// lib/libc25519hip_tune.so, -DC25519_TUNING: the same sources, every knob read once per process from C25519_<name>); the tests and tools that
+// need a knob point C25519_HIP_LIB (a Python-side variable of engine.py) at that file.
+#ifdef C25519_TUNING
+static inline long long c25519_knob_env(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+#define C25519_KNOB(name, dflt) ((int)c25519_knob_env("C25519_" name, (dflt)))
+#define C25519_KNOB_LL(name, dflt) c25519_knob_env("C25519_" name, (dflt))
+#else
+#define C25519_KNOB(name, dflt) (dflt)
+#define C25519_KNOB_LL(name, dflt) ((long long)(dflt))
+#endif
 namespace c25519 {
 // Window layout of the bucket method.  Scalars are reduced mod l (< 2^253, scalar.rs:193-205) in every MSM the reference
 // performs, so the 253 bits are shared out EVENLY (msm_layout); see msm.hip "digits".
@@ -33,7 +48,7 @@ struct long_item;
 //  part -- two dependent additions per bucket of a lane -- is the longest link of the reduction; at least 2 per lane: the kernels start from
 //  the lane's last bucket)
 static inline int red_lb_log2(int half) {
-    static const int lb_min = [] { const char *e = getenv("C25519_RED_LB_MIN"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 3 ? 3 : v); }();   // A/B knob: 3 = rounds 2-3
+    static const int lb_min = [] { const int v = C25519_KNOB("RED_LB_MIN", 1); return v < 1 ? 1 : (v > 3 ? 3 : v); }();   // A/B knob: 3 = rounds 2-3
     if (half <= 512) return 3;                      // a single segment per window: level A writes the column sums itself, no level B
     int lb = lb_min;
     while ((half >> (lb + 6)) > 64) lb++;
@@ -42,12 +57,11 @@ static inline int red_lb_log2(int half) {
 static inline int red_nseg(int half) { const int seg = 64 << red_lb_log2(half); return (half + seg - 1) / seg; }
 // partial-result record = result slot: 56 column sums of 40 u32, then 16 words -- [0..7] counters, [8, 9] the term count the window layout
 // was derived from, [10] passes summed, [11] a magic word
-constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11, REC_C = 12;      // REC_C: the window width of the layout (0 in records of rounds 1-3: derived from the terms alone)
+constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11, REC_C = 12;      // REC_C: the window width of the layout (a record with terms > 0 and no width is rejected by the fold)
 constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
 constexpr uint64_t MSM_SMALL_MAX = 4095;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5, 6 and 7
 }
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
-static inline int env_int(const char *name, int dflt) { const char *e = getenv(name); return e ? atoi(e) : dflt; }
 static inline uint32_t *slot_flags(uint32_t *slot) { return slot + c25519::MSM_MAX_WIN * 40; }
 static inline uint32_t *dslot(c25519_ctx *ctx, int i) { return ctx->d_slots + (size_t)i * C25519_SLOT_U32; }
 static inline const uint32_t *hslot(c25519_ctx *ctx, int i) { return (const uint32_t *)ctx->h_msm + (size_t)i * C25519_SLOT_U32; }

@@ -408,7 +408,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     if (!md && (g.half < 64 || n > (1ull << (part_entry_shift(g) - 1)))) { ctx->err = "msm: internal error (a pass outside the range of the chunk-local sort)"; return -(int32_t)hipErrorInvalidValue; }
     // which sort: the digit-matrix sort for the merged layout and for plain passes below 2^16 terms (the chunk-local partition wants hundreds of
     // chunks: msm_sort_matrix.hip has the numbers); C25519_SORT_CHUNK_LOCAL_MIN lowers the boundary (tests run the chunk-local sort from 2 048 terms)
-    static const uint64_t chunk_local_min = (uint64_t)env_int("C25519_SORT_CHUNK_LOCAL_MIN", 1 << 16);
+    static const uint64_t chunk_local_min = (uint64_t)C25519_KNOB("SORT_CHUNK_LOCAL_MIN", 1 << 16);
     const bool matrix = md != nullptr || nc < chunk_local_min;
     // every region BEFORE the buckets (oK) must be sized from nc, the number of terms the call's passes are carved for, never from
     // this pass's own n: a shorter last pass that CONTINUES its predecessor's bucket sums has to find them at the same offset
@@ -437,11 +437,11 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const bool use_part = matrix && g.c >= 13 && n <= (1ull << 23) && n >= (1ull << 16);          // the two-pass partition of the digit-matrix sort
     // block shapes of the chunk-local sort: the large ones are the fastest alone; the small ones fit beside a k_accumulate held at two waves
     // per SIMD (one wave per SIMD at 128 VGPRs / two at 56; profiles/r04_ab_sort_beside_accumulate.txt).  Read once per process.
-    static const int small_blocks = env_int("C25519_SORT_SMALL", 0);
+    static const int small_blocks = C25519_KNOB("SORT_SMALL", 0);
     // C25519_SWEEP_THREADS=512: the partition in 512-thread blocks (chunks of 4096 terms: two waves per SIMD at 64 VGPRs and 25 KB of LDS) with the
     // per-bin sort in its large shape (four waves per SIMD at 32 VGPRs, 76 KB) -- the pairing that fits beside a two-wave k_accumulate without
     // the 16-entry runs of the all-small arm
-    static const int sweep_threads = small_blocks ? 256 : (env_int("C25519_SWEEP_THREADS", SWEEP_THREADS) == 512 ? 512 : SWEEP_THREADS);
+    static const int sweep_threads = small_blocks ? 256 : (C25519_KNOB("SWEEP_THREADS", SWEEP_THREADS) == 512 ? 512 : SWEEP_THREADS);
     const int sweep_chunk = sweep_threads * SWEEP_TPT;
     const int SL = std::max(1, g.half >> g.bps_log2), PART_CHUNK = matrix ? part_chunk(SL) : sweep_chunk, pchunks = (int)((n + PART_CHUNK - 1) / PART_CHUNK), pchunks_c = (int)((nc + PART_CHUNK - 1) / PART_CHUNK);
     // chunk-local form: P1 holds whole chunk blocks, oCC the slice starts [window][SL + 1][chunk], oBB the bin totals and the chunks' flags

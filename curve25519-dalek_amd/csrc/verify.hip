@@ -425,7 +425,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
 // pass keeps its own identity check.  All passes run even after a failure so that the reference's precedence -- key
 // decoding, then ScalarFormat for ANY non-canonical s (batch.rs:208-211), then Verify -- does not depend on where the
 // batch was cut.
-static const int VERIFY_PASS_LOG2 = [] { int v = env_int("C25519_VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 21 ? 21 : v); }();   // A/B knob
+static const int VERIFY_PASS_LOG2 = [] { int v = C25519_KNOB("VERIFY_PASS_LOG2", 20); return v < 15 ? 15 : (v > 21 ? 21 : v); }();   // A/B knob
 static const uint64_t VERIFY_PASS = 1ull << VERIFY_PASS_LOG2, VERIFY_PASS_MAX = 3ull << (VERIFY_PASS_LOG2 - 1);
 // flags of a folded verify_batch record + its point -> the reference's verdict (precedence: key decoding, then ScalarFormat
 // for ANY non-canonical s, batch.rs:208-211, then Verify, :244-250)

@@ -23,6 +23,7 @@ force_collective=True makes a world of ONE rank go through the collectives as we
 calls on a single GPU).
 """
 import ctypes as C
+import threading
 
 import numpy as np
 
@@ -58,22 +59,31 @@ def _dist_state(group, force_collective):
     return dist, world
 
 
-_PINNED = {}
+_PINNED = {}                     # (numel, dtype) -> page-locked buffer; at most _PINNED_MAX entries of at most _PINNED_BYTES each
+_PINNED_MAX, _PINNED_BYTES = 8, 1 << 20
+_PINNED_LOCK = threading.Lock()
 
 
 def _to_host(t):
     """device tensor -> numpy array through a cached page-locked buffer (one asynchronous copy + one stream synchronisation; a
-    plain .cpu() stages through pageable memory, which costs tens of microseconds on a 9 KB record)"""
+    plain .cpu() stages through pageable memory, which costs tens of microseconds on a 9 KB record).  The cache is bounded (the record
+    sizes of a job are few: world x 9 KB and the small int64 / int32 vectors; anything else, or larger, takes .cpu()) and held under a lock
+    from the copy until the bytes have left the buffer, so concurrent gathers of one size never see each other's data."""
     import torch
     if not t.is_cuda:
         return t.numpy()
     key = (t.numel(), t.dtype)
-    buf = _PINNED.get(key)
-    if buf is None:
-        buf = _PINNED[key] = torch.empty((t.numel(),), dtype=t.dtype, pin_memory=True)
-    buf.copy_(t.reshape(-1), non_blocking=True)
-    torch.cuda.current_stream(t.device).synchronize()
-    return buf.numpy().copy()
+    if t.numel() * t.element_size() > _PINNED_BYTES:
+        return t.reshape(-1).cpu().numpy()
+    with _PINNED_LOCK:
+        buf = _PINNED.get(key)
+        if buf is None:
+            if len(_PINNED) >= _PINNED_MAX:
+                return t.reshape(-1).cpu().numpy()
+            buf = _PINNED[key] = torch.empty((t.numel(),), dtype=t.dtype, pin_memory=True)
+        buf.copy_(t.reshape(-1), non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return buf.numpy().copy()
 
 
 def all_gather_rows(local_t, group=None, force_collective=False):

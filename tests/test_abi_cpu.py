@@ -20,6 +20,25 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(pkg.engine.ABI_SYMBOLS), declared ^ set(pkg.engine.ABI_SYMBOLS)
 
 
+def test_release_library_reads_no_environment():
+    """(`strings libc25519hip.so | grep -c '^C25519_'` is 0.)  The release library takes every choice from its arguments and its own geometry (c25519_msm_geometry): no C25519_* knob string is left in
+    the file and getenv is not even imported.  The knobs live in the tuning build of the same sources (make tune, -DC25519_TUNING)."""
+    import subprocess
+    import curve25519_dalek_amd as pkg
+    rel = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip.so")
+    tune = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip_tune.so")
+    assert os.path.samefile(pkg.engine.lib_path(), rel) or os.environ.get("C25519_HIP_LIB")
+    def knob_strings(path):
+        data = open(path, "rb").read()
+        return sorted(set(m.decode() for m in re.findall(rb"(?<![\x20-\x7e])(C25519_[A-Z][A-Z0-9_]{2,})\x00", data)))
+    assert knob_strings(rel) == [], knob_strings(rel)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", rel], capture_output=True, text=True)
+    if nm.returncode == 0:
+        assert "getenv" not in nm.stdout
+    assert os.path.exists(tune), "run __graft_entry__.build() (make tune)"
+    assert "C25519_MSM_PASS_LOG2" in knob_strings(tune) and "C25519_VERIFY_PASS_LOG2" in knob_strings(tune)
+
+
 def test_no_cpu_fallback():
     import torch
     import curve25519_dalek_amd as pkg

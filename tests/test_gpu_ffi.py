@@ -181,7 +181,7 @@ def test_verify_batch_host_twin_multi_pass_fresh_process():
             assert eng.verify_batch(msgs, bad, P, z) == 3, z
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    e = dict(os.environ); e["C25519_VERIFY_PASS_LOG2"] = "15"
+    e = util.tune_env(C25519_VERIFY_PASS_LOG2="15")
     r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
 

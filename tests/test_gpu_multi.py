@@ -117,6 +117,8 @@ def _launch(world, backend, force, extra_env=None, timeout=900):
         env.update({"RANK": str(r), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "TEST_BACKEND": backend,
                     "TEST_FORCE": "1" if force else "0", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         env.update(extra_env or {})
+        if any(k.startswith("C25519_") for k in (extra_env or {})):      # knobs exist only in the tuning build (csrc/msm_internal.h C25519_KNOB)
+            env["C25519_HIP_LIB"] = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip_tune.so")
         procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:

@@ -1,8 +1,23 @@
 """Shared helpers for the GPU parity tests: seeded input generators (numpy) and oracle batch calls."""
+import os
+
 import numpy as np
 
 L = 2**252 + 27742317777372353535851937790883648493
 P = 2**255 - 19
+
+# The release library reads no environment; the C25519_* knobs (A/B arms, pass-size overrides that make small inputs run many passes) exist only
+# in the tuning build of the same sources (make tune, csrc/msm_internal.h C25519_KNOB).  Tests that need a knob run a fresh process on that file.
+TUNE_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "curve25519-dalek_amd", "lib", "libc25519hip_tune.so")
+
+
+def tune_env(knobs=None, **more):
+    """environment of a child process that loads the tuning build with the given C25519_* knobs set"""
+    assert os.path.exists(TUNE_LIB), "run __graft_entry__.build() (make tune)"
+    env = dict(os.environ, C25519_HIP_LIB=TUNE_LIB)
+    env.update(knobs or {})
+    env.update(more)
+    return env
 
 
 def rand_bytes(seed, n, width=32):

@@ -10,7 +10,8 @@ run() {   # label, env..., -- bench args
     while [ "$1" != "--" ]; do envs+=("$1"); shift; done
     shift
     local line
-    line=$(env "${envs[@]}" timeout 300 python bench.py --no-cpu-baseline --no-sub "$@" 2>>gpurun_out/ab_err.log | tail -1)
+    # (the C25519_* knobs exist only in the tuning build; a cfg line may still name another library)
+    line=$(env C25519_HIP_LIB=$PWD/curve25519-dalek_amd/lib/libc25519hip_tune.so "${envs[@]}" timeout 300 python bench.py --no-cpu-baseline --no-sub "$@" 2>>gpurun_out/ab_err.log | tail -1)
     python3 - "$label" "$line" >> "$out" <<'PY'
 import json, sys
 label, line = sys.argv[1], sys.argv[2]
