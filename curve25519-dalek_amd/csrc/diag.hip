@@ -13,6 +13,7 @@
 #include "selftest.h"
 #include "fe26x.h"
 #include "sc28.h"
+#include "fe9_probe.h"
 #include "ctx.h"
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -319,6 +320,57 @@ __global__ void __launch_bounds__(256) k_probe_femul51(u32 *out, int iters, u32 
     if ((u32)r == 0x12345678u) out[0] = (u32)(r >> 32);
 }
 
+// ---- ds_bpermute_b32 under different SELECTOR patterns (which = 50 .. 57: eight independent permutes per trip; 60 .. 67: eight DEPENDENT ones, i.e.
+//      latency) -- the measurement behind the cross-lane table fetch of the constant-time fixed base (kernels.hip k_mul_base_ctp): does the duration
+//      of a permute depend on which lanes the lanes pull from?  Patterns (source lane of lane l, group = 32-lane half):
+//        0 identity   1 all lanes pull lane 5   2 pseudo-random inside the own 32-lane half (what k_mul_base_ctp<5> issues)
+//        3 pairs 32 lanes apart inside a half: lanes alternate between s and s + 32 (same bank, different lane, if the crossbar had 32 banks)
+//        4 pseudo-random over the whole wave   5 two sources only (lane 0 / lane 32)   6 rotate by one   7 pseudo-random, new selectors every trip
+template <int PAT, bool DEP>
+__global__ void __launch_bounds__(256) k_probe_bpermute(u32 *out, int iters, u32 seed) {
+    const u32 lane = threadIdx.x & 63u;
+    u32 h = (lane * 2654435761u) ^ (blockIdx.x * 40503u) ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    u32 src = lane;
+    if (PAT == 1) src = 5;
+    else if (PAT == 2 || PAT == 7) src = (lane & 32u) | (h & 31u);
+    else if (PAT == 3) src = ((lane & 1u) << 5) | ((lane >> 1) & 31u);
+    else if (PAT == 4) src = h & 63u;
+    else if (PAT == 5) src = (lane & 1u) << 5;
+    else if (PAT == 6) src = (lane + 1u) & 63u;
+    int sel = (int)(src << 2);
+    int a0 = (int)(threadIdx.x + seed), a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    for (int i = 0; i < iters; i++) {
+        if (DEP) {
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+            asm volatile("ds_bpermute_b32 %0, %1, %0\n\ts_waitcnt lgkmcnt(0)" : "+v"(a0) : "v"(sel));
+        } else {
+            asm volatile("ds_bpermute_b32 %0, %8, %0\n\tds_bpermute_b32 %1, %8, %1\n\tds_bpermute_b32 %2, %8, %2\n\tds_bpermute_b32 %3, %8, %3\n\t"
+                         "ds_bpermute_b32 %4, %8, %4\n\tds_bpermute_b32 %5, %8, %5\n\tds_bpermute_b32 %6, %8, %6\n\tds_bpermute_b32 %7, %8, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sel));
+        }
+        if (PAT == 7) { h = h * 1664525u + 1013904223u; sel = (int)(((lane & 32u) | ((h >> 9) & 31u)) << 2); }
+    }
+    const int r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+    if (r == 0x12345678) out[0] = (u32)r;
+}
+// 9-limb field products (which = 70, 71): fe9_probe.h
+template <bool SQ>
+__global__ void __launch_bounds__(256) k_probe_fe9(u32 *out, int iters, u32 seed) {
+    fe9 x, y, z;
+    for (int i = 0; i < 9; i++) { x.v[i] = (out[i] + seed + threadIdx.x) & ((1u << 28) - 1u); y.v[i] = (out[10 + i] + threadIdx.x) & ((1u << 28) - 1u); z.v[i] = ((out[20 + i] ^ seed) + threadIdx.x) & ((1u << 28) - 1u); }
+    for (int i = 0; i < iters; i++) {
+        if (SQ) { x = fe9_sq(x); y = fe9_sq(y); } else { x = fe9_mul(x, z); y = fe9_mul(y, z); }
+    }
+    u32 r = 0;
+    for (int i = 0; i < 9; i++) r ^= x.v[i] ^ y.v[i];
+    if (r == 0x12345678u) out[0] = r;
+}
 hipError_t launch_selftest_c1(int op, const uint32_t *a, const uint32_t *b, uint64_t n, uint8_t *out, hipStream_t st) {   // chained-carry unit
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_selftest_field<1>, dim3(div_up(n, 256)), dim3(256), 0, st, op, a, b, n, out);
@@ -367,6 +419,13 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 33: hipLaunchKernelGGL(k_probe_mix_add<1>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 34: hipLaunchKernelGGL(k_probe_mix_add<2>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 35: hipLaunchKernelGGL(k_probe_mix_add<3>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+#define C25519_BP(PAT) \
+    case 50 + PAT: hipLaunchKernelGGL((k_probe_bpermute<PAT, false>), dim3(grid), dim3(256), 0, st, out, iters, 12345u); break; \
+    case 60 + PAT: hipLaunchKernelGGL((k_probe_bpermute<PAT, true>), dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    C25519_BP(0) C25519_BP(1) C25519_BP(2) C25519_BP(3) C25519_BP(4) C25519_BP(5) C25519_BP(6) C25519_BP(7)
+#undef C25519_BP
+    case 70: hipLaunchKernelGGL(k_probe_fe9<false>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    case 71: hipLaunchKernelGGL(k_probe_fe9<true>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -407,7 +466,7 @@ EXPORT double c25519_microbench(c25519_ctx *ctx, int which, int iters) {
     if (ms <= 0) return -1.0;
     // 6, 7: the mixed probes count their v_mad_u64_u32 only (8 per iteration), so the result reads as
     // "MAC rate with R simple integer ops issued beside every MAC"
-    double per_lane = (which >= 40 && which <= 42) ? 3.0 * iters : (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
+    double per_lane = (which >= 40 && which <= 42) ? 3.0 * iters : (which >= 70 && which <= 71) ? 2.0 * iters : (which == 0 || which >= 4) ? 8.0 * iters : 2.0 * iters;
     double total = per_lane * 256.0 * grid;
     return total / (ms * 1e-3) / 1e9;
 }

@@ -6,6 +6,7 @@
 #include "devio.h"
 #include "kernels.h"
 #include "fe26x.h"
+#include "knobs.h"
 #ifndef C25519_PREPC_ATTR
 #define C25519_PREPC_ATTR
 #endif
@@ -198,6 +199,159 @@ __global__ void __launch_bounds__(BS) k_mul_base_ct_split(const uint8_t *__restr
     }
     // secrets do not stay in LDS: the exchanged partial points are wiped
     for (int i = threadIdx.x; i < PER * 10; i += BS) lds[i] = make_uint4(0, 0, 0, 0);
+}
+
+// ---- constant-time fixed base by CROSS-LANE FETCH (round 5): no scan, no selects ------------------------------------------
+// The full-window scan above is at its issue bound with 434 v_cndmask per window beside the 757 multiplier instructions of the addition
+// (a select costs a whole 4-cycle slot on gfx950: profiles/r04_ab_fixed_base_ct.txt).  What the reference's LookupTable::select
+// (window.rs:54-76) has to guarantee is that no ADDRESS and no BRANCH depends on the digit.  Here the digit never reaches an address at all:
+//   * group of 2^W lanes (W = 5: the two 32-lane halves of a wave; W = 6: the wave): lane j of its group reads, from LDS, the table entry of the
+//     SIGNED digit value dv = j - 2^(W-1) of the current window -- |dv| selects the entry, and for dv < 0 the lane takes (y-x, y+x, p - 2dxy),
+//     i.e. the negated point (curve_models.rs:501-512), all decided by its LANE INDEX: six ds_read_b128 at lane-id addresses per window;
+//   * every lane then pulls the 24 words of ITS digit from lane (group base + d + 2^(W-1)) with ds_bpermute_b32 -- a register-to-register
+//     crossbar transfer through the LDS unit that reads no memory.  The digit is the permute's lane selector, nothing else.
+// No select on the digit, no conditional negation (the sign is part of the selector), 24 permutes + 6 reads instead of 96 reads + 434 selects.
+// Whether the permute's duration depends on the selector pattern was measured before adopting it (c25519_microbench 50 .. 67, tools/probes.py,
+// profiles/r05_bpermute_probe.txt: all-equal, identity, random within the group, pairs 32 lanes apart, random over the wave -- see the
+// constant-time paragraph of include/c25519_hip.h); with W = 5 a lane's sources stay inside its own 32-lane half by construction.
+// EXEC must be all ones at the permutes (an inactive source lane would return zeros): the scalar loop is block-uniform, lanes past the end
+// of the batch run on a zero scalar and are masked at the store.
+// LDS table: [window][part 0..2 = y+x, y-x, 2dxy][16-byte half 0..1][entry 0..2^(W-1)]: consecutive lanes read consecutive 16-byte pieces.
+template <int W>
+struct ctp_lane {
+    static constexpr int GS = 1 << W, HALF = GS / 2, ENT = HALF + 1, WSTRIDE = 6 * ENT;
+    u32 a0, a1, b0, b1, c0, c1;      // uint4 offsets of this lane's six pieces inside a window's table
+    u32 group;                       // first lane of this lane's group
+    bool neg;                        // this lane serves a negative digit value
+    __device__ __forceinline__ void init(u32 lane) {
+        const int j = (int)(lane & (GS - 1)), dv = j - HALF;
+        neg = dv < 0;
+        const u32 mag = (u32)(neg ? -dv : dv);
+        const u32 pa = neg ? 1u : 0u, pb = neg ? 0u : 1u;
+        a0 = (pa * 2 + 0) * ENT + mag; a1 = (pa * 2 + 1) * ENT + mag;
+        b0 = (pb * 2 + 0) * ENT + mag; b1 = (pb * 2 + 1) * ENT + mag;
+        c0 = (2 * 2 + 0) * ENT + mag; c1 = (2 * 2 + 1) * ENT + mag;
+        group = lane & ~(u32)(GS - 1);
+    }
+};
+// stage the table of gtab ([window][entry] x 6 uint4, the layout of build_window_table) into the LDS layout above
+template <int W, int BS>
+__device__ __forceinline__ void ctp_stage(uint4 *lds, const uint4 *__restrict__ gtab) {
+    constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
+    for (int i = threadIdx.x; i < NWIN * ENT * 6; i += BS) {
+        const int win = i / (ENT * 6), r = i - win * (ENT * 6), e = r / 6, q = r - e * 6;
+        lds[win * (ENT * 6) + q * ENT + e] = gtab[i];
+    }
+}
+// the affine Niels point of signed digit dsel - 2^(W-1) of the window whose table starts at wtab (dsel in [0, 2^W))
+template <int W>
+__device__ __forceinline__ ge_aniels ctp_fetch(const uint4 *wtab, const ctp_lane<W> &L, u32 dsel) {
+    uint4 v[6] = {wtab[L.a0], wtab[L.a1], wtab[L.b0], wtab[L.b1], wtab[L.c0], wtab[L.c1]};
+    {   // p - 2dxy for the lanes that serve a negative digit value (a choice by lane index)
+        const u32 c[8] = {v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
+        u32 m[8];
+        u64 borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const u64 pi = (i == 0) ? 0xffffffedull : (i == 7 ? 0x7fffffffull : 0xffffffffull);
+            const u64 d = pi - (u64)c[i] - borrow;
+            borrow = (d >> 63) & 1;
+            m[i] = L.neg ? (u32)d : c[i];
+        }
+        v[4] = make_uint4(m[0], m[1], m[2], m[3]); v[5] = make_uint4(m[4], m[5], m[6], m[7]);
+    }
+    const int sel = (int)((L.group + dsel) << 2);        // byte address of the source lane's register
+    u32 tw[24];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        tw[4 * i + 0] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)v[i].x);
+        tw[4 * i + 1] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)v[i].y);
+        tw[4 * i + 2] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)v[i].z);
+        tw[4 * i + 3] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)v[i].w);
+    }
+    return aniels_from_words(tw);
+}
+// SPLIT = false: one lane per scalar, all windows (large batches).  SPLIT = true: two lanes per scalar, windows [0, NWIN/2) and [NWIN/2, NWIN)
+// (small batches: every compute unit gets a block; the partial sums meet through the table's LDS space -- cf. k_mul_base_ct_split)
+template <int W, int BS, int OUT, bool SPLIT>
+__global__ void __launch_bounds__(BS) k_mul_base_ctp(const uint8_t *__restrict__ scalars, u64 n, const uint4 *__restrict__ gtab, u32 *__restrict__ scratch,
+                                                     uint8_t *__restrict__ out_raw) {
+    constexpr int NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1, PER = SPLIT ? BS / 2 : BS, WLO = NWIN / 2;
+    extern __shared__ uint4 lds[];
+    ctp_stage<W, BS>(lds, gtab);
+    __syncthreads();
+    ctp_lane<W> L;
+    L.init(threadIdx.x & 63u);
+    // (wave-uniform: PER is a multiple of 64 -- said to the compiler with readfirstlane, so that the window loop below is a SCALAR loop:
+    //  a loop on a per-lane trip count would run under an exec mask, and the permutes need all 64 lanes)
+    const int part = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= (unsigned)PER)) : 0, j = (int)threadIdx.x - part * PER;
+    const int win0 = part ? WLO : 0, win1 = (SPLIT && !part) ? WLO : NWIN;
+#pragma unroll 1
+    for (u64 base = (u64)blockIdx.x * PER; base < n; base += (u64)gridDim.x * PER) {    // block-uniform trip count (permutes and barriers inside)
+        const u64 idx = base + (u64)j;
+        const bool valid = idx < n;
+        u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) load8(scalars, idx, s);
+        u32 carry = 0;
+#pragma unroll 1
+        for (int win = 0; win < win0; win++) {               // the recoding's carry into this thread's first window (scalar.rs:1136-1147)
+            const u32 d = (s[0] & (2u * HALF - 1u)) + carry;
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = (s[i] >> W) | (s[i + 1] << (32 - W));
+            s[7] >>= W;
+            carry = d >= (u32)HALF ? 1u : 0u;
+        }
+        ge_p3 P = ge_identity();
+        const uint4 *wtab = lds + win0 * (ENT * 6);
+#pragma unroll 1
+        for (int win = win0; win < win1; win++) {
+            const u32 d = (s[0] & (2u * HALF - 1u)) + carry;                 // 0 .. 2^W
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = (s[i] >> W) | (s[i + 1] << (32 - W));
+            s[7] >>= W;
+            // recentre to [-HALF, HALF) except in the top window (scalar.rs:1136-1147): digit value d - 2^W when d >= HALF; the selector is
+            // (digit value + HALF) in [0, 2^W) -- i.e. d + HALF, or d - HALF after a carry out
+            const bool hi = (win != NWIN - 1) && (d >= (u32)HALF);
+            carry = hi ? 1u : 0u;
+            const u32 dsel = hi ? d - (u32)HALF : d + (u32)HALF;
+            P = ge_p1p1_to_p3(ge_madd(P, ctp_fetch<W>(wtab, L, dsel)));
+            wtab += ENT * 6;
+        }
+        if (SPLIT) {
+            // the upper halves go through LDS (the table's space: every wave is past its last table read after the barrier)
+            __syncthreads();
+            uint4 *xch = lds + (size_t)j * 10;
+            if (part) {
+                u32 t[40];
+                for (int i = 0; i < 10; i++) { t[i] = P.X.v[i]; t[10 + i] = P.Y.v[i]; t[20 + i] = P.Z.v[i]; t[30 + i] = P.T.v[i]; }
+                for (int i = 0; i < 10; i++) xch[i] = make_uint4(t[4 * i], t[4 * i + 1], t[4 * i + 2], t[4 * i + 3]);
+            }
+            __syncthreads();
+            if (!part) {
+                u32 t[40];
+                for (int i = 0; i < 10; i++) { const uint4 v = xch[i]; t[4 * i] = v.x; t[4 * i + 1] = v.y; t[4 * i + 2] = v.z; t[4 * i + 3] = v.w; }
+                ge_p3 Q;
+                for (int i = 0; i < 10; i++) { Q.X.v[i] = t[i]; Q.Y.v[i] = t[10 + i]; Q.Z.v[i] = t[20 + i]; Q.T.v[i] = t[30 + i]; }
+                P = ge_add(P, Q);
+            }
+        }
+        if (valid && !part) {
+            if (OUT == 1) raw160_store(out_raw, idx, P);
+            else if (OUT == 2) {
+                uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
+                u32 o[40];
+                for (int i = 0; i < 10; i++) { o[i] = P.X.v[i]; o[10 + i] = P.Y.v[i]; o[20 + i] = P.Z.v[i]; o[30 + i] = P.T.v[i]; }
+                for (int i = 0; i < 10; i++) q[i] = make_uint4(o[4 * i], o[4 * i + 1], o[4 * i + 2], o[4 * i + 3]);
+            } else p32_store(scratch, idx, P.X, P.Y, P.Z);
+        }
+        if (SPLIT) {
+            // a further iteration needs the table again: restore it (only batches that outgrow the grid take this path)
+            __syncthreads();
+            if (base + (u64)gridDim.x * PER < n) { ctp_stage<W, BS>(lds, gtab); __syncthreads(); }
+        }
+    }
+    // secrets do not stay in LDS: the exchanged partial points are wiped
+    if (SPLIT) for (int i = threadIdx.x; i < PER * 10; i += BS) lds[i] = make_uint4(0, 0, 0, 0);
 }
 
 // ================================================================================================
@@ -559,9 +713,35 @@ static hipError_t launch_ct_split(const uint8_t *scalars, u64 n, const uint32_t 
 #undef C25519_CT_SPLIT_LAUNCH
     return hipGetLastError();
 }
+// the cross-lane-fetch form (k_mul_base_ctp)
+template <int W, int BS, bool SPLIT>
+static hipError_t launch_ctp(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
+    constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
+    const size_t lds_bytes = (size_t)NWIN * ENT * 96;      // (SPLIT: the exchange of BS/2 x 160 bytes reuses it: 80 KB <= 85 KB at BS = 1024)
+    unsigned grid = div_up(n, SPLIT ? BS / 2 : BS);
+    if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+#define C25519_CTP_LAUNCH(OUTV)                                                                                                        \
+    {                                                                                                                                  \
+        auto kfn = k_mul_base_ctp<W, BS, OUTV, SPLIT>;                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+        if (e != hipSuccess) return e;                                                                                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab_ct), scratch, out_raw); \
+    }
+    if (p40) C25519_CTP_LAUNCH(2) else if (out_raw) C25519_CTP_LAUNCH(1) else C25519_CTP_LAUNCH(0)
+#undef C25519_CTP_LAUNCH
+    return hipGetLastError();
+}
+// A/B knob (tuning build only): 0 = the full-window scan of rounds 2-4 (k_mul_base<5, CT>, k_mul_base_ct_split), 1 = the cross-lane fetch
+static int ct_fetch() { static const int v = C25519_KNOB("CT_FETCH", 1); return v; }
 // the kernel launch_mul_base_ct picks for n scalars (what the timing records attribute phase 0 to)
 const char *mul_base_ct_kernel_name(u64 n, int num_cus) {
     const u64 per_cu = (n + (u64)num_cus - 1) / (u64)(num_cus > 0 ? num_cus : 1);
+    if (ct_fetch()) {
+        if (per_cu <= 128) return "c25519::k_mul_base_ctp<5, 256, OUT, split> (constant-time cross-lane fetch, two lanes per scalar)";
+        if (per_cu <= 256) return "c25519::k_mul_base_ctp<5, 512, OUT, split> (constant-time cross-lane fetch, two lanes per scalar)";
+        if (per_cu <= 512) return "c25519::k_mul_base_ctp<5, 1024, OUT, split> (constant-time cross-lane fetch, two lanes per scalar)";
+        return "c25519::k_mul_base_ctp<5, 1024, OUT> (constant-time cross-lane fetch, radix-2^5 tables in LDS)";
+    }
     if (per_cu <= 128) return "c25519::k_mul_base_ct_split<256, OUT> (constant-time scan, two lanes per scalar)";
     if (per_cu <= 256) return "c25519::k_mul_base_ct_split<512, OUT> (constant-time scan, two lanes per scalar)";
     if (per_cu <= 512) return "c25519::k_mul_base_ct_split<1024, OUT> (constant-time scan, two lanes per scalar)";
@@ -569,14 +749,20 @@ const char *mul_base_ct_kernel_name(u64 n, int num_cus) {
 }
 hipError_t launch_mul_base_ct(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
     if (n == 0) return hipSuccess;
-    // small batches: two threads per scalar, one block per compute unit (k_mul_base_ct_split); the block grows with the batch
+    // small batches: two threads per scalar, one block per compute unit; the block grows with the batch
     const u64 per_cu = (n + (u64)num_cus - 1) / (u64)num_cus;
-    if (per_cu <= 128) return launch_ct_split<256>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
-    if (per_cu <= 256) return launch_ct_split<512>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
-    if (per_cu <= 512) return launch_ct_split<1024>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
 #ifndef C25519_CT_BS
 #define C25519_CT_BS 1024
 #endif
+    if (ct_fetch()) {
+        if (per_cu <= 128) return launch_ctp<C25519_CT_W, 256, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+        if (per_cu <= 256) return launch_ctp<C25519_CT_W, 512, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+        if (per_cu <= 512) return launch_ctp<C25519_CT_W, 1024, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+        return launch_ctp<C25519_CT_W, C25519_CT_BS, false>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+    }
+    if (per_cu <= 128) return launch_ct_split<256>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+    if (per_cu <= 256) return launch_ct_split<512>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
+    if (per_cu <= 512) return launch_ct_split<1024>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
     return launch_mul_base_w<C25519_CT_W, C25519_CT_BS, true>(scalars, n, tab_ct, scratch, out_raw, num_cus, st, p40);
 }
 

@@ -3,6 +3,7 @@
 // Test-only: built by tests/test_fe26_host.py into tests/host/libfe26host.so.
 #define C25519_CHECK_BOUNDS 1
 #include "../../curve25519-dalek_amd/csrc/ge26.h"
+#include "../../curve25519-dalek_amd/csrc/fe9_probe.h"
 #include <string.h>
 using namespace c25519;
 
@@ -10,6 +11,13 @@ static feT load(const uint8_t b[32]) { u32 w[8]; memcpy(w, b, 32); return fe_fro
 static void store(uint8_t b[32], const feW &a) { u32 w[8]; fe_to_words(a, w); memcpy(b, w, 32); }
 
 extern "C" {
+// the nine-limb probe representation (csrc/fe9_probe.h): raw limbs in, raw limbs out (9 x u32), op 0 = mul, 1 = sq
+void h_fe9(int op, const uint32_t *a, const uint32_t *b, uint32_t *o) {
+    fe9 x, y;
+    for (int i = 0; i < 9; i++) { x.v[i] = a[i]; y.v[i] = b[i]; }
+    const fe9 r = op ? fe9_sq(x) : fe9_mul(x, y);
+    for (int i = 0; i < 9; i++) o[i] = r.v[i];
+}
 void h_fe_mul(const uint8_t *a, const uint8_t *b, uint8_t *o) { store(o, fe_mul(load(a), load(b))); }
 void h_fe_sq(const uint8_t *a, uint8_t *o) { store(o, fe_sq(load(a))); }
 void h_fe_add(const uint8_t *a, const uint8_t *b, uint8_t *o) { store(o, fe_add(load(a), load(b))); }

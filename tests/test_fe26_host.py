@@ -36,7 +36,7 @@ def host(request):
     """Both forms of fe_mul / fe_sq (fe26.h C25519_CHAIN: independent column sums, chained carries)."""
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libfe26host%d.so" % request.param)
-    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h")]
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "fe9_probe.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DC25519_CHAIN=%d" % request.param, "-o", so, src])
     return C.CDLL(so)
@@ -267,3 +267,30 @@ def test_sc28_device_scalar_arithmetic_vs_bigint(host):
     for v, want in [(0, 1), (1, 1), (L - 1, 1), (L, 0), (L + 1, 0), (2**255 - 1, 0), (2**255, 0), (2**256 - 1, 0), (2**252, 1), (2**252 + C_ - 1, 1)] + \
                    [(rng.getrandbits(256), None) for _ in range(300)] + [(L - d, None) for d in range(-40, 40)]:
         assert host.h_sc28_canonical(i2b(v)) == (want if want is not None else int(v < L)), hex(v)
+
+
+def test_nine_limb_probe_products_vs_bigint(host):
+    """csrc/fe9_probe.h (the 9 x 28.33-bit representation priced by c25519_microbench 70 / 71): product and square equal the big-integer
+    product mod p for random limbs and for limbs at their extreme -- every limb at 2^width - 1 + the slack a carried output may have
+    (limb 1 takes the final x19 carry) -- and the outputs are carried again (so products can be chained)."""
+    pos = [(85 * i + 2) // 3 for i in range(10)]
+    wid = [pos[i + 1] - pos[i] for i in range(9)]
+    assert pos[:9] == [0, 29, 57, 85, 114, 142, 170, 199, 227] and pos[9] == 255
+    rng = random.Random(909)
+    val = lambda l: sum(int(v) << pos[i] for i, v in enumerate(l))
+    def run(op, a, b):
+        A = (C.c_uint32 * 9)(*a); B = (C.c_uint32 * 9)(*b); O = (C.c_uint32 * 9)()
+        host.h_fe9(op, A, B, O)
+        return list(O)
+    for t in range(600):
+        extreme = t % 3 == 0
+        slack = 1 << 20                                      # what a carried output may exceed its width by
+        mk = lambda: [((1 << wid[i]) - 1 + (slack if i == 1 else 0)) if (extreme and rng.random() < 0.8) else rng.randrange(1 << wid[i]) for i in range(9)]
+        a, b = mk(), mk()
+        r = run(0, a, b)
+        assert val(r) % P == val(a) * val(b) % P
+        assert all(r[i] < (1 << wid[i]) + (slack if i == 1 else 0) for i in range(9)), r
+        q = run(1, a, a)
+        assert val(q) % P == val(a) ** 2 % P
+        r2 = run(0, r, q)                                    # outputs are valid inputs
+        assert val(r2) % P == val(r) * val(q) % P

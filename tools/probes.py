@@ -14,7 +14,8 @@ names = {0: "v_mad_u64_u32 (8 independent chains)", 22: "v_mad_u64_u32 (ONE depe
          29: "v_perm_b32", 30: "v_add_u32_sdwa (src1 WORD_1)", 31: "v_lshl_or_b32", 32: "v_add_co_u32 + v_addc_co_u32 (pair = 1)",
          6: "v_mad_u64_u32 with 1 v_xad_u32 beside each", 7: "v_mad_u64_u32 with 2 v_xad_u32 beside each",
          33: "v_mad_u64_u32 with 1 v_add_u32 beside each", 34: "v_mad_u64_u32 with 2 v_add_u32 beside each", 35: "v_mad_u64_u32 with 3 v_add_u32 beside each",
-         1: "fe_mul (chained carries)", 2: "fe_sq (chained carries)"}
+         1: "fe_mul (chained carries)", 2: "fe_sq (chained carries)",
+         70: "fe9_mul (9 limbs of 28.33 bits, chained: csrc/fe9_probe.h)", 71: "fe9_sq (9 limbs)"}
 for _ in range(60):
     e.microbench(0, 4000)                      # bring the clock up
 cus = 256
@@ -33,3 +34,20 @@ print("%-44s %10s %10s %10s" % ("three independent products, shape", "8 waves", 
 for w, nm in {40: "3 x fe_mul, chained, one after another", 41: "fe_mul_chain_n<3>: chained, in lockstep", 42: "3 x ten-column fe_mul"}.items():
     r = [max(e.microbench(w + o, 2000) for _ in range(5)) for o in (0, 200, 100)]
     print("%-44s %10.1f %10.1f %10.1f" % (nm, *r))
+
+# ds_bpermute_b32 under different selector patterns (diag.hip k_probe_bpermute): the measurement behind the cross-lane table fetch of the
+# constant-time fixed base (kernels.hip k_mul_base_ctp).  Throughput = eight independent permutes per trip at 8 waves per SIMD; latency = a chain of
+# DEPENDENT permutes (s_waitcnt after each) at ONE wave per SIMD.  If the crossbar serialised on any selector pattern, that row would be slower.
+print()
+print("%-72s %14s %14s %16s" % ("ds_bpermute_b32, source lane of lane l", "Gop/s chip", "cycles/wave*", "latency cycles*"))
+pats = {0: "identity (l)", 1: "all lanes pull lane 5", 2: "pseudo-random inside the own 32-lane half (k_mul_base_ctp<5>)", 3: "pairs 32 lanes apart inside a half (s, s + 32 alternating)",
+        4: "pseudo-random over the whole wave", 5: "two sources only (lane 0 / lane 32)", 6: "rotate by one", 7: "pseudo-random inside the half, new selectors every trip"}
+rows = []
+for ppat, nm in pats.items():
+    thr = max(e.microbench(50 + ppat, 4000) for _ in range(5))
+    lat = max(e.microbench(160 + ppat, 2000) for _ in range(5))      # + 100: one wave per SIMD; the chain is dependent: rate = 1 / latency
+    rows.append((thr, lat))
+    print("%-72s %14.1f %14.2f %16.1f" % (nm, thr, 1024 * 64 * 2.4 / thr, 1024 * 64 * 2.4 / lat))
+spread_t = max(r[0] for r in rows) / min(r[0] for r in rows)
+spread_l = max(r[1] for r in rows) / min(r[1] for r in rows)
+print("spread over the patterns: throughput x%.3f, latency x%.3f" % (spread_t, spread_l))
