@@ -97,6 +97,7 @@ class Workload:
         self.log2n, self.n = log2n, 1 << log2n
         self.variant = ""
         self.force_collective = False
+        self.step_times = None         # multi.StepTimes while the timed steps of a launcher run are measured (shard / collective / read-back + fold)
         self.result = {}
         gen = torch.Generator(device=dev)
         gen.manual_seed(0xC25519 + 1000 * rank + {"msm": 1, "verify": 2, "fixed_base": 3, "x25519": 4}[name])
@@ -122,7 +123,7 @@ class Workload:
         def run():
             # this rank's partial sum, then the one exchange step (160 B per rank over RCCL) + fold
             # (under a launcher the collective runs even at world size 1, so that a one-GPU run exercises RCCL as well)
-            st, out = self.pkg.multi.msm_vartime_sharded(self.eng, self.xs, self.pts, E.FMT_RAW160, E.FMT_EDWARDS_Y, force_collective=self.force_collective)
+            st, out = self.pkg.multi.msm_vartime_sharded(self.eng, self.xs, self.pts, E.FMT_RAW160, E.FMT_EDWARDS_Y, force_collective=self.force_collective, times=self.step_times)
             assert st == 0
             self.result["out"] = out
         self.run = run
@@ -189,6 +190,7 @@ class Workload:
             got = self.pkg.multi.fold_partials([part], E.FMT_EDWARDS_Y)
             if st != 0 or got != want:
                 raise SystemExit("SELF-CHECK FAILURE: MSM result differs from (sum x_i y_i) B")
+            self.sum_xy, self.msm_enc = (acc % L_ORDER).to_bytes(32, "little"), got      # for the oracle comparison of the cpu_baseline leg
             del self.ys
 
     # -- kernel timings from the HIP events the library records on the launch streams -----------------------------------
@@ -286,6 +288,10 @@ class Workload:
                 raise SystemExit("PARITY FAILURE: MSM result differs from the CPU restatement's")
             if orc.ed_compress(orc.ed_msm_mt_np(xa[:m0], pa[:m0], min(cores, 4))) != want:
                 raise SystemExit("PARITY FAILURE: the sliced CPU MSM differs from the single call")
+            # the FULL-SIZE result of the headline workload against the oracle: (sum x_i y_i mod l) B by the oracle's own fixed-base multiplication
+            # (self_check compared it with the product's fixed-base kernel only)
+            if getattr(self, "sum_xy", None) is not None and orc.ed_compress(orc.ed_mul_base(self.sum_xy)) != self.msm_enc:
+                raise SystemExit("PARITY FAILURE: the full-size MSM result differs from the oracle's (sum x_i y_i mod l) B")
             probe = 4096
             f = lambda m, t: orc.ed_msm_np(xa[:m], pa[:m]) if t == 1 else orc.ed_msm_mt_np(xa[:m], pa[:m], t)
         else:
@@ -659,13 +665,51 @@ def main():
             dist.broadcast(t, 0)
             k = int(t.item())
         args.steps = k
-    dt = time_steps(w.run, args.steps, args.warmup, barrier)
+    step_break = None
+    if use_dist and head == "msm":
+        # one collective outside the timed region (communicator set-up, first-use allocations of RCCL), then the per-step breakdown: every step
+        # adds its shard / collective / read-back + fold to a StepTimes (HIP events on the launch stream: no extra synchronisation)
+        for _ in range(2):
+            w.run()
+        barrier()
+        w.step_times = pkg.multi.StepTimes()
+        time_steps(w.run, 0, args.warmup, barrier)          # the warm-up steps count for nothing: reset after them
+        w.step_times = pkg.multi.StepTimes()
+        dt = time_steps(w.run, args.steps, 0, barrier)
+        step_break = w.step_times.mean()
+        w.step_times = None
+    else:
+        dt = time_steps(w.run, args.steps, args.warmup, barrier)
     w.kt = w.kernel_times(args.steps)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rccl_ranks = dist.get_world_size() if use_dist else 1
+    multi_gpu = None
+    if step_break is not None:
+        # max over ranks of each part (the step is as long as its slowest rank), beside the model of what this N should show: the shard as this
+        # rank measured it, the fold of N records measured alone on the host, and the exchange ASSUMED at 0.05 ms by scale_model (N = 1 line)
+        v = torch.tensor([step_break["shard_ms"], step_break["collective_ms"], step_break["d2h_fold_ms"], step_break["sum_ms"]], dtype=torch.float64, device=dev)
+        vmin = v.clone()
+        dist.all_reduce(v, op=dist.ReduceOp.MAX); dist.all_reduce(vmin, op=dist.ReduceOp.MIN)
+        mx, mn = v.tolist(), vmin.tolist()
+        import numpy as np
+        rec1 = eng.msm_partial_record_t(w.xs[:1 << 12].contiguous(), w.pts[:1 << 12].contiguous(), E.FMT_RAW160).cpu().numpy()
+        recs = np.ascontiguousarray(np.tile(rec1.reshape(1, -1), (world, 1)))
+        ts = []
+        for _ in range(7):
+            c0 = time.perf_counter(); E.fold_partial_records(recs, E.FMT_EDWARDS_Y); ts.append((time.perf_counter() - c0) * 1e3)
+        fold_alone = sorted(ts)[len(ts) // 2]
+        multi_gpu = {"what": "per step, mean over the timed steps: max (min) over ranks of this rank's shard on its GPU [HIP events on the launch stream], the all_gather of the records "
+                             "[events around all_gather_into_tensor], and the rest of the call (read-back of N records + host fold + launch latency); sum_ms = the call's wall-clock",
+                     "shard_ms": mx[0], "collective_ms": mx[1], "d2h_fold_ms": mx[2], "sum_ms": mx[3],
+                     "min_over_ranks": {"shard_ms": mn[0], "collective_ms": mn[1], "d2h_fold_ms": mn[2], "sum_ms": mn[3]},
+                     "ranks_seen_by_rccl": rccl_ranks, "rccl_warmup_collectives_outside_timed_region": 2 + args.warmup,
+                     "model": {"shard_ms": mx[0], "fold_of_N_records_alone_ms": fold_alone, "exchange_ms_assumed_by_scale_model": 0.05,
+                               "predicted_step_ms": mx[0] + fold_alone + 0.05,
+                               "how": "scale_model (the N = 1 line) predicts step(N) = shard(2^24 / N terms on one GPU) + fold(N records) + 0.05 ms assumed for the exchange: "
+                                      "compare collective_ms with the 0.05 and d2h_fold_ms with the fold measured alone"}}
 
     want_cpu = (rank == 0 and world == 1 and not args.no_cpu_baseline)
     budget = float(os.environ.get("C25519_BENCH_CPU_S", "10"))
@@ -674,6 +718,9 @@ def main():
         res = record(w, dt, args.steps, args.warmup, world, mac_peak, w.cpu_baseline(budget) if want_cpu else None, scaling, clock_hz)
         res["ranks_seen_by_rccl"] = rccl_ranks
         res["collective_executed_per_step"] = bool(use_dist and head == "msm")
+        if multi_gpu is not None:
+            multi_gpu["measured_step_ms"] = res["ms_per_step"]
+            res["multi_gpu"] = multi_gpu
     if use_dist:
         dist.barrier()
 

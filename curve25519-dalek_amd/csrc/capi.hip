@@ -179,11 +179,15 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreateWithFlags(&ctx->ev_in, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_z, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_pts, hipEventDisableTiming);
+    for (int q = 0; q < 4; q++) hipEventCreateWithFlags(&ctx->ev_grp[q], hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_lists[0], hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_lists[1], hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
     // C25519_MAX_SLOTS pass slots + the context's own record (msm.hip drec)
     if (hipMalloc((void **)&ctx->d_slots, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4) != hipSuccess) return false;
-    return hipHostMalloc(&ctx->h_msm, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4, hipHostMallocDefault) == hipSuccess;
+    // (coherent + mapped: the publishing kernel writes the slots and the "published" word straight into this buffer while the host polls it)
+    if (hipHostMalloc(&ctx->h_msm, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4 + 256, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return false;
+    memset((uint8_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4, 0, 256);
+    return true;
 }
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
 c25519_ctx *ctx_peer(c25519_ctx *ctx) {
@@ -247,7 +251,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all};
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all, &ctx->dom};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
     if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
@@ -265,6 +269,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
     if (ctx->ev_pts) hipEventDestroy(ctx->ev_pts);
     for (int q = 0; q < 2; q++) if (ctx->ev_lists[q]) hipEventDestroy(ctx->ev_lists[q]);
+    for (int q = 0; q < 4; q++) if (ctx->ev_grp[q]) hipEventDestroy(ctx->ev_grp[q]);
     if (ctx->s_h2d) { hipStreamSynchronize(ctx->s_h2d); hipStreamDestroy(ctx->s_h2d); }
     if (ctx->s_d2h) { hipStreamSynchronize(ctx->s_d2h); hipStreamDestroy(ctx->s_d2h); }
     for (int i = 0; i < c25519_ctx::FFI_MAXCH; i++) { if (ctx->ev_up[i]) hipEventDestroy(ctx->ev_up[i]); if (ctx->ev_kd[i]) hipEventDestroy(ctx->ev_kd[i]); }
@@ -337,6 +342,13 @@ EXPORT float c25519_last_call_phase_ms(c25519_ctx *ctx, int phase, uint32_t *pas
 }
 
 // ---- host-pointer staging (ffi.h) ---------------------------------------------------------------------------------
+double wall_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+// host clock of the phases of the latest synchronous MSM / verify_batch call on this context, microseconds since its entry: [0] inputs staged / upload
+// enqueued (0 for the device-pointer forms), [1] all kernels enqueued, [2] results on the host, [3] folded and encoded: the call returns
+EXPORT int32_t c25519_last_call_host_us(const c25519_ctx *ctx, double *out4) {
+    for (int i = 0; i < 4; i++) out4[i] = ctx->host_us[i + 1] >= ctx->host_us[0] ? ctx->host_us[i + 1] - ctx->host_us[0] : 0.0;
+    return C25519_OK;
+}
 static inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int32_t ffi_begin(c25519_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));

@@ -32,8 +32,14 @@ struct c25519_ctx {
     void *d_flag = nullptr;        // 256 bytes of device flags / small results
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr, ev_pts = nullptr;
+    hipEvent_t ev_grp[4] = {nullptr, nullptr, nullptr, nullptr};   // single-pass MSM in window groups: [q] = the accumulation of group q has finished (msm.hip msm_enqueue_acc)
     hipEvent_t ev_lists[2] = {nullptr, nullptr};        // multi-pass MSM: [q] = recorded when the pass with list parity q was enqueued (the accumulation before it has finished)
-    void *h_msm = nullptr;                               // pinned: C25519_MAX_SLOTS result slots
+    void *h_msm = nullptr;                               // pinned, coherent, device-mapped: C25519_MAX_SLOTS + 1 result slots and the "published" word behind them (msm.hip publish_and_wait)
+    uint32_t publish_seq = 0;                            // sequence number of the latest publication
+    hipEvent_t coarse_wait = nullptr;                    // set by an enqueue function of a long call: the host blocks on it before it polls for the results
+    // host clock of the latest synchronous MSM / verify_batch call, microseconds: [0] entry, [1] inputs staged / upload enqueued, [2] all kernels enqueued,
+    // [3] results on the host, [4] folded / encoded (c25519_last_call_host_us)
+    double host_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void *h_stage = nullptr; size_t h_stage_cap = 0;     // pinned, grown on demand: hram / s / z of the strict z-mode of verify_batch (ctx_host_stage)
     uint32_t *d_slots = nullptr;                         // device: C25519_MAX_SLOTS result slots (written by this context and its peer)
     // a second set of streams / workspaces on the same device (shares the fixed-base tables): multi-pass MSM and
@@ -44,6 +50,7 @@ struct c25519_ctx {
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
     devbuf tmp_a, tmp_b, tmp_c, tmp_c2, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
     const uint32_t *cont_buckets = nullptr;                    // where the latest MSM pass on this context keeps its bucket sums (checked by a continuing pass)
+    devbuf dom; std::vector<uint8_t> h_dom;                      // Ed25519ph: dom2 of the latest prehashed call (device copy / host source of its upload)
     devbuf pts_all;                                            // gather records of passes 1.. of a multi-pass MSM (prepared ahead in one launch)
     // names of the kernels the latest entry point launched: [0] its dominant kernel (k_mul_base*, k_x25519, k_var_base, k_accumulate),
     // [1] the decompression of R_i in a verify_batch pass -- what c25519_phase_ms phases 0 and 3 time
@@ -69,6 +76,7 @@ struct stream_wipe {
 };
 
 int32_t c25519_fail(c25519_ctx *ctx, hipError_t e, const char *where);
+double wall_us();
 int32_t ctx_reserve(c25519_ctx *ctx, devbuf &b, size_t bytes);
 // page-locked host staging of at least `bytes` bytes, kept by the context (fresh pageable buffers pay first-touch faults at ~5 GB/s inside a copy)
 int32_t ctx_host_stage(c25519_ctx *ctx, size_t bytes);

@@ -354,7 +354,11 @@ __global__ void __launch_bounds__(256) k_probe_bpermute(u32 *out, int iters, u32
                          "ds_bpermute_b32 %4, %8, %4\n\tds_bpermute_b32 %5, %8, %5\n\tds_bpermute_b32 %6, %8, %6\n\tds_bpermute_b32 %7, %8, %7\n\ts_waitcnt lgkmcnt(0)"
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(sel));
         }
-        if (PAT == 7) { h = h * 1664525u + 1013904223u; sel = (int)(((lane & 32u) | ((h >> 9) & 31u)) << 2); }
+        // (every pattern runs the same selector arithmetic, so that the rows differ by the selectors only; pattern 7 alone USES the new one)
+        h = h * 1664525u + 1013904223u;
+        const int nsel = (int)(((lane & 32u) | ((h >> 9) & 31u)) << 2);
+        asm volatile("" :: "v"(nsel));
+        if (PAT == 7) sel = nsel;
     }
     const int r = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
     if (r == 0x12345678) out[0] = (u32)r;

@@ -16,6 +16,9 @@ hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st);
 // flags[0] += signatures with a non-canonical s; flags[1] |= 1 if the message offsets are not monotone / run past msgs_len
 hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st);
+// Ed25519ph / Ed25519ctx: SHA-512(dom2 || R || A || M); msg_off == nullptr: messages of fixed_len bytes (verify.hip k_hram_dom)
+hipError_t launch_hram_dom(const uint8_t *dom, uint32_t dom_len, const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, uint32_t fixed_len, const uint8_t *sigs, const uint8_t *pks,
+                           uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st);
 hipError_t launch_compress_p32(const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_x25519(const uint8_t *k, const uint8_t *u, uint64_t n, uint32_t *scratch, hipStream_t st);
 hipError_t launch_ratio_p32(int mode, const uint32_t *scratch, uint32_t *prefix, uint64_t n, uint8_t *out, hipStream_t st);

@@ -467,6 +467,26 @@ void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
     for (int k = g.nwin; k < MSM_MAX_WIN; k++) { g.pos[k] = 0; g.wid[k] = 1; }
     msm_slice_params(g);
     for (int i = 0; i < 8; i++) g.addk[i] = a[i];
+    g.ngroups = 1; g.gstart[0] = 0;
+    for (int i = 1; i <= MSM_MAX_GROUPS; i++) g.gstart[i] = (unsigned char)g.nwin;
+}
+// Window groups of a single-pass call (msm_geom): `groups` groups of consecutive windows; `last` (0 = equal shares) = content windows of the final
+// group, whose bucket reduction is the exposed tail of the call.  The overflow window (a handful of entries) rides with the final group.  Only layouts
+// whose windows have at least 1024 buckets (a block of the bucket-order kernel must not straddle groups) and at least two windows per group.
+void msm_set_groups(msm_geom &g, int groups, int last) {
+    g.ngroups = 1; g.gstart[0] = 0;
+    for (int i = 1; i <= MSM_MAX_GROUPS; i++) g.gstart[i] = (unsigned char)g.nwin;
+    groups = std::min(groups, MSM_MAX_GROUPS);
+    const int content = g.nwin - 1;
+    if (groups < 2 || g.half < 1024 || content < 2 * groups) return;
+    if (last < 1 || last > content - (groups - 1)) last = 0;
+    int at = 0;
+    for (int q = 0; q < groups - 1; q++) {
+        const int left = content - at - last, share = last ? (left + (groups - 2 - q)) / (groups - 1 - q) : (content - at + (groups - 1 - q)) / (groups - q);
+        at += share;
+        g.gstart[q + 1] = (unsigned char)at;
+    }
+    g.ngroups = (unsigned char)groups;
 }
 // diagnostics (host only, no GPU needed): the layout the MSM would use for n terms
 EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_t *pos, uint8_t *wid, uint32_t *addk) {
@@ -534,16 +554,30 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     //  the next pass -- 18.2 - 20.3 ms per 2^24 terms against 16.5; 512-thread blocks, i.e. two waves per SIMD with 176
     //  registers: 16.9 - 17.0 against 16.6 - 16.9; an LDS reservation to the same effect: 16.2 against 15.9; four waves per SIMD
     //  without a prefetched record: 16.0 / 15.5 against 15.1 - 15.3; un-serialised accumulations of neighbouring passes: +3 - 9 %)
-    ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm, pl.nb, pl.n, g, pl.buckets, cont ? 1 : 0, st);
+    static const int coop_reduce = C25519_KNOB("REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
+    // Window groups (msm_geom, single-pass calls): k_accumulate is launched once per group on the main stream -- the groups' stretches of the bucket
+    // order are separate -- and the second (high-priority) stream reduces group q as soon as ITS accumulation has finished, beside the accumulation
+    // of group q + 1: what remains exposed at the end of the call is the reduction of the last group only.
+    const int groups = (g.ngroups > 1 && reduce && !cont && coop_reduce) ? g.ngroups : 1;
+    for (int q = 0; q < groups; q++) {
+        const int k0 = groups > 1 ? g.gstart[q] : 0, k1 = groups > 1 ? g.gstart[q + 1] : g.nwin;
+        ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm + (size_t)k0 * g.half, (uint64_t)(k1 - k0) * g.half, pl.n, g, pl.buckets, cont ? 1 : 0, st);
+        if (groups > 1) {
+            HIPCHK(hipEventRecord(ctx->ev_grp[q], st));
+            HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_grp[q], 0));        // (behind the long-bucket kernels the second stream already holds)
+            launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux, k0, k1);
+            HIPCHK(hipGetLastError());
+        }
+    }
     HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     // The bucket reduction runs on the SECOND (high-priority) stream, behind the long-bucket kernels it depends on anyway.  On the
     // main stream its few small blocks had normal priority: once the sort of the next pass stopped being late (round 3) the next
     // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
     // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
-    if (reduce) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));      // (without a reduction nothing on the second stream needs the accumulated buckets)
-    static const int coop_reduce = C25519_KNOB("REDUCE_COOP", 1);     // A/B knob: 0 = rounds 2-3's one-lane-per-point reduction (k_reduce_a / k_reduce_b below)
-    if (reduce && coop_reduce) {
+    if (reduce && groups == 1) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));      // (without a reduction nothing on the second stream needs the accumulated buckets)
+    if (groups > 1) {
+    } else if (reduce && coop_reduce) {
         launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, ctx->aux);
         HIPCHK(hipGetLastError());
     } else if (reduce) {
@@ -593,17 +627,64 @@ ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
     }
     return hp3_to(total);
 }
-// read slots [0, count) back (one copy, one synchronisation of the context's main stream)
-int32_t slots_collect(c25519_ctx *ctx, int count) {
-    HIPCHK(hipMemcpyAsync(ctx->h_msm, ctx->d_slots, (size_t)count * C25519_SLOT_U32 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+// ---- how a call's results reach the host (round 5) ------------------------------------------------------------------------------
+// Rounds 1-4: hipMemcpyAsync of the slots into page-locked memory + hipStreamSynchronize -- a copy-engine launch, an interrupt and a thread
+// wake-up at the end of EVERY call: 40 - 60 us, a third of a 1-term MSM and 2 - 3 % of a 2^21-term one (profiles/r05_small_call_phases.txt).
+// Now the last kernel on the stream WRITES the slots into the context's page-locked, coherent host buffer itself (the buffer is mapped into the
+// device's address space) and then stores a sequence number behind a system-scope release fence; the host polls that word.  No copy engine, no
+// interrupt.  So that a long call does not burn a core for milliseconds, the host first blocks on an event recorded earlier in the call (the end
+// of the last accumulation: ctx->coarse_wait, set by the enqueue functions for calls of more than ~0.3 ms) and only polls through the tail.
+// A GPU fault never sets the word: every ~0.5 ms of polling the stream's status is queried and an error returned.
+namespace c25519 {
+__global__ void __launch_bounds__(1024) k_publish(const u32 *__restrict__ src, u32 *__restrict__ host_dst, u32 words, u32 *__restrict__ host_flag, u32 seq) {
+    for (u32 i = threadIdx.x; i < words; i += 1024) host_dst[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(host_flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace c25519
+static inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
+static int32_t publish_and_wait(c25519_ctx *ctx, const uint32_t *d_src, uint32_t *h_dst, size_t words) {
+    uint32_t *flag = (uint32_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;      // the word behind the slots (ctx_make_streams)
+    uint32_t seq = ++ctx->publish_seq;
+    if (seq == 0) seq = ++ctx->publish_seq;
+    ctx->host_us[2] = wall_us();                                          // everything is enqueued
+    static const int publish = C25519_KNOB("PUBLISH", 1);                // A/B knob: 0 = rounds 1-4 (copy engine + hipStreamSynchronize)
+    if (!publish) {
+        ctx->coarse_wait = nullptr;
+        HIPCHK(hipMemcpyAsync(h_dst, d_src, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        ctx->host_us[3] = wall_us();
+        return C25519_OK;
+    }
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, ctx->stream, d_src, h_dst, (uint32_t)words, flag, seq);
+    HIPCHK(hipGetLastError());
+    if (ctx->coarse_wait) { (void)hipEventSynchronize(ctx->coarse_wait); ctx->coarse_wait = nullptr; }      // (blocking: the long part of a long call)
+    volatile uint32_t *vf = flag;
+    for (uint64_t spins = 1;; spins++) {
+        if (*vf == seq) break;
+        cpu_relax();
+        if ((spins & 0x3ffff) == 0) {                                     // ~ every half millisecond of polling: is the stream still healthy?
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return c25519_fail(ctx, e, "waiting for a call's results");
+            if (e == hipSuccess && *vf != seq) return c25519_fail(ctx, hipErrorUnknown, "results were not published");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    ctx->host_us[3] = wall_us();                                          // the results are on the host
     return C25519_OK;
+}
+// slots [0, count) -> the host
+int32_t slots_collect(c25519_ctx *ctx, int count) {
+    return publish_and_wait(ctx, ctx->d_slots, (uint32_t *)ctx->h_msm, (size_t)count * C25519_SLOT_U32);
 }
 // the context's own record (slot C25519_MAX_SLOTS of d_slots / h_msm): where a call that answers on the host sums its passes
 int32_t rec_collect(c25519_ctx *ctx) {
-    HIPCHK(hipMemcpyAsync((uint32_t *)ctx->h_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32, drec(ctx), (size_t)C25519_SLOT_U32 * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
-    return C25519_OK;
+    return publish_and_wait(ctx, drec(ctx), (uint32_t *)ctx->h_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32, C25519_SLOT_U32);
 }
 void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st, int c) {
     hipLaunchKernelGGL(k_slot_init, dim3(1), dim3(256), 0, st, d_slot, (uint32_t)terms, (uint32_t)(terms >> 32), terms ? 1u : 0u, (uint32_t)c, d_pre);
@@ -872,13 +953,25 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     pl.bad_sticky = d_bad_sticky;
     // (normalisation first, then the sort on the second stream: 2.26 against 2.34 ms at 2^21 terms the other way round)
     static const int serial_sort = C25519_KNOB("PROFILE_SERIAL_SORT", 0);     // profiling: the sort only starts after the normaliser, so that its kernels can be timed alone
+    // SORT_FIRST (A/B knob): 1 = the sort is enqueued (second, high-priority stream) BEFORE the normaliser, so that its first kernel -- whose
+    // 1024-thread blocks of 128 VGPRs need an empty compute unit -- is dispatched first instead of picking up the compute units the normaliser's
+    // blocks leave one by one; 2 = the normaliser additionally waits for the partition half of the sort (k_sweep_local, k_bin_totals).
+    // Measured and NOT adopted (profiles/r05_ab_window_groups.txt): one box 2.00 -> 1.92 ms per 2^21 terms, another 1.85 -> 1.89, four interleaved
+    // repetitions on a third 1.959 (normaliser first) against 1.993; 2^20 level, 2^18 +2 %.  The default stays 0.
+    static const int sort_first = C25519_KNOB("SORT_FIRST", 0);
+    const bool sorted_first = sort_first && !ahead && !serial_sort && !cont && !wait_in;      // (measured on device-resident single / first passes only)
+    if (sorted_first) {
+        pl.ev_partition = sort_first >= 2 ? ctx->ev_z : nullptr;
+        if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve, lists_free, sweep_early >= 2 ? parity : -1))) return r;
+        if (pl.ev_partition) HIPCHK(hipStreamWaitEvent(ctx->stream, pl.ev_partition, 0));
+    }
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
     else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
     if (serial_sort) { HIPCHK(hipEventRecord(ctx->ev_z, ctx->stream)); HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_z, 0)); }
-    if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve, lists_free, sweep_early >= 2 ? parity : -1))) return r;
+    if (!sorted_first && (r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve, lists_free, sweep_early >= 2 ? parity : -1))) return r;
     // a continuing pass adds onto the bucket sums its predecessor on this stream set left: they must be where it left them
     if (cont && pl.buckets != ctx->cont_buckets) { ctx->err = "msm: internal error (the workspace of a continuing pass moved its buckets)"; return -(int32_t)hipErrorInvalidValue; }
     ctx->cont_buckets = pl.buckets;
@@ -919,7 +1012,15 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // carries the number the layout was derived from (records_fold re-derives it from there).
     const uint64_t layout_terms = (passes > (uint64_t)ps.lanes && per >= (1ull << 20)) ? std::max<uint64_t>(per, 1ull << 21) : per;
     msm_layout(layout_terms, g);
+    // A/B knobs (tuning build): window groups of a single-pass call (msm_geom / msm_enqueue_acc), ACC_LAST = content windows of the final group
+    // Measured and NOT adopted (profiles/r05_ab_window_groups.txt): with two groups the exposed tail of a 2^21-term call shrinks from 0.26 to 0.18 ms, but
+    // the reduction of group 0 takes its issue slots and registers from the second group's accumulation (k_accumulate 1.16 -> 1.17 - 1.26 ms over the two
+    // launches, each with its own ramp-down): four interleaved repetitions on one box give 1.959 ms (one group) against 1.965 (two); three and four
+    // groups 2.06 / 2.18; at 2^20 and 2^18 terms two groups lose 8 % and 17 %.  The default stays ONE group.
+    static const int acc_groups = C25519_KNOB("ACC_GROUPS", 1), acc_last = C25519_KNOB("ACC_LAST", 0);
+    if (passes == 1 && n > MSM_SMALL_MAX) msm_set_groups(g, acc_groups, acc_last);
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
+    hipEvent_t prev_acc_last = nullptr;
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later
     // passes in one launch beside the sort and the accumulation of pass 0 (pts_ahead; 128 bytes per point stay allocated)
     // (not with a fetch: the later passes' points are not on the device yet)
@@ -946,7 +1047,10 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
             return r;
         }
         prev_acc = L > 1 ? c->ev_acc : nullptr;
+        prev_acc_last = c->ev_acc;
     }
+    // a long call: the host blocks on the end of the LAST accumulation before it polls for the published results (publish_and_wait)
+    ctx->coarse_wait = (n >= (1ull << 17) && prev_acc_last) ? prev_acc_last : nullptr;
     if ((r = passes_join(ctx, ps))) return r;
     if (passes > 1) hipLaunchKernelGGL(k_record_sum, dim3(1), dim3(128), 0, ctx->stream, d_record, ctx->d_slots, (int)std::min<uint64_t>((uint64_t)L, passes), g.nwin, 1);
     HIPCHK(hipGetLastError());
@@ -959,6 +1063,7 @@ static int32_t msm_record_status(c25519_ctx *ctx, const uint32_t flags[8]) {
     return flags[1] ? C25519_NONE : C25519_OK;            // the status does not depend on the split
 }
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
+    ctx->host_us[0] = ctx->host_us[1] = wall_us();
     int32_t r = msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, drec(ctx));
     if (r) return r;
     if ((r = rec_collect(ctx))) return r;
@@ -1015,6 +1120,7 @@ EXPORT int32_t c25519_msm_vartime_dev(c25519_ctx *ctx, const uint8_t *d_scalars,
     int32_t r = msm_partial_impl(ctx, d_scalars, d_points, n, in_fmt, R);
     if (r != C25519_OK) return r;
     host_encode(R, out_fmt, out);
+    ctx->host_us[4] = wall_us();
     return C25519_OK;
 }
 EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const uint8_t *points, uint64_t n, int in_fmt, int out_fmt, uint8_t *out) {
@@ -1022,12 +1128,14 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     if (out_fmt < 0 || out_fmt > 2 || in_fmt < 0 || in_fmt > 2) { ctx->err = "msm: bad format"; return -(int32_t)hipErrorInvalidValue; }
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
+    ctx->host_us[0] = wall_us();
     if (n <= MSM_SMALL_MAX) {
-        // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: one staged copy up, the kernels, one copy down
+        // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: one staged copy up, the kernels, the results published to the host
         const void *src[2] = {scalars, points};
         const size_t bytes[2] = {(size_t)n * 32, (size_t)n * psz};
         uint8_t *d[2];
         if ((r = ffi_small_upload(ctx, 2, src, bytes, d))) return r;
+        ctx->host_us[1] = wall_us();
         ge_p3 R;
         uint32_t flags[8];
         r = msm_record_enqueue(ctx, d[0], d[1], n, in_fmt, drec(ctx));
@@ -1038,8 +1146,10 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
         if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
         if ((r = msm_record_status(ctx, flags))) return r;
         host_encode(R, out_fmt, out);
+        ctx->host_us[4] = wall_us();
         return C25519_OK;
     }
+    ctx->host_us[1] = ctx->host_us[0];
     if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 32 + 16)) || (r = ctx_reserve(ctx, ctx->tmp_b, n * psz + 16))) return r;
     uint8_t *d_s = (uint8_t *)ctx->tmp_a.p, *d_p = (uint8_t *)ctx->tmp_b.p;
     if ((r = ffi_begin(ctx))) return r;

@@ -17,7 +17,14 @@ constexpr int MSM_MAX_WIN = 56;
 // bps[k]: log2 of the buckets per slice of window k in the chunk-local sort -- bps_log2 for a window that uses all `half` buckets, less for the
 //   narrower ones (a signed window of c - 1 bits, the unsigned windows), so that every window spreads its entries over all half >> bps_log2
 //   slices (msm_slice_params)
-struct msm_geom { int c, nwin, half, first_unsigned, bps_log2; u32 long_cap; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN], bps[MSM_MAX_WIN]; };
+// ngroups, gstart[]: WINDOW GROUPS of a single-pass call (round 5): the windows are independent until the final fold (pippenger.rs:122-159), so the
+//   bucket order, the accumulation and the bucket reduction can run group by group -- group g = windows [gstart[g], gstart[g + 1]) -- and the reduction
+//   of group g overlaps the accumulation of group g + 1 instead of all of it being the exposed tail of the call.  ngroups = 1: one group (every
+//   multi-pass and small call).
+constexpr int MSM_MAX_GROUPS = 4;
+struct msm_geom { int c, nwin, half, first_unsigned, bps_log2; u32 long_cap; u32 addk[8]; unsigned char pos[MSM_MAX_WIN], wid[MSM_MAX_WIN], bps[MSM_MAX_WIN];
+                  unsigned char ngroups, gstart[MSM_MAX_GROUPS + 1]; };
+__host__ __device__ inline int msm_group_of(const msm_geom &g, int k) { int r = 0; for (int i = 1; i < g.ngroups; i++) r += k >= (int)g.gstart[i] ? 1 : 0; return r; }
 // Precomputed-static MSM: ONE bucket set for all windows.  The table holds T[k][i] = 2^(c k) P_i for every window k, so
 // digit k of scalar i is a term of its own, (k, i) -> point k * ns + i, and all K * ns terms fall into the same 2^(c-1)
 // buckets: one accumulation, one bucket reduction, no Horner fold.
@@ -61,6 +68,7 @@ struct msm_plan {
     c25519::msm_geom g; uint64_t n, nb; int nseg; uint32_t max_items, max_long;
     uint32_t *base, *sorted, *buckets, *perm, *SW, *counters, *lgids, *lfirst, *segs, *bad_ws, *bad_sticky = nullptr; c25519::long_item *items;
     hipStream_t sort_stream;
+    hipEvent_t ev_partition = nullptr;      // in: if set, recorded on the sort's stream after the partition half (k_sweep_local, k_bin_totals) of the chunk-local sort
 };
 void msm_sort_params(uint64_t n, c25519::msm_geom &g);
 void msm_slice_params(c25519::msm_geom &g);
@@ -91,7 +99,9 @@ int32_t passes_join(c25519_ctx *ctx, pass_set &ps);
 hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind);
 void launch_merged_table(const uint8_t *in_raw, uint64_t ns, int c, int K, uint8_t *out_raw, hipStream_t st);
 // bucket reduction with four waves per point operation (reduce.hip)
-void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st);
+// (windows [k0, k1): one window group, msm_geom)
+void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st, int k0 = 0, int k1 = -1);
+void msm_set_groups(c25519::msm_geom &g, int groups, int last);
 void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
 void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);
 // bucket accumulation (accum.hip); returns the kernel's name for the timing records

@@ -245,7 +245,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
         // block's share of them (the bucket order and the accumulation walk ALL half buckets of every window)
         const int per = (1 << g.bps_log2) - PART_BPS, first = (SL << g.bps[k]) + sidx * per;
         for (int i = tid; i < per; i += 64 * NW) { totals[(u64)k * g.half + first + i] = 0; base[(u64)k * (g.half + 1) + first + i] = wtot; }
-        if (per > 0 && tid == 0) atomicAdd(&ord_hist[255], (u32)per);                  // (length class of an empty list)
+        if (per > 0 && tid == 0) atomicAdd(&ord_hist[256 * msm_group_of(g, k) + 255], (u32)per);      // (length class of an empty list; one histogram per window group)
     }
     u32 *dst = sorted + (u64)k * n + b0;
     if (fits) {
@@ -287,7 +287,7 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
     __syncthreads();
     if (tid < PART_BPS) order_note_bucket(cnt[tid], (u64)k * g.half + (u64)sidx * PART_BPS + tid, g, base, oh, max_items, items, counters, long_gids, long_first);
     __syncthreads();
-    if (tid < 256 && oh[tid]) atomicAdd(&ord_hist[tid], oh[tid]);
+    if (tid < 256 && oh[tid]) atomicAdd(&ord_hist[256 * msm_group_of(g, k) + tid], oh[tid]);
     if (fits) {
 #pragma unroll 1
         for (int t0 = 0; t0 < nslots; t0 += 8) {
@@ -333,11 +333,16 @@ k_part2g(const u32 *__restrict__ P1, u64 n, u64 wstride, u32 chunk, msm_geom g, 
 
 // the same with the scan inside: every block scans the 256-bin histogram itself (read-only) and takes its slots from a
 // separate cursor array (zeroed by k_sweep_local) -- one launch less in the chain
+// Window groups (msm_geom): every group has its own length histogram, its own cursors and its own stretch of perm -- the buckets of windows
+// [gstart[q], gstart[q + 1]) in decreasing list length at perm[gstart[q] * half ..) -- so that k_accumulate can be launched group by group.  A block's
+// buckets belong to ONE window (groups are only formed when half >= BS).
 template <int BS>                                            // 256 bins, BS >= 256 threads: a block's buckets per bin take their slots with ONE global atomic per bin
-__global__ void __launch_bounds__(BS) k_order_place(const u32 *__restrict__ totals, u64 nb, const u32 *__restrict__ ord_hist, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm) {
+__global__ void __launch_bounds__(BS) k_order_place(const u32 *__restrict__ totals, u64 nb, const u32 *__restrict__ ord_hist, u32 *__restrict__ ord_cursor, u32 *__restrict__ perm, msm_geom g) {
     C25519_PRIO_CHAIN();
     __shared__ u32 h[256], start[256], basep[256];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int grp = g.ngroups > 1 ? msm_group_of(g, (int)(((u64)blockIdx.x * BS) / (u64)g.half)) : 0;
+    ord_hist += 256 * grp; ord_cursor += 256 * grp; perm += (u64)g.gstart[grp] * (u64)g.half;
     if (threadIdx.x < 256) {
         const u32 mine = ord_hist[threadIdx.x];
         u32 inc = mine;
@@ -427,7 +432,7 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const size_t szB = ((size_t)g.nwin * (g.half + 1) * 4 + 255) & ~(size_t)255, szS = ((size_t)g.nwin * nc * 4 + 255) & ~(size_t)255, szPerm = (nb * 4 + 255) & ~(size_t)255;
     const size_t oD = carve(matrix ? (size_t)g.nwin * nc * 2 : 0), oC = carve(matrix ? (size_t)g.nwin * nchunk * g.half * 4 : 0), oB = carve(szB * copies) + szB * cp;
     const size_t oS = carve(szS * copies) + szS * cp, oK = carve(nb * 160), oT = carve(nb * 4);
-    const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(8192), oPerm = carve(szPerm * copies) + szPerm * cp;
+    const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oF = carve(16384), oPerm = carve(szPerm * copies) + szPerm * cp;
     // long-bucket path: at most (#entries / LONG_SEG + #long buckets) work items; a long bucket has > LONG_CAP entries
     const uint64_t entries = (uint64_t)g.nwin * nc;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
@@ -454,8 +459,12 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     uint32_t *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK);
     // small words of the chain (u32 index): [8..] long-bucket counters, [64..319] bucket-order histogram, [320..575] its cursors,
     // [576] "a scalar has bit 255 set" (ORed into the result slot by the bucket reduction: the sort itself never touches the slot)
-    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *ord_cursor = flags + 320, *bad_ws = flags + 576, *perm = (uint32_t *)(ws + oPerm);
-    constexpr int ZERO_WORDS = 576;
+    uint32_t *flags = (uint32_t *)(ws + oF), *totals = (uint32_t *)(ws + oT), *ord_hist = flags + 64, *perm = (uint32_t *)(ws + oPerm);
+    // (one 256-bin length histogram and one set of cursors per window group: 64 + 512 G words, G <= MSM_MAX_GROUPS, zeroed by the partition kernel)
+    const int ngr = g.ngroups > 1 ? g.ngroups : 1;
+    uint32_t *ord_cursor = flags + 64 + 256 * ngr, *bad_ws = flags + 64 + 512 * ngr;
+    const int ZERO_WORDS = 64 + 512 * ngr;
+    if (ngr > 1 && (matrix || g.half < 1024)) { ctx->err = "msm: internal error (window groups outside the chunk-local sort)"; return -(int32_t)hipErrorInvalidValue; }
     pl.g = g; pl.n = n; pl.nb = nb; pl.nseg = nseg; pl.max_items = max_items; pl.max_long = max_long;
     pl.base = base; pl.sorted = sorted; pl.buckets = buckets; pl.perm = perm; pl.SW = (uint32_t *)(ws + oSW); pl.counters = flags + 8; pl.bad_ws = bad_ws;
     pl.items = (long_item *)(ws + oLI); pl.lgids = (uint32_t *)(ws + oLG); pl.lfirst = (uint32_t *)(ws + oLF); pl.segs = (uint32_t *)(ws + oLS);
@@ -488,13 +497,14 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
         hipLaunchKernelGGL(k_sweep_local<SWEEP_THREADS>, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
     }
     hipLaunchKernelGGL(k_bin_totals, dim3((g.nwin * SL + 3) / 4), dim3(256), 0, st, lsg, pchunks, SL, g.nwin * SL, binm, bad_blk, bad_ws, pl.bad_sticky);
+    if (pl.ev_partition) HIPCHK(hipEventRecord(pl.ev_partition, st));
     // lists_free: the partition above writes only the sort's own scratch (chunk blocks, slice starts, bin totals, the small counters of the chain);
     // the gather lists, bucket bases, totals and the bucket order -- what the accumulation of the PREVIOUS pass on this workspace still reads --
     // are written from here on
     if (lists_free) HIPCHK(hipStreamWaitEvent(st, lists_free, 0));
     if (small_blocks) hipLaunchKernelGGL((k_part2g<8, ITER_SMALL>), dim3(g.nwin, SL), dim3(512), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
     else hipLaunchKernelGGL((k_part2g<16, P2G_ITER>), dim3(g.nwin, SL), dim3(1024), lds2, st, P1, n, wstride, (u32)sweep_chunk, g, SL, pchunks, lsg, binm, totals, base, sorted, ord_hist, max_items, pl.items, pl.counters, pl.lgids, pl.lfirst);
-    hipLaunchKernelGGL(k_order_place<1024>, dim3(div_up64(nb, 1024)), dim3(1024), 0, st, totals, nb, ord_hist, ord_cursor, perm);
+    hipLaunchKernelGGL(k_order_place<1024>, dim3(div_up64(nb, 1024)), dim3(1024), 0, st, totals, nb, ord_hist, ord_cursor, perm, g);
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }

@@ -138,14 +138,15 @@ __device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 
 __device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i = 0; i < 10; i++) r.v[i] = tot[c * 10 + i]; return r; }
 
 // level A: block = segment `seg` (64 x 2^lb buckets, 2^lb per logical lane: 512 / 8, or 1024 / 16 for 17-bit windows) of window k.  direct: the window has a single segment, write col_k itself.
+// k0: first window of the launch (a window group, msm_geom: the blocks of the launch are the segments of windows k0 ..)
 __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ buckets, int half, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
-                                                   const u32 *__restrict__ bad_ws) {
+                                                   const u32 *__restrict__ bad_ws, int k0) {
     C25519_PRIO_SIDE();
     __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     // (the roles rotate with the block index: the waves of the ~4 blocks that share a SIMD then play different roles, whose loads differ)
     const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x) & 3), lane = threadIdx.x & 63;
-    const int k = blockIdx.x / nseg, seg = blockIdx.x % nseg;
-    if (bad_ws && blockIdx.x == 0 && threadIdx.x == 0 && *bad_ws) atomicOr(cols + MSM_MAX_WIN * 40, 1u);
+    const int bid = k0 * nseg + (int)blockIdx.x, k = bid / nseg, seg = bid % nseg;
+    if (bad_ws && bid == 0 && threadIdx.x == 0 && *bad_ws) atomicOr(cols + MSM_MAX_WIN * 40, 1u);
     const int LB = 1 << lb, b0 = (seg * 64 + lane) * LB;
     const u32 *B = buckets + (u64)k * half * 40;
     auto bucket = [&](int b) { return [=](int c) { return b < half ? rc_global(B, (u64)b, c) : rc_ident(c); }; };
@@ -166,16 +167,16 @@ __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ bucke
         rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
         if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
     } else if (lane == 0) {
-        rc_global_put(SW, 2 * (u64)blockIdx.x, mc, rc_tot(tot, mc));
-        rc_global_put(SW, 2 * (u64)blockIdx.x + 1, mc, rc_get(S, 0, mc));
+        rc_global_put(SW, 2 * (u64)bid, mc, rc_tot(tot, mc));
+        rc_global_put(SW, 2 * (u64)bid + 1, mc, rc_get(S, 0, mc));
     }
 }
 // level B: one block per window over its nseg <= 64 segment pairs (weight 2^(lb + 6) per segment)
-__global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols) {
+__global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols, int k0) {
     C25519_PRIO_SIDE();
     __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int k = blockIdx.x, mc = rc_coord(role);
+    const int k = k0 + (int)blockIdx.x, mc = rc_coord(role);
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
@@ -187,7 +188,10 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
 }  // namespace c25519
 
 // the bucket reduction of a pass (level A over the segments, level B over the windows) on stream st
-void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, d_slot, nseg == 1 ? 1 : 0, bad_ws);
-    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, nseg, red_lb_log2(g.half), d_slot);
+void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st, int k0, int k1) {
+    if (k1 < 0) k1 = g.nwin;
+    if (k1 <= k0) return;
+    // (bad_ws is folded into the slot by the block of window 0, segment 0: the launch of the first group)
+    hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)((k1 - k0) * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, d_slot, nseg == 1 ? 1 : 0, k0 == 0 ? bad_ws : nullptr, k0);
+    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)(k1 - k0)), dim3(256), 0, st, SW, nseg, red_lb_log2(g.half), d_slot, k0);
 }

@@ -237,6 +237,22 @@ __global__ void __launch_bounds__(256) k_sign_nonce(const uint8_t *__restrict__ 
     sc28_to_words(sc28_from_wide(d), r);
     store8(rscal, i, r);
 }
+// Ed25519ph: r_i = SHA-512(dom2 || prefix_i || PH(M_i)) mod l (signing.rs:952-960); ph: n x 64 bytes
+__global__ void __launch_bounds__(256) k_sign_nonce_dom(const uint8_t *__restrict__ dom, u32 dom_len, const uint8_t *__restrict__ prefix, const uint8_t *__restrict__ ph, u64 n,
+                                                        uint8_t *__restrict__ rscal) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    sha512_stream st;
+    st.init();
+    st.put_bytes(dom, dom_len);
+    st.put_bytes(prefix + 32 * i, 32);
+    st.put_bytes(ph + 64 * i, 64);
+    st.finish();
+    u32 d[16], r[8];
+    sha512_digest_words(st.h, d);
+    sc28_to_words(sc28_from_wide(d), r);
+    store8(rscal, i, r);
+}
 // s_i = k_i * a_i + r_i mod l;  sig_i = R_i || s_i      (k_i = H(R||A||M) mod l given as 64-byte digests)
 __global__ void __launch_bounds__(256) k_sign_finish(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ scal_a, const uint8_t *__restrict__ rscal,
                                                      const uint8_t *__restrict__ Renc, u64 n, uint8_t *__restrict__ sigs) {
@@ -464,9 +480,24 @@ EXPORT int32_t c25519_double_base_batch(c25519_ctx *ctx, const uint8_t *a, const
 }
 
 // ---- per-signature verify ---------------------------------------------------------------------------------
-EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
-                                       const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status) {
-    HIPCHK(hipSetDevice(ctx->device));
+// dom2 of Ed25519ph (RFC 8032 5.1: "SigEd25519 no Ed25519 collisions" || 0x01 || len(ctx) || ctx) into the context's small device buffer; the host
+// copy lives in the context until the next call, so the asynchronous upload never reads a dead frame
+static int32_t dom2_upload(c25519_ctx *ctx, const uint8_t *context, uint32_t context_len, const uint8_t **d_dom, uint32_t *dom_len) {
+    if (context_len > 255) { ctx->err = "prehashed: the context must not be longer than 255 octets"; return C25519_PREHASHED_CONTEXT_LENGTH; }    // signing.rs:931-933
+    if (context_len && !context) { ctx->err = "prehashed: null context"; return -(int32_t)hipErrorInvalidValue; }
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->dom, 512))) return r;
+    ctx->h_dom.assign(34 + context_len, 0);
+    memcpy(ctx->h_dom.data(), "SigEd25519 no Ed25519 collisions", 32);
+    ctx->h_dom[32] = 1; ctx->h_dom[33] = (uint8_t)context_len;
+    if (context_len) memcpy(ctx->h_dom.data() + 34, context, context_len);
+    HIPCHK(hipMemcpyAsync(ctx->dom.p, ctx->h_dom.data(), ctx->h_dom.size(), hipMemcpyHostToDevice, ctx->stream));
+    *d_dom = (const uint8_t *)ctx->dom.p; *dom_len = (uint32_t)ctx->h_dom.size();
+    return C25519_OK;
+}
+// d_dom == nullptr: plain Ed25519 (messages through d_msg_off); otherwise Ed25519ph: d_msgs = n x 64 bytes of prehashes, d_msg_off unused
+static int32_t verify_each_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status, const uint8_t *d_dom, uint32_t dom_len) {
     if (n == 0) return C25519_OK;
     hipStream_t st = ctx->stream;
     int32_t r;
@@ -481,7 +512,8 @@ EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, c
     hipEvent_t *ring = ctx_ring_item(ctx);
     HIPCHK(hipEventRecord(ctx->ev0, st));
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
-    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
+    if (d_dom) HIPCHK(launch_hram_dom(d_dom, dom_len, d_msgs, nullptr, n * 64, 64, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
+    else HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));
     hipLaunchKernelGGL(k_hram_reduce, dim3(dup(n, 256)), dim3(256), 0, st, hram, d_sigs, n, kscal, sscal, s_ok);
     HIPCHK(hipEventRecord(ring[0], st));
     if ((r = var_base_launch(ctx, kscal, d_pks, n, C25519_FMT_EDWARDS_Y, true, false, P40, a_ok))) return r;    // [k](-A), k public
@@ -495,6 +527,35 @@ EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, c
     HIPCHK(hipEventRecord(ring[2], st));
     HIPCHK(hipEventRecord(ctx->ev1, st));
     return C25519_OK;
+}
+EXPORT int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                       const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return verify_each_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, strict, d_status, nullptr, 0);
+}
+// Ed25519ph / Ed25519ctx, per signature (verifying.rs:230-257 raw_verify_prehashed / :284 verify_prehashed; strict: :424-461): d_prehashes = n x 64
+// bytes (SHA-512 of each message: the reference takes the digest state and finalises it), context = HOST pointer, at most 255 bytes, one for the batch
+EXPORT int32_t ed25519_verify_each_prehashed_dev(c25519_ctx *ctx, const uint8_t *d_prehashes, const uint8_t *context, uint32_t context_len,
+                                                 const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint8_t *d_dom = nullptr; uint32_t dom_len = 0;
+    int32_t r = dom2_upload(ctx, context, context_len, &d_dom, &dom_len);
+    if (r) return r;
+    return verify_each_impl(ctx, d_prehashes, nullptr, n * 64, d_sigs, d_pks, n, strict, d_status, d_dom, dom_len);
+}
+EXPORT int32_t ed25519_verify_each_prehashed(c25519_ctx *ctx, const uint8_t *prehashes, const uint8_t *context, uint32_t context_len, const uint8_t *sigs, const uint8_t *pks,
+                                             uint64_t n, int strict, uint8_t *status) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (context_len > 255) { ctx->err = "prehashed: the context must not be longer than 255 octets"; return C25519_PREHASHED_CONTEXT_LENGTH; }
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 64 + 64)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64 + n * 32 + n + 64))) return r;
+    uint8_t *dph = (uint8_t *)ctx->tmp_a.p, *dsig = (uint8_t *)ctx->tmp_c.p, *dpk = dsig + n * 64, *dst = dpk + n * 32;
+    const ffi_in in[3] = {{prehashes, dph, 64}, {sigs, dsig, 64}, {pks, dpk, 32}};
+    const ffi_out o = {status, dst, 1};
+    return ffi_pipeline(ctx, n, ffi_chunk_units(n, 1u << 16), in, 3, &o, 1, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return ed25519_verify_each_prehashed_dev(ctx, dph + lo * 64, context, context_len, dsig + lo * 64, dpk + lo * 32, m, strict, dst + lo);
+    });
 }
 EXPORT int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                    uint64_t n, int strict, uint8_t *status) {
@@ -534,8 +595,10 @@ EXPORT int32_t ed25519_keygen_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds,
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }
+// d_dom != nullptr: Ed25519ph (signing.rs:917-976) -- d_msgs = n x 64 bytes of prehashes, dom2 in front of both hashes
 static int32_t sign_body(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len, uint64_t n,
-                         uint8_t *d_pks, uint8_t *d_sigs, uint8_t *a, uint8_t *prefix, uint8_t *rscal, uint8_t *Renc, uint8_t *hram) {
+                         uint8_t *d_pks, uint8_t *d_sigs, uint8_t *a, uint8_t *prefix, uint8_t *rscal, uint8_t *Renc, uint8_t *hram,
+                         const uint8_t *d_dom = nullptr, uint32_t dom_len = 0) {
     hipStream_t st = ctx->stream;
     const bool secret = ctx_secret_default(ctx);
     int32_t r;
@@ -543,20 +606,21 @@ static int32_t sign_body(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t 
     // r = H(prefix || M) does not depend on A, and a batch of 2^16 signatures is two launches' worth of latency otherwise
     // (2 x (0.21 + 0.10) ms of a 0.83 ms call, profiles/r03_sign_keygen_2p16.txt).  rscal = a + 32 n, Renc = AR + 32 n.
     hipLaunchKernelGGL(k_expand_seed, dim3(dup(n, 256)), dim3(256), 0, st, d_seeds, n, a, prefix);
-    hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, msgs_len, n, rscal);
+    if (d_dom) hipLaunchKernelGGL(k_sign_nonce_dom, dim3(dup(n, 256)), dim3(256), 0, st, d_dom, dom_len, prefix, d_msgs, n, rscal);
+    else hipLaunchKernelGGL(k_sign_nonce, dim3(dup(n, 256)), dim3(256), 0, st, prefix, d_msgs, d_msg_off, msgs_len, n, rscal);
     uint8_t *AR = Renc - n * 32;
     if ((r = mul_base_impl(ctx, a, 2 * n, C25519_FMT_EDWARDS_Y, AR, secret))) return r;
     HIPCHK(hipMemcpyAsync(d_pks, AR, n * 32, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_place_R, dim3(dup(n, 256)), dim3(256), 0, st, Renc, n, d_sigs);
     HIPCHK(hipMemsetAsync(ctx->d_flag, 0, 16, st));
-    HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
+    if (d_dom) HIPCHK(launch_hram_dom(d_dom, dom_len, d_msgs, nullptr, n * 64, 64, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));      // k = H(dom2||R||A||PH(M))
+    else HIPCHK(launch_hram(d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, (uint32_t *)ctx->d_flag, st));          // k = H(R||A||M)
     hipLaunchKernelGGL(k_sign_finish, dim3(dup(n, 256)), dim3(256), 0, st, hram, a, rscal, Renc, n, d_sigs);
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }
-EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
-                                      uint64_t n, uint8_t *d_pks, uint8_t *d_sigs) {
-    HIPCHK(hipSetDevice(ctx->device));
+static int32_t sign_batch_dev_impl(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                   uint64_t n, uint8_t *d_pks, uint8_t *d_sigs, const uint8_t *d_dom, uint32_t dom_len) {
     if (n == 0) return C25519_OK;
     int32_t r;
     size_t off = 0;
@@ -565,7 +629,7 @@ EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, c
     size_t oA = carve(2 * n * 32), oPre = carve(n * 32), oAR = carve(2 * n * 32), oH = carve(n * 64);
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
-    r = sign_body(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, ws + oA, ws + oPre, ws + oA + n * 32, ws + oAR + n * 32, ws + oH);
+    r = sign_body(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, ws + oA, ws + oPre, ws + oA + n * 32, ws + oAR + n * 32, ws + oH, d_dom, dom_len);
     hipError_t e = hipMemsetAsync(ws, 0, oAR, ctx->stream);     // wipe secret scalars / nonces / prefixes on EVERY exit path
     if (r) return r;
     HIPCHK(e);
@@ -574,6 +638,38 @@ EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, c
     HIPCHK(hipMemcpy(fl, ctx->d_flag, 16, hipMemcpyDeviceToHost));      // (blocking: no copy is ever pending into this frame)
     if (fl[1]) { ctx->err = "sign_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
     return C25519_OK;
+}
+EXPORT int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
+                                      uint64_t n, uint8_t *d_pks, uint8_t *d_sigs) {
+    HIPCHK(hipSetDevice(ctx->device));
+    return sign_batch_dev_impl(ctx, d_seeds, d_msgs, d_msg_off, msgs_len, n, d_pks, d_sigs, nullptr, 0);
+}
+// Ed25519ph signing (signing.rs:312 sign_prehashed / :917 raw_sign_prehashed): d_prehashes = n x 64 bytes, context = HOST pointer (<= 255 bytes,
+// C25519_PREHASHED_CONTEXT_LENGTH otherwise: InternalError::PrehashedContextLength), one context for the batch
+EXPORT int32_t ed25519_sign_batch_prehashed_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_prehashes, const uint8_t *context, uint32_t context_len,
+                                                uint64_t n, uint8_t *d_pks, uint8_t *d_sigs) {
+    HIPCHK(hipSetDevice(ctx->device));
+    const uint8_t *d_dom = nullptr; uint32_t dom_len = 0;
+    int32_t r = dom2_upload(ctx, context, context_len, &d_dom, &dom_len);
+    if (r) return r;
+    return sign_batch_dev_impl(ctx, d_seeds, d_prehashes, nullptr, n * 64, n, d_pks, d_sigs, d_dom, dom_len);
+}
+EXPORT int32_t ed25519_sign_batch_prehashed(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *prehashes, const uint8_t *context, uint32_t context_len, uint64_t n,
+                                            uint8_t *pks, uint8_t *sigs) {
+    HIPCHK(hipSetDevice(ctx->device));
+    if (context_len > 255) { ctx->err = "prehashed: the context must not be longer than 255 octets"; return C25519_PREHASHED_CONTEXT_LENGTH; }
+    if (n == 0) return C25519_OK;
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, n * 64 + 64)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 128 + 64))) return r;
+    uint8_t *dph = (uint8_t *)ctx->tmp_a.p, *dseed = (uint8_t *)ctx->tmp_c.p, *dpk = dseed + n * 32, *dsig = dpk + n * 32;
+    stream_wipe wipe(ctx->stream);
+    wipe.add(dseed, n * 32);                              // the staged secret keys, on every path
+    const ffi_in in[2] = {{seeds, dseed, 32}, {prehashes, dph, 64}};
+    const ffi_out o[2] = {{pks, dpk, 32}, {sigs, dsig, 64}};
+    // one chunk: the signing body reads its error flag back (a synchronisation per call)
+    return ffi_pipeline(ctx, n, n, in, 2, o, 2, [&](uint64_t lo, uint64_t m) -> int32_t {
+        return ed25519_sign_batch_prehashed_dev(ctx, dseed + lo * 32, dph + lo * 64, context, context_len, m, dpk + lo * 32, dsig + lo * 64);
+    });
 }
 EXPORT int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs) {
     HIPCHK(hipSetDevice(ctx->device));

@@ -65,6 +65,34 @@ __global__ void __launch_bounds__(256) k_hram(const uint8_t *__restrict__ msgs, 
         store8(hred, i, o);
     }
 }
+// Ed25519ph / Ed25519ctx (RFC 8032 5.1; verifying.rs:520-534 RCompute::new with prehash_ctx = Some(ctx)): hram_i = SHA-512(dom2 || R_i || A_i || M_i),
+// dom2 = "SigEd25519 no Ed25519 collisions" || 0x01 || len(ctx) || ctx (built by the host, `dom_len` bytes in device memory: the same for the whole
+// batch).  The prefix has any length from 34 to 289 bytes, so R and A are absorbed at an arbitrary byte position (sha512_stream::put_bytes) -- a
+// kernel of its own: k_hram keeps its register-resident first block.  msg_off == nullptr: messages of `fixed_len` bytes each (the 64-byte prehashes).
+__global__ void __launch_bounds__(256) k_hram_dom(const uint8_t *__restrict__ dom, u32 dom_len, const uint8_t *__restrict__ msgs, const u64 *__restrict__ msg_off, u64 msgs_len,
+                                                  u32 fixed_len, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ pks, u64 n, uint8_t *__restrict__ hram, u32 *__restrict__ flags) {
+    C25519_PRIO_CHAIN();
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 s[8];
+    load8(sigs, 2 * i + 1, s);
+    if (!sc28_words_canonical(s)) atomicAdd(&flags[0], 1u);     // signature.rs:89-94 check_scalar
+    sha512_stream st;
+    st.init();
+    st.put_bytes(dom, dom_len);
+    st.put_bytes(sigs + 64 * i, 32);                            // R
+    st.put_bytes(pks + 32 * i, 32);                             // A
+    u64 o0 = i * (u64)fixed_len, o1 = o0 + fixed_len;
+    if (msg_off) { o0 = msg_off[i]; o1 = msg_off[i + 1]; }
+    const bool okoff = o0 <= o1 && o1 <= msgs_len;
+    if (!okoff) atomicOr(&flags[1], 1u);
+    st.put_bytes(msgs + o0, okoff ? o1 - o0 : 0);
+    st.finish();
+    u32 w[16];
+    sha512_digest_words(st.h, w);
+    uint4 *q = reinterpret_cast<uint4 *>(hram) + 4 * i;
+    for (int j = 0; j < 4; j++) q[j] = make_uint4(w[4 * j], w[4 * j + 1], w[4 * j + 2], w[4 * j + 3]);
+}
 // the same reduction for hashes that were computed elsewhere
 __global__ void __launch_bounds__(256) k_hram_mod_l(const uint8_t *__restrict__ hram, u64 n, uint8_t *__restrict__ hred) {
     C25519_PRIO_CHAIN();
@@ -270,7 +298,12 @@ hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t ms
     hipLaunchKernelGGL(k_hram, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, msgs, msg_off, msgs_len, sigs, pks, n, hram, flags);
     return hipGetLastError();
 }
-
+hipError_t launch_hram_dom(const uint8_t *dom, uint32_t dom_len, const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, uint32_t fixed_len, const uint8_t *sigs, const uint8_t *pks,
+                           uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_hram_dom, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dom, dom_len, msgs, msg_off, msgs_len, fixed_len, sigs, pks, n, hram, flags);
+    return hipGetLastError();
+}
 
 }  // namespace c25519
 
@@ -546,6 +579,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             HIPCHK(hipMemcpyAsync(d_z_all, hz, n * 16, hipMemcpyHostToDevice, ctx->stream));
             if ((r = verify_record_enqueue(ctx, d_sigs, d_pks, d_pk_points, d_hram_all, d_z_all, n, drec(ctx), pre_pts.ready ? &pre_pts : nullptr))) return r;
         } catch (const std::exception &e) { ctx->err = std::string("verify_batch: ") + e.what(); return -(int32_t)hipErrorOutOfMemory; }
+        if (n >= (1ull << 16)) ctx->coarse_wait = ctx->ev_acc;          // a long call blocks on its accumulation before it polls for the published record (msm.hip publish_and_wait)
         if ((r = rec_collect(ctx))) return r;
         HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
         ge_p3 R;
@@ -573,6 +607,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
                                     nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
+            if (n >= (1ull << 16)) ctx->coarse_wait = c->ev_acc;
         }
         if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
         for (int i = 0; i < cnt; i++) {
@@ -617,10 +652,13 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
         const void *src[5] = {msgs, msg_off, sigs, pks, pk_points};
         const size_t bytes[5] = {(size_t)mlen, (size_t)(n + 1) * 8, (size_t)n * 64, (size_t)n * 32, pk_points ? (size_t)n * 160 : 0};
         uint8_t *d[5];
+        ctx->host_us[0] = wall_us();
         if ((r = ffi_small_upload(ctx, 5, src, bytes, d, (size_t)n * 144 + 64))) return r;
+        ctx->host_us[1] = wall_us();
         r = verify_batch_impl(ctx, d[0], (const uint64_t *)d[1], mlen, d[2], d[3], pk_points ? d[4] : nullptr, n, z_mode, nullptr);
         if (r < 0) (void)hipStreamSynchronize(ctx->stream);      // (an error before the call's own synchronisation: the upload may still be reading the staging buffer)
         ffi_small_end(ctx, mlen + (n + 1) * 8 + n * 96 + (pk_points ? n * 160 : 0), 0);
+        ctx->host_us[4] = wall_us();
         return r;
     }
     if ((r = ctx_reserve(ctx, ctx->tmp_a, mlen + 64)) || (r = ctx_reserve(ctx, ctx->tmp_b, (n + 1) * 8)) || (r = ctx_reserve(ctx, ctx->tmp_c, n * 64)) ||

@@ -9,6 +9,7 @@ error behaviour), batched, on top of Engine.  Reference entry points mirrored:
   verify_batch                                ed25519-dalek/src/batch.rs:146
   VerifyingKey::verify / verify_strict        ed25519-dalek/src/verifying.rs:565 / :359   (verify_each)
   SigningKey::sign                            ed25519-dalek/src/signing.rs:878-905        (sign_batch)
+  VerifyingKey::verify_prehashed[_strict] / SigningKey::sign_prehashed   verifying.rs:284 / :424, signing.rs:312   (Ed25519ph: verify_each_prehashed, sign_batch_prehashed)
   EdwardsPoint::multiscalar_mul               curve25519-dalek/src/edwards.rs:966-1000
   VartimeEdwardsPrecomputation                curve25519-dalek/src/edwards.rs:1037-1076
   RistrettoPoint::double_and_compress_batch   curve25519-dalek/src/ristretto.rs:564
@@ -265,6 +266,37 @@ def verify_each(messages, signatures, verifying_keys, strict=False, engine=None)
     st = eng.verify_each(list(messages), list(signatures), list(verifying_keys), strict)
     names = {_e.SCALAR_FORMAT: "ScalarFormat", _e.VERIFY: "Verify", _e.NONE: "PointDecompression"}
     return [None if c == _e.OK else SignatureError(names[int(c)]) for c in st]
+
+
+def verify_each_prehashed(prehashed_messages, signatures, verifying_keys, context=None, strict=False, engine=None):
+    """VerifyingKey::verify_prehashed (verifying.rs:284) / verify_prehashed_strict (:424) per signature -- Ed25519ph.  prehashed_messages: hashlib.sha512
+    objects (the reference takes a Digest state and finalises it) or their 64-byte digests; context: None (= empty, as in the reference) or up to 255
+    bytes, one for the batch.  -> a list with None for Ok(()) and a SignatureError otherwise.  A context beyond 255 bytes raises
+    SignatureError("PrehashedContextLength") (the reference debug-asserts on verification and returns that error when signing)."""
+    eng = engine or default_engine()
+    st = eng.verify_each_prehashed([_digest64(m) for m in prehashed_messages], list(signatures), list(verifying_keys), context or b"", strict)
+    if isinstance(st, int):
+        raise SignatureError("PrehashedContextLength")
+    names = {_e.SCALAR_FORMAT: "ScalarFormat", _e.VERIFY: "Verify", _e.NONE: "PointDecompression"}
+    return [None if c == _e.OK else SignatureError(names[int(c)]) for c in st]
+
+
+def sign_batch_prehashed(secret_keys, prehashed_messages, context=None, engine=None):
+    """SigningKey::from_bytes(sk).sign_prehashed(digest, context) for every pair (signing.rs:312 -> :917-976): -> (verifying keys, signatures);
+    raises SignatureError("PrehashedContextLength") for a context beyond 255 bytes (signing.rs:931-933)."""
+    eng = engine or default_engine()
+    r = eng.sign_batch_prehashed(list(secret_keys), [_digest64(m) for m in prehashed_messages], context or b"")
+    if isinstance(r, int):
+        raise SignatureError("PrehashedContextLength")
+    pks, sigs = r
+    return [pks[i].tobytes() for i in range(len(secret_keys))], [sigs[i].tobytes() for i in range(len(secret_keys))]
+
+
+def _digest64(m):
+    d = m.digest() if hasattr(m, "digest") else bytes(m)
+    if len(d) != 64:
+        raise SignatureError("prehashed message: a 512-bit digest is required")
+    return d
 
 
 def sign_batch(secret_keys, messages, engine=None):

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH = 0, 1, 2, 3, 4
+OK, NONE, SCALAR_FORMAT, VERIFY, ARRAY_LENGTH, PREHASHED_CONTEXT_LENGTH = 0, 1, 2, 3, 4, 5
 FMT_EDWARDS_Y, FMT_RISTRETTO, FMT_RAW160 = 0, 1, 2
 POINT_DECODES, POINT_SMALL_ORDER, POINT_TORSION_FREE = 1, 2, 4      # flags of c25519_point_order_checks_batch
 Z_TRANSCRIPT, Z_DEVICE = 0, 1
@@ -105,8 +105,13 @@ def load_library():
         "c25519_mul_batch": (i32, [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_double_base_batch_dev": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_double_base_batch": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
+        "c25519_last_call_host_us": (i32, [vp, vp]),
         "ed25519_verify_each_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_each": (i32, [vp, vp, vp, vp, vp, u64, C.c_int, vp]),
+        "ed25519_verify_each_prehashed_dev": (i32, [vp, vp, C.c_char_p, C.c_uint32, vp, vp, u64, C.c_int, vp]),
+        "ed25519_verify_each_prehashed": (i32, [vp, vp, C.c_char_p, C.c_uint32, vp, vp, u64, C.c_int, vp]),
+        "ed25519_sign_batch_prehashed_dev": (i32, [vp, vp, vp, C.c_char_p, C.c_uint32, u64, vp, vp]),
+        "ed25519_sign_batch_prehashed": (i32, [vp, vp, vp, C.c_char_p, C.c_uint32, u64, vp, vp]),
         "ed25519_keygen_batch_dev": (i32, [vp, vp, u64, vp]),
         "ed25519_sign_batch_dev": (i32, [vp, vp, vp, vp, u64, u64, vp, vp]),
         "ed25519_sign_batch": (i32, [vp, vp, vp, vp, u64, vp, vp]),
@@ -143,6 +148,7 @@ ABI_SYMBOLS = [
     "ed25519_batch_hram_dev", "ed25519_batch_transcript_zs", "ed25519_verify_batch_record_dev", "ed25519_fold_verify_records", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_selftest_scalar", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
+    "c25519_last_call_host_us", "ed25519_verify_each_prehashed_dev", "ed25519_verify_each_prehashed", "ed25519_sign_batch_prehashed_dev", "ed25519_sign_batch_prehashed",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
     "c25519_precomp_create", "c25519_precomp_destroy", "c25519_precomp_len", "c25519_precomp_msm_vartime",
     "c25519_msm_consttime", "c25519_double_and_compress_batch_dev", "c25519_double_and_compress_batch",
@@ -209,6 +215,12 @@ class Engine:
         assert t.numel() % width == 0
         assert t.data_ptr() % 16 == 0, "device buffers must be 16-byte aligned"
         return t.numel() // width
+
+    def last_call_host_us(self):
+        """host clock of the latest synchronous MSM / verify_batch call, microseconds since its entry: (upload enqueued, kernels enqueued, results on the host, folded)"""
+        out = (C.c_double * 4)()
+        self._chk(self.lib.c25519_last_call_host_us(self.ctx, out))
+        return tuple(out)
 
     def synchronize(self):
         self._chk(self.lib.c25519_ctx_synchronize(self.ctx))
@@ -396,6 +408,26 @@ class Engine:
         self._chk(self.lib.ed25519_verify_each_dev(self.ctx, msgs.data_ptr(), msg_off.data_ptr(), msgs.numel(), sigs.data_ptr(), pks.data_ptr(),
                                                    n, 1 if strict else 0, status.data_ptr()))
         return status
+
+    def verify_each_prehashed_t(self, prehashes, sigs, pks, context=b"", strict=False):
+        """Ed25519ph on device tensors (prehashes: n x 64 bytes).  -> status tensor, or PREHASHED_CONTEXT_LENGTH for a context beyond 255 bytes"""
+        n = self._t(sigs, 64)
+        assert self._t(pks, 32) == n and self._t(prehashes, 64) == n
+        status = self.torch.empty((n,), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        st = self._chk(self.lib.ed25519_verify_each_prehashed_dev(self.ctx, prehashes.data_ptr(), bytes(context), len(context), sigs.data_ptr(), pks.data_ptr(),
+                                                                  n, 1 if strict else 0, status.data_ptr()), (OK, PREHASHED_CONTEXT_LENGTH))
+        return status if st == OK else st
+
+    def sign_batch_prehashed_t(self, seeds, prehashes, context=b""):
+        n = self._t(seeds, 32)
+        assert self._t(prehashes, 64) == n
+        pks = self.torch.empty((n, 32), dtype=self.torch.uint8, device=self.device)
+        sigs = self.torch.empty((n, 64), dtype=self.torch.uint8, device=self.device)
+        self._bind_stream()
+        st = self._chk(self.lib.ed25519_sign_batch_prehashed_dev(self.ctx, seeds.data_ptr(), prehashes.data_ptr(), bytes(context), len(context), n, pks.data_ptr(), sigs.data_ptr()),
+                       (OK, PREHASHED_CONTEXT_LENGTH))
+        return (pks, sigs) if st == OK else st
 
     def keygen_batch_t(self, seeds):
         n = self._t(seeds, 32)
@@ -625,6 +657,32 @@ class Engine:
         self._bind_stream()
         self._chk(self.lib.ed25519_verify_each(self.ctx, blob.ctypes.data, off.ctypes.data, s.ctypes.data, p.ctypes.data, n, 1 if strict else 0, status.ctypes.data))
         return status
+
+    def verify_each_prehashed(self, prehashes, sigs, pks, context=b"", strict=False):
+        """Ed25519ph / Ed25519ctx per signature (verifying.rs:284 / :424): prehashes = the 64-byte SHA-512 of each message.
+        -> numpy uint8 status per signature, or PREHASHED_CONTEXT_LENGTH (an int) when the context exceeds 255 bytes."""
+        n = len(prehashes)
+        assert len(sigs) == n and len(pks) == n
+        status = np.empty((n,), dtype=np.uint8)
+        self._check_items(sigs, 64, "signature"); self._check_items(pks, 32, "public key"); self._check_items(prehashes, 64, "prehash")
+        ph = _np8(b"".join(prehashes), 64) if n else np.empty((0, 64), np.uint8)
+        s = _np8(b"".join(sigs), 64) if n else np.empty((0, 64), np.uint8); p = _np8(b"".join(pks), 32) if n else np.empty((0, 32), np.uint8)
+        self._bind_stream()
+        st = self._chk(self.lib.ed25519_verify_each_prehashed(self.ctx, ph.ctypes.data, bytes(context), len(context), s.ctypes.data, p.ctypes.data, n, 1 if strict else 0,
+                                                              status.ctypes.data), (OK, PREHASHED_CONTEXT_LENGTH))
+        return status if st == OK else st
+
+    def sign_batch_prehashed(self, seeds, prehashes, context=b""):
+        """Ed25519ph signing (signing.rs:312): -> (pks, sigs) numpy arrays, or PREHASHED_CONTEXT_LENGTH (an int)."""
+        n = len(seeds)
+        assert len(prehashes) == n
+        pks = np.empty((n, 32), dtype=np.uint8); sigs = np.empty((n, 64), dtype=np.uint8)
+        self._check_items(seeds, 32, "seed"); self._check_items(prehashes, 64, "prehash")
+        sd = _np8(b"".join(seeds), 32) if n else np.empty((0, 32), np.uint8); ph = _np8(b"".join(prehashes), 64) if n else np.empty((0, 64), np.uint8)
+        self._bind_stream()
+        st = self._chk(self.lib.ed25519_sign_batch_prehashed(self.ctx, sd.ctypes.data, ph.ctypes.data, bytes(context), len(context), n, pks.ctypes.data, sigs.ctypes.data),
+                       (OK, PREHASHED_CONTEXT_LENGTH))
+        return (pks, sigs) if st == OK else st
 
     def sign_batch(self, seeds, msgs):
         """-> (pks (n,32), sigs (n,64)) numpy arrays; seeds: list of 32-byte secret keys."""

@@ -118,12 +118,68 @@ def gather_fold(partial160, out_fmt=_e.FMT_EDWARDS_Y, group=None, device=None, f
     return out
 
 
-def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None, force_collective=False):
+class StepTimes:
+    """Where a sharded step spends its time, accumulated over calls (bench.py --gpus N): `shard` = this rank's pipeline on its GPU (HIP events on
+    the stream the library launches on), `collective` = the all_gather of the records (events around it on the same stream with the nccl backend --
+    RCCL orders its work against the caller's stream; host clock with gloo), `d2h_fold` = what is left of the call's wall-clock: the read-back of the
+    gathered records, the host fold (c25519_fold_partial_records) and launch latency.  The three add up to the wall-clock of the calls by
+    construction; none of the measurements synchronises anything the call does not synchronise anyway (the events are read after the read-back)."""
+
+    def __init__(self):
+        self.calls, self.shard_ms, self.collective_ms, self.d2h_fold_ms, self.wall_ms = 0, 0.0, 0.0, 0.0, 0.0
+
+    def mean(self):
+        k = max(self.calls, 1)
+        return {"shard_ms": self.shard_ms / k, "collective_ms": self.collective_ms / k, "d2h_fold_ms": self.d2h_fold_ms / k, "sum_ms": self.wall_ms / k, "calls": self.calls}
+
+
+def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=_e.FMT_EDWARDS_Y, group=None, force_collective=False, times=None):
     """scalars_t / points_t: THIS rank's shard, already on its GPU.  -> (status, bytes | None), the same on every rank.
     status NONE if any rank saw a point that does not decompress (the counters ride in the records).  ONE collective per
-    call, and this rank's result reaches the host only as part of the gathered records."""
+    call, and this rank's result reaches the host only as part of the gathered records.  times: a StepTimes to add this call to."""
+    if times is None:
+        rec = eng.msm_partial_record_t(scalars_t, points_t, in_fmt)
+        return _e.fold_partial_records(all_gather_rows(rec, group, force_collective), out_fmt)
+    import time
+    import torch
+    on_gpu = bool(getattr(scalars_t, "is_cuda", False))
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)] if on_gpu else None
+    t0 = time.perf_counter()
+    if on_gpu:
+        ev[0].record()
     rec = eng.msm_partial_record_t(scalars_t, points_t, in_fmt)
-    return _e.fold_partial_records(all_gather_rows(rec, group, force_collective), out_fmt)
+    t1 = time.perf_counter()
+    dist, _ = _dist_state(group, force_collective)
+    device_collective = on_gpu and dist is not None and dist.get_backend(group) == "nccl"
+    if on_gpu:
+        ev[1].record()
+    if device_collective:
+        # the collective alone, between two events on the caller's stream; the read-back comes after the second one
+        world = dist.get_world_size(group)
+        allp = torch.empty((world * rec.numel(),), dtype=torch.uint8, device=rec.device)
+        dist.all_gather_into_tensor(allp, rec.contiguous(), group=group)
+        ev[2].record()
+        rows = _to_host(allp).reshape(world, rec.numel())
+        t2 = t1
+    else:
+        if on_gpu:
+            ev[2].record()
+        c0 = time.perf_counter()
+        rows = all_gather_rows(rec, group, force_collective)          # gloo / no group: host clock (includes the copy of this rank's record to the host)
+        t2 = t1 + (time.perf_counter() - c0)
+    out = _e.fold_partial_records(rows, out_fmt)
+    wall = (time.perf_counter() - t0) * 1e3
+    if on_gpu:
+        ev[2].synchronize()
+        shard = ev[0].elapsed_time(ev[1])
+        coll = ev[1].elapsed_time(ev[2]) if device_collective else (t2 - t1) * 1e3
+    else:
+        shard, coll = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+    if not device_collective and dist is None:
+        coll = 0.0                                                   # no collective ran: the read-back belongs to d2h_fold
+    times.calls += 1
+    times.shard_ms += shard; times.collective_ms += coll; times.d2h_fold_ms += max(wall - shard - coll, 0.0); times.wall_ms += wall
+    return out
 
 
 # the reference's error precedence (batch.rs:208-211 before :244-250; a key that does not decode never reaches

@@ -48,6 +48,7 @@ extern "C" {
 #define C25519_SCALAR_FORMAT 2
 #define C25519_VERIFY 3
 #define C25519_ARRAY_LENGTH 4
+#define C25519_PREHASHED_CONTEXT_LENGTH 5   /* Ed25519ph: context longer than 255 octets (errors.rs InternalError::PrehashedContextLength) */
 
 #define C25519_FMT_EDWARDS_Y 0
 #define C25519_FMT_RISTRETTO 1
@@ -123,6 +124,11 @@ const char *c25519_last_kernel_name(const c25519_ctx *ctx, int which);
 /* milliseconds the device spent in the most recent entry point's kernels (hipEvent pair on the
  * context's stream); valid after the call returned / the stream was synchronised. */
 float c25519_last_kernel_ms(c25519_ctx *ctx);
+/* Host clock of the phases of the latest synchronous MSM / verify_batch call on this context, microseconds since the call was entered:
+ * out4[0] inputs staged and their upload enqueued (0 for the device-pointer forms), [1] every kernel enqueued, [2] results on the host (the last
+ * kernel writes them into page-locked host memory and the host polls a sequence word: no copy engine, no interrupt), [3] folded and encoded. */
+int32_t c25519_last_call_host_us(const c25519_ctx *ctx, double *out4);
+
 /* Per-call phase timing from a ring of hipEvents recorded on the launch streams (the last 64 calls of this context):
  * phase 0 = the dominant kernel of the call made `back` calls ago (0 = most recent) -- k_mul_base_*, k_x25519,
  * k_var_base, or k_accumulate for an MSM / verify_batch pass; phase 1 = the kernels after it (batched compression;
@@ -345,6 +351,17 @@ int32_t ed25519_verify_each_dev(c25519_ctx *ctx, const uint8_t *d_msgs, const ui
 int32_t ed25519_verify_each(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                             uint64_t n, int strict, uint8_t *status);
 
+/* Ed25519ph / Ed25519ctx, per signature (RFC 8032 5.1; replaces VerifyingKey::verify_prehashed ed25519-dalek/src/verifying.rs:284 ->
+ * raw_verify_prehashed :230-257, verify_prehashed_strict :424-461, challenge by RCompute::new :520-534 with prehash_ctx = Some(ctx)):
+ * hram_i = SHA-512("SigEd25519 no Ed25519 collisions" || 0x01 || len(ctx) || ctx || R_i || A_i || PH(M_i)).
+ * prehashes: n x 64 bytes, PH(M_i) = SHA-512(M_i) (the reference takes the digest state and finalises it); context: HOST pointer in both
+ * forms, 0 .. 255 bytes (NULL allowed when context_len = 0 -- the reference's `None`), ONE context for the batch; a longer context returns
+ * C25519_PREHASHED_CONTEXT_LENGTH.  status per signature as ed25519_verify_each. */
+int32_t ed25519_verify_each_prehashed_dev(c25519_ctx *ctx, const uint8_t *d_prehashes, const uint8_t *context, uint32_t context_len,
+                                          const uint8_t *d_sigs, const uint8_t *d_pks, uint64_t n, int strict, uint8_t *d_status);
+int32_t ed25519_verify_each_prehashed(c25519_ctx *ctx, const uint8_t *prehashes, const uint8_t *context, uint32_t context_len, const uint8_t *sigs, const uint8_t *pks,
+                                      uint64_t n, int strict, uint8_t *status);
+
 /* ---- batched key generation and signing (consumers of the fixed-base kernel) ---------------------------
  * keygen: pk_i = compress(clamp(SHA-512(seed_i)[0..32]) * B)   (verifying.rs:97-101, RFC 8032 5.1.5)
  * sign:   RFC 8032 5.1.6 as in signing.rs:878-905; also returns the public keys.  seeds: n x 32. */
@@ -352,6 +369,12 @@ int32_t ed25519_keygen_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, uint64
 int32_t ed25519_sign_batch_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                uint64_t n, uint8_t *d_pks, uint8_t *d_sigs);
 int32_t ed25519_sign_batch(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *msgs, const uint64_t *msg_off, uint64_t n, uint8_t *pks, uint8_t *sigs);
+/* Ed25519ph signing (SigningKey::sign_prehashed signing.rs:312 -> raw_sign_prehashed :917-976): r = H(dom2 || prefix || PH(M)), k = H(dom2 || R || A ||
+ * PH(M)); prehashes n x 64 bytes, context a HOST pointer of 0 .. 255 bytes (as ed25519_verify_each_prehashed). */
+int32_t ed25519_sign_batch_prehashed_dev(c25519_ctx *ctx, const uint8_t *d_seeds, const uint8_t *d_prehashes, const uint8_t *context, uint32_t context_len,
+                                         uint64_t n, uint8_t *d_pks, uint8_t *d_sigs);
+int32_t ed25519_sign_batch_prehashed(c25519_ctx *ctx, const uint8_t *seeds, const uint8_t *prehashes, const uint8_t *context, uint32_t context_len, uint64_t n,
+                                     uint8_t *pks, uint8_t *sigs);
 
 /* ---- precomputed static points: VartimePrecomputedMultiscalarMul (traits.rs:304-419) ---------------------
  * replaces backend::VartimePrecomputedStraus::{new, len, optional_mixed_multiscalar_mul}

@@ -260,6 +260,47 @@ EXPORT int orc_ed25519_verify_strict(const uint8_t pk[32], const uint8_t *m, siz
     ge_compress(Rcheck, ge_vartime_double_base_mul(kb, ge_neg(A), sig + 32, g_naf8B));
     return memcmp(Rcheck, sig, 32) == 0 ? ST_OK : ST_VERIFY;
 }
+/* ---- Ed25519ph / Ed25519ctx: the prehashed variants (RFC 8032 5.1 with dom2; verifying.rs:230-257 raw_verify_prehashed, :424-461
+ * verify_prehashed_strict, :520-534 RCompute::new with prehash_ctx = Some(ctx); signing.rs:917-976 raw_sign_prehashed).
+ * dom2 = "SigEd25519 no Ed25519 collisions" || 0x01 || len(ctx) || ctx is hashed BEFORE R || A (resp. before the hash prefix of the nonce);
+ * the message is the 64-byte SHA-512 of the original message (the reference takes the digest state and finalises it itself). */
+static void dom2_update(sha512_ctx *c, const uint8_t *ctx, size_t ctxlen) {
+    const uint8_t two[2] = {1, (uint8_t)ctxlen};
+    sha512_update(c, (const uint8_t *)"SigEd25519 no Ed25519 collisions", 32); sha512_update(c, two, 2); sha512_update(c, ctx, ctxlen);
+}
+static void hram_hash_ph(uint8_t out[64], const uint8_t *ctx, size_t ctxlen, const uint8_t R[32], const uint8_t A[32], const uint8_t ph[64]) {
+    sha512_ctx c; sha512_init(&c); dom2_update(&c, ctx, ctxlen); sha512_update(&c, R, 32); sha512_update(&c, A, 32); sha512_update(&c, ph, 64); sha512_final(&c, out);
+}
+#define ST_PREHASHED_CONTEXT_LENGTH 5      /* errors.rs InternalError::PrehashedContextLength */
+EXPORT int orc_ed25519_sign_prehashed(const uint8_t sk[32], const uint8_t ph[64], const uint8_t *ctx, size_t ctxlen, uint8_t sig[64]) {
+    ensure_tables();
+    if (ctxlen > 255) return ST_PREHASHED_CONTEXT_LENGTH;      /* signing.rs:931-933 */
+    uint8_t a[32], prefix[32], pk[32], h[64], rb[32], kb[32];
+    expand_secret(sk, a, prefix);
+    ge_compress(pk, ge_mul_base_table(g_btab, a));
+    sha512_ctx c; sha512_init(&c); dom2_update(&c, ctx, ctxlen); sha512_update(&c, prefix, 32); sha512_update(&c, ph, 64); sha512_final(&c, h);     /* :952-958 */
+    sc52 r = sc_from_bytes_wide(h); sc_to_bytes(rb, r);
+    ge_compress(sig, ge_mul_base_table(g_btab, rb));
+    hram_hash_ph(h, ctx, ctxlen, sig, pk, ph);                                                                                                    /* :963-970 */
+    sc52 k = sc_from_bytes_wide(h); sc_to_bytes(kb, k);
+    sc52 as = sc_from_bytes_mod_order(a);
+    sc_to_bytes(sig + 32, sc_add(sc_mul(k, as), r));
+    return ST_OK;
+}
+EXPORT int orc_ed25519_verify_prehashed(const uint8_t pk[32], const uint8_t ph[64], const uint8_t *ctx, size_t ctxlen, const uint8_t sig[64], int strict) {
+    ensure_tables();
+    if (ctxlen > 255) return ST_PREHASHED_CONTEXT_LENGTH;      /* (the reference debug_asserts; a release build would truncate the length byte) */
+    ge_p3 A, R; if (!ge_decompress(&A, pk)) return ST_NONE;
+    if (!sc_is_canonical_bytes(sig + 32)) return ST_SCALAR_FORMAT;
+    if (strict) {                                              /* verifying.rs:443-451 */
+        if (!ge_decompress(&R, sig)) return ST_VERIFY;
+        if (ge_is_small_order(R) || ge_is_small_order(A)) return ST_VERIFY;
+    }
+    uint8_t h[64], kb[32], Rcheck[32];
+    hram_hash_ph(h, ctx, ctxlen, sig, pk, ph); sc_to_bytes(kb, sc_from_bytes_wide(h));
+    ge_compress(Rcheck, ge_vartime_double_base_mul(kb, ge_neg(A), sig + 32, g_naf8B));
+    return memcmp(Rcheck, sig, 32) == 0 ? ST_OK : ST_VERIFY;
+}
 
 /* batch.rs:168-222: the transcript-derived 128-bit z_i.  hrams: n x 64, ss: n x 32, zs out: n x 16 */
 EXPORT void orc_batch_transcript_zs(const uint8_t *hrams, const uint8_t *ss, size_t n, uint8_t *zs) {

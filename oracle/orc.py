@@ -241,6 +241,18 @@ def ed25519_verify_strict(pk, msg, sig):
     return lib().orc_ed25519_verify_strict(_b(pk, 32), bytes(msg), C.c_size_t(len(msg)), _b(sig, 64))
 
 
+def ed25519_sign_prehashed(sk, prehash, context=b""):
+    """Ed25519ph (signing.rs:917-976): prehash = the 64-byte SHA-512 of the message; -> (status, signature)"""
+    o = _out(64)
+    st = lib().orc_ed25519_sign_prehashed(_b(sk, 32), _b(prehash, 64), bytes(context), C.c_size_t(len(context)), o)
+    return st, o.raw
+
+
+def ed25519_verify_prehashed(pk, prehash, sig, context=b"", strict=False):
+    """verifying.rs:230-257 (strict: :424-461) -> status"""
+    return lib().orc_ed25519_verify_prehashed(_b(pk, 32), _b(prehash, 64), bytes(context), C.c_size_t(len(context)), _b(sig, 64), 1 if strict else 0)
+
+
 def _pack_msgs(msgs):
     off = np.zeros(len(msgs) + 1, dtype=np.uint64)
     for i, m in enumerate(msgs):

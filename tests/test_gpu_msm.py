@@ -3,6 +3,7 @@ MSM beyond two terms has no embedded answers in the reference; it is pinned the 
 pins it (edwards.rs:2276-2296, pippenger.rs:169-198): sum x_i (x_i B) = (sum x_i^2) B, and against
 the oracle's own Straus/Pippenger on arbitrary points at sizes the oracle finishes in seconds."""
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -254,7 +255,11 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_MSM_MIDRANGE_WINDOWS": "0", "C25519_MSM_CMAX": "16", "C25519_RED_LB_MIN": "3"},
                                  {"C25519_MSM_MIDRANGE_WINDOWS": "0", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
                                  # every pass normalises its own points; the 512-thread partition
-                                 {"C25519_PREP_AHEAD": "0", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_SWEEP_THREADS": "512", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"}])
+                                 {"C25519_PREP_AHEAD": "0", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_SWEEP_THREADS": "512", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
+                                 # round 5: single-pass calls in window groups (bucket order, accumulation and reduction group by group), the sort enqueued
+                                 # ahead of the normaliser
+                                 {"C25519_ACC_GROUPS": "2"}, {"C25519_ACC_GROUPS": "4", "C25519_ACC_LAST": "2"}, {"C25519_ACC_GROUPS": "3", "C25519_SORT_FIRST": "1"},
+                                 {"C25519_SORT_FIRST": "2"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
@@ -444,7 +449,10 @@ def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
     for i in range(nmax):
         acc = (acc + int.from_bytes(x[i].tobytes(), "little") ** 2) % L
         pref.append(acc)
-    want = eng.mul_base_batch(np.frombuffer(b"".join(i2b(v) for v in pref), np.uint8).reshape(-1, 32))
+    # (the expected encodings come from the ORACLE's fixed-base multiplication of the prefix sums -- round 4 took them from the engine's own
+    #  fixed-base kernel, i.e. compared the product with the product)
+    want = orc.mul_base_compress_batch(np.frombuffer(b"".join(i2b(v) for v in pref), np.uint8).reshape(-1, 32), threads=os.cpu_count() or 1)
+    assert np.array_equal(want, eng.mul_base_batch(np.frombuffer(b"".join(i2b(v) for v in pref), np.uint8).reshape(-1, 32)))
     for n in range(1, nmax + 1):
         st, got = eng.msm_vartime(x[:n], pts[:n], in_fmt=2, out_fmt=0)
         assert st == 0 and got == want[n - 1].tobytes(), n

@@ -54,6 +54,14 @@ xi = x.cpu().numpy(); yi = y.cpu().numpy()
 acc = sum(int.from_bytes(xi[i].tobytes(), "little") * int.from_bytes(yi[i].tobytes(), "little") for i in range(n)) %% L
 want = orc.ed_compress(orc.ed_mul_base(acc.to_bytes(32, "little")))
 out["msm"] = (st == 0 and st1 == 0 and got == single == want)
+# the per-step breakdown a --gpus N bench line reports (multi.StepTimes): same result, and the three parts add up to the wall-clock of the calls
+tm = pkg.multi.StepTimes()
+for _ in range(3):
+    st_t, got_t = pkg.multi.msm_vartime_sharded(eng, x[lo:hi].contiguous(), pts[lo:hi].contiguous(), E.FMT_RAW160, E.FMT_EDWARDS_Y, force_collective=force, times=tm)
+bm = tm.mean()
+out["step_times"] = bm
+out["step_times_ok"] = bool(st_t == 0 and got_t == want and bm["calls"] == 3 and all(bm[k] >= 0 for k in ("shard_ms", "collective_ms", "d2h_fold_ms"))
+                            and abs(bm["shard_ms"] + bm["collective_ms"] + bm["d2h_fold_ms"] - bm["sum_ms"]) <= 0.05 * bm["sum_ms"] and bm["shard_ms"] > 0)
 # Ristretto / raw outputs take the same exchange
 st, got_r = pkg.multi.msm_vartime_sharded(eng, x[lo:hi].contiguous(), pts[lo:hi].contiguous(), E.FMT_RAW160, E.FMT_RISTRETTO, force_collective=force)
 out["msm_ristretto"] = (st == 0 and got_r == orc.ris_compress(orc.ed_mul_base(acc.to_bytes(32, "little"))))
@@ -144,6 +152,7 @@ def _check(outs):
             assert [v for v, _ in got] == [OK, VERIFY, SCALAR_FORMAT], (z_mode, got)
             assert all(v == v1 for v, v1 in got), (z_mode, got)         # sharded verdict == single-context verdict
         assert o["one_transcript"], o
+        assert o["step_times_ok"], o["step_times"]              # shard_ms + collective_ms + d2h_fold_ms = the step, within 5 %
         assert o["verdict_collective"] == [OK, VERIFY, SCALAR_FORMAT, NONE]
 
 
@@ -192,3 +201,12 @@ def test_bench_under_torch_distributed_run_one_gpu():
     j = json.loads(line)
     assert j["n_gpus"] == 1 and j["ranks_seen_by_rccl"] == 1 and j["collective_executed_per_step"] is True
     assert j["value"] > 1e8 and j["roofline"]["bound"] == "valu_int_mac" and 0 < j["roofline"]["frac"] < 1
+    # the N > 1 line explains itself: shard / collective / read-back + fold per step (max over ranks), summing to the step within 5 %, the ranks RCCL
+    # saw, the warm-up collectives outside the timed region and the model's prediction beside the measured step
+    mg = j["multi_gpu"]
+    for k in ("shard_ms", "collective_ms", "d2h_fold_ms", "sum_ms", "measured_step_ms", "ranks_seen_by_rccl", "rccl_warmup_collectives_outside_timed_region", "model", "min_over_ranks"):
+        assert k in mg, k
+    assert mg["ranks_seen_by_rccl"] == 1 and mg["rccl_warmup_collectives_outside_timed_region"] >= 1
+    assert abs(mg["shard_ms"] + mg["collective_ms"] + mg["d2h_fold_ms"] - mg["sum_ms"]) <= 0.05 * mg["sum_ms"]
+    assert abs(mg["sum_ms"] - mg["measured_step_ms"]) <= 0.10 * mg["measured_step_ms"]
+    assert mg["collective_ms"] > 0 and mg["model"]["predicted_step_ms"] > mg["shard_ms"]

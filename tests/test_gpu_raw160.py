@@ -86,3 +86,32 @@ def test_raw_point_with_affine_z_and_big_limbs(eng):
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); x[:, 31] &= 0x0F
     want = eng.msm_vartime(x, aff)
     assert eng.msm_vartime(x, big) == want and eng.msm_vartime(x, mixed) == want
+
+
+def test_msm_on_unreduced_limbs_against_the_oracle(eng):
+    """The metamorphic test above compares engine(big limbs) with engine(canonical limbs); here the ORACLE is the judge: its fe51 arithmetic accepts limbs
+    in [2^51, 2^52) (u64/field.rs:125-166 bounds), so the same unreduced raw points go to the oracle's Pippenger / Straus and to the HIP MSM, and the
+    encodings must agree -- on the small path, the digit-matrix range and the chunk-local sort, with points outside the prime-order subgroup."""
+    from curve25519_dalek_amd import engine as E
+    from oracle import orc
+    import util
+    rng = np.random.default_rng(5150)
+    rnd = util.rand_bytes(5151, 9000)
+    rnd = rnd[orc.ed_decompress_ok_batch(rnd) == 1][:3000]
+    st, pts, ok = eng.decompress_batch(rnd)
+    assert st == 0 and ok.all()
+    big = relimb(pts, rng, 1)
+    lim = big.view("<u8")
+    assert (lim >= (1 << 51) - 19).all() and (lim < (1 << 52)).all()
+    s = util.rand_scalars(5152, big.shape[0])
+    for n in (1, 7, 190, 1000, 3000):
+        want = orc.ed_compress(orc.ed_msm([s[i].tobytes() for i in range(n)], [big[i].tobytes() for i in range(n)]))
+        assert eng.msm_vartime(s[:n], big[:n], in_fmt=E.FMT_RAW160, out_fmt=E.FMT_EDWARDS_Y) == (0, want), n
+    # the bucket pipeline (4096 .. 2^16: digit-matrix sort; above: chunk-local sort): the sum-of-squares identity on unreduced limbs, expected point by the oracle
+    n = 70001
+    x = util.rand_scalars(5153, n)
+    pts2 = relimb(eng.mul_base_batch(x, out_fmt=E.FMT_RAW160), rng, 1)
+    for m in (5000, n):
+        tot = sum(int.from_bytes(x[i].tobytes(), "little") ** 2 for i in range(m)) % util.L
+        want = orc.ed_compress(orc.ed_mul_base(tot.to_bytes(32, "little")))
+        assert eng.msm_vartime(x[:m], pts2[:m], in_fmt=E.FMT_RAW160, out_fmt=E.FMT_EDWARDS_Y) == (0, want), m

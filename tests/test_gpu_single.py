@@ -166,3 +166,93 @@ def test_sign_then_verify_roundtrip_large(eng, orc):
     st = eng.verify_each_t(dmsg, doff, dsig, dpk, False).cpu().numpy()
     assert st[4242] == 3 and st.sum() == 3            # exactly the tampered one is located
     assert eng.verify_batch_t(dmsg, doff, dsig, dpk, 1) == 3
+
+
+# ---- Ed25519ph / Ed25519ctx (RFC 8032 5.1 with dom2): verify_prehashed[_strict] / sign_prehashed -----------------------------------
+def test_ed25519ph_rfc8032_vector(eng, orc):
+    """The reference's own prehash test (ed25519-dalek/tests/ed25519.rs:104-146, RFC 8032 7.3): sign_prehashed(SHA-512("abc"), None) reproduces the
+    vector byte for byte, verify_prehashed and verify_prehashed_strict accept it, and the signature is bound to the context, the prehash and the
+    variant (plain Ed25519 rejects it) -- through the host-pointer entry points, the device-pointer ones and the dalek front end."""
+    import hashlib, torch
+    from test_oracle_kat import ED25519PH_SK as SK, ED25519PH_PK as PK, ED25519PH_MSG as MSG, ED25519PH_SIG as SIG
+    import curve25519_dalek_amd.dalek as dalek
+    ph = hashlib.sha512(MSG).digest()
+    pks, sigs = eng.sign_batch_prehashed([SK], [ph])
+    assert pks[0].tobytes() == PK and sigs[0].tobytes() == SIG
+    for strict in (False, True):
+        st = eng.verify_each_prehashed([ph, ph, hashlib.sha512(b"abd").digest()], [SIG, SIG[:7] + bytes([SIG[7] ^ 1]) + SIG[8:], SIG], [PK, PK, PK], strict=strict)
+        assert list(st) == [0, 3, 3]
+        assert list(eng.verify_each_prehashed([ph], [SIG], [PK], context=b"edtest", strict=strict)) == [3]        # context mismatch
+    assert list(eng.verify_each([MSG, ph], [SIG, SIG], [PK, PK])) == [3, 3]                                       # not a plain Ed25519 signature
+    # device-pointer forms
+    dph = torch.from_numpy(np.frombuffer(ph, np.uint8).copy()).cuda(); dsk = torch.from_numpy(np.frombuffer(SK, np.uint8).copy()).cuda()
+    dpk, dsig = eng.sign_batch_prehashed_t(dsk, dph)
+    assert dpk.cpu().numpy().tobytes() == PK and dsig.cpu().numpy().tobytes() == SIG
+    assert eng.verify_each_prehashed_t(dph, dsig, dpk, strict=True).cpu().numpy().tolist() == [0]
+    assert eng.verify_each_prehashed_t(dph, dsig, dpk, context=b"x").cpu().numpy().tolist() == [3]
+    # the front end takes the digest STATE, as the reference does
+    vk, sg = dalek.sign_batch_prehashed([SK], [hashlib.sha512(MSG)], engine=eng)
+    assert vk == [PK] and sg == [SIG]
+    assert dalek.verify_each_prehashed([hashlib.sha512(MSG)], [SIG], [PK], strict=True, engine=eng) == [None]
+    err = dalek.verify_each_prehashed([hashlib.sha512(MSG)], [SIG], [PK], context=b"edtest", engine=eng)[0]
+    assert isinstance(err, dalek.SignatureError)
+    # a context beyond 255 octets: InternalError::PrehashedContextLength (signing.rs:931-933), on every entry point
+    assert eng.sign_batch_prehashed([SK], [ph], context=bytes(256)) == 5 and eng.verify_each_prehashed([ph], [SIG], [PK], context=bytes(256)) == 5
+    with pytest.raises(dalek.SignatureError):
+        dalek.sign_batch_prehashed([SK], [ph], context=bytes(300), engine=eng)
+
+
+def test_ed25519ph_contexts_and_batches_vs_oracle(eng, orc):
+    """Random keys, prehashes and contexts of every alignment class (the dom2 prefix is 34 + len(ctx) bytes: R, A and the prehash are absorbed at
+    any byte position of the SHA-512 block, across one, two and three block boundaries): signatures byte-equal to the oracle's, verdicts equal to the
+    oracle's for valid, tampered and cross-context pairs, plain and strict; a batch large enough for several blocks of the grid."""
+    import hashlib
+    rng = np.random.default_rng(2024)
+    for ctx in (b"", b"e", b"edtest", bytes(range(30)), bytes(range(94)), bytes(range(95)), bytes(range(200)), bytes(range(255))):
+        n = 37
+        sks = [rng.bytes(32) for _ in range(n)]
+        phs = [hashlib.sha512(rng.bytes(int(rng.integers(0, 90)))).digest() for _ in range(n)]
+        pks, sigs = eng.sign_batch_prehashed(sks, phs, context=ctx)
+        for i in range(n):
+            st, want = orc.ed25519_sign_prehashed(sks[i], phs[i], ctx)
+            assert st == 0 and sigs[i].tobytes() == want and pks[i].tobytes() == orc.ed25519_pubkey(sks[i]), (len(ctx), i)
+        S = [sigs[i].tobytes() for i in range(n)]; P = [pks[i].tobytes() for i in range(n)]
+        bad = list(S); bad[5] = bad[5][:40] + bytes([bad[5][40] ^ 4]) + bad[5][41:]; bad[9] = S[10]
+        for strict in (False, True):
+            assert not eng.verify_each_prehashed(phs, S, P, context=ctx, strict=strict).any()
+            got = eng.verify_each_prehashed(phs, bad, P, context=ctx, strict=strict)
+            want = [orc.ed25519_verify_prehashed(P[i], phs[i], bad[i], context=ctx, strict=strict) for i in range(n)]
+            assert list(got) == want and got[5] != 0 and got[9] != 0
+            other = ctx[:-1] + b"\xff" if ctx else b"\x00"
+            assert eng.verify_each_prehashed(phs, S, P, context=other, strict=strict).all()
+    n = 5000
+    sks = util.rand_bytes(81, n); phs = util.rand_bytes(82, n, 64)
+    pks, sigs = eng.sign_batch_prehashed([r.tobytes() for r in sks], [r.tobytes() for r in phs], context=b"batch")
+    for i in (0, 1, 255, 256, 4095, 4999):
+        assert sigs[i].tobytes() == orc.ed25519_sign_prehashed(sks[i].tobytes(), phs[i].tobytes(), b"batch")[1]
+    st = eng.verify_each_prehashed([r.tobytes() for r in phs], [r.tobytes() for r in sigs], [r.tobytes() for r in pks], context=b"batch", strict=True)
+    assert not st.any()
+
+
+def test_ed25519ph_repudiation_weak_key(eng, orc):
+    """ed25519-dalek/tests/ed25519.rs:248-292 (repudiation_prehash): for the order-2 public key (EIGHT_TORSION[4]) a signature R = sB - A, s can be found
+    that verify_prehashed accepts for TWO messages under the context "edtest", and verify_prehashed_strict rejects both (small-order key)."""
+    import hashlib
+    A = bytes([236] + [255] * 30 + [127])
+    m1, m2 = hashlib.sha512(b"Send 100 USD to Alice").digest(), hashlib.sha512(b"Send 100000 USD to Alice").digest()
+    ctx = b"edtest"
+    Apt = orc.ed_decompress(A)
+    assert Apt is not None
+    rng = np.random.default_rng(77)
+    found = None
+    for _ in range(400):
+        s = (int.from_bytes(rng.bytes(32), "little") % (util.L - 1) + 1).to_bytes(32, "little")
+        R = orc.ed_compress(orc.ed_add(orc.ed_mul_base(s), orc.ed_neg(Apt)))
+        sig = R + s
+        if orc.ed25519_verify_prehashed(A, m1, sig, context=ctx) == 0 and orc.ed25519_verify_prehashed(A, m2, sig, context=ctx) == 0:
+            found = sig
+            break
+    assert found is not None
+    assert list(eng.verify_each_prehashed([m1, m2], [found, found], [A, A], context=ctx)) == [0, 0]
+    assert list(eng.verify_each_prehashed([m1, m2], [found, found], [A, A], context=ctx, strict=True)) == [3, 3]
+    assert [orc.ed25519_verify_prehashed(A, m, found, context=ctx, strict=True) for m in (m1, m2)] == [3, 3]

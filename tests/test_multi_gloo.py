@@ -33,7 +33,25 @@ def _worker(rank, world, port, n, q):
     out = pkg.multi.gather_fold(partial, pkg.engine.FMT_EDWARDS_Y)
     total = sum(int.from_bytes(x[i].tobytes(), "little") ** 2 for i in range(n)) % L
     want = orc.ed_compress(orc.ed_mul_base(total.to_bytes(32, "little")))
-    q.put((rank, out == want, (lo, hi)))
+    # the sharded entry point itself with a stand-in engine (the record of a shard = its oracle partial sum, packed), and its per-step breakdown
+    # (multi.StepTimes, what a --gpus N bench line reports): the three parts are non-negative and add up to the wall-clock of the calls
+    import torch
+
+    class OracleEngine:
+        def msm_partial_record_t(self, scalars_t, points_t, in_fmt):
+            sc = scalars_t.numpy(); pt = points_t.numpy()
+            part = orc.ed_msm([sc[i].tobytes() for i in range(sc.shape[0])], [pt[i].tobytes() for i in range(pt.shape[0])])
+            return torch.frombuffer(bytearray(pkg.engine.partial_record_pack(part)), dtype=torch.uint8)
+    xs_t = torch.from_numpy(x[lo:hi].copy()); pts_t = torch.from_numpy(np.frombuffer(b"".join(pts), np.uint8).reshape(-1, 160).copy()) if hi > lo else torch.zeros((0, 160), dtype=torch.uint8)
+    tm = pkg.multi.StepTimes()
+    ok_t = True
+    for _ in range(2):
+        st_t, got_t = pkg.multi.msm_vartime_sharded(OracleEngine(), xs_t, pts_t, pkg.engine.FMT_RAW160, pkg.engine.FMT_EDWARDS_Y, times=tm)
+        ok_t = ok_t and st_t == 0 and got_t == want
+    bm = tm.mean()
+    ok_t = ok_t and bm["calls"] == 2 and min(bm["shard_ms"], bm["collective_ms"], bm["d2h_fold_ms"]) >= 0 and bm["collective_ms"] > 0
+    ok_t = ok_t and abs(bm["shard_ms"] + bm["collective_ms"] + bm["d2h_fold_ms"] - bm["sum_ms"]) <= 0.05 * bm["sum_ms"]
+    q.put((rank, out == want and ok_t, (lo, hi)))
     dist.barrier()
     dist.destroy_process_group()
 
