@@ -271,17 +271,74 @@ __device__ __forceinline__ ge_aniels ctp_fetch(const uint4 *wtab, const ctp_lane
     }
     return aniels_from_words(tw);
 }
+// ---- the same with the table kept as LIMBS in LDS (C25519_CT_LIMBS, the default): an entry is 3 x 10 tight limbs, each field element padded to three
+// 16-byte pieces (144 bytes per entry, 52 x 17 x 144 = 127 KB) -- nine ds_read_b128 and THIRTY permutes per window, but no unpacking of three 255-bit
+// values into limbs per window (~70 VALU instructions) and the negation is limb-wise (2p - x: ten subtractions, no borrow chain).
+// LDS layout: [window][part 0..2][piece 0..2][entry].
+template <int W>
+struct ctp_lane_l {
+    static constexpr int GS = 1 << W, HALF = GS / 2, ENT = HALF + 1, WSTRIDE = 9 * ENT;
+    u32 a0, b0, c0;                  // uint4 offsets of the first piece of this lane's three field elements (pieces are ENT apart)
+    u32 group;
+    bool neg;
+    __device__ __forceinline__ void init(u32 lane) {
+        const int j = (int)(lane & (GS - 1)), dv = j - HALF;
+        neg = dv < 0;
+        const u32 mag = (u32)(neg ? -dv : dv);
+        a0 = (neg ? 3u : 0u) * ENT + mag; b0 = (neg ? 0u : 3u) * ENT + mag; c0 = 6u * ENT + mag;
+        group = lane & ~(u32)(GS - 1);
+    }
+};
+template <int W, int BS>
+__device__ __forceinline__ void ctp_stage_l(uint4 *lds, const uint4 *__restrict__ gtab) {
+    constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
+    for (int i = threadIdx.x; i < NWIN * ENT * 3; i += BS) {             // one field element per trip: words -> limbs once per block
+        const int win = i / (ENT * 3), r = i - win * (ENT * 3), e = r / 3, part = r - e * 3;
+        const uint4 lo = gtab[(win * ENT + e) * 6 + 2 * part], hi = gtab[(win * ENT + e) * 6 + 2 * part + 1];
+        const feT f = fe_from_q(lo, hi);
+        uint4 *dst = lds + win * (ENT * 9) + (part * 3) * ENT + e;
+        dst[0] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]); dst[ENT] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]); dst[2 * ENT] = make_uint4(f.v[8], f.v[9], 0u, 0u);
+    }
+}
+template <int W>
+__device__ __forceinline__ ge_aniels ctp_fetch_l(const uint4 *wtab, const ctp_lane_l<W> &L, u32 dsel) {
+    constexpr int ENT = (1 << (W - 1)) + 1;
+    const uint4 a0 = wtab[L.a0], a1 = wtab[L.a0 + ENT], a2 = wtab[L.a0 + 2 * ENT];
+    const uint4 b0 = wtab[L.b0], b1 = wtab[L.b0 + ENT], b2 = wtab[L.b0 + 2 * ENT];
+    const uint4 c0 = wtab[L.c0], c1 = wtab[L.c0 + ENT], c2 = wtab[L.c0 + 2 * ENT];
+    u32 own[30] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y,
+                   c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w, c2.x, c2.y};
+    // 2p - 2dxy, limb-wise, for the lanes that serve a negative digit value (a choice by lane index); tight in, below 2p's limbs out: a legal `g` operand
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const u32 m = (i == 0 ? 0x7ffffdau : (i & 1) ? 0x3fffffeu : 0x7fffffeu) - own[20 + i];
+        own[20 + i] = L.neg ? m : own[20 + i];
+    }
+    const int sel = (int)((L.group + dsel) << 2);
+    ge_aniels A;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        A.ypx.v[i] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)own[i]);
+        A.ymx.v[i] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)own[10 + i]);
+        A.xy2d.v[i] = (u32)__builtin_amdgcn_ds_bpermute(sel, (int)own[20 + i]);
+    }
+    return A;
+}
+#ifndef C25519_CT_LIMBS
+#define C25519_CT_LIMBS 1
+#endif
 // SPLIT = false: one lane per scalar, all windows (large batches).  SPLIT = true: two lanes per scalar, windows [0, NWIN/2) and [NWIN/2, NWIN)
 // (small batches: every compute unit gets a block; the partial sums meet through the table's LDS space -- cf. k_mul_base_ct_split)
-template <int W, int BS, int OUT, bool SPLIT>
+template <int W, int BS, int OUT, bool SPLIT, bool LIMBS>
 __global__ void __launch_bounds__(BS) k_mul_base_ctp(const uint8_t *__restrict__ scalars, u64 n, const uint4 *__restrict__ gtab, u32 *__restrict__ scratch,
                                                      uint8_t *__restrict__ out_raw) {
-    constexpr int NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1, PER = SPLIT ? BS / 2 : BS, WLO = NWIN / 2;
+    constexpr int NWIN = (256 + W - 1) / W, HALF = 1 << (W - 1), ENT = HALF + 1, PER = SPLIT ? BS / 2 : BS, WLO = NWIN / 2, EQ = LIMBS ? 9 : 6;
     extern __shared__ uint4 lds[];
-    ctp_stage<W, BS>(lds, gtab);
+    if (LIMBS) ctp_stage_l<W, BS>(lds, gtab); else ctp_stage<W, BS>(lds, gtab);
     __syncthreads();
     ctp_lane<W> L;
-    L.init(threadIdx.x & 63u);
+    ctp_lane_l<W> LL;
+    L.init(threadIdx.x & 63u); LL.init(threadIdx.x & 63u);
     // (wave-uniform: PER is a multiple of 64 -- said to the compiler with readfirstlane, so that the window loop below is a SCALAR loop:
     //  a loop on a per-lane trip count would run under an exec mask, and the permutes need all 64 lanes)
     const int part = SPLIT ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >= (unsigned)PER)) : 0, j = (int)threadIdx.x - part * PER;
@@ -302,7 +359,7 @@ __global__ void __launch_bounds__(BS) k_mul_base_ctp(const uint8_t *__restrict__
             carry = d >= (u32)HALF ? 1u : 0u;
         }
         ge_p3 P = ge_identity();
-        const uint4 *wtab = lds + win0 * (ENT * 6);
+        const uint4 *wtab = lds + win0 * (ENT * EQ);
 #pragma unroll 1
         for (int win = win0; win < win1; win++) {
             const u32 d = (s[0] & (2u * HALF - 1u)) + carry;                 // 0 .. 2^W
@@ -314,8 +371,9 @@ __global__ void __launch_bounds__(BS) k_mul_base_ctp(const uint8_t *__restrict__
             const bool hi = (win != NWIN - 1) && (d >= (u32)HALF);
             carry = hi ? 1u : 0u;
             const u32 dsel = hi ? d - (u32)HALF : d + (u32)HALF;
-            P = ge_p1p1_to_p3(ge_madd(P, ctp_fetch<W>(wtab, L, dsel)));
-            wtab += ENT * 6;
+            if (LIMBS) P = ge_p1p1_to_p3(ge_madd(P, ctp_fetch_l<W>(wtab, LL, dsel)));
+            else P = ge_p1p1_to_p3(ge_madd(P, ctp_fetch<W>(wtab, L, dsel)));
+            wtab += ENT * EQ;
         }
         if (SPLIT) {
             // the upper halves go through LDS (the table's space: every wave is past its last table read after the barrier)
@@ -347,7 +405,7 @@ __global__ void __launch_bounds__(BS) k_mul_base_ctp(const uint8_t *__restrict__
         if (SPLIT) {
             // a further iteration needs the table again: restore it (only batches that outgrow the grid take this path)
             __syncthreads();
-            if (base + (u64)gridDim.x * PER < n) { ctp_stage<W, BS>(lds, gtab); __syncthreads(); }
+            if (base + (u64)gridDim.x * PER < n) { if (LIMBS) ctp_stage_l<W, BS>(lds, gtab); else ctp_stage<W, BS>(lds, gtab); __syncthreads(); }
         }
     }
     // secrets do not stay in LDS: the exchanged partial points are wiped
@@ -525,7 +583,12 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
 //     (as_affine :409; invert(0) = 0 so low-order inputs give the all-zero output).
 //     The scalar is kept as a 256-bit shift register so no register is indexed dynamically.
 // ================================================================================================
-__global__ void __launch_bounds__(256) k_x25519(const uint8_t *__restrict__ ks, const uint8_t *__restrict__ us, u64 n,
+#ifdef C25519_X25519_WAVES       // A/B arm (tools/build_variant.sh): a register budget for this many waves per SIMD (default: the compiler's 137 VGPRs = 3 waves)
+#define C25519_X25519_ATTR __attribute__((amdgpu_waves_per_eu(C25519_X25519_WAVES, C25519_X25519_WAVES)))
+#else
+#define C25519_X25519_ATTR
+#endif
+__global__ void __launch_bounds__(256) C25519_X25519_ATTR k_x25519(const uint8_t *__restrict__ ks, const uint8_t *__restrict__ us, u64 n,
                                                 u32 *__restrict__ scratch) {
     u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
@@ -536,6 +599,27 @@ __global__ void __launch_bounds__(256) k_x25519(const uint8_t *__restrict__ ks, 
     feT au = fe_from_words(uw);
     mont_pp x0, x1;
     x0.U = fe_one(); x0.W = fe_zero(); x1.U = au; x1.W = fe_one();
+#ifdef C25519_X25519_SCALAR_LDS
+    // A/B arm: the clamped scalar waits in LDS (word w of thread t at [w][t]: conflict-free) and ONE word at a time is a shift register -- seven
+    // registers and seven of the eight funnel shifts of a ladder step less.  The LDS address is the loop counter: public.
+    __shared__ u32 sk[8 * 256];
+#pragma unroll
+    for (int w = 0; w < 8; w++) sk[w * 256 + threadIdx.x] = s[w];
+    u32 prev = 0, word = 0;
+#pragma unroll 1
+    for (int i = 0; i < 255; i++) {
+        const int bit = 254 - i;                               // bits 254 .. 0 of the clamped scalar (bit 255 is clear)
+        if ((bit & 31) == 31 || i == 0) word = sk[(bit >> 5) * 256 + threadIdx.x] << (31 - (bit & 31));
+        const u32 cur = word >> 31;
+        word <<= 1;
+        const u32 sw = prev ^ cur;
+        fe_cswap(x0.U, x1.U, sw); fe_cswap(x0.W, x1.W, sw);
+        mont_diff_add_and_double(x0, x1, au);
+        prev = cur;
+    }
+#pragma unroll
+    for (int w = 0; w < 8; w++) sk[w * 256 + threadIdx.x] = 0;        // the secret does not stay in LDS
+#else
     // bit 254 -> position 255
 #pragma unroll
     for (int i = 7; i > 0; i--) s[i] = (s[i] << 1) | (s[i - 1] >> 31);
@@ -552,6 +636,7 @@ __global__ void __launch_bounds__(256) k_x25519(const uint8_t *__restrict__ ks, 
         mont_diff_add_and_double(x0, x1, au);
         prev = cur;
     }
+#endif
     fe_cswap(x0.U, x1.U, prev); fe_cswap(x0.W, x1.W, prev);
     p32_store(scratch, idx, x0.U, x0.U, x0.W);     // (U : W); the division is batched in k_ratio_p32
 }
@@ -713,21 +798,24 @@ static hipError_t launch_ct_split(const uint8_t *scalars, u64 n, const uint32_t 
 #undef C25519_CT_SPLIT_LAUNCH
     return hipGetLastError();
 }
-// the cross-lane-fetch form (k_mul_base_ctp)
+// the cross-lane-fetch form (k_mul_base_ctp).  The limb tables serve the P32 output (the batched compressor: mul_base, keygen, sign -- 122 VGPRs, no
+// scratch); the raw-point and P40 outputs keep the packed tables (with 30 more live words their 1024-thread kernels would spill 9 - 14 registers
+// into the window loop)
 template <int W, int BS, bool SPLIT>
 static hipError_t launch_ctp(const uint8_t *scalars, u64 n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40) {
     constexpr int NWIN = (256 + W - 1) / W, ENT = (1 << (W - 1)) + 1;
-    const size_t lds_bytes = (size_t)NWIN * ENT * 96;      // (SPLIT: the exchange of BS/2 x 160 bytes reuses it: 80 KB <= 85 KB at BS = 1024)
+    const bool limbs = C25519_CT_LIMBS && !p40 && !out_raw;
+    const size_t lds_bytes = (size_t)NWIN * ENT * (limbs ? 144 : 96);      // (SPLIT: the exchange of BS/2 x 160 bytes reuses it: 80 KB at BS = 1024)
     unsigned grid = div_up(n, SPLIT ? BS / 2 : BS);
     if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
-#define C25519_CTP_LAUNCH(OUTV)                                                                                                        \
+#define C25519_CTP_LAUNCH(OUTV, LIMBSV)                                                                                                \
     {                                                                                                                                  \
-        auto kfn = k_mul_base_ctp<W, BS, OUTV, SPLIT>;                                                                                 \
+        auto kfn = k_mul_base_ctp<W, BS, OUTV, SPLIT, LIMBSV>;                                                                         \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
         if (e != hipSuccess) return e;                                                                                                 \
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(BS), lds_bytes, st, scalars, n, reinterpret_cast<const uint4 *>(tab_ct), scratch, out_raw); \
     }
-    if (p40) C25519_CTP_LAUNCH(2) else if (out_raw) C25519_CTP_LAUNCH(1) else C25519_CTP_LAUNCH(0)
+    if (p40) C25519_CTP_LAUNCH(2, false) else if (out_raw) C25519_CTP_LAUNCH(1, false) else if (limbs) C25519_CTP_LAUNCH(0, true) else C25519_CTP_LAUNCH(0, false)
 #undef C25519_CTP_LAUNCH
     return hipGetLastError();
 }

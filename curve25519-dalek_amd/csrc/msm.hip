@@ -627,14 +627,14 @@ ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
     }
     return hp3_to(total);
 }
-// ---- how a call's results reach the host (round 5) ------------------------------------------------------------------------------
-// Rounds 1-4: hipMemcpyAsync of the slots into page-locked memory + hipStreamSynchronize -- a copy-engine launch, an interrupt and a thread
-// wake-up at the end of EVERY call: 40 - 60 us, a third of a 1-term MSM and 2 - 3 % of a 2^21-term one (profiles/r05_small_call_phases.txt).
-// Now the last kernel on the stream WRITES the slots into the context's page-locked, coherent host buffer itself (the buffer is mapped into the
-// device's address space) and then stores a sequence number behind a system-scope release fence; the host polls that word.  No copy engine, no
-// interrupt.  So that a long call does not burn a core for milliseconds, the host first blocks on an event recorded earlier in the call (the end
-// of the last accumulation: ctx->coarse_wait, set by the enqueue functions for calls of more than ~0.3 ms) and only polls through the tail.
-// A GPU fault never sets the word: every ~0.5 ms of polling the stream's status is queried and an error returned.
+// ---- how a call's results reach the host ----------------------------------------------------------------------------------------
+// hipMemcpyAsync of the slots into page-locked memory + hipStreamSynchronize (rounds 1-4, the default).  The round-4 verdict suspected 40 - 60 us of
+// copy-engine launch, interrupt and wake-up in there; round 5 built the alternative -- the last kernel WRITES the slots into the context's coherent,
+// device-mapped host buffer and releases a sequence word the host polls (k_publish; a long call first blocks on an event recorded at the end of its
+// last accumulation, ctx->coarse_wait, so that it does not burn a core for milliseconds; a GPU fault is caught by querying the stream every ~0.5 ms of
+// polling) -- and measured it: 111.8 against 114.8 us for a 1-term MSM, level at every other size (profiles/r05_small_call_phases.txt,
+// r05_ab_publish.txt).  The end of a call costs ~3 us; what a small call spends is the host's launch work (~25 us), ~65 us of kernels and launch gaps on the
+// GPU and the host fold (~28 us).  The polling arm stays behind the PUBLISH knob of the tuning build; the release library compiles it out.
 namespace c25519 {
 __global__ void __launch_bounds__(1024) k_publish(const u32 *__restrict__ src, u32 *__restrict__ host_dst, u32 words, u32 *__restrict__ host_flag, u32 seq) {
     for (u32 i = threadIdx.x; i < words; i += 1024) host_dst[i] = src[i];
@@ -653,7 +653,9 @@ static int32_t publish_and_wait(c25519_ctx *ctx, const uint32_t *d_src, uint32_t
     uint32_t seq = ++ctx->publish_seq;
     if (seq == 0) seq = ++ctx->publish_seq;
     ctx->host_us[2] = wall_us();                                          // everything is enqueued
-    static const int publish = C25519_KNOB("PUBLISH", 1);                // A/B knob: 0 = rounds 1-4 (copy engine + hipStreamSynchronize)
+    // Measured and NOT adopted (profiles/r05_small_call_phases.txt, r05_ab_publish.txt): 111.8 against 114.8 us for a 1-term MSM, level everywhere else -- the
+    // copy engine + hipStreamSynchronize of rounds 1-4 cost ~3 us, not the 40 - 60 the verdict suspected; the default stays the simple path (knob 0).
+    static const int publish = C25519_KNOB("PUBLISH", 0);
     if (!publish) {
         ctx->coarse_wait = nullptr;
         HIPCHK(hipMemcpyAsync(h_dst, d_src, words * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -164,6 +164,8 @@ def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=
     else:
         if on_gpu:
             ev[2].record()
+            ev[1].synchronize()                                          # (the host-side exchange starts by copying the record to the host, which waits for the shard anyway:
+            #                                                               waiting here keeps the shard's GPU time out of the collective's host clock)
         c0 = time.perf_counter()
         rows = all_gather_rows(rec, group, force_collective)          # gloo / no group: host clock (includes the copy of this rank's record to the host)
         t2 = t1 + (time.perf_counter() - c0)
@@ -173,6 +175,10 @@ def msm_vartime_sharded(eng, scalars_t, points_t, in_fmt=_e.FMT_RAW160, out_fmt=
         ev[2].synchronize()
         shard = ev[0].elapsed_time(ev[1])
         coll = ev[1].elapsed_time(ev[2]) if device_collective else (t2 - t1) * 1e3
+        # (ev[0] is processed when the GPU reaches it: the host's launch latency before the first kernel is inside `shard`; whatever of the wall-clock the
+        #  two parts do not cover -- read-back, fold, Python -- is d2h_fold)
+        if shard + coll > wall:
+            shard = max(wall - coll, 0.0)
     else:
         shard, coll = (t1 - t0) * 1e3, (t2 - t1) * 1e3
     if not device_collective and dist is None:

@@ -5,7 +5,7 @@ entry of a window is read and the wanted one kept by a select -- no address and 
 source says so, but the compiler is free to turn `hit ? table[j] : acc` into a read that only the lanes with `hit` perform,
 behind a branch on "does any lane of the wave have this digit" (it did: round 2 found s_cbranch_execz around the LDS reads
 of k_mul_base<5, CT>).  So the property is asserted on the instruction stream:
-  * the window loop of k_mul_base_ctp<5, *, *, *> (round 5, the default: cross-lane fetch): six LDS reads at lane-index addresses, 24
+  * the window loop of k_mul_base_ctp<5, *, *, *> (round 5, the default: cross-lane fetch): six LDS reads at lane-index addresses, 24 / 30
     ds_bpermute_b32, the addition -- no other LDS or memory read, no exec-mask branch;
   * the scan loop of k_mul_base<5, 1024, *, CT> (rounds 2-4, kept as the A/B arm): 6 ds_read_b128 + 24 v_cndmask per entry, no exec-mask branch;
   * the scan loop of k_var_base<*, *, CT>: only unconditional loads and selects, no exec-mask branch;
@@ -77,19 +77,21 @@ def test_fixed_base_cross_lane_fetch_loop(kernels_asm):
     from another lane's registers (24 ds_bpermute_b32: the digit is the lane selector of a register-to-register transfer).  Asserted on every
     instantiation (block sizes 256 / 512 / 1024, three output formats, split and unsplit): exactly these LDS operations in the window loop, no
     other LDS / global / scratch read there (nothing a digit could address), no branch on exec or vcc (nothing a digit could steer)."""
-    fns = _functions(kernels_asm, r"_ZN6c2551914k_mul_base_ctpILi5ELi\d+ELi\dELb[01]E")
-    assert len(fns) >= 12, sorted(fns)
+    fns = _functions(kernels_asm, r"_ZN6c2551914k_mul_base_ctpILi5ELi\d+ELi\dELb[01]ELb[01]E")
+    assert len(fns) >= 16, sorted(fns)
     for name, body in fns.items():
         loops = [ops for _, ops in _loops(body) if ops.get("ds_bpermute_b32", 0) and ops.get("v_mad_u64_u32", 0) > 500]
         assert loops, name
         inner = min(loops, key=lambda o: sum(o.values()))                      # the window loop (the scalar loop around it contains it)
-        assert inner["ds_bpermute_b32"] == 24, (name, dict(inner))
-        assert inner["ds_read_b128"] == 6 and sum(v for k, v in inner.items() if k.startswith("ds_read")) == 6, (name, dict(inner))
+        limbs = name.endswith("ELb1EEEvPKhmPK15HIP_vector_typeIjLj4EEPjPh")       # the limb-table form: 9 reads (3 x 3 pieces) and 30 permutes; packed tables: 6 and 24
+        assert inner["ds_bpermute_b32"] == (30 if limbs else 24), (name, dict(inner))
+        # (the third 16-byte piece of a limb element holds two limbs: the compiler reads it as ds_read_b64)
+        assert inner["ds_read_b128"] == 6 and inner.get("ds_read_b64", 0) == (3 if limbs else 0) and sum(v for k, v in inner.items() if k.startswith("ds_read")) == (9 if limbs else 6), (name, dict(inner))
         # (a scratch_load is a register spill at a compile-time offset of the lane's private stack -- the raw / P40 output forms of the 1024-thread
         #  kernel spill six words at the 128-register budget -- not a table access; global / buffer / flat loads would be)
         assert sum(v for k, v in inner.items() if k.startswith(("global_load", "buffer_load", "flat_load"))) == 0, (name, dict(inner))
         assert sum(v for k, v in inner.items() if k.startswith("scratch_load")) <= 2, (name, dict(inner))
-        assert sum(v for k, v in inner.items() if k.startswith("ds_") and not k.startswith(("ds_read_b128", "ds_bpermute_b32"))) == 0, (name, dict(inner))
+        assert sum(v for k, v in inner.items() if k.startswith("ds_") and not k.startswith(("ds_read_b128", "ds_read_b64", "ds_bpermute_b32"))) == 0, (name, dict(inner))
         assert _exec_branches(inner) == 0, (name, dict(inner))
         # all 64 lanes take part in every permute: no exec manipulation anywhere inside the window loop
         assert not any("exec" in k for k in inner), (name, [k for k in inner if "exec" in k])
