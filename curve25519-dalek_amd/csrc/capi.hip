@@ -251,7 +251,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all, &ctx->dom};
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all, &ctx->dom, &ctx->prefix2};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
     if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
@@ -260,6 +260,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->aux) { hipStreamSynchronize(ctx->aux); hipStreamDestroy(ctx->aux); }
+    if (ctx->s_prep) { hipStreamSynchronize(ctx->s_prep); hipStreamDestroy(ctx->s_prep); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_sort) hipEventDestroy(ctx->ev_sort);

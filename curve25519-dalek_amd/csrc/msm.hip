@@ -820,7 +820,10 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
 
 // points in any format -> packed affine Niels at d_pts[dst0..]; *d_badcount counts the encodings that do not decode
 int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
-    hipStream_t st = ctx->stream;
+    return prep_points_on(ctx, d_points, n, in_fmt, d_pts, dst0, d_badcount, ctx->stream, ctx->prefix);
+}
+// the same on stream st with the prefix-product scratch `pre` (a second normaliser of one context beside the first needs its own: msm_pass_enqueue)
+int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, hipStream_t st, devbuf &pre) {
     if (n == 0) return C25519_OK;
     if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
     else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
@@ -836,22 +839,22 @@ int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in
         constexpr int wpb = 4;
         const unsigned blocks = (unsigned)div_up64((n + CH - 1) / CH, 64 * wpb);
         // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
-        r = ctx_reserve(ctx, ctx->prefix, (size_t)blocks * wpb * CH * 3 * 64 * 16);
+        r = ctx_reserve(ctx, pre, (size_t)blocks * wpb * CH * 3 * 64 * 16);
         if (r) return r;
         // A/B proxy (profiles/r04_ab_prep_two_waves.txt): what the normaliser's memory system does with TWO waves per compute unit -- the occupancy
         // an LDS-resident inversion tree (prefix products of 16 points per lane kept in LDS: 40 KB per wave) would leave it
         static const int two_waves = C25519_KNOB("PREP_TWO_WAVES", 0);
         if (two_waves && CH == 16) {
             const unsigned b2 = (unsigned)div_up64((n + CH - 1) / CH, 64 * 2);
-            if ((r = ctx_reserve(ctx, ctx->prefix, (size_t)b2 * 2 * CH * 3 * 64 * 16))) return r;
+            if ((r = ctx_reserve(ctx, pre, (size_t)b2 * 2 * CH * 3 * 64 * 16))) return r;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_raw2<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
-            hipLaunchKernelGGL((k_prep_raw2<16, 2>), dim3(b2), dim3(128), 100 * 1024, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+            hipLaunchKernelGGL((k_prep_raw2<16, 2>), dim3(b2), dim3(128), 100 * 1024, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
         } else
-        if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
-        else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
-        else if (CH == 8) hipLaunchKernelGGL((k_prep_raw2<8, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
-        else if (CH == 4) hipLaunchKernelGGL((k_prep_raw2<4, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
-        else hipLaunchKernelGGL((k_prep_raw2<16, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)ctx->prefix.p, d_pts, dst0);
+        if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else if (CH == 8) hipLaunchKernelGGL((k_prep_raw2<8, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else if (CH == 4) hipLaunchKernelGGL((k_prep_raw2<4, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else hipLaunchKernelGGL((k_prep_raw2<16, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
     } else { ctx->err = "msm: bad in_fmt"; return -(int32_t)hipErrorInvalidValue; }
     HIPCHK(hipGetLastError());
     return C25519_OK;
@@ -911,13 +914,18 @@ hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind) {
 //                                   of 512 hide the latency of the normaliser's 64-step chains, and no later pass has
 //                                   a normalisation between the reduction before it and its accumulation
 //   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
-struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
+// (r5) split: the launching pass normalises only ITS OWN points on its main stream and the points of all later passes on a third stream, behind the sorts
+//   of the first two passes (first_sorted: pass 0's) -- the accumulations of passes 0 and 1 no longer wait for a 1.8 ms normaliser
+struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; bool split; hipEvent_t first_sorted; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
                                 hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr,
                                 bool cont = false, bool reduce = true, uint64_t n_carve = 0, uint32_t *d_bad_sticky = nullptr, int parity = -1) {
     int32_t r;
     uint32_t *d_pts;
     if (wait_in) HIPCHK(hipStreamWaitEvent(ctx->stream, wait_in, 0));      // host-pointer calls: this pass's inputs are still on their way up
+    // (r5, pts_ahead split) the second pass leaves the machine to the first one until ITS sort is through: its own accumulation cannot start before
+    // the first one's has finished anyway, and two normalisers + two sorts at once kept the first accumulation waiting for 1.9 ms
+    if (ahead && ahead->launch && ahead->split && ahead->n > n && ahead->first_sorted) HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->first_sorted, 0));
     if (!ahead) {
         if ((r = ctx_reserve(ctx, ctx->tmp_e, std::max(n, n_carve) * PTS_BYTES + 256))) return r;
         d_pts = (uint32_t *)ctx->tmp_e.p;
@@ -968,7 +976,11 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
         if (pl.ev_partition) HIPCHK(hipStreamWaitEvent(ctx->stream, pl.ev_partition, 0));
     }
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
-    else if (ahead->launch) {
+    else if (ahead->launch && ahead->split && ahead->n > n) {
+        // (r5) the records of THIS pass now, on this stream; those of the passes after it on the context's third stream, enqueued below once the sort
+        // of this pass is on its way -- see pts_ahead
+        if ((r = prep_points(ctx, d_points, n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
+    } else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
@@ -977,7 +989,18 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     // a continuing pass adds onto the bucket sums its predecessor on this stream set left: they must be where it left them
     if (cont && pl.buckets != ctx->cont_buckets) { ctx->err = "msm: internal error (the workspace of a continuing pass moved its buckets)"; return -(int32_t)hipErrorInvalidValue; }
     ctx->cont_buckets = pl.buckets;
-    return msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc, cont, reduce, d_bad_sticky);
+    if ((r = msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc, cont, reduce, d_bad_sticky))) return r;
+    if (ahead && ahead->launch && ahead->split && ahead->n > n) {
+        // the records of the passes AFTER this one: third stream of this context, own prefix scratch, behind the sorts of the first two passes (whose
+        // 1024-thread partition blocks need empty compute units and starved beside a normaliser that was launched first: profiles/r05_ab_prep_split.txt)
+        if (!ctx->s_prep) HIPCHK(hipStreamCreateWithFlags(&ctx->s_prep, hipStreamNonBlocking));
+        HIPCHK(hipStreamWaitEvent(ctx->s_prep, owner->ev_in, 0));              // the inputs are complete (recorded by passes_begin on the caller's stream)
+        HIPCHK(hipStreamWaitEvent(ctx->s_prep, ctx->ev_sort, 0));              // this pass's sort (recorded by msm_enqueue_acc above)
+        if (ahead->first_sorted) HIPCHK(hipStreamWaitEvent(ctx->s_prep, ahead->first_sorted, 0));      // pass 0's sort
+        if ((r = prep_points_on(ctx, d_points + n * 160, ahead->n - n, in_fmt, ahead->pts, n, slot_flags(d_slot) + 1, ctx->s_prep, ctx->prefix2))) return r;
+        HIPCHK(hipEventRecord(ahead->done, ctx->s_prep));
+    }
+    return C25519_OK;
 }
 // The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column
 // sums + counters + header) left at d_record.  Nothing here waits for the host.
@@ -1039,7 +1062,11 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         const int l = (int)(p % L);
         c25519_ctx *c = ps.c[l];
         const bool first = p < (uint64_t)L, last = p + L >= passes;
-        pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p == 1};
+        // A/B knob, measured and NOT adopted (profiles/r05_ab_prep_split.txt): 1 = the launching pass normalises only its own points and the rest goes to a
+        // third stream behind the first two sorts, so that the first accumulations start 1.4 ms earlier -- 13.68 against 13.35 - 13.53 ms per 2^24 terms, 7.26
+        // against 7.10 per 2^23: the normaliser is HBM-bound work that is conserved; beside it every accumulation runs 5 - 7 % longer
+        static const int prep_split = C25519_KNOB("PREP_SPLIT", 0);
+        pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p == 1, prep_split != 0 && passes > 2, ctx->ev_sort};
         uint32_t *slot = passes == 1 ? d_record : dslot(ctx, l);         // a single pass writes the record itself
         hipEvent_t in_ev = nullptr;
         if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;

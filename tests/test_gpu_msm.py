@@ -259,7 +259,9 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  # round 5: single-pass calls in window groups (bucket order, accumulation and reduction group by group), the sort enqueued
                                  # ahead of the normaliser
                                  {"C25519_ACC_GROUPS": "2"}, {"C25519_ACC_GROUPS": "4", "C25519_ACC_LAST": "2"}, {"C25519_ACC_GROUPS": "3", "C25519_SORT_FIRST": "1"},
-                                 {"C25519_SORT_FIRST": "2"}])
+                                 {"C25519_SORT_FIRST": "2"},
+                                 # the records of the later passes normalised on a third stream (three and more passes of 2^16 terms)
+                                 {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
