@@ -15,7 +15,7 @@ fails loudly.
 At N = 1 the same line carries, as `sub`, the other BASELINE configurations timed the same way (K steps after W warmup
 steps each, their own HIP-event kernel timings): configs[2] verify_batch of 2^20 signatures (VerifyingKey mode, device
 z-mode; plus the strict-transcript z-mode at 2^14 and 2^20), configs[1] 2^20 fixed-base multiplications (radix-2^16
-tables and the constant-time scan), configs[4] 2^20 X25519 ladders -- each with its own `roofline`, `valu` and
+tables and the constant-time lookups), configs[4] 2^20 X25519 ladders -- each with its own `roofline`, `valu` and
 `cpu_baseline` objects -- and, as `ffi_path`, the same workloads through the HOST-POINTER entry points a Rust caller binds
 (wall-clock per call, units/s, achieved PCIe GB/s against the link peak).  `--workload X` makes X the headline and drops both.
 """
@@ -361,7 +361,7 @@ def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling, clock_h
     hbm_achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms and dom_ms > 0 else None
     # PMC traffic of the kernel the roofline object describes
     pk = {"msm": "k_accumulate", "verify": "k_prep_compressed" if kt.get("dominant_is_prep") else "k_accumulate",
-          "fixed_base": "k_mul_base_comb" if w.variant == "comb" else ("k_mul_base<" if w.variant == "ct" else "k_mul_base_wide"), "x25519": "k_x25519"}[name]
+          "fixed_base": "k_mul_base_comb" if w.variant == "comb" else ("k_mul_base_ctp<" if w.variant == "ct" else "k_mul_base_wide"), "x25519": "k_x25519"}[name]
     traffic, traffic_src = pmc_traffic(name if not w.variant else name + "_" + w.variant, pk)
     if traffic and name == "msm":
         # the PMC profile of the MSM is taken on ONE 2^21-term launch (tools/profile_all.sh: the counters of a 2^24-term call would be
@@ -539,7 +539,7 @@ def _describe(self):
             "keys as 32 bytes (decompressed inside)" if self.keys_as_bytes else "keys = VerifyingKey (bytes + cached point), as in the reference")
     if self.name == "fixed_base":
         return "fixed_base: %s scalar*B -> CompressedEdwardsY per step, %s; inputs resident in HBM" % (
-            n, {"": "radix-2^16 tables in HBM (public scalars)", "comb": "LDS comb", "ct": "constant-time full-window scan (secret scalars)"}[self.variant])
+            n, {"": "radix-2^16 tables in HBM (public scalars)", "comb": "LDS comb", "ct": "constant-time cross-lane table fetch (secret scalars)"}[self.variant])
     return "x25519: %s Montgomery ladders (constant-time cswap) per step; inputs resident in HBM" % n
 
 
@@ -586,7 +586,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sub", action="store_true", help="headline only")
     ap.add_argument("--z-mode", default="device", choices=["device", "transcript"], help="verify headline: z derivation")
-    ap.add_argument("--fixed-base-variant", default="ct", choices=["ct", "vartime"], help="fixed_base headline: ct = constant-time scan (the reference's mul_base semantics), vartime = radix-2^16 tables (public scalars)")
+    ap.add_argument("--fixed-base-variant", default="ct", choices=["ct", "vartime"], help="fixed_base headline: ct = constant-time table lookups (the reference's mul_base semantics), vartime = radix-2^16 tables (public scalars)")
     ap.add_argument("--keys-as-bytes", action="store_true",
                     help="verify: pass only the 32-byte keys (A_i is decompressed inside the call); default: the keys' points "
                          "are cached like the reference's VerifyingKey (verifying.rs:64-71, batch.rs:236)")

@@ -61,11 +61,11 @@ def fixed_base_comb():
 
 
 def fixed_base_ct(W=5):
-    """kernels.hip:k_mul_base<W, CT>: ceil(256/W) mixed additions, every table entry of the window scanned (constant
-    address); the scan is v_cndmask work, not multiplier work, and is therefore not in this count."""
+    """kernels.hip:k_mul_base_ctp<W> (round 5; rounds 2-4: k_mul_base<W, CT>): ceil(256/W) mixed additions; the table entry reaches the lane by a
+    cross-lane fetch (LDS reads at lane-index addresses + ds_bpermute), which is not multiplier work and therefore not in this count."""
     nw = -(-256 // W)
     c = _add({"M": 7 * nw, "S": 0}, compress_batch())
-    c["what"] = "%d madd x 7 M (radix-2^%d LDS tables, full-window scan per lookup) + 5 M compress + 1/16 inversion" % (nw, W)
+    c["what"] = "%d madd x 7 M (radix-2^%d LDS tables, constant-time cross-lane fetch per lookup) + 5 M compress + 1/16 inversion" % (nw, W)
     return c
 
 

@@ -206,8 +206,10 @@ C25519_HD feT fe_finish64(const u64 h[10]) {
 #define fe_finish64 fe_carry64
 #endif
 
-// field.rs:111-214 restated for 10 limbs: h_k = sum_{i+j=k} f_i g_j [x2 if i,j odd]
-//                                              + 19 sum_{i+j=k+10} f_i g_j [x2 if i,j odd]
+// What it computes: FieldElement51::mul (u64/field.rs:111-214), the value mod p.  How: the 10-limb column schedule of the reference's
+// FieldElement2625::mul (backend/serial/u32/field.rs:128-200 -- which products are doubled, which operand carries the x19: the
+// multiplication table of radix 2^25.5, ref10 lineage): h_k = sum_{i+j=k} f_i g_j [x2 if i,j odd] + 19 sum_{i+j=k+10} f_i g_j [x2 if i,j odd].
+// Unsigned limbs, bound classes in the type, v_mad_u64_u32 chaining and the carry forms around it are this library's.
 C25519_HD feT fe_mul(const feW &f, const feL &g) {
     C25519_BOUND(f.v, W_EVEN, W_ODD, "fe_mul f");
     C25519_BOUND(g.v, L_EVEN, L_ODD, "fe_mul g");
@@ -262,7 +264,9 @@ C25519_HD feT fe_mul(const feW &f, const feL &g) {
     return fe_finish64(h);
 }
 
-// field.rs:454-559 (pow2k body) restated for 10 limbs: 55 products.
+// FieldElement51::pow2k body (u64/field.rs:454-559), the value mod p; the 55 products of FieldElement2625::square_inner
+// (backend/serial/u32/field.rs:551-593), with the x2 that the reference applies to sums of products moved onto an operand (38 f_odd: fits
+// 32 bits for loose limbs, the bound stated at the top of this file).
 C25519_HD feT fe_sq(const feL &f) {
     C25519_BOUND(f.v, L_EVEN, L_ODD, "fe_sq f");
     const u32 f0 = f.v[0], f1 = f.v[1], f2 = f.v[2], f3 = f.v[3], f4 = f.v[4];

@@ -82,9 +82,21 @@ extern "C" {
 
 /* c25519_ctx_create flags, bit 8: VARTIME_TABLES.  By default every entry point that replaces a CONSTANT-TIME function
  * of the reference -- mul_base (edwards.rs:918, :1192-1209), `&EdwardsPoint * &Scalar` (variable_base.rs), sign / keygen,
- * X25519 public keys -- reads its tables the way the reference's LookupTable::select does (window.rs:54-76): every
- * entry of the window is read and the wanted one kept by selects, so no address and no branch depends on the scalar
- * (fixed base: radix-2^5 tables in LDS, 52 additions; variable base: the 8-entry table of variable_base.rs).
+ * X25519 public keys -- gives what the reference's LookupTable::select gives (window.rs:54-76): no memory ADDRESS and no
+ * BRANCH depends on the scalar.
+ *   variable base: the 8-entry table of variable_base.rs, every entry read and the wanted one kept by selects.
+ *   fixed base (round 5): radix-2^5 tables in LDS, 52 additions, and the digit never reaches an address at all -- lane j of each
+ *   32-lane half of a wave reads the table entry of the signed digit value j - 16 (an address made of its LANE INDEX), and every
+ *   lane then pulls the entry of ITS digit out of the registers of lane (half base + digit + 16) with ds_bpermute_b32, a
+ *   register-to-register transfer through the LDS crossbar that reads no memory.  The digit is the permute's lane selector and
+ *   nothing else; the sign is part of the selector (no conditional negation).  MEASURED before it was adopted
+ *   (profiles/r05_instruction_rates.txt, c25519_microbench 50-67): throughput and latency of the permute are the same for
+ *   identity, all-equal, random-within-the-half, pairs 32 lanes apart and two-source selector patterns (24.2 - 24.4 cycles per
+ *   wave-instruction, 71 - 73 cycles of latency); a selector pattern that crosses the two halves at random is 16 % slower --
+ *   which is why a lane's sources stay inside its own 32-lane half BY CONSTRUCTION (radix 2^6 over the whole wave was not
+ *   built).  Asserted on the compiled code: tests/test_ct_isa.py (exactly 6 + 3 LDS reads and 30 permutes per window, no other
+ *   memory access, no exec / vcc branch in the window loop).  The full-window scan of rounds 2-4 remains as k_mul_base<5, CT>
+ *   behind the CT_FETCH knob of the tuning build (2.77 against 1.84 ms per 2^20 scalars).
  * With this flag those entry points use the fast tables instead -- fixed base: the radix-2^16 tables in HBM, 16
  * additions, 4x faster -- whose ADDRESSES depend on the scalar: set it only when every scalar handed to this context
  * is public (or call the *_vartime entry points).  The X25519 ladder is constant-time in either mode; MSM /
@@ -159,8 +171,8 @@ int32_t c25519_mul_base_clamped_batch(c25519_ctx *ctx, const uint8_t *bytes, uin
  * RistrettoBasepointTable::create (ristretto.rs:1080-1110), then `&scalar * &table` = mul_base on that table
  * (edwards.rs:1192-1209).  create: point = 32 bytes (fmt 0 / 1) or 160 bytes (fmt 2), HOST pointer; the table (radix 2^5:
  * 52 windows x 17 affine Niels entries, the layout of the context's own constant-time table) is built once and stays in device
- * memory.  mul_table: out[i] = scalars[i] * P, ALWAYS with the full-window scan of window.rs:54-76 (no address and no
- * branch depends on the scalar), whatever the context's flags -- these tables exist for secret scalars: Pedersen commitments
+ * memory.  mul_table: out[i] = scalars[i] * P, ALWAYS with the constant-time lookup of the default fixed-base kernel (no address and
+ * no branch depends on the scalar: see C25519_FLAG_VARTIME_TABLES above), whatever the context's flags -- these tables exist for secret scalars: Pedersen commitments
  * a*G + b*H, ElGamal / DH keys on a fixed generator.  out_fmt 0 / 1 / 2; fmt 1 gives RistrettoBasepointTable's result. */
 typedef struct c25519_basetable c25519_basetable;
 c25519_basetable *c25519_basetable_create(c25519_ctx *ctx, const uint8_t *point, int in_fmt);

@@ -3,10 +3,10 @@
 # Raw output under gpurun_out/prof_rNN/, summaries under gpurun_out/profiles_rNN/ (copy those to profiles/).
 #   bash tools/profile_all.sh r03 [nopmc]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$R/gpurun_out/profiles_$TAG
 RAW=$R/gpurun_out/prof_$TAG
-mkdir -p $OUT $RAW
+mkdir -p $OUT $RAW $R/gpurun_out/raw
 # instruction-rate probes FIRST: rocprofv3 counter passes can leave the GPU in a lower profiling clock state
 cd $R
 python tools/probes.py > $OUT/${TAG}_instruction_rates.txt 2>&1
