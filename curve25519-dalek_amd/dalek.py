@@ -118,7 +118,7 @@ def is_torsion_free(points, engine=None):
 
 class EdwardsBasepointTable:
     """edwards.rs:1125-1209 for ANY basepoint: `create(&P)` builds the window table once, `mul_base(&s)` = `&s * &table`
-    multiplies secret scalars by P with constant-time table scans (window.rs:54-76) whatever the engine's flags."""
+    multiplies secret scalars by P with constant-time table lookups (window.rs:54-76 semantics) whatever the engine's flags."""
 
     _fmt = _e.FMT_EDWARDS_Y
 
