@@ -559,6 +559,12 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // order are separate -- and the second (high-priority) stream reduces group q as soon as ITS accumulation has finished, beside the accumulation
     // of group q + 1: what remains exposed at the end of the call is the reduction of the last group only.
     const int groups = (g.ngroups > 1 && reduce && !cont && coop_reduce) ? g.ngroups : 1;
+    // (r5) A call of ONE pass has no other stream set to compete with: its reduction goes on the MAIN stream, straight behind the accumulation, and the
+    // read-back behind the reduction -- two cross-stream hand-overs (12 + 20 us of event latency: gpurun_out/r05_timeline_*) less on the critical path
+    // of every single-pass call.  The long-bucket kernels stay on the second stream (they run beside the accumulation); the main stream waits for them
+    // before the reduction -- long since finished.
+    static const int reduce_main = C25519_KNOB("REDUCE_MAIN", 1);       // A/B knob: 0 = always on the second stream (rounds 3-4)
+    const bool red_main = reduce_main && ctx->solo && reduce && !cont && groups == 1 && coop_reduce && !wait_acc;
     for (int q = 0; q < groups; q++) {
         const int k0 = groups > 1 ? g.gstart[q] : 0, k1 = groups > 1 ? g.gstart[q + 1] : g.nwin;
         ctx->kname[0] = launch_accumulate(d_pts, pl.sorted, pl.base, pl.perm + (size_t)k0 * g.half, (uint64_t)(k1 - k0) * g.half, pl.n, g, pl.buckets, cont ? 1 : 0, st);
@@ -575,6 +581,14 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     // main stream its few small blocks had normal priority: once the sort of the next pass stopped being late (round 3) the next
     // accumulation -- on the other stream set -- began before they were dispatched, refilled every hole a retiring block left, and
     // k_reduce_b waited 1.1 ms for its 17 wave slots, holding back this stream set's next pass (profiles/r03_msm_2p24_timeline.txt).
+    if (red_main) {
+        HIPCHK(hipEventRecord(ctx->ev_join, ctx->aux));          // behind the long-bucket kernels
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
+        launch_bucket_reduce4(pl.buckets, g, pl.nseg, pl.SW, d_slot, d_bad_sticky ? d_bad_sticky : pl.bad_ws, st);
+        HIPCHK(hipGetLastError());
+        if (ring) HIPCHK(hipEventRecord(ring[2], st));
+        return C25519_OK;
+    }
     if (reduce && groups == 1) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_acc, 0));      // (without a reduction nothing on the second stream needs the accumulated buckets)
     if (groups > 1) {
     } else if (reduce && coop_reduce) {
@@ -762,6 +776,7 @@ int32_t msm_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const ui
         msm_layout(m, g);
         HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
         if (m) {
+            ctx->solo = true;
             int32_t r = msm_enqueue(ctx, d_scalars + lo * 32, m, d_pts + lo * (PTS_BYTES / 4), g, dslot(ctx, 0), nullptr, nullptr);
             if (r) return r;
             if ((r = slots_collect(ctx, 1))) return r;
@@ -809,6 +824,7 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
     msm_slice_params(g);
     HIPCHK(hipMemsetAsync(dslot(ctx, 0), 0, C25519_SLOT_U32 * 4, ctx->stream));
     msm_plan pl;
+    ctx->solo = true;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, dslot(ctx, 0), nullptr, pl, &m);
     if (r) return r;
     if ((r = msm_enqueue_acc(ctx, pl, d_table, dslot(ctx, 0), nullptr, nullptr))) return r;
@@ -1029,6 +1045,8 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     pass_set ps;
     int32_t r;
     uint32_t *sticky = (uint32_t *)ctx->d_flag + 40;      // "a scalar has bit 255 set", ORed over the passes of the call
+    // (r5: letting the sort start on the second stream without the cross-stream wait when the main stream is idle measured level at 2^14 .. 2^20 terms --
+    //  the ~20 us before the first kernels is launch latency, not the event: profiles/r05_ab_midrange_streams.txt; not kept)
     HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
     if ((r = passes_begin(ctx, passes, ps))) return r;
     // One layout for every pass: their column sums add up window by window.  It is derived from the terms of a pass -- or, when stream sets
@@ -1044,6 +1062,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // groups 2.06 / 2.18; at 2^20 and 2^18 terms two groups lose 8 % and 17 %.  The default stays ONE group.
     static const int acc_groups = C25519_KNOB("ACC_GROUPS", 1), acc_last = C25519_KNOB("ACC_LAST", 0);
     if (passes == 1 && n > MSM_SMALL_MAX) msm_set_groups(g, acc_groups, acc_last);
+    ctx->solo = passes == 1;               // (overwritten by every call: an early error return leaves nothing behind that a later call would read)
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     hipEvent_t prev_acc_last = nullptr;
     // raw points, several passes on two stream sets: pass 1 (the first one on the peer) prepares the records of ALL later

@@ -485,6 +485,7 @@ static int32_t verify_record_enqueue(c25519_ctx *ctx, const uint8_t *d_sigs, con
     int32_t r;
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
+    ctx->solo = passes == 1;               // one pass on this context alone: its reduction runs on the main stream (msm.hip msm_enqueue_acc)
     hipEvent_t prev_acc = nullptr;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
         const int cnt = (int)std::min<uint64_t>(C25519_MAX_SLOTS, passes - p0);
@@ -595,6 +596,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     msm_layout(2 * per + 1, g, 16);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
+    ctx->solo = passes == 1;
     bool seen[5] = {false, false, false, false, false}, bad_off = false, bad_scalar = false;
     hipEvent_t prev_acc = nullptr;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
