@@ -392,6 +392,15 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
     HIPCHK(hipStreamWaitEvent(sa, ctx->ev_fork, 0));
     hipEvent_t ev_sig = nullptr, ev_pk = nullptr, ev_msg = nullptr, ev_pts = nullptr;
+    // (r5) The hash chain is the longer of the two (1.5 against 1.4 ms at 2^20 signatures, everything at 2^14): its first kernel is ENQUEUED first.  The host
+    // needs 5 - 8 us per launch, and with the three decompression launches ahead of it k_hram started 40 us into the call (gpurun_out/r05_timeline_verify_*).
+    // (Host-pointer calls keep the arrival order of their inputs.)
+    const uint8_t *hr = d_hram_pre;
+    static const int hram_first_knob = C25519_KNOB("HRAM_FIRST", 1);      // A/B knob: 0 = behind the decompression launches (rounds 1-4)
+    // (up to 2^18 signatures: 0.594 -> 0.581 ms at 2^14, 1.034 -> 1.018 at 2^18; at 2^20 the hash kernels then take the compute units ahead of the decompression
+    //  and the call is 0.6 % slower: profiles/r05_ab_midrange_streams.txt)
+    const bool hram_first = hram_first_knob && !stage && !hr && n <= (1ull << 18);
+    if (hram_first) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     launch_prep_basepoint(d_pts, 0, st);
     auto prep_A = [&]() -> int32_t {
@@ -431,8 +440,8 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         if ((r = prep_A()) || (r = prep_R())) return r;
     }
     // (A)
-    const uint8_t *hr = d_hram_pre;
-    if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
+    if (hram_first) { }
+    else if (!hr) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
     else if (hred) hipLaunchKernelGGL(k_hram_mod_l, dim3(nblk), dim3(256), 0, sa, hr, n, hred);
     HIPCHK(hipGetLastError());
     const uint8_t *zz = d_z_pre;
