@@ -31,7 +31,12 @@ using namespace c25519;
 
 namespace c25519 {
 
-// LDS point array of 64 points: word i (X 0-9, Y 10-19, Z 20-29, T 30-39) of logical lane l at arr[i * 64 + l]
+// LDS point array of 64 points (X 0-9, Y 10-19, Z 20-29, T 30-39).  Round 5 measured the alternative layout -- the 40 words of logical lane l at arr[42 l ..], a
+// coordinate as five ds_read_b64 / ds_write_b64 (twice the bytes per LDS cycle; stride 42: 42 d mod 64 is never 0 or +-1 for 0 < d < 32, conflict-free for any lane
+// permutation) -- on the suspicion that the ~100 words a point operation moves per lane through the LDS were ~40 % of it at 4.25 blocks per compute unit: level
+// at every size (profiles/r05_ab_reduce_lds.txt).  The chain is latency (two dependent products + two barriers per operation), not LDS bandwidth.  The arm stays
+// behind -DC25519_RC_LANEMAJOR.
+#ifndef C25519_RC_LANEMAJOR      // default: word i of lane l at arr[i * 64 + l], ten ds_read_b32 per coordinate
 constexpr int RC_WORDS = 40 * 64;
 __device__ __forceinline__ feT rc_get(const u32 *arr, int lane, int c) {
     feT r;
@@ -43,6 +48,21 @@ __device__ __forceinline__ void rc_put(u32 *arr, int lane, int c, const feT &a) 
 #pragma unroll
     for (int i = 0; i < 10; i++) arr[(c * 10 + i) * 64 + lane] = a.v[i];
 }
+#else
+constexpr int RC_STRIDE = 42, RC_WORDS = RC_STRIDE * 64;
+__device__ __forceinline__ feT rc_get(const u32 *arr, int lane, int c) {
+    const uint2 *q = reinterpret_cast<const uint2 *>(arr + lane * RC_STRIDE + c * 10);
+    feT r;
+#pragma unroll
+    for (int i = 0; i < 5; i++) { const uint2 v = q[i]; r.v[2 * i] = v.x; r.v[2 * i + 1] = v.y; }
+    return r;
+}
+__device__ __forceinline__ void rc_put(u32 *arr, int lane, int c, const feT &a) {
+    uint2 *q = reinterpret_cast<uint2 *>(arr + lane * RC_STRIDE + c * 10);
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = make_uint2(a.v[2 * i], a.v[2 * i + 1]);
+}
+#endif
 __device__ __forceinline__ feT rc_ident(int c) { return (c == 1 || c == 2) ? fe_one() : fe_zero(); }
 // coordinate c of point idx of a p40 array in global memory (40 consecutive u32 per point; a coordinate is only 8-byte aligned)
 __device__ __forceinline__ feT rc_global(const u32 *base, u64 idx, int c) {
@@ -142,7 +162,7 @@ __device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i
 __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ buckets, int half, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
                                                    const u32 *__restrict__ bad_ws, int k0) {
     C25519_PRIO_SIDE();
-    __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
+    __shared__ __attribute__((aligned(16))) u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     // (the roles rotate with the block index: the waves of the ~4 blocks that share a SIMD then play different roles, whose loads differ)
     const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x) & 3), lane = threadIdx.x & 63;
     const int bid = k0 * nseg + (int)blockIdx.x, k = bid / nseg, seg = bid % nseg;
@@ -174,7 +194,7 @@ __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ bucke
 // level B: one block per window over its nseg <= 64 segment pairs (weight 2^(lb + 6) per segment)
 __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols, int k0) {
     C25519_PRIO_SIDE();
-    __shared__ u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
+    __shared__ __attribute__((aligned(16))) u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int k = k0 + (int)blockIdx.x, mc = rc_coord(role);
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
