@@ -416,7 +416,8 @@ EXPORT int32_t c25519_ctx_trim(c25519_ctx *ctx) {
     for (c25519_ctx *c = ctx; c; c = c->peer) {
         if (c != ctx && c->stream) HIPCHK(hipStreamSynchronize(c->stream));
         if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
-        devbuf *bufs[] = {&c->scratch, &c->prefix, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_c2, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->pts_all};
+        if (c->s_prep) HIPCHK(hipStreamSynchronize(c->s_prep));
+        devbuf *bufs[] = {&c->scratch, &c->prefix, &c->prefix2, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_c2, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->pts_all, &c->dom};
         for (devbuf *b : bufs) if (b->p) { HIPCHK(hipFree(b->p)); b->p = nullptr; b->cap = 0; }
     }
     return C25519_OK;
