@@ -187,6 +187,7 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     // (coherent + mapped: the publishing kernel writes the slots and the "published" word straight into this buffer while the host polls it)
     if (hipHostMalloc(&ctx->h_msm, (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4 + 256, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) return false;
     memset((uint8_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32 * 4, 0, 256);
+    if (hipHostGetDevicePointer((void **)&ctx->hd_msm, ctx->h_msm, 0) != hipSuccess) return false;
     return true;
 }
 EXPORT void c25519_ctx_destroy(c25519_ctx *ctx);
@@ -196,7 +197,7 @@ c25519_ctx *ctx_peer(c25519_ctx *ctx) {
     c25519_ctx *p = new c25519_ctx();
     p->device = ctx->device; p->flags = ctx->flags; p->num_cus = ctx->num_cus; p->w = ctx->w;
     p->d_table = ctx->d_table; p->d_table_ct = ctx->d_table_ct; p->owns_table = false;
-    if (!ctx_make_streams(p) || hipMalloc(&p->d_flag, 256) != hipSuccess) { c25519_ctx_destroy(p); return nullptr; }
+    if (!ctx_make_streams(p) || hipMalloc(&p->d_flag, 256) != hipSuccess || hipMemset(p->d_flag, 0, 256) != hipSuccess) { c25519_ctx_destroy(p); return nullptr; }
     ctx->peer = p;
     return p;
 }
@@ -225,7 +226,7 @@ EXPORT c25519_ctx *c25519_ctx_create(int device, uint32_t flags) {
     if (ctx->w == 9) build_comb_table(tab); else build_window_table(ge_basepoint(), ctx->w, tab);
     if (hipMalloc(&ctx->d_table, tab.size() * 4) != hipSuccess ||
         hipMemcpy(ctx->d_table, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMalloc(&ctx->d_flag, 256) != hipSuccess) {
+        hipMalloc(&ctx->d_flag, 256) != hipSuccess || hipMemset(ctx->d_flag, 0, 256) != hipSuccess) {
         fprintf(stderr, "c25519_ctx_create: device allocation failed\n");
         c25519_ctx_destroy(ctx);
         return nullptr;
@@ -378,7 +379,10 @@ int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
 // copy on the COMPUTE stream -- no copy stream, no events, no second synchronisation.  The chunked path above costs such a call a dozen runtime
 // calls and two pageable copies (each staged by the runtime on its own): ~45 us of a 185 us MSM of 256 terms.  d[i]: where piece i landed
 // (256-byte aligned, in ctx->tmp_a).  The caller synchronises ctx->stream before it returns (the staging buffer is reused by the next call).
-int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d, size_t min_stage) {
+// zero_copy (r5): no upload at all -- d[i] are the DEVICE addresses of the page-locked staging buffer, and the kernels read the inputs in place over the link
+// (a small call's upload is a 6 us copy followed by ~28 us before the first kernel starts: gpurun_out/raw/kt_small2; for a few hundred KB the kernels' own
+// reads are cheaper).  The caller's kernels must read every input once (small.hip does).
+int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d, size_t min_stage, bool zero_copy) {
     HIPCHK(hipSetDevice(ctx->device));
     ctx->ffi_t0 = wall_ms();
     size_t off[8], total = 0;
@@ -387,7 +391,14 @@ int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, co
     int32_t r;
     // min_stage: what the rest of the call will ask of the staging buffer (the strict z-mode of verify_batch keeps its host copies there): it must not
     // be re-allocated while the upload below is still reading it
-    if ((r = ctx_host_stage(ctx, std::max(total + 256, min_stage))) || (r = ctx_reserve(ctx, ctx->tmp_a, total + 256))) return r;
+    if ((r = ctx_host_stage(ctx, std::max(total + 256, min_stage)))) return r;
+    if (zero_copy) {
+        uint8_t *dv = nullptr;
+        HIPCHK(hipHostGetDevicePointer((void **)&dv, ctx->h_stage, 0));
+        for (int i = 0; i < pieces; i++) { if (bytes[i]) memcpy((uint8_t *)ctx->h_stage + off[i], src[i], bytes[i]); d[i] = dv + off[i]; }
+        return C25519_OK;
+    }
+    if ((r = ctx_reserve(ctx, ctx->tmp_a, total + 256))) return r;
     for (int i = 0; i < pieces; i++) { if (bytes[i]) memcpy((uint8_t *)ctx->h_stage + off[i], src[i], bytes[i]); d[i] = (uint8_t *)ctx->tmp_a.p + off[i]; }
     if (total) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
     return C25519_OK;

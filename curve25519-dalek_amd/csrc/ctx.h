@@ -35,6 +35,11 @@ struct c25519_ctx {
     hipEvent_t ev_grp[4] = {nullptr, nullptr, nullptr, nullptr};   // single-pass MSM in window groups: [q] = the accumulation of group q has finished (msm.hip msm_enqueue_acc)
     hipEvent_t ev_lists[2] = {nullptr, nullptr};        // multi-pass MSM: [q] = recorded when the pass with list parity q was enqueued (the accumulation before it has finished)
     void *h_msm = nullptr;                               // pinned, coherent, device-mapped: C25519_MAX_SLOTS + 1 result slots and the "published" word behind them (msm.hip publish_and_wait)
+    // (r5) small calls that answer on the host: the last kernel of the small path writes the record straight into the page-locked host slot (h_msm is coherent and
+    // mapped: hd_msm is the device's view of it) and releases a sequence word; no slot-clearing launches before, no copy launch after (small.hip, msm.hip)
+    uint32_t *hd_msm = nullptr;                          // device pointer of h_msm
+    bool want_direct = false;                            // set by an entry point that will read the record on the host right away
+    uint32_t direct_seq = 0;                             // != 0: the enqueued small pass publishes itself under this sequence number (rec_collect polls for it)
     bool solo = false;                                   // set by the entry points for a call of ONE pass on this context alone: its bucket reduction may run on the main stream (msm.hip msm_enqueue_acc)
     uint32_t publish_seq = 0;                            // sequence number of the latest publication
     hipEvent_t coarse_wait = nullptr;                    // set by an enqueue function of a long call: the host blocks on it before it polls for the results

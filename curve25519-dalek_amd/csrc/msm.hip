@@ -662,6 +662,22 @@ static inline void cpu_relax() {
     __builtin_ia32_pause();
 #endif
 }
+// poll the host's sequence word (behind the slots of h_msm) until a kernel has released `seq` into it; a GPU fault never does: the stream's status is queried
+// every ~0.5 ms of polling
+static int32_t wait_published(c25519_ctx *ctx, uint32_t seq) {
+    volatile uint32_t *vf = (uint32_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
+    for (uint64_t spins = 1;; spins++) {
+        if (*vf == seq) break;
+        cpu_relax();
+        if ((spins & 0x3ffff) == 0) {
+            const hipError_t e = hipStreamQuery(ctx->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return c25519_fail(ctx, e, "waiting for a call's results");
+            if (e == hipSuccess && *vf != seq) return c25519_fail(ctx, hipErrorUnknown, "results were not published");
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return C25519_OK;
+}
 static int32_t publish_and_wait(c25519_ctx *ctx, const uint32_t *d_src, uint32_t *h_dst, size_t words) {
     uint32_t *flag = (uint32_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;      // the word behind the slots (ctx_make_streams)
     uint32_t seq = ++ctx->publish_seq;
@@ -680,17 +696,7 @@ static int32_t publish_and_wait(c25519_ctx *ctx, const uint32_t *d_src, uint32_t
     hipLaunchKernelGGL(k_publish, dim3(1), dim3(1024), 0, ctx->stream, d_src, h_dst, (uint32_t)words, flag, seq);
     HIPCHK(hipGetLastError());
     if (ctx->coarse_wait) { (void)hipEventSynchronize(ctx->coarse_wait); ctx->coarse_wait = nullptr; }      // (blocking: the long part of a long call)
-    volatile uint32_t *vf = flag;
-    for (uint64_t spins = 1;; spins++) {
-        if (*vf == seq) break;
-        cpu_relax();
-        if ((spins & 0x3ffff) == 0) {                                     // ~ every half millisecond of polling: is the stream still healthy?
-            const hipError_t e = hipStreamQuery(ctx->stream);
-            if (e != hipSuccess && e != hipErrorNotReady) return c25519_fail(ctx, e, "waiting for a call's results");
-            if (e == hipSuccess && *vf != seq) return c25519_fail(ctx, hipErrorUnknown, "results were not published");
-        }
-    }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    { const int32_t rw = wait_published(ctx, seq); if (rw) return rw; }
     ctx->host_us[3] = wall_us();                                          // the results are on the host
     return C25519_OK;
 }
@@ -700,6 +706,14 @@ int32_t slots_collect(c25519_ctx *ctx, int count) {
 }
 // the context's own record (slot C25519_MAX_SLOTS of d_slots / h_msm): where a call that answers on the host sums its passes
 int32_t rec_collect(c25519_ctx *ctx) {
+    if (ctx->direct_seq) {                                     // the small path publishes its record itself (small.hip): poll the sequence word
+        const uint32_t seq = ctx->direct_seq;
+        ctx->direct_seq = 0;
+        ctx->host_us[2] = wall_us();
+        const int32_t r = wait_published(ctx, seq);
+        ctx->host_us[3] = wall_us();
+        return r;
+    }
     return publish_and_wait(ctx, drec(ctx), (uint32_t *)ctx->h_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32, C25519_SLOT_U32);
 }
 void slot_init(uint32_t *d_slot, uint64_t terms, const uint32_t *d_pre, hipStream_t st, int c) {
@@ -967,7 +981,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
         if (early) lists_free = sweep_early >= 2 ? ctx->ev_lists[(parity & 1) ^ 1] : ctx->ev_fork;   // (copy `parity` was last read two passes ago: implied by the stream order, stated anyway)
     }
     if (!early) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
-    if (!cont) slot_init(d_slot, terms, nullptr, ctx->stream, g.c);            // (a continuing pass adds its counters to the slot of its stream set)
+    if (!cont && !ctx->direct_seq) slot_init(d_slot, terms, nullptr, ctx->stream, g.c);            // (a continuing pass adds its counters to the slot of its stream set; a directly published small pass writes its whole record itself)
     if (terms <= MSM_SMALL_MAX && g.half <= 64 && g.nwin <= 64 && !cont && reduce && !ahead) {      // (g: a forced width may not be the small path's -- then the bucket pipeline serves)
         // the small path (small.hip): raw points as they are (projective: no normalisation, no inversion); compressed ones through the
         // decompression into records first
@@ -1045,9 +1059,20 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     pass_set ps;
     int32_t r;
     uint32_t *sticky = (uint32_t *)ctx->d_flag + 40;      // "a scalar has bit 255 set", ORed over the passes of the call
+    // (r5) A small call on raw points whose caller reads the record on the host right away (ctx->want_direct, d_record = the context's own record): the small
+    // path publishes the record itself -- no sticky-word memset and no k_slot_init before it, no copy launch behind it (small.hip small_direct):
+    // 112 -> ~65 us for a 1-term call (profiles/r05_small_call_phases.txt).  A/B knob SMALL_DIRECT = 0: rounds 4's five launches.
+    static const int small_direct_knob = C25519_KNOB("SMALL_DIRECT", 1);
+    ctx->direct_seq = 0;
+    if (small_direct_knob && ctx->want_direct && d_record == drec(ctx) && n <= MSM_SMALL_MAX && in_fmt == C25519_FMT_RAW160 && !fetch) {
+        msm_geom gs;
+        msm_layout(n, gs);
+        if (gs.half <= 64 && gs.nwin <= 64) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
+    }
+    ctx->want_direct = false;
     // (r5: letting the sort start on the second stream without the cross-stream wait when the main stream is idle measured level at 2^14 .. 2^20 terms --
     //  the ~20 us before the first kernels is launch latency, not the event: profiles/r05_ab_midrange_streams.txt; not kept)
-    HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
+    if (!ctx->direct_seq) HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
     if ((r = passes_begin(ctx, passes, ps))) return r;
     // One layout for every pass: their column sums add up window by window.  It is derived from the terms of a pass -- or, when stream sets
     // get more than one pass each, from at least 2^21: their passes continue each other's bucket sums, ONE reduction serves all of them, and
@@ -1112,8 +1137,9 @@ static int32_t msm_record_status(c25519_ctx *ctx, const uint32_t flags[8]) {
 }
 static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, ge_p3 &R) {
     ctx->host_us[0] = ctx->host_us[1] = wall_us();
+    ctx->want_direct = true;
     int32_t r = msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, drec(ctx));
-    if (r) return r;
+    if (r) { ctx->direct_seq = 0; return r; }
     if ((r = rec_collect(ctx))) return r;
     uint32_t flags[8];
     if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
@@ -1182,13 +1208,17 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
         const void *src[2] = {scalars, points};
         const size_t bytes[2] = {(size_t)n * 32, (size_t)n * psz};
         uint8_t *d[2];
-        if ((r = ffi_small_upload(ctx, 2, src, bytes, d))) return r;
+        // raw points on the directly published small path are read in place from the staging buffer (A/B knob ZERO_COPY_MAX: 0 = always upload)
+        static const int zero_copy_max = C25519_KNOB("ZERO_COPY_MAX", 4095);
+        const bool zc = in_fmt == C25519_FMT_RAW160 && n <= (uint64_t)zero_copy_max && C25519_KNOB("SMALL_DIRECT", 1);
+        if ((r = ffi_small_upload(ctx, 2, src, bytes, d, 0, zc))) return r;
         ctx->host_us[1] = wall_us();
         ge_p3 R;
         uint32_t flags[8];
+        ctx->want_direct = true;
         r = msm_record_enqueue(ctx, d[0], d[1], n, in_fmt, drec(ctx));
         if (!r) r = rec_collect(ctx);
-        else (void)hipStreamSynchronize(ctx->stream);          // (the upload may still be reading the staging buffer)
+        else { ctx->direct_seq = 0; (void)hipStreamSynchronize(ctx->stream); }          // (the upload may still be reading the staging buffer)
         ffi_small_end(ctx, n * (32 + psz), 0);
         if (r) return r;
         if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;

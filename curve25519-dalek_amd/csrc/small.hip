@@ -68,12 +68,30 @@ __device__ __forceinline__ ge_p3 p3_from_aniels(const ge_aniels &a) {
     return p;
 }
 
+// (r5) DIRECT publication of a small call's record (small_direct.on): the kernels need no cleared slot before them -- the "bit 255" flag travels as one word
+// per block (blockflags) instead of an atomicOr into the slot -- and the LAST block to finish writes the 16 header / counter words and then releases `seq` into the
+// host's sequence word, with the column sums already written to `cols` in page-locked, coherent host memory: the host polls that word instead of launching a
+// copy (msm.hip rec_collect).  done_cnt: a device word that is zero between calls (the last block resets it).
+struct small_direct { int on; u32 *blockflags; u32 *done_cnt; u32 *host_flag; u32 seq; u32 terms; u32 c; };
+__device__ __forceinline__ void small_publish(u32 *cols, const small_direct &dx, u32 bad) {      // one thread, after every column is written and fenced
+    u32 *f = cols + MSM_MAX_WIN * 40;
+    for (int i = 0; i < 16; i++) f[i] = 0;
+    f[0] = bad; f[REC_TERMS_LO] = dx.terms; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = dx.c;
+    __threadfence_system();
+    __hip_atomic_store(dx.host_flag, dx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 // grid: ceil(n / SMALL_T) blocks of SMALL_THREADS threads; dynamic LDS: SMALL_T * half * 160 bytes.
-// partial: [block][window] 160-byte sums (or, with a single block, the column sums themselves: `direct`)
+// partial: [block][window] 160-byte sums (or, with a single block, the column sums themselves)
 __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__restrict__ scalars, const void *__restrict__ points, int src_fmt, u64 n, msm_geom g,
-                                                              u32 *__restrict__ partial, u32 *__restrict__ flags) {
+                                                              u32 *__restrict__ partial, u32 *__restrict__ flags, small_direct dx) {
     extern __shared__ u32 tab[];                          // [SMALL_T][half][40]
+    __shared__ u32 sk[SMALL_T * 8];                       // the block's four scalars: read ONCE (r5: every (window, term) thread used to load its term's 32 bytes
+    //                                                       itself -- 64 loads of the same words, which matters when the inputs are read in place from host memory)
     const int tid = threadIdx.x, ti = tid & (SMALL_T - 1), slot = tid / SMALL_T;
+    if (tid < SMALL_T * 8) {
+        const u64 tt = (u64)blockIdx.x * SMALL_T + (u64)(tid >> 3);
+        sk[tid] = tt < n ? reinterpret_cast<const u32 *>(scalars)[tt * 8 + (tid & 7)] : 0u;
+    }
     const u64 t = (u64)blockIdx.x * SMALL_T + ti;
     const int half = g.half;
     // ---- tables: E[1] = P, then c - 1 rounds of complete additions -----------------------------------------------------------------
@@ -104,10 +122,11 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__r
     }
     // ---- digits of this thread's (window, term) -----------------------------------------------------------------------------------------
     int d = 0;
+    int bad = 0;
     if (slot < g.nwin && t < n) {
         u32 s[9];
-        load8(scalars, t, s);
-        if ((s[7] >> 31) && slot == 0) atomicOr(flags, 1u);
+        for (int i = 0; i < 8; i++) s[i] = sk[ti * 8 + i];        // (written before the barriers of the table rounds above)
+        if ((s[7] >> 31) && slot == 0) { if (dx.on) bad = 1; else atomicOr(flags, 1u); }
         u64 carry = 0;
         for (int i = 0; i < 8; i++) { const u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = v >> 32; }
         s[8] = (u32)carry;
@@ -126,11 +145,21 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__r
     Q = ge_add(Q, p3_quad_xor(Q, 1));
     Q = ge_add(Q, p3_quad_xor(Q, 2));
     if (ti == 0 && slot < g.nwin) p40_store(partial, (u64)blockIdx.x * g.nwin + slot, Q);
+    if (dx.on) {
+        if (gridDim.x == 1) __threadfence_system();           // (a single block writes the host's columns itself; a system-scope fence in each of a thousand
+        //                                                           blocks of a 4000-term call cost 100 us: first version of this path)
+        const int any_bad = __syncthreads_or(bad);
+        if (tid == 0) {
+            if (gridDim.x == 1) small_publish(partial, dx, (u32)any_bad);
+            else dx.blockflags[blockIdx.x] = (u32)any_bad;
+        }
+    }
 }
 
 // one block per window: col_k = sum over the blocks' partials
-__global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ partial, int nblocks, int nwin, u32 *__restrict__ cols) {
+__global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ partial, int nblocks, int nwin, u32 *__restrict__ cols, small_direct dx) {
     __shared__ u32 stage[4 * 40];
+    __shared__ int last;
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     ge_p3 acc = ge_identity();
     bool any = false;
@@ -155,6 +184,17 @@ __global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ pa
         }
     }
     if (tid == 0) p40_store(cols, k, acc);
+    if (dx.on) {
+        // the block that finishes LAST publishes: every block fences its column to the system and then counts itself
+        if (tid == 0) { __threadfence_system(); last = atomicAdd(dx.done_cnt, 1u) == (u32)nwin - 1u; }
+        __syncthreads();
+        if (last) {
+            int b = 0;
+            for (int i = tid; i < nblocks; i += 256) b |= (int)dx.blockflags[i];
+            const int any_bad = __syncthreads_or(b);
+            if (tid == 0) { *dx.done_cnt = 0; small_publish(cols, dx, (u32)any_bad); }
+        }
+    }
 }
 
 }  // namespace c25519
@@ -163,14 +203,23 @@ int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void 
     if (n == 0 || n > MSM_SMALL_MAX || g.half > 64 || g.nwin > SMALL_SLOTS) { ctx->err = "msm: internal error (small path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
     const int nblocks = (int)((n + SMALL_T - 1) / SMALL_T);
     const size_t lds = (size_t)SMALL_T * g.half * 160;
-    uint32_t *partial = d_slot;                                     // a single block writes the column sums themselves
+    // direct publication (ctx->direct_seq, set by msm_record_enqueue): the record goes to the host's slot, not to d_slot
+    small_direct dx = {0, nullptr, nullptr, nullptr, 0, 0, 0};
+    uint32_t *out = d_slot;
+    if (ctx->direct_seq) {
+        out = ctx->hd_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32;
+        dx.on = 1; dx.done_cnt = (uint32_t *)ctx->d_flag + 56; dx.host_flag = ctx->hd_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
+        dx.seq = ctx->direct_seq; dx.terms = (uint32_t)n; dx.c = (uint32_t)g.c;
+    }
+    uint32_t *partial = out;                                        // a single block writes the column sums themselves
     if (nblocks > 1) {
-        int32_t r = ctx_reserve(ctx, ctx->tmp_d, (size_t)nblocks * g.nwin * 160 + 256);
+        int32_t r = ctx_reserve(ctx, ctx->tmp_d, (size_t)nblocks * g.nwin * 160 + (size_t)nblocks * 4 + 512);
         if (r) return r;
         partial = (uint32_t *)ctx->tmp_d.p;
+        dx.blockflags = partial + (size_t)nblocks * g.nwin * 40 + 16;
     }
-    hipLaunchKernelGGL(k_small_cols, dim3(nblocks), dim3(SMALL_THREADS), lds, st, d_scalars, d_points, src_fmt, n, g, partial, slot_flags(d_slot));
-    if (nblocks > 1) hipLaunchKernelGGL(k_small_reduce, dim3(g.nwin), dim3(256), 0, st, partial, nblocks, g.nwin, d_slot);
+    hipLaunchKernelGGL(k_small_cols, dim3(nblocks), dim3(SMALL_THREADS), lds, st, d_scalars, d_points, src_fmt, n, g, partial, slot_flags(d_slot), dx);
+    if (nblocks > 1) hipLaunchKernelGGL(k_small_reduce, dim3(g.nwin), dim3(256), 0, st, partial, nblocks, g.nwin, out, dx);
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }

@@ -261,7 +261,7 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_ACC_GROUPS": "2"}, {"C25519_ACC_GROUPS": "4", "C25519_ACC_LAST": "2"}, {"C25519_ACC_GROUPS": "3", "C25519_SORT_FIRST": "1"},
                                  {"C25519_SORT_FIRST": "2"},
                                  # the records of the later passes normalised on a third stream (three and more passes of 2^16 terms)
-                                 {"C25519_REDUCE_MAIN": "0"},      # the reduction of a single-pass call on the second stream (rounds 3-4)
+                                 {"C25519_REDUCE_MAIN": "0"}, {"C25519_SMALL_DIRECT": "0"},      # the reduction of a single-pass call on the second stream (rounds 3-4)
                                  {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
