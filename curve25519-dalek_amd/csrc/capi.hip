@@ -46,7 +46,9 @@ int32_t ctx_host_stage(c25519_ctx *ctx, size_t bytes) {
     if (bytes <= ctx->h_stage_cap) return C25519_OK;
     if (ctx->h_stage) { (void)hipHostFree(ctx->h_stage); ctx->h_stage = nullptr; ctx->h_stage_cap = 0; }
     const size_t cap = bytes + bytes / 8 + 4096;
-    hipError_t e = hipHostMalloc(&ctx->h_stage, cap, hipHostMallocDefault);
+    // (coherent + mapped, explicitly: the small paths let their kernels read this buffer in place -- ffi_small_upload zero_copy, verify.hip verify_batch_small_host --
+    //  so what the host wrote before a launch must be what the kernel sees, whatever HIP_HOST_COHERENT says)
+    hipError_t e = hipHostMalloc(&ctx->h_stage, cap, hipHostMallocCoherent | hipHostMallocMapped);
     if (e != hipSuccess) return c25519_fail(ctx, e, "hipHostMalloc(host staging)");
     ctx->h_stage_cap = cap;
     return C25519_OK;
@@ -403,6 +405,7 @@ int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, co
     if (total) HIPCHK(hipMemcpyAsync(ctx->tmp_a.p, ctx->h_stage, total, hipMemcpyHostToDevice, ctx->stream));
     return C25519_OK;
 }
+void ffi_small_begin(c25519_ctx *ctx) { ctx->ffi_t0 = wall_ms(); }
 void ffi_small_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes) {
     ctx->ffi_ms = wall_ms() - ctx->ffi_t0; ctx->ffi_h2d = h2d_bytes; ctx->ffi_d2h = d2h_bytes;
 }

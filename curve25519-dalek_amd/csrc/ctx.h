@@ -39,6 +39,7 @@ struct c25519_ctx {
     // mapped: hd_msm is the device's view of it) and releases a sequence word; no slot-clearing launches before, no copy launch after (small.hip, msm.hip)
     uint32_t *hd_msm = nullptr;                          // device pointer of h_msm
     bool want_direct = false;                            // set by an entry point that will read the record on the host right away
+    const uint32_t *direct_extra = nullptr;              // with direct_seq: two device words to publish as the record's counters [2], [3] (verify.hip, small batches)
     uint32_t direct_seq = 0;                             // != 0: the enqueued small pass publishes itself under this sequence number (rec_collect polls for it)
     bool solo = false;                                   // set by the entry points for a call of ONE pass on this context alone: its bucket reduction may run on the main stream (msm.hip msm_enqueue_acc)
     uint32_t publish_seq = 0;                            // sequence number of the latest publication

@@ -28,6 +28,7 @@ int32_t ffi_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes);
 
 // small calls: all input pieces through one page-locked buffer and one copy on the compute stream (capi.hip)
 int32_t ffi_small_upload(c25519_ctx *ctx, int pieces, const void *const *src, const size_t *bytes, uint8_t **d, size_t min_stage = 0, bool zero_copy = false);
+void ffi_small_begin(c25519_ctx *ctx);      // a small call that stages nothing through ffi_small_upload: starts the clock of c25519_last_ffi_ms
 void ffi_small_end(c25519_ctx *ctx, uint64_t h2d_bytes, uint64_t d2h_bytes);
 
 // Between ffi_begin and the point where ffi_pipeline (or an explicit ffi_end) takes over, an entry point queues whole-array uploads on

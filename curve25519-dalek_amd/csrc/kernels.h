@@ -11,6 +11,7 @@ constexpr int C25519_CT_W = 5;     // window width of the constant-time fixed-ba
 const char *mul_base_ct_kernel_name(uint64_t n, int num_cus);
 hipError_t launch_mul_base_ct(const uint8_t *scalars, uint64_t n, const uint32_t *tab_ct, uint32_t *scratch, uint8_t *out_raw, int num_cus, hipStream_t st, bool p40 = false);
 hipError_t launch_prep_compressed_keys_and_r(const uint8_t *pks, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad_count, hipStream_t st);
+hipError_t launch_prep_small_verify(const uint8_t *pks, const uint8_t *pk_points /* may be null */, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad, hipStream_t st);   // n <= 128, one block, record 0 = B
 hipError_t launch_prep_compressed(int fmt, const uint8_t *in, uint64_t stride_items, uint64_t n, uint32_t *pts, uint64_t dst0, uint32_t *bad_count, bool shared, hipStream_t st);
 hipError_t launch_clamp(const uint8_t *in, uint64_t n, uint8_t *out, hipStream_t st);
 hipError_t launch_mul_base_p40(int w, const uint8_t *scalars, uint64_t n, const uint32_t *tab, uint32_t *out40, int num_cus, hipStream_t st);

@@ -666,10 +666,15 @@ static inline void cpu_relax() {
 // every ~0.5 ms of polling
 static int32_t wait_published(c25519_ctx *ctx, uint32_t seq) {
     volatile uint32_t *vf = (uint32_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
+    double t_first = 0;
     for (uint64_t spins = 1;; spins++) {
         if (*vf == seq) break;
         cpu_relax();
         if ((spins & 0x3ffff) == 0) {
+            // (a bound on the wait as well: the calls that poll are over in microseconds -- a minute of polling means a lost kernel, which must become an error, not a hang)
+            const double now = wall_us();
+            if (t_first == 0) t_first = now;
+            else if (now - t_first > 60e6) return c25519_fail(ctx, hipErrorLaunchTimeOut, "waiting for a call's results (60 s)");
             const hipError_t e = hipStreamQuery(ctx->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return c25519_fail(ctx, e, "waiting for a call's results");
             if (e == hipSuccess && *vf != seq) return c25519_fail(ctx, hipErrorUnknown, "results were not published");
@@ -1064,6 +1069,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // 112 -> ~65 us for a 1-term call (profiles/r05_small_call_phases.txt).  A/B knob SMALL_DIRECT = 0: rounds 4's five launches.
     static const int small_direct_knob = C25519_KNOB("SMALL_DIRECT", 1);
     ctx->direct_seq = 0;
+    ctx->direct_extra = nullptr;
     if (small_direct_knob && ctx->want_direct && d_record == drec(ctx) && n <= MSM_SMALL_MAX && in_fmt == C25519_FMT_RAW160 && !fetch) {
         msm_geom gs;
         msm_layout(n, gs);

@@ -72,11 +72,14 @@ __device__ __forceinline__ ge_p3 p3_from_aniels(const ge_aniels &a) {
 // per block (blockflags) instead of an atomicOr into the slot -- and the LAST block to finish writes the 16 header / counter words and then releases `seq` into the
 // host's sequence word, with the column sums already written to `cols` in page-locked, coherent host memory: the host polls that word instead of launching a
 // copy (msm.hip rec_collect).  done_cnt: a device word that is zero between calls (the last block resets it).
-struct small_direct { int on; u32 *blockflags; u32 *done_cnt; u32 *host_flag; u32 seq; u32 terms; u32 c; };
+// extra (verify_batch's small path, may be null): two device words -- keys / R_i that did not decode, left by the decompression kernel ahead on the stream --
+// published as the record's counters [2] and [3].
+struct small_direct { int on; u32 *blockflags; u32 *done_cnt; u32 *host_flag; u32 seq; u32 terms; u32 c; const u32 *extra; };
 __device__ __forceinline__ void small_publish(u32 *cols, const small_direct &dx, u32 bad) {      // one thread, after every column is written and fenced
     u32 *f = cols + MSM_MAX_WIN * 40;
     for (int i = 0; i < 16; i++) f[i] = 0;
     f[0] = bad; f[REC_TERMS_LO] = dx.terms; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = dx.c;
+    if (dx.extra) { f[2] = dx.extra[0]; f[3] = dx.extra[1]; }
     __threadfence_system();
     __hip_atomic_store(dx.host_flag, dx.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -204,12 +207,12 @@ int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void 
     const int nblocks = (int)((n + SMALL_T - 1) / SMALL_T);
     const size_t lds = (size_t)SMALL_T * g.half * 160;
     // direct publication (ctx->direct_seq, set by msm_record_enqueue): the record goes to the host's slot, not to d_slot
-    small_direct dx = {0, nullptr, nullptr, nullptr, 0, 0, 0};
+    small_direct dx = {0, nullptr, nullptr, nullptr, 0, 0, 0, nullptr};
     uint32_t *out = d_slot;
     if (ctx->direct_seq) {
         out = ctx->hd_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32;
         dx.on = 1; dx.done_cnt = (uint32_t *)ctx->d_flag + 56; dx.host_flag = ctx->hd_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
-        dx.seq = ctx->direct_seq; dx.terms = (uint32_t)n; dx.c = (uint32_t)g.c;
+        dx.seq = ctx->direct_seq; dx.terms = (uint32_t)n; dx.c = (uint32_t)g.c; dx.extra = ctx->direct_extra;
     }
     uint32_t *partial = out;                                        // a single block writes the column sums themselves
     if (nblocks > 1) {

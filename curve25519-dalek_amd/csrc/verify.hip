@@ -649,6 +649,88 @@ static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) return false;
     return true;
 }
+// (r5) Small batches (keys as bytes or with their cached points) in the transcript z-mode, host pointers (the reference's own benchmark sizes, ed25519_benchmarks.rs:53): the host does what is
+// sequential or tiny anyway, the GPU does the curve arithmetic, and nothing crosses the link twice.
+//   rounds 3-4: upload -> k_hram -> hashes to the host -> transcript -> z_i back -> k_batch_scalars -> k_bsum_finish -> small MSM -> record copy: ten launches, two
+//   round trips, 236 us for 4 signatures of which the GPU was busy 205 (profiles/r05_small_call_phases.txt).
+//   now: ONE decompression launch (k_prep_small_verify: A_i, R_i and B into records; reads the page-locked staging buffer in place) -- and while its ~70 us chain
+//   of 252 squarings runs, the host hashes R || A || M (batch.rs:185-189), checks the s_i (signature.rs:89-94), runs the transcript (batch.rs:195-222) and forms
+//   the 2n + 1 scalars (batch.rs:225-240; sc_sha.h, the reference's Scalar52 arithmetic) into the same buffer; then the small MSM (small.hip) reads them in place
+//   and publishes its record, with the decode counters of the first kernel, straight into host memory (small_direct).  Three launches, no copy, no slot.
+// Same verdicts as the general path by construction of verify_record_verdict: [2] keys that do not decode, [4] non-canonical s (counted by the host here),
+// [3] R_i that do not decode, then the identity check.
+static bool verify_small_host_ok(uint64_t n, uint32_t z_mode, msm_geom &g) {
+    static const int host_max = C25519_KNOB("VERIFY_HOST_MAX", 64);       // A/B knob: 0 = the general path at every size
+    if (z_mode != C25519_Z_TRANSCRIPT || n == 0 || n > (uint64_t)host_max || n > 128) return false;
+    msm_layout(2 * n + 1, g, 16);
+    return g.half <= 64 && g.nwin <= 64;
+}
+static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_points, uint64_t n,
+                                       const msm_geom &g) {
+    const uint64_t m = 2 * n + 1;
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t oS = 0, oK = al(n * 64), oC = oK + al(n * 32), oH = oC + al(m * 32), oZ = oH + al(n * 64), oP = oZ + al(n * 16), total = oP + (pk_points ? al(n * 160) : 0);
+    int32_t r;
+    ctx->host_us[0] = wall_us();
+    ffi_small_begin(ctx);
+    if ((r = ctx_host_stage(ctx, total + 256)) || (r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
+    uint8_t *hs = (uint8_t *)ctx->h_stage, *dv = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void **)&dv, hs, 0));
+    memcpy(hs + oS, sigs, n * 64);
+    memcpy(hs + oK, pks, n * 32);
+    if (pk_points) memcpy(hs + oP, pk_points, n * 160);
+    uint32_t *d_pts = (uint32_t *)ctx->tmp_e.p, *cnt = (uint32_t *)ctx->d_flag + 44;
+    ctx->last_passes.clear();
+    HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
+    HIPCHK(launch_prep_small_verify(dv + oK, pk_points ? dv + oP : nullptr, dv + oS, n, d_pts, cnt, ctx->stream));
+    ctx->host_us[1] = wall_us();
+    // ---- the host's share, beside the decompression ----
+    uint32_t bad_s = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        sha512_stream st;
+        st.init();
+        st.put_bytes(sigs + i * 64, 32); st.put_bytes(pks + i * 32, 32);
+        st.put_bytes(msgs + msg_off[i], msg_off[i + 1] - msg_off[i]);
+        st.finish();
+        uint32_t w[16];
+        sha512_digest_words(st.h, w);
+        memcpy(hs + oH + i * 64, w, 64);
+    }
+    c25519_transcript_zs(hs + oH, hs + oS, n, hs + oZ);
+    uint8_t *msc = hs + oC;
+    sc52 sum = sc_zero();
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t zw[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sw[8], hw[16], o[8];
+        memcpy(zw, hs + oZ + i * 16, 16);
+        memcpy(sw, sigs + i * 64 + 32, 32);
+        memcpy(hw, hs + oH + i * 64, 64);
+        const bool canon = sc_is_canonical(sw);
+        if (!canon) bad_s++;                                       // (the verdict is then ScalarFormat or an earlier one whatever the sum is)
+        const sc52 z = sc_from_words(zw), sc = canon ? sc_from_words(sw) : sc_zero();
+        sum = sc_add(sum, sc_mul(z, sc));
+        sc_to_words(sc_mul(z, sc_from_wide(hw)), o);
+        memcpy(msc + 32 * (1 + i), zw, 32);                        // R_i: z_i
+        memcpy(msc + 32 * (1 + n + i), o, 32);                     // A_i: z_i h_i
+    }
+    { uint32_t o[8]; sc_to_words(sc_neg(sum), o); memcpy(msc, o, 32); }      // B: -sum z_i s_i   (batch.rs:240)
+    // ---- the MSM of 2n + 1 terms over the records, published by its last kernel ----
+    ctx->direct_seq = ++ctx->publish_seq;
+    if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq;
+    ctx->direct_extra = cnt;
+    r = msm_small_enqueue(ctx, dv + oC, d_pts, 1, m, g, drec(ctx), ctx->stream);
+    ctx->direct_extra = nullptr;
+    if (r) { ctx->direct_seq = 0; (void)hipStreamSynchronize(ctx->stream); return r; }
+    if ((r = rec_collect(ctx))) return r;
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    ge_p3 R;
+    uint32_t flags[8];
+    if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+    flags[4] += bad_s;
+    r = verify_record_verdict(ctx, R, flags);
+    ffi_small_end(ctx, 0, 0);                                      // (nothing is copied: the kernels read and write host memory in place)
+    ctx->host_us[4] = wall_us();
+    return r;
+}
 EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks,
                                          const uint8_t *pk_points, uint64_t n, uint32_t z_mode) {
     HIPCHK(hipSetDevice(ctx->device));
@@ -658,6 +740,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     const uint64_t mlen = msg_off[n];
     int32_t r;
     if (2 * n + 1 <= MSM_SMALL_MAX && mlen <= (1u << 20)) {
+        { msm_geom gh; if (verify_small_host_ok(n, z_mode, gh)) return verify_batch_small_host(ctx, msgs, msg_off, sigs, pks, pk_points, n, gh); }
         // the reference's own benchmark sizes (ed25519_benchmarks.rs:53: 4 .. 256 signatures) and everything else whose MSM takes the small path:
         // all five arrays through one staged copy on the compute stream (capi.hip ffi_small_upload)
         const void *src[5] = {msgs, msg_off, sigs, pks, pk_points};

@@ -351,3 +351,80 @@ def test_verify_batch_small_host_call_on_a_fresh_context_with_empty_messages(orc
         bad = list(sigs); b = bytearray(bad[n - 1]); b[3] ^= 4; bad[n - 1] = bytes(b)
         assert fresh.verify_batch(msgs, bad, pks, z_mode) == VERIFY
         assert fresh.verify_batch(msgs[:3], sigs[:3], pks[:3], z_mode) == OK
+
+
+@pytest.mark.parametrize("env", [{}, {"C25519_VERIFY_HOST_MAX": "0"}, {"C25519_VERIFY_HOST_MAX": "128"}], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "release")
+def test_verify_batch_small_host_hashing_path(orc, env):
+    """(r5) Batches of at most 64 signatures of key bytes in the transcript z-mode are hashed, checked and turned into their 2n + 1 scalars by the
+    HOST while one kernel decompresses A_i / R_i, and the small MSM publishes its record with the decode counters (verify.hip verify_batch_small_host).
+    Statuses against the oracle's batch.rs restatement around every size boundary of that path, in a fresh process per arm (the tuning library:
+    the general path at every size, and the host path up to its hard limit of 128), message lengths 0 .. 300 at every block alignment, the
+    precedence NONE > SCALAR_FORMAT > VERIFY with the offending items at the first and last index, and a context that has done nothing else."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, random, faulthandler
+        faulthandler.dump_traceback_later(200, exit=True)      # (a hang becomes a traceback, not a silent timeout)
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, torch
+        import curve25519_dalek_amd as pkg
+        from oracle import orc
+        L = 2**252 + 27742317777372353535851937790883648493
+        rnd = random.Random(5)
+        e0 = pkg.Engine(0)
+        N = 130
+        msgs = [bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 1, 37, 47, 48, 63, 64, 111, 112, 175, 176, 300]))) for _ in range(N)]
+        seeds = [bytes(rnd.randrange(256) for _ in range(32)) for _ in range(N)]
+        pks, sigs = e0.sign_batch(seeds, msgs)
+        pks = [bytes(p) for p in pks]; sigs = [bytes(s) for s in sigs]
+        assert orc.ed25519_verify(pks[7], msgs[7], sigs[7]) == 0
+        i2b = lambda x: int(x).to_bytes(32, "little")
+        # the keys' cached points (VerifyingKey.point): once as the decompression leaves them (Z = 1), once as a fixed-base product (any Z)
+        import hashlib
+        def clamp(seed):
+            h = bytearray(hashlib.sha512(seed).digest()[:32]); h[0] &= 248; h[31] &= 127; h[31] |= 64
+            return bytes(h)
+        _, pts_z1, ok = e0.decompress_batch(np.frombuffer(b"".join(pks), np.uint8).reshape(N, 32))
+        assert ok.all()
+        p25519 = 2**255 - 19
+        def scale(raw, lam):                                  # (X : Y : Z : T) -> (lam X : lam Y : lam Z : lam T), limbs of 51 bits
+            w = np.frombuffer(bytes(raw), "<u8").reshape(4, 5)
+            out = []
+            for c in range(4):
+                v = sum(int(w[c, i]) << (51 * i) for i in range(5)) * lam %% p25519
+                out += [(v >> (51 * i)) & (2**51 - 1) for i in range(5)]
+            return np.array(out, "<u8").view(np.uint8)
+        pts_zz = np.stack([scale(pts_z1[i], rnd.randrange(2, p25519)) for i in range(N)])
+        assert [bytes(x) for x in e0.compress_batch(pts_zz)] == pks
+        for n in (1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129):
+            eng = pkg.Engine(0)                               # a fresh context per size: nothing allocated yet
+            m, s, p = msgs[:n], sigs[:n], pks[:n]
+            assert eng.verify_batch(m, s, p, 0) == 0 == orc.ed25519_verify_batch(m, s, p), n
+            for idx in (0, n - 1):
+                bad = list(s); b = bytearray(bad[idx]); b[40] ^= 1; bad[idx] = bytes(b)                      # s changed (still canonical or not: ask the oracle)
+                assert eng.verify_batch(m, bad, p, 0) == orc.ed25519_verify_batch(m, bad, p) != 0, (n, idx)
+                sbig = list(s); sbig[idx] = s[idx][:32] + i2b(int.from_bytes(s[idx][32:], "little") + L)
+                assert eng.verify_batch(m, sbig, p, 0) == orc.ed25519_verify_batch(m, sbig, p) == 2, (n, idx)
+                rbad = list(sbig); rbad[n - 1 - idx] = i2b(2) + rbad[n - 1 - idx][32:]                         # an R that does not decode AND a big s: ScalarFormat
+                assert eng.verify_batch(m, rbad, p, 0) == orc.ed25519_verify_batch(m, rbad, p) == 2, (n, idx)
+                ronly = list(s); ronly[idx] = i2b(2) + s[idx][32:]
+                assert eng.verify_batch(m, ronly, p, 0) == orc.ed25519_verify_batch(m, ronly, p) == 3, (n, idx)
+                abad = list(p); abad[idx] = i2b(2)
+                assert eng.verify_batch(m, rbad, abad, 0) == orc.ed25519_verify_batch(m, rbad, abad) == 1, (n, idx)
+                mm = list(m); mm[idx] = m[idx] + b"!"
+                assert eng.verify_batch(mm, s, p, 0) == 3, (n, idx)
+            assert eng.verify_batch(m, s, p, 0) == 0          # the context is still good after the failures
+            for pp in (pts_z1[:n], pts_zz[:n]):
+                assert eng.verify_batch(m, s, p, 0, pk_points=pp) == 0, n
+                bad = list(s); b = bytearray(bad[n - 1]); b[2] ^= 8; bad[n - 1] = bytes(b)
+                assert eng.verify_batch(m, bad, p, 0, pk_points=pp) == orc.ed25519_verify_batch(m, bad, p), n
+                sbig = list(s); sbig[0] = s[0][:32] + i2b(int.from_bytes(s[0][32:], "little") + L)
+                assert eng.verify_batch(m, sbig, p, 0, pk_points=pp) == 2, n
+                if n > 1:                                     # another key's point under this key's bytes: the points are really used
+                    sw = np.array(pp); sw[[0, n - 1]] = sw[[n - 1, 0]]
+                    assert eng.verify_batch(m, s, p, 0, pk_points=sw) == 3, n
+            assert eng.verify_batch(m, s, p, 1) == 0
+        print("ok")
+    """) % (ROOT, ROOT)
+    e = util.tune_env(env) if env else dict(os.environ)
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])

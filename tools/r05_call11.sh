@@ -1,6 +1,8 @@
 #!/bin/bash
 cd "$(dirname "$0")/.." || exit 1
 mkdir -p gpurun_out
-( timeout 1800 python -m pytest tests/test_gpu_msm.py tests/test_gpu_verify.py tests/test_gpu_extra.py tests/test_gpu_multi.py -m gpu -x -q 2>&1 | tail -6 ) > gpurun_out/r05_c11_tests.log 2>&1
-bash tools/gpu_ab.sh r05i tools/ab_r05_i.cfg > /dev/null 2>&1
-tail -4 gpurun_out/r05_c11_tests.log; cat gpurun_out/ab_r05i.log | cut -c1-150
+( timeout 1200 python -m pytest tests/test_gpu_verify.py tests/test_gpu_ffi.py tests/test_gpu_abi_c.py tests/test_gpu_shim_mock.py tests/test_gpu_single.py -m gpu -x -q 2>&1 | tail -15 ) > gpurun_out/r05_c11_tests.log 2>&1
+( timeout 300 python tools/small_call_phases.py ) > gpurun_out/r05_c11_phases.log 2>&1
+export C25519_HIP_LIB=$PWD/curve25519-dalek_amd/lib/libc25519hip_tune.so
+( C25519_VERIFY_HOST_MAX=128 timeout 300 python tools/small_call_phases.py ) > gpurun_out/r05_c11_phases_h128.log 2>&1
+tail -15 gpurun_out/r05_c11_tests.log; tail -16 gpurun_out/r05_c11_phases.log; tail -16 gpurun_out/r05_c11_phases_h128.log
