@@ -426,5 +426,13 @@ def test_verify_batch_small_host_hashing_path(orc, env):
         print("ok")
     """) % (ROOT, ROOT)
     e = util.tune_env(env) if env else dict(os.environ)
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    # (One child of this test -- of 37 so far -- once sat until a 900 s timeout on a gpurun box, before the polling of the published record was bounded and before
+    #  the child had a watchdog; 64 repeats on other boxes did not reproduce it (DESIGN.md section 7).  A child that produces NOTHING within its watchdog is
+    #  therefore started once more, with a warning; a wrong status, an error or a second silence fails.)
+    import warnings
+    for attempt in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=400)
+        if r.returncode == 0 or attempt == 1 or "Timeout (0:03:20)" not in r.stderr:
+            break
+        warnings.warn("the child process of test_verify_batch_small_host_hashing_path hit its watchdog once: " + r.stderr[-1500:])
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
