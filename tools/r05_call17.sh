@@ -1,0 +1,7 @@
+#!/bin/bash
+cd "$(dirname "$0")/.." || exit 1
+mkdir -p gpurun_out
+( timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 ) > gpurun_out/r05_c17_tests.log 2>&1
+( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ) > gpurun_out/r05_c17_smoke.log 2>&1
+s=$(date +%s); ( timeout 900 python bench.py > gpurun_out/r05_c17_bench.json 2> gpurun_out/r05_c17_bench.err ); e=$(date +%s); echo "bench wall $((e-s)) s" > gpurun_out/r05_c17_bench.time
+tail -5 gpurun_out/r05_c17_tests.log; cat gpurun_out/r05_c17_smoke.log; cat gpurun_out/r05_c17_bench.time; head -c 1500 gpurun_out/r05_c17_bench.json
