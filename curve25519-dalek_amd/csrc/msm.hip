@@ -1210,7 +1210,8 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     int32_t r;
     ctx->host_us[0] = wall_us();
     if (n <= MSM_SMALL_MAX) {
-        // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: one staged copy up, the kernels, the results published to the host
+        // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: the inputs into the page-locked staging buffer (raw points: read
+        // there in place by the kernels; encodings: one staged copy up), the kernels, the record published to the host by the last of them
         const void *src[2] = {scalars, points};
         const size_t bytes[2] = {(size_t)n * 32, (size_t)n * psz};
         uint8_t *d[2];
