@@ -346,6 +346,50 @@ static int32_t zchain_enqueue(c25519_ctx *ctx, hipStream_t sa, const uint8_t *hr
     return C25519_OK;
 }
 
+// The same derivation on the HOST (the tree of k_ztree_first / k_ztree_block and k_zderive, word for word): for the small batches whose hashes the host
+// computes anyway (verify_batch_small_host) -- a tree over <= 128 signatures is ~50 SHA-512 compressions.  hred: n x 32 bytes (h_i mod l, canonical);
+// z16: room for 4 * ceil(n / 4) entries.  Equality with the device derivation: tests/test_gpu_verify.py (c25519_debug_batch_zs, z_mode 2 against 1).
+static inline u64 host_le64(const uint8_t *p) { u64 v; memcpy(&v, p, 8); return v; }
+static void ztree_host_zs(const uint8_t *hred, const uint8_t *sigs, uint64_t n, uint8_t *z16) {
+    ztree_ivs ivs;
+    ztree_make_ivs(n, ivs);
+    uint64_t m = (n + 3) / 4;
+    std::vector<u64> cur(4 * m), nxt;
+    for (uint64_t j = 0; j < m; j++) {                       // level 0: (h_c mod l) || s_c of four signatures, two blocks
+        u64 hs[8], rec[32];
+        for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
+        for (int r = 0; r < 4; r++) {
+            const uint64_t c = 4 * j + r;
+            for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? bswap64(host_le64(hred + 32 * c + 8 * q)) : 0ull;
+            for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? bswap64(host_le64(sigs + 64 * c + 32 + 8 * q)) : 0ull;
+        }
+        for (int blk = 0; blk < 2; blk++) { u64 w[16]; for (int q = 0; q < 16; q++) w[q] = rec[16 * blk + q]; sha512_compress(hs, w); }
+        for (int q = 0; q < 4; q++) cur[4 * j + q] = hs[q];
+    }
+    for (uint32_t level = 1; m > 1; level++) {               // upper levels: four children, one block
+        const uint64_t mo = (m + 3) / 4;
+        nxt.assign(4 * mo, 0);
+        for (uint64_t j = 0; j < mo; j++) {
+            u64 hs[8], w[16];
+            for (int q = 0; q < 8; q++) hs[q] = ivs.iv[level][q];
+            for (int ch = 0; ch < 4; ch++) for (int q = 0; q < 4; q++) w[4 * ch + q] = 4 * j + ch < m ? cur[4 * (4 * j + ch) + q] : 0ull;
+            sha512_compress(hs, w);
+            for (int q = 0; q < 4; q++) nxt[4 * j + q] = hs[q];
+        }
+        cur.swap(nxt); m = mo;
+    }
+    for (uint64_t i = 0; i < (n + 3) / 4; i++) {             // k_zderive: the four quarters of SHA-512(root || LE64(i))
+        u64 hs[8], w[16];
+        sha512_init(hs);
+        for (int q = 0; q < 4; q++) w[q] = cur[q];
+        w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
+        for (int q = 6; q < 15; q++) w[q] = 0;
+        w[15] = 40 * 8;
+        sha512_compress(hs, w);
+        for (int q = 0; q < 8; q++) { const u64 v = bswap64(hs[q]); memcpy(z16 + 64 * i + 8 * q, &v, 8); }
+    }
+}
+
 // One random-linear-combination check over at most VERIFY_PASS_MAX signatures (an MSM of 2n+1 terms), enqueued on
 // context ctx (the caller's or its peer); column sums and counters go to d_slot, nothing waits for the host.
 // d_pk_points (may be NULL): the keys' decompressed points, n x 160 raw -- what VerifyingKey carries beside its bytes
@@ -649,7 +693,7 @@ static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
     for (uint64_t i = 0; i < n; i++) if (msg_off[i] > msg_off[i + 1]) return false;
     return true;
 }
-// (r5) Small batches (keys as bytes or with their cached points) in the transcript z-mode, host pointers (the reference's own benchmark sizes, ed25519_benchmarks.rs:53): the host does what is
+// (r5) Small batches (keys as bytes or with their cached points; either z-mode), host pointers (the reference's own benchmark sizes, ed25519_benchmarks.rs:53): the host does what is
 // sequential or tiny anyway, the GPU does the curve arithmetic, and nothing crosses the link twice.
 //   rounds 3-4: upload -> k_hram -> hashes to the host -> transcript -> z_i back -> k_batch_scalars -> k_bsum_finish -> small MSM -> record copy: ten launches, two
 //   round trips, 236 us for 4 signatures of which the GPU was busy 205 (profiles/r05_small_call_phases.txt).
@@ -661,15 +705,15 @@ static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
 // [3] R_i that do not decode, then the identity check.
 static bool verify_small_host_ok(uint64_t n, uint32_t z_mode, msm_geom &g) {
     static const int host_max = C25519_KNOB("VERIFY_HOST_MAX", 64);       // A/B knob: 0 = the general path at every size
-    if (z_mode != C25519_Z_TRANSCRIPT || n == 0 || n > (uint64_t)host_max || n > 128) return false;
+    if (z_mode > 1 || n == 0 || n > (uint64_t)host_max || n > 128) return false;
     msm_layout(2 * n + 1, g, 16);
     return g.half <= 64 && g.nwin <= 64;
 }
 static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, const uint8_t *pk_points, uint64_t n,
-                                       const msm_geom &g) {
+                                       uint32_t z_mode, const msm_geom &g) {
     const uint64_t m = 2 * n + 1;
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t oS = 0, oK = al(n * 64), oC = oK + al(n * 32), oH = oC + al(m * 32), oZ = oH + al(n * 64), oP = oZ + al(n * 16), total = oP + (pk_points ? al(n * 160) : 0);
+    const size_t oS = 0, oK = al(n * 64), oC = oK + al(n * 32), oH = oC + al(m * 32), oZ = oH + al(n * 64), oP = oZ + al((n + 4) * 16 + n * 32), total = oP + (pk_points ? al(n * 160) : 0);
     int32_t r;
     ctx->host_us[0] = wall_us();
     ffi_small_begin(ctx);
@@ -696,7 +740,19 @@ static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, con
         sha512_digest_words(st.h, w);
         memcpy(hs + oH + i * 64, w, 64);
     }
-    c25519_transcript_zs(hs + oH, hs + oS, n, hs + oZ);
+    const bool dev_z = z_mode == C25519_Z_DEVICE;
+    if (!dev_z) c25519_transcript_zs(hs + oH, hs + oS, n, hs + oZ);
+    else {
+        // the device z-mode's derivation (header: NOT the reference's), computed here: h_i mod l, the hash tree, the quarters (ztree_host_zs)
+        uint8_t *hred = hs + oZ + (n + 4) * 16;
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t hw[16], o[8];
+            memcpy(hw, hs + oH + i * 64, 64);
+            sc_to_words(sc_from_wide(hw), o);
+            memcpy(hred + 32 * i, o, 32);
+        }
+        ztree_host_zs(hred, hs + oS, n, hs + oZ);
+    }
     uint8_t *msc = hs + oC;
     sc52 sum = sc_zero();
     for (uint64_t i = 0; i < n; i++) {
@@ -706,7 +762,13 @@ static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, con
         memcpy(hw, hs + oH + i * 64, 64);
         const bool canon = sc_is_canonical(sw);
         if (!canon) bad_s++;                                       // (the verdict is then ScalarFormat or an earlier one whatever the sum is)
-        const sc52 z = sc_from_words(zw), sc = canon ? sc_from_words(sw) : sc_zero();
+        // (device z-mode: sign-magnitude, bit 127 = sign.  The general path keeps |z_i| as the scalar and negates the stored R_i so that the R terms stay out of
+        //  the upper windows of a 2^20-term sort; here every term goes through every window anyway: the scalar is z_i mod l)
+        const bool neg = dev_z && (zw[3] >> 31);
+        if (dev_z) zw[3] &= 0x7fffffffu;
+        sc52 z = sc_from_words(zw);
+        if (neg) { z = sc_neg(z); sc_to_words(z, zw); }
+        const sc52 sc = canon ? sc_from_words(sw) : sc_zero();
         sum = sc_add(sum, sc_mul(z, sc));
         sc_to_words(sc_mul(z, sc_from_wide(hw)), o);
         memcpy(msc + 32 * (1 + i), zw, 32);                        // R_i: z_i
@@ -740,7 +802,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     const uint64_t mlen = msg_off[n];
     int32_t r;
     if (2 * n + 1 <= MSM_SMALL_MAX && mlen <= (1u << 20)) {
-        { msm_geom gh; if (verify_small_host_ok(n, z_mode, gh)) return verify_batch_small_host(ctx, msgs, msg_off, sigs, pks, pk_points, n, gh); }
+        { msm_geom gh; if (verify_small_host_ok(n, z_mode, gh)) return verify_batch_small_host(ctx, msgs, msg_off, sigs, pks, pk_points, n, z_mode, gh); }
         // the reference's own benchmark sizes (ed25519_benchmarks.rs:53: 4 .. 256 signatures) and everything else whose MSM takes the small path:
         // all five arrays through one staged copy on the compute stream (capi.hip ffi_small_upload)
         const void *src[5] = {msgs, msg_off, sigs, pks, pk_points};
@@ -809,7 +871,24 @@ EXPORT int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const
                                      uint32_t z_mode, uint8_t *out_z16) {
     HIPCHK(hipSetDevice(ctx->device));
     if (n == 0) return C25519_OK;
-    if (n > VERIFY_PASS_MAX || z_mode > 1 || !offsets_ok(msg_off, n)) { ctx->err = "debug_batch_zs: bad arguments"; return -(int32_t)hipErrorInvalidValue; }
+    if (n > VERIFY_PASS_MAX || z_mode > 2 || !offsets_ok(msg_off, n)) { ctx->err = "debug_batch_zs: bad arguments"; return -(int32_t)hipErrorInvalidValue; }
+    if (z_mode == 2) {
+        // the device z-mode's values computed by the HOST restatement (ztree_host_zs): must equal z_mode 1 byte for byte
+        std::vector<uint8_t> hred(n * 32), z((n + 4) * 16);
+        for (uint64_t i = 0; i < n; i++) {
+            sha512_stream st;
+            st.init();
+            st.put_bytes(sigs + i * 64, 32); st.put_bytes(pks + i * 32, 32); st.put_bytes(msgs + msg_off[i], msg_off[i + 1] - msg_off[i]);
+            st.finish();
+            uint32_t w[16], o[8];
+            sha512_digest_words(st.h, w);
+            sc_to_words(sc_from_wide(w), o);
+            memcpy(&hred[32 * i], o, 32);
+        }
+        ztree_host_zs(hred.data(), sigs, n, z.data());
+        memcpy(out_z16, z.data(), n * 16);
+        return C25519_OK;
+    }
     const uint64_t mlen = msg_off[n];
     int32_t r;
     size_t off = 0;

@@ -279,6 +279,9 @@ def test_z_derivation_depends_on_every_input(eng, orc):
     assert [z0[i].tobytes() for i in range(n)] == orc.batch_transcript_zs(hr, [s[32:] for s in S])
     z1 = eng.debug_batch_zs(M, S, P, 1)
     assert len({z1[i].tobytes() for i in range(n)}) == n
+    # (r5) batches of at most 64 signatures derive the same values on the HOST (verify.hip ztree_host_zs): z_mode 2 = that code, at every tree shape
+    for m in (1, 2, 3, 4, 5, 8, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000):
+        assert np.array_equal(eng.debug_batch_zs(M[:m], S[:m], P[:m], 2), eng.debug_batch_zs(M[:m], S[:m], P[:m], 1)), m
     assert np.array_equal(z1, eng.debug_batch_zs(M, S, P, 1))                   # deterministic
     def changed(za, zb):
         return int((za != zb).any(axis=1).sum())
@@ -355,7 +358,7 @@ def test_verify_batch_small_host_call_on_a_fresh_context_with_empty_messages(orc
 
 @pytest.mark.parametrize("env", [{}, {"C25519_VERIFY_HOST_MAX": "0"}, {"C25519_VERIFY_HOST_MAX": "128"}], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "release")
 def test_verify_batch_small_host_hashing_path(orc, env):
-    """(r5) Batches of at most 64 signatures of key bytes in the transcript z-mode are hashed, checked and turned into their 2n + 1 scalars by the
+    """(r5) Batches of at most 64 signatures (either z-mode; keys as bytes or with cached points) are hashed, checked and turned into their 2n + 1 scalars by the
     HOST while one kernel decompresses A_i / R_i, and the small MSM publishes its record with the decode counters (verify.hip verify_batch_small_host).
     Statuses against the oracle's batch.rs restatement around every size boundary of that path, in a fresh process per arm (the tuning library:
     the general path at every size, and the host path up to its hard limit of 128), message lengths 0 .. 300 at every block alignment, the
@@ -398,23 +401,24 @@ def test_verify_batch_small_host_hashing_path(orc, env):
         for n in (1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 127, 128, 129):
             eng = pkg.Engine(0)                               # a fresh context per size: nothing allocated yet
             m, s, p = msgs[:n], sigs[:n], pks[:n]
-            assert eng.verify_batch(m, s, p, 0) == 0 == orc.ed25519_verify_batch(m, s, p), n
-            for idx in (0, n - 1):
-                bad = list(s); b = bytearray(bad[idx]); b[40] ^= 1; bad[idx] = bytes(b)                      # s changed (still canonical or not: ask the oracle)
-                assert eng.verify_batch(m, bad, p, 0) == orc.ed25519_verify_batch(m, bad, p) != 0, (n, idx)
-                sbig = list(s); sbig[idx] = s[idx][:32] + i2b(int.from_bytes(s[idx][32:], "little") + L)
-                assert eng.verify_batch(m, sbig, p, 0) == orc.ed25519_verify_batch(m, sbig, p) == 2, (n, idx)
-                rbad = list(sbig); rbad[n - 1 - idx] = i2b(2) + rbad[n - 1 - idx][32:]                         # an R that does not decode AND a big s: ScalarFormat
-                assert eng.verify_batch(m, rbad, p, 0) == orc.ed25519_verify_batch(m, rbad, p) == 2, (n, idx)
-                ronly = list(s); ronly[idx] = i2b(2) + s[idx][32:]
-                assert eng.verify_batch(m, ronly, p, 0) == orc.ed25519_verify_batch(m, ronly, p) == 3, (n, idx)
-                abad = list(p); abad[idx] = i2b(2)
-                assert eng.verify_batch(m, rbad, abad, 0) == orc.ed25519_verify_batch(m, rbad, abad) == 1, (n, idx)
-                mm = list(m); mm[idx] = m[idx] + b"!"
-                assert eng.verify_batch(mm, s, p, 0) == 3, (n, idx)
+            for zm in (0, 1):
+                assert eng.verify_batch(m, s, p, zm) == 0 == orc.ed25519_verify_batch(m, s, p), n
+                for idx in (0, n - 1):
+                    bad = list(s); b = bytearray(bad[idx]); b[40] ^= 1; bad[idx] = bytes(b)                      # s changed (still canonical or not: ask the oracle)
+                    assert eng.verify_batch(m, bad, p, zm) == orc.ed25519_verify_batch(m, bad, p) != 0, (n, idx)
+                    sbig = list(s); sbig[idx] = s[idx][:32] + i2b(int.from_bytes(s[idx][32:], "little") + L)
+                    assert eng.verify_batch(m, sbig, p, zm) == orc.ed25519_verify_batch(m, sbig, p) == 2, (n, idx)
+                    rbad = list(sbig); rbad[n - 1 - idx] = i2b(2) + rbad[n - 1 - idx][32:]                         # an R that does not decode AND a big s: ScalarFormat
+                    assert eng.verify_batch(m, rbad, p, zm) == orc.ed25519_verify_batch(m, rbad, p) == 2, (n, idx)
+                    ronly = list(s); ronly[idx] = i2b(2) + s[idx][32:]
+                    assert eng.verify_batch(m, ronly, p, zm) == orc.ed25519_verify_batch(m, ronly, p) == 3, (n, idx)
+                    abad = list(p); abad[idx] = i2b(2)
+                    assert eng.verify_batch(m, rbad, abad, zm) == orc.ed25519_verify_batch(m, rbad, abad) == 1, (n, idx)
+                    mm = list(m); mm[idx] = m[idx] + b"!"
+                    assert eng.verify_batch(mm, s, p, zm) == 3, (n, idx)
             assert eng.verify_batch(m, s, p, 0) == 0          # the context is still good after the failures
             for pp in (pts_z1[:n], pts_zz[:n]):
-                assert eng.verify_batch(m, s, p, 0, pk_points=pp) == 0, n
+                assert eng.verify_batch(m, s, p, 0, pk_points=pp) == 0 == eng.verify_batch(m, s, p, 1, pk_points=pp), n
                 bad = list(s); b = bytearray(bad[n - 1]); b[2] ^= 8; bad[n - 1] = bytes(b)
                 assert eng.verify_batch(m, bad, p, 0, pk_points=pp) == orc.ed25519_verify_batch(m, bad, p), n
                 sbig = list(s); sbig[0] = s[0][:32] + i2b(int.from_bytes(s[0][32:], "little") + L)
