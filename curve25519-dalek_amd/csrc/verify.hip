@@ -703,8 +703,36 @@ static bool offsets_ok(const uint64_t *msg_off, uint64_t n) {
 //   and publishes its record, with the decode counters of the first kernel, straight into host memory (small_direct).  Three launches, no copy, no slot.
 // Same verdicts as the general path by construction of verify_record_verdict: [2] keys that do not decode, [4] non-canonical s (counted by the host here),
 // [3] R_i that do not decode, then the identity check.
+// H(R || A || M) on the host, block-wise (sha512_stream's select chains are written for registers of a GPU lane; a 64-bit core wants plain buffers)
+static void host_hram_words(const uint8_t *R, const uint8_t *A, const uint8_t *m, uint64_t len, uint32_t w16[16]) {
+    u64 h[8];
+    sha512_init(h);
+    uint8_t blk[128];
+    memcpy(blk, R, 32); memcpy(blk + 32, A, 32);
+    size_t fill = 64;
+    const uint64_t bits = (64 + len) * 8;
+    auto flush = [&]() {
+        u64 w[16];
+        for (int q = 0; q < 16; q++) { u64 v; memcpy(&v, blk + 8 * q, 8); w[q] = bswap64(v); }
+        sha512_compress(h, w);
+        fill = 0;
+    };
+    while (len) {
+        const size_t k = std::min<uint64_t>(len, 128 - fill);
+        memcpy(blk + fill, m, k);
+        fill += k; m += k; len -= k;
+        if (fill == 128) flush();
+    }
+    blk[fill++] = 0x80;
+    if (fill > 112) { memset(blk + fill, 0, 128 - fill); flush(); }
+    memset(blk + fill, 0, 120 - fill);                       // (the upper 64 bits of the 128-bit length are zero)
+    for (int b = 0; b < 8; b++) blk[120 + b] = (uint8_t)(bits >> (56 - 8 * b));
+    flush();
+    sha512_digest_words(h, w16);
+}
 static bool verify_small_host_ok(uint64_t n, uint32_t z_mode, msm_geom &g) {
-    static const int host_max = C25519_KNOB("VERIFY_HOST_MAX", 64);       // A/B knob: 0 = the general path at every size
+    static const int host_max = C25519_KNOB("VERIFY_HOST_MAX", 128);      // A/B knob: 0 = the general path at every size (128 = the one-block decompression kernel's limit;
+    //                                                                         the host needs 0.7 - 0.85 us per signature, hidden behind that kernel up to ~100: profiles/r05_small_call_phases.txt)
     if (z_mode > 1 || n == 0 || n > (uint64_t)host_max || n > 128) return false;
     msm_layout(2 * n + 1, g, 16);
     return g.half <= 64 && g.nwin <= 64;
@@ -731,13 +759,8 @@ static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, con
     // ---- the host's share, beside the decompression ----
     uint32_t bad_s = 0;
     for (uint64_t i = 0; i < n; i++) {
-        sha512_stream st;
-        st.init();
-        st.put_bytes(sigs + i * 64, 32); st.put_bytes(pks + i * 32, 32);
-        st.put_bytes(msgs + msg_off[i], msg_off[i + 1] - msg_off[i]);
-        st.finish();
         uint32_t w[16];
-        sha512_digest_words(st.h, w);
+        host_hram_words(sigs + i * 64, pks + i * 32, msgs + msg_off[i], msg_off[i + 1] - msg_off[i], w);
         memcpy(hs + oH + i * 64, w, 64);
     }
     const bool dev_z = z_mode == C25519_Z_DEVICE;

@@ -312,7 +312,7 @@ int32_t ed25519_fold_verify_records(c25519_ctx *ctx, const uint8_t *records, uin
 /* diagnostics for the tests that pin the z derivation: the z_i a batch of n <= 1.5 x 2^20 signatures gets, 16 bytes each
  * to the HOST buffer out_z16 (HOST pointers throughout).  z_mode 0: little-endian u128, the reference's values;
  * z_mode 1: bit 127 = sign, bits 0..126 = magnitude; z_mode 2 (this entry point only): the values of z_mode 1 computed by the host
- * restatement of the derivation that batches of at most 64 signatures use (no kernel runs) -- equal to z_mode 1 byte for byte. */
+ * restatement of the derivation that batches of at most 128 signatures use (no kernel runs) -- equal to z_mode 1 byte for byte. */
 int32_t c25519_debug_batch_zs(c25519_ctx *ctx, const uint8_t *msgs, const uint64_t *msg_off, const uint8_t *sigs, const uint8_t *pks, uint64_t n,
                               uint32_t z_mode, uint8_t *out_z16);
 

@@ -279,7 +279,7 @@ def test_z_derivation_depends_on_every_input(eng, orc):
     assert [z0[i].tobytes() for i in range(n)] == orc.batch_transcript_zs(hr, [s[32:] for s in S])
     z1 = eng.debug_batch_zs(M, S, P, 1)
     assert len({z1[i].tobytes() for i in range(n)}) == n
-    # (r5) batches of at most 64 signatures derive the same values on the HOST (verify.hip ztree_host_zs): z_mode 2 = that code, at every tree shape
+    # (r5) batches of at most 128 signatures derive the same values on the HOST (verify.hip ztree_host_zs): z_mode 2 = that code, at every tree shape
     for m in (1, 2, 3, 4, 5, 8, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000):
         assert np.array_equal(eng.debug_batch_zs(M[:m], S[:m], P[:m], 2), eng.debug_batch_zs(M[:m], S[:m], P[:m], 1)), m
     assert np.array_equal(z1, eng.debug_batch_zs(M, S, P, 1))                   # deterministic
@@ -356,12 +356,12 @@ def test_verify_batch_small_host_call_on_a_fresh_context_with_empty_messages(orc
         assert fresh.verify_batch(msgs[:3], sigs[:3], pks[:3], z_mode) == OK
 
 
-@pytest.mark.parametrize("env", [{}, {"C25519_VERIFY_HOST_MAX": "0"}, {"C25519_VERIFY_HOST_MAX": "128"}], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "release")
+@pytest.mark.parametrize("env", [{}, {"C25519_VERIFY_HOST_MAX": "0"}, {"C25519_VERIFY_HOST_MAX": "64"}], ids=lambda e: ",".join(f"{k[7:]}={v}" for k, v in e.items()) or "release")
 def test_verify_batch_small_host_hashing_path(orc, env):
-    """(r5) Batches of at most 64 signatures (either z-mode; keys as bytes or with cached points) are hashed, checked and turned into their 2n + 1 scalars by the
+    """(r5) Batches of at most 128 signatures (either z-mode; keys as bytes or with cached points) are hashed, checked and turned into their 2n + 1 scalars by the
     HOST while one kernel decompresses A_i / R_i, and the small MSM publishes its record with the decode counters (verify.hip verify_batch_small_host).
     Statuses against the oracle's batch.rs restatement around every size boundary of that path, in a fresh process per arm (the tuning library:
-    the general path at every size, and the host path up to its hard limit of 128), message lengths 0 .. 300 at every block alignment, the
+    the general path at every size, and the host path up to 64 only), message lengths 0 .. 300 at every block alignment, the
     precedence NONE > SCALAR_FORMAT > VERIFY with the offending items at the first and last index, and a context that has done nothing else."""
     import subprocess, sys, textwrap
     code = textwrap.dedent("""

@@ -32,8 +32,8 @@ print("page-locked memory, polled); folded and encoded = the call returns.  GPU 
 print("from Python around the bare ctypes call and around Engine.msm_vartime (numpy checks, output allocation).")
 print()
 print("ed25519_verify_batch (keys as bytes), host pointers; medians of 200 calls, microseconds")
-print("%6s %7s | %9s %9s %9s | %9s" % ("n", "z_mode", "upload", "returns", "GPU span", "Engine"))
-for n in (4, 16, 64, 256, 1024):
+print("%6s %7s | %9s %9s %9s %9s | %9s | %9s" % ("n", "z_mode", "upload", "enqueued", "on host", "returns", "GPU span", "Engine"))
+for n in [int(x) for x in os.environ.get("PHASES_VERIFY_SIZES", "4,16,64,256,1024").split(",")]:
     seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda")
     dm = torch.randint(0, 256, (59 * n,), dtype=torch.uint8, device="cuda"); doff = torch.arange(0, 59 * (n + 1), 59, dtype=torch.int64, device="cuda")
     dpk, dsg = e.sign_batch_t(seeds, dm, doff)
@@ -45,4 +45,4 @@ for n in (4, 16, 64, 256, 1024):
         for _ in range(200):
             t0 = time.perf_counter(); e.verify_batch(msgs, sigs, pks, zm); py.append((time.perf_counter() - t0) * 1e6)
             ph.append(e.last_call_host_us()); gpu.append(e.last_kernel_ms() * 1e3)
-        print("%6d %7d | %9.1f %9.1f %9.1f | %9.1f" % (n, zm, med([q[0] for q in ph]), med([q[3] for q in ph]), med(gpu), med(py)))
+        print("%6d %7d | %9.1f %9.1f %9.1f %9.1f | %9.1f | %9.1f" % (n, zm, med([q[0] for q in ph]), med([q[1] for q in ph]), med([q[2] for q in ph]), med([q[3] for q in ph]), med(gpu), med(py)))
