@@ -431,6 +431,9 @@ void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
 // in the reduction), 16 for the merged layout (u16 digit matrix) and verify_batch.
 static int pick_window(uint64_t n, int cmax) {
     int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
+    // the small path (small.hip): 5-bit windows below 1024 terms, 6-bit ones above (A/B knob MSM_SMALL_C; rounds 4 and early 5: 7 bits from 2048 terms and
+    // the bucket pipeline from 4096 -- profiles/r05_ab_small_path_range.txt: 7-bit tables are 40 KB of LDS per block, four blocks per compute unit)
+    if (n >= 1024 && n <= msm_small_max()) return C25519_KNOB("MSM_SMALL_C", 6);
     static const int mid = C25519_KNOB("MSM_MIDRANGE_WINDOWS", 1);      // A/B knob: 0 = c = log2 n - 4 throughout (rounds 1-3)
     int c = lg - 4;
     if (mid && lg >= 12 && lg <= 19) c += lg <= 12 ? 2 : lg <= 16 ? 3 : lg == 17 ? 2 : 1;
@@ -448,7 +451,7 @@ void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
     static const int cforce = C25519_KNOB("MSM_CFORCE", 0);       // A/B knob: this width for every plain layout of the process (0 = choose)
     // (a forced width only where the kernels behind it were built for it: the small path's tables hold windows of 5 .. 7 bits, the chunk-local and
     //  digit-matrix sorts scan at least 64 buckets per slice, i.e. windows of >= 7 bits)
-    const bool force_ok = cforce >= 5 && cforce <= 17 && !cmax_call && (n <= MSM_SMALL_MAX ? cforce <= 7 : cforce >= 7);
+    const bool force_ok = cforce >= 5 && cforce <= 17 && !cmax_call && (n <= msm_small_max() ? cforce <= 7 : cforce >= 7);
     g.c = c_exact ? c_exact : force_ok ? cforce : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
@@ -502,7 +505,7 @@ EXPORT int32_t c25519_msm_geometry(uint64_t n, int32_t *c, int32_t *nwin, uint8_
 // stream -- for kernel traces of the sort without an accumulation beside it (tools/sort_only.py)
 EXPORT int32_t c25519_debug_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, uint64_t layout_terms, int32_t reps) {
     HIPCHK(hipSetDevice(ctx->device));
-    if (n <= MSM_SMALL_MAX || n > (1ull << 22)) { ctx->err = "debug_sort: n outside the range of a bucket-method pass"; return -(int32_t)hipErrorInvalidValue; }
+    if (n <= msm_small_max() || n > (1ull << 22)) { ctx->err = "debug_sort: n outside the range of a bucket-method pass"; return -(int32_t)hipErrorInvalidValue; }
     msm_geom g;
     msm_layout(layout_terms ? layout_terms : n, g);
     for (int i = 0; i < reps; i++) {
@@ -604,7 +607,7 @@ int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_p
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     return C25519_OK;
 }
-// A pass of at most MSM_SMALL_MAX terms: no sort, no buckets -- small.hip's two launches on the main stream, after whatever the caller
+// A pass of at most msm_small_max() terms: no sort, no buckets -- small.hip's two launches on the main stream, after whatever the caller
 // put on sort_stream (verify_batch: the batch scalars) and after wait_acc.  src_fmt: 0 raw 160-byte points, 1 affine Niels records.
 static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                               hipStream_t sort_stream, hipEvent_t wait_acc) {
@@ -624,7 +627,7 @@ static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const v
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                     hipStream_t sort_stream, hipEvent_t wait_acc) {
-    if (n <= MSM_SMALL_MAX && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
+    if (n <= msm_small_max() && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
@@ -979,7 +982,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     // another; 1 and 2 measure the same (the accumulation beside a sort stretches by what the sort no longer costs afterwards), so the
     // default is the one without a second copy of the lists.
     static const int sweep_early = C25519_KNOB("SWEEP_EARLY", 1);
-    const bool early = sweep_early && cont && !wait_in && terms > MSM_SMALL_MAX && parity >= 0;
+    const bool early = sweep_early && cont && !wait_in && terms > msm_small_max() && parity >= 0;
     hipEvent_t lists_free = nullptr;
     if (parity >= 0) {
         HIPCHK(hipEventRecord(ctx->ev_lists[parity & 1], ctx->stream));                 // the accumulation before this pass (list copy parity ^ 1) is behind this point
@@ -987,7 +990,7 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     }
     if (!early) HIPCHK(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));
     if (!cont && !ctx->direct_seq) slot_init(d_slot, terms, nullptr, ctx->stream, g.c);            // (a continuing pass adds its counters to the slot of its stream set; a directly published small pass writes its whole record itself)
-    if (terms <= MSM_SMALL_MAX && g.half <= 64 && g.nwin <= 64 && !cont && reduce && !ahead) {      // (g: a forced width may not be the small path's -- then the bucket pipeline serves)
+    if (terms <= msm_small_max() && g.half <= 64 && g.nwin <= 64 && !cont && reduce && !ahead) {      // (g: a forced width may not be the small path's -- then the bucket pipeline serves)
         // the small path (small.hip): raw points as they are (projective: no normalisation, no inversion); compressed ones through the
         // decompression into records first
         if (in_fmt == C25519_FMT_RAW160) return msm_small_pass(ctx, d_scalars, d_points, 0, n, g, d_slot, ring, nullptr, wait_acc);
@@ -1070,7 +1073,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     static const int small_direct_knob = C25519_KNOB("SMALL_DIRECT", 1);
     ctx->direct_seq = 0;
     ctx->direct_extra = nullptr;
-    if (small_direct_knob && ctx->want_direct && d_record == drec(ctx) && n <= MSM_SMALL_MAX && in_fmt == C25519_FMT_RAW160 && !fetch) {
+    if (small_direct_knob && ctx->want_direct && d_record == drec(ctx) && n <= msm_small_max() && in_fmt == C25519_FMT_RAW160 && !fetch) {
         msm_geom gs;
         msm_layout(n, gs);
         if (gs.half <= 64 && gs.nwin <= 64) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
@@ -1092,7 +1095,9 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // launches, each with its own ramp-down): four interleaved repetitions on one box give 1.959 ms (one group) against 1.965 (two); three and four
     // groups 2.06 / 2.18; at 2^20 and 2^18 terms two groups lose 8 % and 17 %.  The default stays ONE group.
     static const int acc_groups = C25519_KNOB("ACC_GROUPS", 1), acc_last = C25519_KNOB("ACC_LAST", 0);
-    if (passes == 1 && n > MSM_SMALL_MAX) msm_set_groups(g, acc_groups, acc_last);
+    // (groups exist in the chunk-local sort only: single passes below its lower boundary -- the digit-matrix sort's range -- keep one group)
+    static const uint64_t chunk_local_min = (uint64_t)C25519_KNOB("SORT_CHUNK_LOCAL_MIN", 1 << 16);
+    if (passes == 1 && n > msm_small_max() && n >= chunk_local_min) msm_set_groups(g, acc_groups, acc_last);
     ctx->solo = passes == 1;               // (overwritten by every call: an early error return leaves nothing behind that a later call would read)
     hipEvent_t prev_acc = nullptr;                         // the accumulation of the previous pass (on the other stream set)
     hipEvent_t prev_acc_last = nullptr;
@@ -1209,7 +1214,7 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     const size_t psz = in_fmt == C25519_FMT_RAW160 ? 160 : 32;
     int32_t r;
     ctx->host_us[0] = wall_us();
-    if (n <= MSM_SMALL_MAX) {
+    if (n <= msm_small_max()) {
         // the reference's own benchmark sizes (1 .. 1024 terms) and everything else small.hip serves: the inputs into the page-locked staging buffer (raw points: read
         // there in place by the kernels; encodings: one staged copy up), the kernels, the record published to the host by the last of them
         const void *src[2] = {scalars, points};

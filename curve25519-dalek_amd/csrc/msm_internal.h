@@ -53,7 +53,11 @@ static inline int red_nseg(int half) { const int seg = 64 << red_lb_log2(half); 
 // was derived from, [10] passes summed, [11] a magic word
 constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11, REC_C = 12;      // REC_C: the window width of the layout (a record with terms > 0 and no width is rejected by the fold)
 constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
-constexpr uint64_t MSM_SMALL_MAX = 4095;                  // inputs up to this many terms take the single-pass small path (small.hip): window widths 5, 6 and 7
+// inputs up to this many terms take the single-pass small path (small.hip): 5-bit windows below 1024 terms, 6-bit ones from there (A/B knobs of the tuning
+// build: MSM_SMALL_MAX, and MSM_SMALL_C = the width from 1024 terms).  Rounds 4 and early 5: 4095 terms, 7-bit windows from 2048.  Measured
+// (profiles/r05_ab_small_path_range.txt, r05_ab_verify_small_range.txt): with 6-bit windows (20 KB of tables per block instead of 40) the small path beats the
+// bucket pipeline's fifteen launches up to ~14 000 terms -- 4096 terms 0.320 -> 0.158 ms, 8192 0.313 -> 0.227, 12 000 0.331 -> 0.281; 16 384: level.
+inline uint64_t msm_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("MSM_SMALL_MAX", 12287); return v; }
 }
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 static inline uint32_t *slot_flags(uint32_t *slot) { return slot + c25519::MSM_MAX_WIN * 40; }
@@ -81,10 +85,10 @@ struct msm_matrix_sort_args {
 int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const c25519::msm_geom &g, const c25519::msm_merged *md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st);
 int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont = false, bool reduce = true,
                         const uint32_t *d_bad_sticky = nullptr);
-// sort + accumulate + reduce of one pass over prepared records; inputs of at most MSM_SMALL_MAX terms take the small path
+// sort + accumulate + reduce of one pass over prepared records; inputs of at most msm_small_max() terms take the small path
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const c25519::msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                     hipStream_t sort_stream, hipEvent_t wait_acc = nullptr);
-// the whole MSM of at most MSM_SMALL_MAX terms in two launches, column sums of the layout g to d_slot (small.hip).  src_fmt: 0 = raw 160-byte points,
+// the whole MSM of at most msm_small_max() terms in two launches, column sums of the layout g to d_slot (small.hip).  src_fmt: 0 = raw 160-byte points,
 // 1 = affine Niels records (128 bytes); flags: the slot's counters (bit 255 of a scalar is ORed into flags[0])
 int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t st);
 c25519::ge_p3 host_p40(const uint32_t *t);

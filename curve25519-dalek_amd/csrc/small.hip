@@ -1,4 +1,4 @@
-// Small multiscalar multiplications -- up to MSM_SMALL_MAX = 4095 terms: the reference's own benchmark shapes (benches/dalek_benchmarks.rs:16
+// Small multiscalar multiplications -- up to msm_small_max() = 12 287 terms (round 4: 4095): the reference's own benchmark shapes (benches/dalek_benchmarks.rs:16
 // MULTISCALAR_SIZES 1 .. 1024; ed25519_benchmarks.rs:53 verify_batch of 4 .. 256 signatures = 9 .. 513 terms) and everything the reference
 // hands to Straus (edwards.rs:1025, below 190 terms).
 //
@@ -11,14 +11,15 @@
 //   k_small_cols    a block owns 4 terms.  It builds their tables of multiples {1 .. 2^(c-1)} P in LDS by REPEATED COMPLETE ADDITION in c - 1
 //                   rounds (round r: E[2^r + j] = E[2^r] + E[j], j = 1 .. 2^r -- edwards.rs:795 is complete, so the same code doubles), straight
 //                   from the raw projective point: no normalisation, no inversion.  Then thread (window k, term i) looks its signed digit
-//                   up -- the SAME window layout as the bucket pipeline (msm_layout: c = 5 below 1024 terms, 6 below 2048, 7 below 4096), so the
+//                   up -- the SAME window layout as the bucket pipeline (msm_layout: c = 5 below 1024 terms, 6 from there; round 4: 7 from 2048), so the
 //                   column sums are a partial-result record like any other -- and the four terms of a window are added across the
 //                   lanes of a quad.  Chain: c - 1 + 2 additions.
 //   k_small_reduce  one block per window: the <= 1024 block partials are added in a shuffle / LDS tree.  Chain: <= 12 additions.
 //
 // and the Horner fold over the windows stays where it always was (host, msm_horner).  Work is n (2^(c-1) + 2 nwin) additions instead of the
-// bucket method's n nwin / 2 -- irrelevant: below 4096 terms the GPU is latency-bound, not throughput-bound (from 4096 on the tables no longer
-// pay: 82 KB of LDS per block, one block per CU, eight rounds of blocks: the digit-matrix sort and the bucket pipeline take over).  Variable time like the path it
+// bucket method's n nwin / 2 -- irrelevant while the GPU is latency-bound, not throughput-bound: up to ~14 000 terms with 6-bit windows (20 KB of tables per
+// block, eight blocks per compute unit; the call grows by ~17 ns per term and meets the bucket pipeline's ~0.33 ms there: profiles/r05_ab_small_path_range.txt --
+// round 4 stopped at 4095 terms because its 7-bit tables, 40 KB per block, were already losing: 0.181 against 0.156 ms at 4095 terms).  Variable time like the path it
 // replaces (digits index the table): vartime_multiscalar_mul and verify_batch only; the constant-time MSM is extra.hip's.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
@@ -203,7 +204,7 @@ __global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ pa
 }  // namespace c25519
 
 int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, hipStream_t st) {
-    if (n == 0 || n > MSM_SMALL_MAX || g.half > 64 || g.nwin > SMALL_SLOTS) { ctx->err = "msm: internal error (small path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
+    if (n == 0 || n > msm_small_max() || g.half > 64 || g.nwin > SMALL_SLOTS) { ctx->err = "msm: internal error (small path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
     const int nblocks = (int)((n + SMALL_T - 1) / SMALL_T);
     const size_t lds = (size_t)SMALL_T * g.half * 160;
     // direct publication (ctx->direct_seq, set by msm_record_enqueue): the record goes to the host's slot, not to d_slot

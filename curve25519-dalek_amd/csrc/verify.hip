@@ -824,7 +824,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
     const uint64_t mlen = msg_off[n];
     int32_t r;
-    if (2 * n + 1 <= MSM_SMALL_MAX && mlen <= (1u << 20)) {
+    if (2 * n + 1 <= msm_small_max() && mlen <= (1u << 20)) {
         { msm_geom gh; if (verify_small_host_ok(n, z_mode, gh)) return verify_batch_small_host(ctx, msgs, msg_off, sigs, pks, pk_points, n, z_mode, gh); }
         // the reference's own benchmark sizes (ed25519_benchmarks.rs:53: 4 .. 256 signatures) and everything else whose MSM takes the small path:
         // all five arrays through one staged copy on the compute stream (capi.hip ffi_small_upload)

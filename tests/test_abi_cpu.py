@@ -69,8 +69,7 @@ def test_msm_window_layout_recomposes_every_scalar():
     L = 2**252 + 27742317777372353535851937790883648493
     rng = random.Random(7)
     seen_c = set()
-    for lg in range(0, 41):
-        n = 1 << lg
+    for n in sorted([1 << lg for lg in range(0, 41)] + [12287, 12288]):
         c = C.c_int32(); nwin = C.c_int32()
         pos = (C.c_uint8 * 56)(); wid = (C.c_uint8 * 56)(); addk = (C.c_uint32 * 8)()
         assert lib.c25519_msm_geometry(n, C.byref(c), C.byref(nwin), pos, wid, addk) == 0
@@ -99,4 +98,6 @@ def test_msm_window_layout_recomposes_every_scalar():
                     assert abs(d) <= 1 << (wid[k] - 1)     # a signed window of w bits uses 2^(w-1) buckets (msm_slice_params relies on it)
                 total += d << pos[k]
             assert total == s
-    assert seen_c == {5, 6, 7, 10, 12, 13, 14, 15, 16, 17}      # at powers of two: log2 n - 4 up to 2^11 and from 2^20 terms, wider in between (msm.hip pick_window)
+    # the small path's 5- and 6-bit windows up to 12 287 terms (round 5; rounds 1-4 also used 7 .. 11 bits there), then the bucket pipeline's: wider than
+    # log2 n - 4 in the latency-bound mid range, log2 n - 4 from 2^20 terms (msm.hip pick_window)
+    assert seen_c == {5, 6, 12, 13, 14, 15, 16, 17}

@@ -166,7 +166,7 @@ def test_msm_random_sizes_and_formats(eng, orc):
     windows, the mid-range layouts in between) in all three input encodings: sum-of-squares identity against the oracle's fixed-base multiplication."""
     import torch
     rng = np.random.default_rng(20260924)
-    sizes = sorted(set(int(2 ** rng.uniform(0, 21)) for _ in range(48)) | {4095, 4096, 8191, 8192, 131071, 1 << 19, (1 << 20) + 1})
+    sizes = sorted(set(int(2 ** rng.uniform(0, 21)) for _ in range(48)) | {1023, 1024, 4095, 4096, 8191, 8192, 12287, 12288, 131071, 1 << 19, (1 << 20) + 1})
     for i, n in enumerate(sizes):
         g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
         dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
@@ -261,7 +261,9 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_ACC_GROUPS": "2"}, {"C25519_ACC_GROUPS": "4", "C25519_ACC_LAST": "2"}, {"C25519_ACC_GROUPS": "3", "C25519_SORT_FIRST": "1"},
                                  {"C25519_SORT_FIRST": "2"},
                                  # the records of the later passes normalised on a third stream (three and more passes of 2^16 terms)
-                                 {"C25519_REDUCE_MAIN": "0"}, {"C25519_SMALL_DIRECT": "0"},      # the reduction of a single-pass call on the second stream (rounds 3-4)
+                                 {"C25519_REDUCE_MAIN": "0"}, {"C25519_SMALL_DIRECT": "0"},      # the reduction of a single-pass call on the second stream (rounds 3-4); small calls through their slot
+                                 # the small path's range and window widths: round 4's (4095 terms, 7-bit windows), and 5-bit windows far beyond the default boundary
+                                 {"C25519_MSM_SMALL_MAX": "4095"}, {"C25519_MSM_SMALL_C": "7"}, {"C25519_MSM_SMALL_MAX": "40000", "C25519_MSM_SMALL_C": "5"},
                                  {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
@@ -276,7 +278,7 @@ def test_msm_kernel_variants_in_a_fresh_process(orc, env):
         from oracle import orc
         eng = pkg.Engine(0)
         L = util.L
-        for n in (1, 63, 65, 4097, 3 * 65536 + 5, 262144 + 64 * 37 + 1, 18 * 65536 + 77):
+        for n in (1, 63, 65, 1500, 4097, 12000, 20001, 3 * 65536 + 5, 262144 + 64 * 37 + 1, 18 * 65536 + 77):
             x = util.rand_scalars(500 + n, n)
             pts = eng.mul_base_batch(x, out_fmt=2)
             pts[::3] = eng.decompress_batch(eng.compress_batch(pts[::3]))[1]          # a third of the points affine (Z = 1)
@@ -441,8 +443,8 @@ def test_msm_continuing_last_pass_one_sort_chunk_shorter(orc, log2pass, n):
 def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
     """The reference's benchmark shapes (dalek_benchmarks.rs:16 MULTISCALAR_SIZES = 1 .. 1024) and everything it hands to Straus
     (edwards.rs:1025): EVERY n in 1 .. 1024 through the small path (small.hip: tables by repeated addition, one lane per (window, term)),
-    then its upper sizes (c = 6 from 1024 terms, c = 7 from 2048), both sides of its boundary at 4095 / 4096 terms and the window-width steps of the
-    digit-matrix sort below 2^16 terms (c = 8 .. 12).  Expected: (sum_{i < n} x_i^2) B for every prefix, from ONE fixed-base batch over the prefix sums."""
+    then its upper sizes (c = 6 from 1024 terms), both sides of its round-4 boundary at 4095 / 4096 terms and of its boundary now, 12287 / 12288, and the
+    window-width steps of the digit-matrix sort below 2^16 terms.  Expected: (sum_{i < n} x_i^2) B for every prefix, from ONE fixed-base batch over the prefix sums."""
     nmax = 1024
     x = util.rand_scalars(7001, nmax)
     pts = eng.mul_base_batch(x, out_fmt=2)
@@ -487,7 +489,7 @@ def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
         eng.msm_vartime(hi, pts[:100], in_fmt=2, out_fmt=0)
     # the boundary of the small path and the narrow windows of the sort
     import torch
-    for n in (2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 16383, 16384, 32767, 32768, 50001):
+    for n in (2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 12287, 12288, 12289, 16383, 16384, 32767, 32768, 50001):
         g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
         dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
         dx[:, 31] &= 0x0F

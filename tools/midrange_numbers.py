@@ -14,7 +14,7 @@ for _ in range(40):
 print("%10s %16s %16s %8s" % ("n", "host-pointer ms", "device-resident ms", "window"))
 import ctypes as C
 lib = pkg.load_library()
-for n in (256, 1024, 2047, 2048, 4096, 8192, 16384, 32768, 65535, 65536, 1 << 17, 1 << 18, 1 << 19, 1 << 20):
+for n in [int(v) for v in os.environ.get('MIDRANGE_SIZES', '256,1024,2047,2048,4096,8192,16384,32768,65535,65536,131072,262144,524288,1048576').split(',')]:
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); x[:, 31] &= 0x0F
     dx = torch.from_numpy(x).cuda()
     dp = e.mul_base_batch_vartime_t(dx, E.FMT_RAW160)
