@@ -91,6 +91,8 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__r
     extern __shared__ u32 tab[];                          // [SMALL_T][half][40]
     __shared__ u32 sk[SMALL_T * 8];                       // the block's four scalars: read ONCE (r5: every (window, term) thread used to load its term's 32 bytes
     //                                                       itself -- 64 loads of the same words, which matters when the inputs are read in place from host memory)
+    // (Measured and dropped, profiles/r05_ab_small_path_range.txt: numbering the threads ROTATED by whole waves with the block index -- on the suspicion that wave 0
+    //  of every block, the only one busy in the table phase, shares one SIMD with the wave 0s of its neighbours -- is 5 - 9 % SLOWER from 4096 terms, level below.)
     const int tid = threadIdx.x, ti = tid & (SMALL_T - 1), slot = tid / SMALL_T;
     if (tid < SMALL_T * 8) {
         const u64 tt = (u64)blockIdx.x * SMALL_T + (u64)(tid >> 3);
