@@ -313,3 +313,78 @@ def batch_transcript_zs(hrams, ss):
         t.append_message(b"sig.s", s)
     t.rng_finalize(bytes(32))
     return [t.rng_fill(16) for _ in hrams]
+
+
+# ---- the device z-mode's derivation (include/c25519_hip.h, C25519_Z_DEVICE), restated from its written description --------------------------
+# NOT the reference's derivation: a hash tree over (H(R||A||M) mod l, s) of every signature, whose root is expanded into the z_i.  A node is the first
+# 32 bytes of a SHA-512 chaining value after a one-block domain tag (level, inputs of the level, batch size) and fixed-length data with NO padding -- not a
+# standard hash call, so the compression function is written out here (FIPS 180-4, 6.4.2).
+_SHA512_IV = [0x6a09e667f3bcc908, 0xbb67ae8584caa73b, 0x3c6ef372fe94f82b, 0xa54ff53a5f1d36f1, 0x510e527fade682d1, 0x9b05688c2b3e6c1f, 0x1f83d9abfb41bd6b, 0x5be0cd19137e2179]
+_M64 = (1 << 64) - 1
+
+
+def _sha512_k():
+    """the 80 round constants: the first 64 bits of the fractional parts of the cube roots of the first 80 primes"""
+    ks, p = [], 2
+    while len(ks) < 80:
+        if all(p % q for q in range(2, int(p ** 0.5) + 1)):
+            lo, hi = 0, 1 << 80                              # floor(p^(1/3) * 2^64) by integer bisection
+            while hi - lo > 1:
+                mid = (lo + hi) // 2
+                if mid ** 3 <= p << 192:
+                    lo = mid
+                else:
+                    hi = mid
+            ks.append(lo & _M64)
+        p += 1
+    return ks
+
+
+_SHA512_K = _sha512_k()
+assert _SHA512_K[0] == 0x428a2f98d728ae22 and _SHA512_K[79] == 0x6c44198c4a475817
+
+
+def sha512_compress(h, block):
+    """one application of the SHA-512 compression function: h = 8 words, block = 128 bytes -> 8 words"""
+    rotr = lambda x, r: ((x >> r) | (x << (64 - r))) & _M64
+    w = [int.from_bytes(block[8 * i:8 * i + 8], "big") for i in range(16)]
+    for t in range(16, 80):
+        s0 = rotr(w[t - 15], 1) ^ rotr(w[t - 15], 8) ^ (w[t - 15] >> 7)
+        s1 = rotr(w[t - 2], 19) ^ rotr(w[t - 2], 61) ^ (w[t - 2] >> 6)
+        w.append((w[t - 16] + s0 + w[t - 7] + s1) & _M64)
+    a, b, c, d, e, f, g, hh = h
+    for t in range(80):
+        t1 = (hh + (rotr(e, 14) ^ rotr(e, 18) ^ rotr(e, 41)) + ((e & f) ^ (~e & _M64 & g)) + _SHA512_K[t] + w[t]) & _M64
+        t2 = ((rotr(a, 28) ^ rotr(a, 34) ^ rotr(a, 39)) + ((a & b) ^ (a & c) ^ (b & c))) & _M64
+        a, b, c, d, e, f, g, hh = (t1 + t2) & _M64, a, b, c, (d + t1) & _M64, e, f, g
+    return [(x + y) & _M64 for x, y in zip(h, [a, b, c, d, e, f, g, hh])]
+
+
+def device_zs(hrams, ss):
+    """hrams = [H(R||A||M)] (64 bytes each), ss = [s] (32 bytes each) -> the n sign-magnitude z_i of the device z-mode (16 bytes each: bit 127 = sign)."""
+    import hashlib
+    n = len(hrams)
+    L = 2**252 + 27742317777372353535851937790883648493
+
+    def iv(level, count):
+        tag = b"c25519-hip/verify_batch/z-tree/v4"
+        blk = tag + bytes(104 - len(tag)) + level.to_bytes(8, "big") + count.to_bytes(8, "big") + n.to_bytes(8, "big")
+        return sha512_compress(_SHA512_IV, blk)
+
+    node = lambda h: b"".join(x.to_bytes(8, "big") for x in h[:4])
+    leaves = [(int.from_bytes(h, "little") % L).to_bytes(32, "little") + s for h, s in zip(hrams, ss)]
+    count, level, nodes = n, 0, []
+    h0 = iv(0, count)
+    for j in range((n + 3) // 4):                            # level 0: four 64-byte records, two blocks
+        data = b"".join(leaves[4 * j:4 * j + 4]).ljust(256, b"\0")
+        nodes.append(node(sha512_compress(sha512_compress(h0, data[:128]), data[128:])))
+    while len(nodes) > 1:                                    # upper levels: four children, one block
+        count = (count + 3) // 4
+        level += 1
+        hl = iv(level, count)
+        nodes = [node(sha512_compress(hl, b"".join(nodes[4 * j:4 * j + 4]).ljust(128, b"\0"))) for j in range((len(nodes) + 3) // 4)]
+    out = []
+    for i in range((n + 3) // 4):
+        d = hashlib.sha512(nodes[0] + i.to_bytes(8, "little")).digest()
+        out += [d[16 * q:16 * q + 16] for q in range(4)]
+    return out[:n]

@@ -280,8 +280,12 @@ def test_z_derivation_depends_on_every_input(eng, orc):
     z1 = eng.debug_batch_zs(M, S, P, 1)
     assert len({z1[i].tobytes() for i in range(n)}) == n
     # (r5) batches of at most 128 signatures derive the same values on the HOST (verify.hip ztree_host_zs): z_mode 2 = that code, at every tree shape
+    # ... and both equal the construction as the header DESCRIBES it, restated at spec level in tests/pyref.py (own SHA-512 compression function, hashlib for the rest)
+    import pyref
     for m in (1, 2, 3, 4, 5, 8, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000):
-        assert np.array_equal(eng.debug_batch_zs(M[:m], S[:m], P[:m], 2), eng.debug_batch_zs(M[:m], S[:m], P[:m], 1)), m
+        zk = eng.debug_batch_zs(M[:m], S[:m], P[:m], 1)
+        assert np.array_equal(eng.debug_batch_zs(M[:m], S[:m], P[:m], 2), zk), m
+        assert [zk[i].tobytes() for i in range(m)] == pyref.device_zs(hr[:m], [s[32:] for s in S[:m]]), m
     assert np.array_equal(z1, eng.debug_batch_zs(M, S, P, 1))                   # deterministic
     def changed(za, zb):
         return int((za != zb).any(axis=1).sum())
