@@ -162,31 +162,36 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__r
     }
 }
 
-// one block per window: col_k = sum over the blocks' partials
-__global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ partial, int nblocks, int nwin, u32 *__restrict__ cols, small_direct dx) {
-    __shared__ u32 stage[4 * 40];
+// one block per window: col_k = sum over the blocks' partials.  TH threads: every thread adds nblocks / TH partials one after the other, then a shuffle tree
+// inside each wave and a second one over the waves' sums (round 5; before, thread 0 added the waves' sums one after the other: 4096 terms 0.158 -> 0.151 ms).
+// Measured and dropped (profiles/r05_ab_small_path_range.txt): 512 threads above 256 partials -- a shorter chain on paper (12 000 terms: 14 links instead of
+// 20), 3 - 10 % SLOWER at every size from 2048 terms.
+template <int TH>
+__global__ void __launch_bounds__(TH) k_small_reduce(const u32 *__restrict__ partial, int nblocks, int nwin, u32 *__restrict__ cols, small_direct dx) {
+    __shared__ u32 stage[(TH / 64) * 40];
     __shared__ int last;
     const int k = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     ge_p3 acc = ge_identity();
     bool any = false;
-    for (int b = tid; b < nblocks; b += 256) {
+    for (int b = tid; b < nblocks; b += TH) {
         const ge_p3 v = p40_load(partial, (u64)b * nwin + k);
         acc = any ? ge_add(acc, v) : v;
         any = true;
     }
     // shuffle tree over the lanes that hold something (wave-uniform trip count)
-    const int active = nblocks < 256 ? nblocks : 256;
+    const int active = nblocks < TH ? nblocks : TH;
     const int in_wave = active - 64 * w < 64 ? active - 64 * w : 64;
     for (int dd = 1; dd < in_wave; dd <<= 1) {
         const ge_p3 o = p3_quad_xor(acc, dd);                 // (lanes beyond `active` hold the identity)
         acc = ge_add(acc, o);
     }
     if (active > 64) {
-        if (lane == 0 && w < 4) p3_to_lds(stage + w * 40, acc);
+        if (lane == 0) p3_to_lds(stage + w * 40, acc);
         __syncthreads();
-        if (tid == 0) {
+        if (w == 0) {                                         // the waves' sums: a second tree, in wave 0
             const int waves = (active + 63) / 64;
-            for (int q = 1; q < waves; q++) acc = ge_add(acc, p3_from_lds(stage + q * 40));
+            acc = lane < waves ? p3_from_lds(stage + lane * 40) : ge_identity();
+            for (int dd = 1; dd < waves; dd <<= 1) acc = ge_add(acc, p3_quad_xor(acc, dd));
         }
     }
     if (tid == 0) p40_store(cols, k, acc);
@@ -196,7 +201,7 @@ __global__ void __launch_bounds__(256) k_small_reduce(const u32 *__restrict__ pa
         __syncthreads();
         if (last) {
             int b = 0;
-            for (int i = tid; i < nblocks; i += 256) b |= (int)dx.blockflags[i];
+            for (int i = tid; i < nblocks; i += TH) b |= (int)dx.blockflags[i];
             const int any_bad = __syncthreads_or(b);
             if (tid == 0) { *dx.done_cnt = 0; small_publish(cols, dx, (u32)any_bad); }
         }
@@ -225,7 +230,7 @@ int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void 
         dx.blockflags = partial + (size_t)nblocks * g.nwin * 40 + 16;
     }
     hipLaunchKernelGGL(k_small_cols, dim3(nblocks), dim3(SMALL_THREADS), lds, st, d_scalars, d_points, src_fmt, n, g, partial, slot_flags(d_slot), dx);
-    if (nblocks > 1) hipLaunchKernelGGL(k_small_reduce, dim3(g.nwin), dim3(256), 0, st, partial, nblocks, g.nwin, out, dx);
+    if (nblocks > 1) hipLaunchKernelGGL(k_small_reduce<256>, dim3(g.nwin), dim3(256), 0, st, partial, nblocks, g.nwin, out, dx);
     HIPCHK(hipGetLastError());
     return C25519_OK;
 }
