@@ -590,6 +590,8 @@ def main():
     ap.add_argument("--keys-as-bytes", action="store_true",
                     help="verify: pass only the 32-byte keys (A_i is decompressed inside the call); default: the keys' points "
                          "are cached like the reference's VerifyingKey (verifying.rs:64-71, batch.rs:236)")
+    ap.add_argument("--lib", default=os.environ.get("C25519_HIP_LIB"), help="A/B runs: another build of the library (the tuning build, a variant); the package itself reads no environment, "
+                    "this HARNESS passes the choice on with an explicit select_library()")
     args = ap.parse_args()
 
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -597,6 +599,8 @@ def main():
 
     import torch
     import curve25519_dalek_amd as pkg
+    if args.lib:
+        pkg.select_library(args.lib)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

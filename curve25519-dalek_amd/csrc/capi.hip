@@ -353,6 +353,9 @@ EXPORT int32_t c25519_last_call_host_us(const c25519_ctx *ctx, double *out4) {
     for (int i = 0; i < 4; i++) out4[i] = ctx->host_us[i + 1] >= ctx->host_us[0] ? ctx->host_us[i + 1] - ctx->host_us[0] : 0.0;
     return C25519_OK;
 }
+// event counters of a context (diagnostics of the small path's direct publication, msm.hip wait_published): which = 0 publications that outlasted the spin
+// phase (the host blocked on the stream instead), 1 lost publications (each re-run through the copy path), 2 directly published calls; anything else: 0
+EXPORT uint64_t c25519_ctx_counter(const c25519_ctx *ctx, int32_t which) { return (ctx && which >= 0 && which < 8) ? ctx->counters[which] : 0; }
 static inline double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int32_t ffi_begin(c25519_ctx *ctx) {
     HIPCHK(hipSetDevice(ctx->device));

@@ -7,6 +7,10 @@
 #include <vector>
 
 struct devbuf { void *p = nullptr; size_t cap = 0; };
+constexpr int C25519_CTR_PUBLISH_BLOCKED = 0, C25519_CTR_PUBLISH_LOST = 1, C25519_CTR_PUBLISH_DIRECT = 2;
+// internal status of rec_collect / wait_published (msm.hip): the stream drained without error and the small path's record never arrived -- the caller re-runs the
+// call through the slot + copy path; no entry point returns this value
+constexpr int32_t C25519_LOST_PUBLICATION = INT32_MIN + 7;
 
 // result slot of one MSM / verify_batch pass (msm.hip): 56 column sums of 40 u32 + 16 u32 of flags and counters
 constexpr int C25519_SLOT_U32 = 56 * 40 + 16, C25519_MAX_SLOTS = 16;
@@ -40,9 +44,11 @@ struct c25519_ctx {
     uint32_t *hd_msm = nullptr;                          // device pointer of h_msm
     bool want_direct = false;                            // set by an entry point that will read the record on the host right away
     const uint32_t *direct_extra = nullptr;              // with direct_seq: two device words to publish as the record's counters [2], [3] (verify.hip, small batches)
+    bool no_direct_once = false;                         // (r6) set by a caller that re-runs a call whose publication was lost: the next enqueue takes the slot + copy path
     uint32_t direct_seq = 0;                             // != 0: the enqueued small pass publishes itself under this sequence number (rec_collect polls for it)
     bool solo = false;                                   // set by the entry points for a call of ONE pass on this context alone: its bucket reduction may run on the main stream (msm.hip msm_enqueue_acc)
     uint32_t publish_seq = 0;                            // sequence number of the latest publication
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};       // c25519_ctx_counter: [0] publications that outlasted the spin phase (the host blocked on the stream), [1] lost publications (re-run through the copy path), [2] directly published calls
     hipEvent_t coarse_wait = nullptr;                    // set by an enqueue function of a long call: the host blocks on it before it polls for the results
     // host clock of the latest synchronous MSM / verify_batch call, microseconds: [0] entry, [1] inputs staged / upload enqueued, [2] all kernels enqueued,
     // [3] results on the host, [4] folded / encoded (c25519_last_call_host_us)

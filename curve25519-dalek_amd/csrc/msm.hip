@@ -28,6 +28,7 @@
 // Window width c is chosen per call from n (reference: w = 6/7/8, pippenger.rs:81-87).
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 #include <stdexcept>
@@ -431,9 +432,6 @@ void host_encode(const ge_p3 &R, int out_fmt, uint8_t *out) {
 // in the reduction), 16 for the merged layout (u16 digit matrix) and verify_batch.
 static int pick_window(uint64_t n, int cmax) {
     int lg = 0; while ((1ull << (lg + 1)) <= n) lg++;
-    // the small path (small.hip): 5-bit windows below 1024 terms, 6-bit ones above (A/B knob MSM_SMALL_C; rounds 4 and early 5: 7 bits from 2048 terms and
-    // the bucket pipeline from 4096 -- profiles/r05_ab_small_path_range.txt: 7-bit tables are 40 KB of LDS per block, four blocks per compute unit)
-    if (n >= 1024 && n <= msm_small_max()) return C25519_KNOB("MSM_SMALL_C", 6);
     static const int mid = C25519_KNOB("MSM_MIDRANGE_WINDOWS", 1);      // A/B knob: 0 = c = log2 n - 4 throughout (rounds 1-3)
     int c = lg - 4;
     if (mid && lg >= 12 && lg <= 19) c += lg <= 12 ? 2 : lg <= 16 ? 3 : lg == 17 ? 2 : 1;
@@ -452,7 +450,12 @@ void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
     // (a forced width only where the kernels behind it were built for it: the small path's tables hold windows of 5 .. 7 bits, the chunk-local and
     //  digit-matrix sorts scan at least 64 buckets per slice, i.e. windows of >= 7 bits)
     const bool force_ok = cforce >= 5 && cforce <= 17 && !cmax_call && (n <= msm_small_max() ? cforce <= 7 : cforce >= 7);
-    g.c = c_exact ? c_exact : force_ok ? cforce : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
+    // the small path (small.hip): 5-bit windows below 1024 terms (pick_window's lower clamp), 6-bit ones above (A/B knob MSM_SMALL_C; rounds 4 and early 5: 7 bits from
+    // 2048 terms and the bucket pipeline from 4096 -- profiles/r05_ab_small_path_range.txt: 7-bit tables are 40 KB of LDS per block, four blocks per compute unit).
+    // (r6) The choice lives HERE, for plain layouts only: inside pick_window it also narrowed msm_merged_layout's windows (the precomputed-static
+    // MSM never takes the small path) from 7 .. 12 bits to 6 for 121 .. 722 static points -- twice the digit-terms, all in 32 buckets.
+    const bool small_c = n >= 1024 && n <= msm_small_max();
+    g.c = c_exact ? c_exact : force_ok ? cforce : small_c ? C25519_KNOB("MSM_SMALL_C", 6) : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
     uint32_t a[9] = {0};
@@ -648,10 +651,10 @@ ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
 // hipMemcpyAsync of the slots into page-locked memory + hipStreamSynchronize (rounds 1-4, the default).  The round-4 verdict suspected 40 - 60 us of
 // copy-engine launch, interrupt and wake-up in there; round 5 built the alternative -- the last kernel WRITES the slots into the context's coherent,
 // device-mapped host buffer and releases a sequence word the host polls (k_publish; a long call first blocks on an event recorded at the end of its
-// last accumulation, ctx->coarse_wait, so that it does not burn a core for milliseconds; a GPU fault is caught by querying the stream every ~0.5 ms of
-// polling) -- and measured it: 111.8 against 114.8 us for a 1-term MSM, level at every other size (profiles/r05_small_call_phases.txt,
+// last accumulation, ctx->coarse_wait, so that it does not burn a core for milliseconds) -- and measured it: 111.8 against 114.8 us for a 1-term MSM, level at every other size (profiles/r05_small_call_phases.txt,
 // r05_ab_publish.txt).  The end of a call costs ~3 us; what a small call spends is the host's launch work (~25 us), ~65 us of kernels and launch gaps on the
-// GPU and the host fold (~28 us).  The polling arm stays behind the PUBLISH knob of the tuning build; the release library compiles it out.
+// GPU and the host fold (~28 us).  The k_publish arm for LARGE calls stays behind the PUBLISH knob of the tuning build; the SMALL path's own publication
+// (small.hip small_direct, the release default since round 5) ends in wait_published below.
 namespace c25519 {
 __global__ void __launch_bounds__(1024) k_publish(const u32 *__restrict__ src, u32 *__restrict__ host_dst, u32 words, u32 *__restrict__ host_flag, u32 seq) {
     for (u32 i = threadIdx.x; i < words; i += 1024) host_dst[i] = src[i];
@@ -665,23 +668,43 @@ static inline void cpu_relax() {
     __builtin_ia32_pause();
 #endif
 }
-// poll the host's sequence word (behind the slots of h_msm) until a kernel has released `seq` into it; a GPU fault never does: the stream's status is queried
-// every ~0.5 ms of polling
+// Wait for a kernel to release `seq` into the host's sequence word (behind the slots of h_msm).  (r6) Three phases, none bounded by wall-clock alone:
+//   1  spin on the word for at most PUBLISH_SPIN_US (2 ms: the calls that publish are over in 0.06 - 0.3 ms once the stream gets to them)
+//   2  hipStreamSynchronize: the stream is busy with a caller's earlier work, or the GPU is shared -- block like every other path of the library does, for as
+//      long as the STREAM takes; a GPU fault surfaces here as the stream's own error (round 5 returned hipErrorLaunchTimeOut after 60 s of polling whatever
+//      the stream was doing: ADVICE r5)
+//   3  the stream has drained without error and the word is still not there: a LOST publication.  Nothing of the kind has been observed (profiles/r06_soak_small.txt);
+//      the state is recorded in ctx->err (sequence word, expected number, the device's block counter), counted (c25519_ctx_counter), and the caller re-runs
+//      the call once through the slot + copy path of rounds 1-4, which needs no publication (C25519_LOST_PUBLICATION is internal: no entry point returns it).
 static int32_t wait_published(c25519_ctx *ctx, uint32_t seq) {
     volatile uint32_t *vf = (uint32_t *)ctx->h_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
-    double t_first = 0;
-    for (uint64_t spins = 1;; spins++) {
-        if (*vf == seq) break;
+    static const double spin_us = (double)C25519_KNOB("PUBLISH_SPIN_US", 2000);
+    const double t0 = wall_us();
+    bool seen = false;
+    for (uint64_t spins = 1; !(seen = (*vf == seq)); spins++) {
         cpu_relax();
-        if ((spins & 0x3ffff) == 0) {
-            // (a bound on the wait as well: the calls that poll are over in microseconds -- a minute of polling means a lost kernel, which must become an error, not a hang)
-            const double now = wall_us();
-            if (t_first == 0) t_first = now;
-            else if (now - t_first > 60e6) return c25519_fail(ctx, hipErrorLaunchTimeOut, "waiting for a call's results (60 s)");
-            const hipError_t e = hipStreamQuery(ctx->stream);
-            if (e != hipSuccess && e != hipErrorNotReady) return c25519_fail(ctx, e, "waiting for a call's results");
-            if (e == hipSuccess && *vf != seq) return c25519_fail(ctx, hipErrorUnknown, "results were not published");
+        if ((spins & 0xff) == 0 && wall_us() - t0 > spin_us) break;
+    }
+    if (!seen) {
+        ctx->counters[C25519_CTR_PUBLISH_BLOCKED]++;
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) return c25519_fail(ctx, e, "waiting for a call's results");
+        // (the release store precedes the end of the kernel; a drained stream means it has been performed -- a short grace period all the same)
+        const double t1 = wall_us();
+        for (uint64_t spins = 1; !(seen = (*vf == seq)); spins++) {
+            cpu_relax();
+            if ((spins & 0xff) == 0 && wall_us() - t1 > 200.0) break;
         }
+    }
+    if (!seen) {
+        ctx->counters[C25519_CTR_PUBLISH_LOST]++;
+        uint32_t dev_cnt = 0xffffffffu;
+        (void)hipMemcpy(&dev_cnt, (uint32_t *)ctx->d_flag + 56, 4, hipMemcpyDeviceToHost);
+        char buf[200];
+        snprintf(buf, sizeof buf, "a small call's record was not published (sequence word %u, expected %u, device block counter %u, %.0f us waited): re-run through the copy path",
+                 (unsigned)*vf, (unsigned)seq, (unsigned)dev_cnt, wall_us() - t0);
+        ctx->err = buf;
+        return C25519_LOST_PUBLICATION;
     }
     __atomic_thread_fence(__ATOMIC_ACQUIRE);
     return C25519_OK;
@@ -1073,12 +1096,13 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     static const int small_direct_knob = C25519_KNOB("SMALL_DIRECT", 1);
     ctx->direct_seq = 0;
     ctx->direct_extra = nullptr;
-    if (small_direct_knob && ctx->want_direct && d_record == drec(ctx) && n <= msm_small_max() && in_fmt == C25519_FMT_RAW160 && !fetch) {
+    if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && n <= msm_small_max() && in_fmt == C25519_FMT_RAW160 && !fetch) {
         msm_geom gs;
         msm_layout(n, gs);
         if (gs.half <= 64 && gs.nwin <= 64) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
     }
     ctx->want_direct = false;
+    ctx->no_direct_once = false;
     // (r5: letting the sort start on the second stream without the cross-stream wait when the main stream is idle measured level at 2^14 .. 2^20 terms --
     //  the ~20 us before the first kernels is launch latency, not the event: profiles/r05_ab_midrange_streams.txt; not kept)
     if (!ctx->direct_seq) HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));
@@ -1151,7 +1175,14 @@ static int32_t msm_partial_impl(c25519_ctx *ctx, const uint8_t *d_scalars, const
     ctx->want_direct = true;
     int32_t r = msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, drec(ctx));
     if (r) { ctx->direct_seq = 0; return r; }
-    if ((r = rec_collect(ctx))) return r;
+    r = rec_collect(ctx);
+    if (r == C25519_LOST_PUBLICATION) {                     // (r6) never observed; see wait_published: once more through the slot + copy path
+        ctx->no_direct_once = true;
+        if ((r = msm_record_enqueue(ctx, d_scalars, d_points, n, in_fmt, drec(ctx)))) return r;
+        r = rec_collect(ctx);
+        if (!r) ctx->err.clear();
+    }
+    if (r) return r;
     uint32_t flags[8];
     if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
     return msm_record_status(ctx, flags);
@@ -1231,6 +1262,12 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
         r = msm_record_enqueue(ctx, d[0], d[1], n, in_fmt, drec(ctx));
         if (!r) r = rec_collect(ctx);
         else { ctx->direct_seq = 0; (void)hipStreamSynchronize(ctx->stream); }          // (the upload may still be reading the staging buffer)
+        if (r == C25519_LOST_PUBLICATION) {                 // (r6) never observed; see wait_published: once more through the slot + copy path (the staged inputs are still there)
+            ctx->no_direct_once = true;
+            r = msm_record_enqueue(ctx, d[0], d[1], n, in_fmt, drec(ctx));
+            if (!r) r = rec_collect(ctx);
+            if (!r) ctx->err.clear();
+        }
         ffi_small_end(ctx, n * (32 + psz), 0);
         if (r) return r;
         if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;

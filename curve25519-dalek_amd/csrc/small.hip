@@ -72,7 +72,9 @@ __device__ __forceinline__ ge_p3 p3_from_aniels(const ge_aniels &a) {
 // (r5) DIRECT publication of a small call's record (small_direct.on): the kernels need no cleared slot before them -- the "bit 255" flag travels as one word
 // per block (blockflags) instead of an atomicOr into the slot -- and the LAST block to finish writes the 16 header / counter words and then releases `seq` into the
 // host's sequence word, with the column sums already written to `cols` in page-locked, coherent host memory: the host polls that word instead of launching a
-// copy (msm.hip rec_collect).  done_cnt: a device word that is zero between calls (the last block resets it).
+// copy (msm.hip rec_collect).  done_cnt: a device word that counts the finished blocks of k_small_reduce.  (r6) It is zeroed by k_small_cols -- the kernel that
+// ALWAYS precedes k_small_reduce on the stream -- and no longer by the last block of the previous call: a call that died between the two kernels (a fault, a
+// context error) used to leave the word non-zero, and every later direct call on that context then never published (round-5 advice).
 // extra (verify_batch's small path, may be null): two device words -- keys / R_i that did not decode, left by the decompression kernel ahead on the stream --
 // published as the record's counters [2] and [3].
 struct small_direct { int on; u32 *blockflags; u32 *done_cnt; u32 *host_flag; u32 seq; u32 terms; u32 c; const u32 *extra; };
@@ -94,6 +96,7 @@ __global__ void __launch_bounds__(SMALL_THREADS) k_small_cols(const uint8_t *__r
     // (Measured and dropped, profiles/r05_ab_small_path_range.txt: numbering the threads ROTATED by whole waves with the block index -- on the suspicion that wave 0
     //  of every block, the only one busy in the table phase, shares one SIMD with the wave 0s of its neighbours -- is 5 - 9 % SLOWER from 4096 terms, level below.)
     const int tid = threadIdx.x, ti = tid & (SMALL_T - 1), slot = tid / SMALL_T;
+    if (dx.on && blockIdx.x == 0 && tid == SMALL_THREADS - 1 && gridDim.x > 1) *dx.done_cnt = 0;      // (k_small_reduce starts after this kernel has ended)
     if (tid < SMALL_T * 8) {
         const u64 tt = (u64)blockIdx.x * SMALL_T + (u64)(tid >> 3);
         sk[tid] = tt < n ? reinterpret_cast<const u32 *>(scalars)[tt * 8 + (tid & 7)] : 0u;
@@ -203,7 +206,7 @@ __global__ void __launch_bounds__(TH) k_small_reduce(const u32 *__restrict__ par
             int b = 0;
             for (int i = tid; i < nblocks; i += TH) b |= (int)dx.blockflags[i];
             const int any_bad = __syncthreads_or(b);
-            if (tid == 0) { *dx.done_cnt = 0; small_publish(cols, dx, (u32)any_bad); }
+            if (tid == 0) small_publish(cols, dx, (u32)any_bad);
         }
     }
 }
@@ -221,6 +224,11 @@ int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void 
         out = ctx->hd_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32;
         dx.on = 1; dx.done_cnt = (uint32_t *)ctx->d_flag + 56; dx.host_flag = ctx->hd_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32;
         dx.seq = ctx->direct_seq; dx.terms = (uint32_t)n; dx.c = (uint32_t)g.c; dx.extra = ctx->direct_extra;
+        // fault injection (TUNING build only; the release library compiles this to nothing): every FAULT_LOSE_PUBLICATION-th directly published call releases a
+        // WRONG sequence number, so that the host's recovery -- wait_published phase 3 and the re-run through the copy path -- is exercised by a test
+        static const int lose_every = C25519_KNOB("FAULT_LOSE_PUBLICATION", 0);
+        const uint64_t nth = ++ctx->counters[C25519_CTR_PUBLISH_DIRECT];
+        if (lose_every > 0 && nth % (uint64_t)lose_every == 0) dx.seq ^= 0x40000000u;
     }
     uint32_t *partial = out;                                        // a single block writes the column sums themselves
     if (nblocks > 1) {

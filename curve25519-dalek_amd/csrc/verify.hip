@@ -805,11 +805,23 @@ static int32_t verify_batch_small_host(c25519_ctx *ctx, const uint8_t *msgs, con
     r = msm_small_enqueue(ctx, dv + oC, d_pts, 1, m, g, drec(ctx), ctx->stream);
     ctx->direct_extra = nullptr;
     if (r) { ctx->direct_seq = 0; (void)hipStreamSynchronize(ctx->stream); return r; }
-    if ((r = rec_collect(ctx))) return r;
+    r = rec_collect(ctx);
+    uint32_t late_cnt[2] = {0, 0};
+    if (r == C25519_LOST_PUBLICATION) {
+        // (r6) never observed (msm.hip wait_published): the small MSM once more, into the device slot, and the record by copy; the decode counters of the
+        // first kernel (still in d_flag) with it.  The staged scalars and the records of A_i, R_i, B are where they were.
+        slot_init(drec(ctx), m, nullptr, ctx->stream, g.c);
+        if ((r = msm_small_enqueue(ctx, dv + oC, d_pts, 1, m, g, drec(ctx), ctx->stream))) { (void)hipStreamSynchronize(ctx->stream); return r; }
+        if ((r = rec_collect(ctx))) return r;
+        HIPCHK(hipMemcpy(late_cnt, cnt, 8, hipMemcpyDeviceToHost));
+        ctx->err.clear();
+    }
+    if (r) return r;
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     ge_p3 R;
     uint32_t flags[8];
     if ((r = records_fold((const uint8_t *)hslot(ctx, C25519_MAX_SLOTS), 1, R, flags, &ctx->err))) return r;
+    flags[2] += late_cnt[0]; flags[3] += late_cnt[1];
     flags[4] += bad_s;
     r = verify_record_verdict(ctx, R, flags);
     ffi_small_end(ctx, 0, 0);                                      // (nothing is copied: the kernels read and write host memory in place)

@@ -23,9 +23,23 @@ class EngineError(RuntimeError):
     pass
 
 
+_LIB_OVERRIDE = None
+
+
 def lib_path():
-    # C25519_HIP_LIB: developer knob for A/B runs of two builds of the same library
-    return os.environ.get("C25519_HIP_LIB") or os.path.join(_HERE, "lib", "libc25519hip.so")
+    """the library this process loads: lib/libc25519hip.so unless select_library() named another build.  Nothing here reads the environment."""
+    return _LIB_OVERRIDE or os.path.join(_HERE, "lib", "libc25519hip.so")
+
+
+def select_library(path):
+    """Load another build of the same sources (the tuning build lib/libc25519hip_tune.so with its A/B knobs, the bound-checking debug build, a variant
+    made by tools/build_variant.sh) instead of the release library.  An explicit call of the test harness / an A/B tool, before the first Engine; the
+    package itself never looks at the environment for this (a crypto library must not be substitutable through a variable)."""
+    global _LIB_OVERRIDE
+    path = os.path.abspath(path)
+    if _LIB is not None and os.path.abspath(lib_path()) != path:
+        raise EngineError("select_library(%s): %s is already loaded in this process" % (path, lib_path()))
+    _LIB_OVERRIDE = path
 
 
 def load_library():
@@ -106,6 +120,7 @@ def load_library():
         "c25519_double_base_batch_dev": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_double_base_batch": (i32, [vp, vp, vp, vp, u64, C.c_int, C.c_int, vp, vp]),
         "c25519_last_call_host_us": (i32, [vp, vp]),
+        "c25519_ctx_counter": (u64, [vp, i32]),
         "ed25519_verify_each_dev": (i32, [vp, vp, vp, u64, vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_each": (i32, [vp, vp, vp, vp, vp, u64, C.c_int, vp]),
         "ed25519_verify_each_prehashed_dev": (i32, [vp, vp, C.c_char_p, C.c_uint32, vp, vp, u64, C.c_int, vp]),
@@ -148,7 +163,7 @@ ABI_SYMBOLS = [
     "ed25519_batch_hram_dev", "ed25519_batch_transcript_zs", "ed25519_verify_batch_record_dev", "ed25519_fold_verify_records", "c25519_msm_vartime_multi", "ed25519_verify_batch_multi", "ed25519_verify_batch_dev", "ed25519_verify_batch", "ed25519_verify_batch_keys_dev", "ed25519_verify_batch_keys", "c25519_microbench", "c25519_selftest_field", "c25519_selftest_scalar", "c25519_msm_geometry",
     "c25519_mul_batch_dev", "c25519_mul_batch", "c25519_double_base_batch_dev", "c25519_double_base_batch", "ed25519_verify_each_dev", "ed25519_verify_each",
     "ed25519_keygen_batch_dev", "ed25519_sign_batch_dev", "ed25519_sign_batch",
-    "c25519_last_call_host_us", "ed25519_verify_each_prehashed_dev", "ed25519_verify_each_prehashed", "ed25519_sign_batch_prehashed_dev", "ed25519_sign_batch_prehashed",
+    "c25519_last_call_host_us", "c25519_ctx_counter", "ed25519_verify_each_prehashed_dev", "ed25519_verify_each_prehashed", "ed25519_sign_batch_prehashed_dev", "ed25519_sign_batch_prehashed",
     "c25519_to_montgomery_batch_dev", "c25519_to_montgomery_batch",
     "c25519_precomp_create", "c25519_precomp_destroy", "c25519_precomp_len", "c25519_precomp_msm_vartime",
     "c25519_msm_consttime", "c25519_double_and_compress_batch_dev", "c25519_double_and_compress_batch",
@@ -177,10 +192,8 @@ class Engine:
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible to PyTorch-ROCm: the engine has no CPU fallback")
         self.device = torch.device("cuda", device)
-        if window == 0:                       # test knob: run any caller against another fixed-base algorithm
-            window = int(os.environ.get("C25519_DEFAULT_WINDOW", "0"))
-        if flags == 0 and os.environ.get("C25519_DEFAULT_VARTIME_TABLES", "0") == "1":    # test knob
-            flags = FLAG_VARTIME_TABLES
+        # (round 5 let C25519_DEFAULT_WINDOW / C25519_DEFAULT_VARTIME_TABLES steer these two from the environment: a default context could be talked out of
+        #  its constant-time tables by a variable.  The arguments are the only way now; tests pass them.)
         self.ctx = self.lib.c25519_ctx_create(device, (window & 0x1f) | flags)
         if not self.ctx:
             raise EngineError("c25519_ctx_create(%d) failed" % device)
@@ -221,6 +234,10 @@ class Engine:
         out = (C.c_double * 4)()
         self._chk(self.lib.c25519_last_call_host_us(self.ctx, out))
         return tuple(out)
+
+    def counter(self, which):
+        """event counters of the context (c25519_ctx_counter): 0 publications that blocked on the stream, 1 lost publications (re-run), 2 directly published calls"""
+        return int(self.lib.c25519_ctx_counter(self.ctx, which))
 
     def synchronize(self):
         self._chk(self.lib.c25519_ctx_synchronize(self.ctx))

@@ -140,6 +140,13 @@ float c25519_last_kernel_ms(c25519_ctx *ctx);
  * out4[0] inputs staged and their upload enqueued (0 for the device-pointer forms), [1] every kernel enqueued, [2] results on the host (the last
  * kernel writes them into page-locked host memory and the host polls a sequence word: no copy engine, no interrupt), [3] folded and encoded. */
 int32_t c25519_last_call_host_us(const c25519_ctx *ctx, double *out4);
+/* Event counters of a context since its creation (diagnostics; tools/soak_small.py logs them).  Small MSM / verify_batch calls (at most 12 287 terms,
+ * vartime_multiscalar_mul at the sizes of benches/dalek_benchmarks.rs:16, verify_batch of ed25519-dalek/benches/ed25519_benchmarks.rs:53) end with their last
+ * kernel writing the record into page-locked host memory and the host polling a sequence word.  which = 0: calls whose record had not arrived after 2 ms of polling --
+ * the host then blocked on the stream (a busy stream, a shared GPU); 1: calls whose record never arrived although the stream drained without error -- each was re-run
+ * through the slot + copy path and returned its normal status (none observed: profiles/r06_soak_small.txt); 2: directly published calls.  Like
+ * ed25519-dalek/src/batch.rs:146-251, a call returns or errs; it never waits on wall-clock alone. */
+uint64_t c25519_ctx_counter(const c25519_ctx *ctx, int32_t which);
 
 /* Per-call phase timing from a ring of hipEvents recorded on the launch streams (the last 64 calls of this context):
  * phase 0 = the dominant kernel of the call made `back` calls ago (0 = most recent) -- k_mul_base_*, k_x25519,

@@ -27,7 +27,7 @@ def test_release_library_reads_no_environment():
     import curve25519_dalek_amd as pkg
     rel = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip.so")
     tune = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip_tune.so")
-    assert os.path.samefile(pkg.engine.lib_path(), rel) or os.environ.get("C25519_HIP_LIB")
+    assert os.path.samefile(pkg.engine.lib_path(), rel)
     def knob_strings(path):
         data = open(path, "rb").read()
         return sorted(set(m.decode() for m in re.findall(rb"(?<![\x20-\x7e])(C25519_[A-Z][A-Z0-9_]{2,})\x00", data)))
@@ -37,6 +37,32 @@ def test_release_library_reads_no_environment():
         assert "getenv" not in nm.stdout
     assert os.path.exists(tune), "run __graft_entry__.build() (make tune)"
     assert "C25519_MSM_PASS_LOG2" in knob_strings(tune) and "C25519_VERIFY_PASS_LOG2" in knob_strings(tune)
+
+
+def test_python_front_end_reads_no_environment():
+    """(r6) Neither does the Python front end: the library file, the fixed-base algorithm and the constant-time / variable-time table choice come from ARGUMENTS
+    (Engine(window=, flags=), select_library(path)) -- round 5 still honoured C25519_HIP_LIB, C25519_DEFAULT_WINDOW and C25519_DEFAULT_VARTIME_TABLES here, one layer
+    above the library it had just made environment-free."""
+    import ast
+    pkgdir = os.path.join(ROOT, "curve25519-dalek_amd")
+    for f in sorted(os.listdir(pkgdir)):
+        if not f.endswith(".py"):
+            continue
+        tree = ast.parse(open(os.path.join(pkgdir, f)).read())
+        for node in ast.walk(tree):
+            if isinstance(node, ast.Attribute) and node.attr in ("environ", "getenv", "putenv"):
+                raise AssertionError("%s:%d touches the environment" % (f, node.lineno))
+            if isinstance(node, ast.Name) and node.id in ("environ", "getenv"):
+                raise AssertionError("%s:%d touches the environment" % (f, node.lineno))
+    import curve25519_dalek_amd as pkg
+    rel = os.path.join(pkgdir, "lib", "libc25519hip.so")
+    old = dict(os.environ)
+    try:
+        os.environ["C25519_HIP_LIB"] = "/nonexistent/libevil.so"
+        os.environ["C25519_DEFAULT_VARTIME_TABLES"] = "1"
+        assert os.path.samefile(pkg.engine.lib_path(), rel)
+    finally:
+        os.environ.clear(); os.environ.update(old)
 
 
 def test_no_cpu_fallback():

@@ -85,7 +85,7 @@ def _run(code, lib):
         env["C25519_HIP_LIB"] = lib
     else:
         env.pop("C25519_HIP_LIB", None)
-    return subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    return subprocess.run(util.child_argv(code), capture_output=True, text=True, timeout=900, env=env)
 
 
 def test_workloads_run_clean_with_device_bound_checks():

@@ -62,7 +62,7 @@ def test_precomputed_vs_nonprecomputed(eng, orc):
     eng.precomp_destroy(h)
 
 
-@pytest.mark.parametrize("ns", [1, 2, 17, 1000, 4096, 70000])
+@pytest.mark.parametrize("ns", [1, 2, 17, 130, 500, 720, 1000, 4096, 70000])      # (130 / 500 / 720: 17 ns falls into the SMALL path's term range -- the merged layout must keep its own widths)
 def test_precomputed_tables_all_window_layouts(eng, orc, ns):
     """precomputed_straus.rs:57-127 through the merged-window tables (2^(c k) P_i for every window k): the table layout
     changes with the number of static points (c = 6 .. 16), every layout must give the oracle's result -- edge scalars

@@ -182,7 +182,7 @@ def test_verify_batch_host_twin_multi_pass_fresh_process():
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     e = util.tune_env(C25519_VERIFY_PASS_LOG2="15")
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=900)
+    r = subprocess.run(util.child_argv(code), env=e, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-3000:])
 
 

@@ -288,7 +288,7 @@ def test_msm_kernel_variants_in_a_fresh_process(orc, env):
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     e = util.tune_env(env) if env else dict(os.environ)          # ({}: the release library, which has no knobs)
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(util.child_argv(code), env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-500:], r.stderr[-2000:])
 
 
@@ -409,7 +409,7 @@ def test_msm_small_sort_blocks_256_slices(orc):
             assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(T.i2b(T._sumsq_device(dx)))), n
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    r = subprocess.run([sys.executable, "-c", code], env=util.tune_env(C25519_SORT_SMALL="1"), capture_output=True, text=True, timeout=600)
+    r = subprocess.run(util.child_argv(code), env=util.tune_env(C25519_SORT_SMALL="1"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
 
 
@@ -436,7 +436,7 @@ def test_msm_continuing_last_pass_one_sort_chunk_shorter(orc, log2pass, n):
         print("ok")
     """) % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), n)
     e = util.tune_env(C25519_MSM_PASS_LOG2=str(log2pass))
-    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(util.child_argv(code), env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])
 
 

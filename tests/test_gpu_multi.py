@@ -15,6 +15,7 @@ import subprocess
 import sys
 
 import pytest
+import util
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,7 +128,7 @@ def _launch(world, backend, force, extra_env=None, timeout=900):
         env.update(extra_env or {})
         if any(k.startswith("C25519_") for k in (extra_env or {})):      # knobs exist only in the tuning build (csrc/msm_internal.h C25519_KNOB)
             env["C25519_HIP_LIB"] = os.path.join(ROOT, "curve25519-dalek_amd", "lib", "libc25519hip_tune.so")
-        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+        procs.append(subprocess.Popen(util.child_argv(code), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:

@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+import util
 
 pytestmark = pytest.mark.gpu
 L = 2**252 + 27742317777372353535851937790883648493
@@ -134,5 +135,5 @@ assert np.array_equal(e.selftest_scalar(2, T.limbs(a, 10), T.limbs(b, 10)), T.en
 print("dbg scalar selftest ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, C25519_HIP_LIB=dbg)
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(util.child_argv(code), env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "dbg scalar selftest ok" in r.stdout, r.stdout + r.stderr

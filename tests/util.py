@@ -20,6 +20,18 @@ def tune_env(knobs=None, **more):
     return env
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def child_argv(code):
+    """argv of a child process that runs `code` against the library C25519_HIP_LIB of ITS environment names (the tuning / debug build).  The variable belongs to the
+    TEST HARNESS: the package reads no environment (tests/test_abi_cpu.py asserts it); the child selects the build with an explicit select_library() call."""
+    import sys
+    pre = ("import os as _os, sys as _sys\n_sys.path.insert(0, %r)\n_p = _os.environ.get('C25519_HIP_LIB')\n"
+           "if _p:\n    import curve25519_dalek_amd as _pkg\n    _pkg.select_library(_p)\n" % ROOT)
+    return [sys.executable, "-c", pre + code]
+
+
 def rand_bytes(seed, n, width=32):
     return np.random.default_rng(seed).integers(0, 256, size=(n, width), dtype=np.uint8)
 

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 
 t0 = time.perf_counter(); e = pkg.Engine(0); t1 = time.perf_counter()
 print("ctx_create, first in the process (both table sets): %.1f ms" % ((t1 - t0) * 1e3))

@@ -13,6 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 import curve25519_dalek_amd as pkg  # noqa: E402
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 
 E = pkg.engine
 LINK_GBS = 64.0          # PCIe Gen5 x16, per direction (measured: 56 - 57 GB/s, profiles/r03_pcie_probe.txt)

@@ -6,12 +6,13 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 
 e = pkg.Engine(0, flags=pkg.engine.FLAG_VARTIME_TABLES)
 rng = np.random.default_rng(1)
 print("%10s %14s %14s %14s %10s %12s" % ("n_static", "create ms", "precomp ms", "plain msm ms", "speed-up", "table MB"))
-for lg in (10, 12, 14, 16, 18, 20):
-    n = 1 << lg
+for n in (128, 256, 500, 720, 1 << 10, 1 << 12, 1 << 14, 1 << 16, 1 << 18, 1 << 20):
+    lg = n.bit_length() - 1
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); x[:, 31] &= 0x0F
     y = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); y[:, 31] &= 0x0F
     pts = e.mul_base_batch(y, out_fmt=2)

@@ -5,6 +5,7 @@ at 8 waves per SIMD, and at ONE wave per SIMD (which + 100: how much a lone wave
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 
 e = pkg.Engine(0)
 names = {0: "v_mad_u64_u32 (8 independent chains)", 22: "v_mad_u64_u32 (ONE dependent chain)", 5: "v_mul_lo_u32", 18: "v_mul_hi_u32", 16: "v_mul_u32_u24 (VOP2)",

@@ -2,6 +2,7 @@ import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 e = pkg.Engine(0); E = pkg.engine
 rng = np.random.default_rng(1)
 for _ in range(40): e.microbench(0, 4000)

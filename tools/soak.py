@@ -7,6 +7,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 E = pkg.engine
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 eng = pkg.Engine(0)

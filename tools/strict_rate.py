@@ -1,6 +1,7 @@
 import sys, time, torch
 sys.path.insert(0, '.')
 import curve25519_dalek_amd as pkg
+import devlib; devlib.apply(pkg)      # (C25519_HIP_LIB of this TOOL's environment selects another build; the package reads no environment)
 E = pkg.engine
 eng = pkg.Engine(0)
 dev = torch.device('cuda', 0)
