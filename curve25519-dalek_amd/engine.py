@@ -212,6 +212,8 @@ class Engine:
 
     # -- plumbing ----------------------------------------------------------------------------
     def _bind_stream(self):
+        if not self.ctx:
+            raise EngineError("this Engine has been closed")
         st = self.torch.cuda.current_stream(self.device).cuda_stream
         self.lib.c25519_ctx_set_stream(self.ctx, C.c_void_p(st))
 

@@ -7,6 +7,7 @@ import subprocess
 import sys
 
 import pytest
+import util
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

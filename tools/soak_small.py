@@ -25,6 +25,7 @@ L = 2**252 + 27742317777372353535851937790883648493
 calls = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rnd = random.Random(seed)
+faulthandler.enable()                     # (a crash inside the library prints the Python stack of the call)
 faulthandler.dump_traceback_later(600, exit=True)
 
 NMAX = 12287
@@ -87,13 +88,13 @@ fresh_every, large_every = 4000, 1500
 closed, nfresh = [0, 0, 0], 0
 done = 0
 while done < calls:
-    eng = rnd.choice(ctxs)
     r = rnd.random()
     if done and done % fresh_every == 0:                             # a fresh context replaces a long-lived one (its first call allocates everything)
         i = rnd.randrange(1, len(ctxs))
         for w in range(3):
             closed[w] += ctxs[i].counter(w)
         ctxs[i].close(); ctxs[i] = pkg.Engine(0); nfresh += 1
+    eng = rnd.choice(ctxs)                                           # (after the replacement: a closed Engine has no context)
     if done and done % large_every == 0:
         t0 = time.perf_counter(); st, got = eng.msm_vartime_t(lx, lraw, in_fmt=2, out_fmt=0); note("large msm 2^17 (device)", NL, time.perf_counter() - t0)
         wrong += (st != 0 or got != large_want)
