@@ -1,0 +1,476 @@
+// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in FOUR launches on ONE stream.
+//
+// Reference: the same algorithm as msm.hip -- backend/serial/scalar_mul/pippenger.rs:67-160 (signed digits, buckets, running-sum reduction, Horner fold), for the sizes
+// where the reference's heaviest real callers live (edwards.rs:1002-1031 vartime_multiscalar_mul of a Bulletproofs verification; ed25519-dalek/src/batch.rs:225-244
+// verify_batch of 2^13 .. 2^17 signatures).
+//
+// Why a third path.  Between the small path (small.hip, up to 12 287 terms) and the throughput regime (2^20 terms and beyond) the bucket pipeline of msm.hip is a
+// chain of 15 - 27 short kernels on two streams: the HOST's launch loop (5 - 8 us per launch, a dozen event operations) put k_accumulate 150 us into a 330 us call
+// at 2^14 terms, the batched inversion of the normaliser is a 78 us latency chain on 64 waves, and the eleven sort kernels of 2 - 9 us each are separated by as much
+// again (profiles/r05_timeline_msm_2p14.txt; whole call 0.03 - 0.17 of the multiplier roof).  Here:
+//
+//   k_mid_front   one lane per term: the window digits of s' = s + addk as a u16 matrix D[window][term], and -- raw points -- the point as a PROJECTIVE Niels
+//                 record (Y+X, Y-X, Z, 2dT) of (XZ : YZ : Z^2 : XY): five field operations, NO inversion.  The accumulation then costs 8 M per addition instead
+//                 of 7 M, which is nothing beside a 265-operation inversion chain while the machine is not full (the small path made the same choice).
+//                 Also zeroes the small counters of the kernels behind it (it always precedes them on the stream: nothing relies on a previous call's clean-up).
+//   k_mid_sort    one block per (window, slice of <= 1024 buckets): count -> scan -> place over the window's row of D, straight into the final gather lists
+//                 (two reads of a row that sits in L2; no partition pass, no digit re-derivation), the bucket bases, a block-local bucket order by list length
+//                 (lanes of a wave walk lists of similar length; a global order is not needed), and the work items of over-long lists.
+//   k_mid_acc     one lane per bucket walking its list (8 M additions on projective Niels records, or 7 M mixed additions on the affine records a decompression
+//                 left: verify_batch / compressed inputs); extra blocks at the END of the grid fold the over-long lists segment by segment, the wave that
+//                 finishes a bucket's last segment sums the segments (no separate combine launch, no second stream).
+//   k_reduce_fused4 (reduce.hip)  level A of the bucket reduction; the block that finishes a window's last segment runs level B for it; the block that finishes the
+//                 last window writes the record's header -- and, for a caller that reads the record on the host right away, publishes it into page-locked host
+//                 memory and releases the sequence word the host polls (the small path's mechanism, msm.hip wait_published, with the same recovery).
+//
+// Same window layout (msm_layout), same record format, same host fold as the other two paths: a partial-result record of this path folds with any other.
+// Variable time like the paths beside it (digits index gather lists): vartime_multiscalar_mul and verify_batch only.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <stdlib.h>
+#include <string>
+#define C25519_CHAIN 1
+#include "../../include/c25519_hip.h"
+#include "devio.h"
+#include "ctx.h"
+#include "msm_internal.h"
+#include "msm_sort.h"
+#include "fe26x.h"
+
+using namespace c25519;
+#define HIPCHK(call)                                                \
+    do {                                                            \
+        hipError_t _e = (call);                                     \
+        if (_e != hipSuccess) return c25519_fail(ctx, _e, #call);   \
+    } while (0)
+
+namespace c25519 {
+
+constexpr int MID_REC_Q = 10;                 // a projective Niels record: 4 x 10 tight limbs = 160 bytes = ten 16-byte pieces
+struct mid_item { u32 gid, lo, hi, first, lb, nseg, pad0, pad1; };      // one segment of an over-long list: bucket, entries [lo, hi), the bucket's first item, its index, its segments
+
+// ---- front: digits + records --------------------------------------------------------------------------------------------------------------------------------
+// SRC 0: raw 160-byte points -> projective Niels records (the same X, Y, Z-only reading as the other two paths: T is whatever the caller stored and is not used);
+// SRC 1: the records exist already (affine Niels, made by a decompression): digits only.
+template <int SRC>
+__global__ void __launch_bounds__(256) k_mid_front(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points, u64 n, msm_geom g, uint16_t *__restrict__ D, u64 dstride,
+                                                   u32 *__restrict__ recs, u32 *__restrict__ zero_words, int nzero, u32 *__restrict__ blockflags) {
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
+    const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
+    int bad = 0;
+    if (t < n) {
+        u32 s[8];
+        load8(scalars, t, s);
+        bad = (int)(s[7] >> 31);
+        u32 carry = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const u64 v = (u64)s[i] + g.addk[i] + carry; s[i] = (u32)v; carry = (u32)(v >> 32); }
+        // the windows are contiguous from bit 0 (msm_layout): window k is the low wid[k] bits, then the scalar moves down -- no dynamic register index
+#pragma unroll 1
+        for (int k = 0; k < g.nwin; k++) {
+            const int wd = g.wid[k];
+            D[(u64)k * dstride + t] = (uint16_t)(s[0] & ((1u << wd) - 1u));
+#pragma unroll
+            for (int i = 0; i < 7; i++) s[i] = __funnelshift_r(s[i], s[i + 1], (u32)wd);
+            s[7] >>= wd;
+        }
+        if (SRC == 0) {
+            const feT X = raw160_fe(points, t, 0), Y = raw160_fe(points, t, 1), Z = raw160_fe(points, t, 2);
+            const feT x = fe_mul(X, Z), y = fe_mul(Y, Z), zz = fe_sq(Z), tt = fe_mul(fe_mul(X, Y), fe_d2());
+            const feT a = fe_carry(fe_add(y, x)), b = fe_carry(fe_sub(y, x));
+            u32 w[40];
+#pragma unroll
+            for (int i = 0; i < 10; i++) { w[i] = a.v[i]; w[10 + i] = b.v[i]; w[20 + i] = zz.v[i]; w[30 + i] = tt.v[i]; }
+            uint4 *q = reinterpret_cast<uint4 *>(recs) + MID_REC_Q * t;
+#pragma unroll
+            for (int i = 0; i < MID_REC_Q; i++) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+        }
+    }
+    const int any = __syncthreads_or(bad);
+    if (threadIdx.x == 0) blockflags[blockIdx.x] = (u32)any;      // "a scalar has bit 255 set", one word per block (ORed by the reduction's last block: no cleared word needed)
+}
+
+// ---- sort: one block per (window, slice) --------------------------------------------------------------------------------------------------------------------------
+// D row of window k (dstride u16, a multiple of 8): read twice as 16-byte vectors.  Pass 1 counts the bucket occupancies of THIS slice, the entries of the slices before
+// it (= where this slice's lists start in the window's sorted array) and of the whole window; then scan, bases, bucket order, long-list items; pass 2 places
+// term | sign << 31 at its final position (LDS cursors).  Any digit distribution is correct (all terms in one bucket: one long list, LDS atomics on one counter).
+// Slices are LARGE (up to 4096 buckets: 32 KB of LDS counters), i.e. few blocks -- 22 at 2^14 terms, 76 at 2^18: every block of a window reads the window's whole row,
+// so the work is (slices per window) x n x windows, and the first version (512 buckets per slice: 32 slices per window at 2^16 terms) spent 96 us at 2^16 and 407 us at
+// 2^18 terms re-deriving the same digits 32 times (profiles/r06_timeline_mid_first.txt).  A block's time is n / 1024 digits per thread and pass whatever the slicing.
+constexpr int MID_BPS_MAX = 4096, MID_SORT_THREADS = 1024, MID_PER_MAX = MID_BPS_MAX / MID_SORT_THREADS;
+__global__ void __launch_bounds__(MID_SORT_THREADS) k_mid_sort(const uint16_t *__restrict__ D, u64 n, u64 dstride, msm_geom g, int bps, u32 *__restrict__ sorted, u32 *__restrict__ base,
+                                                               u32 *__restrict__ perm, u32 max_items, mid_item *__restrict__ items, u32 *__restrict__ counters,
+                                                               u32 *__restrict__ long_gids) {
+    __shared__ u32 cnt[MID_BPS_MAX], cur[MID_BPS_MAX], oh[256], ostart[256], red[3][16];
+    const int k = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int BPS = 1 << bps, PER = BPS > MID_SORT_THREADS ? BPS / MID_SORT_THREADS : 1;      // consecutive buckets per thread (1, 2 or 4)
+    const u32 bmask = (u32)BPS - 1u;
+    for (int i = tid; i < BPS; i += MID_SORT_THREADS) cnt[i] = 0;
+    if (tid < 256) oh[tid] = 0;
+    __syncthreads();
+    const uint4 *row = reinterpret_cast<const uint4 *>(D + (u64)k * dstride);
+    const u64 nvec = dstride / 8;
+    u32 before = 0, nz = 0;
+    // four 16-byte loads in flight per thread
+#pragma unroll 1
+    for (u64 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const u64 i = i0 + (u64)q * MID_SORT_THREADS; v[q] = i < nvec ? row[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 i = i0 + (u64)q * MID_SORT_THREADS;
+            if (i >= nvec) break;
+            const u32 x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const u64 t = 8 * i + h;
+                const int d = t < n ? digit_of((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g) : 0;
+                if (d != 0) {
+                    const u32 b = (u32)((d > 0 ? d : -d) - 1), sl = b >> bps;
+                    nz++;
+                    before += sl < (u32)s ? 1u : 0u;
+                    if (sl == (u32)s) atomicAdd(&cnt[b & bmask], 1u);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int dd = 32; dd > 0; dd >>= 1) { before += (u32)__shfl_xor((int)before, dd, 64); nz += (u32)__shfl_xor((int)nz, dd, 64); }
+    if (lane == 0) { red[0][w] = before; red[1][w] = nz; }
+    __syncthreads();                                             // the counts are complete
+    before = 0; nz = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) { before += red[0][q]; nz += red[1][q]; }
+    // exclusive scan of the slice's bucket counts: thread tid owns buckets tid * PER .. tid * PER + PER - 1
+    u32 c[MID_PER_MAX], csum = 0;
+#pragma unroll
+    for (int j = 0; j < MID_PER_MAX; j++) { c[j] = (j < PER && tid * PER + j < BPS) ? cnt[tid * PER + j] : 0u; csum += c[j]; }
+    u32 inc = csum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const u32 y = (u32)__shfl_up((int)inc, off, 64); if (lane >= off) inc += y; }
+    if (lane == 63) red[2][w] = inc;
+    // bucket order of the slice by list length (255 - min(c, 255): longest first), block-local
+    u32 bin[MID_PER_MAX], local[MID_PER_MAX];
+#pragma unroll
+    for (int j = 0; j < MID_PER_MAX; j++)
+        if (j < PER && tid * PER + j < BPS) { bin[j] = 255u - (c[j] > 255u ? 255u : c[j]); local[j] = atomicAdd(&oh[bin[j]], 1u); }
+    __syncthreads();
+    u32 wb = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) wb += q < w ? red[2][q] : 0u;
+    u32 lo[MID_PER_MAX];
+    {
+        u32 run = before + wb + inc - csum;                      // start of this thread's first list in the window's sorted array
+#pragma unroll
+        for (int j = 0; j < MID_PER_MAX; j++) {
+            lo[j] = run; run += c[j];
+            if (j < PER && tid * PER + j < BPS) {
+                cur[tid * PER + j] = lo[j];
+                base[(u64)k * (g.half + 1) + (u64)s * BPS + tid * PER + j] = lo[j];
+            }
+        }
+    }
+    if (s == (int)gridDim.y - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = nz;
+    if (tid < 256) {                                            // exclusive scan of the 256 length classes (four waves)
+        const u32 mine = oh[tid];
+        u32 i2 = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const u32 y = (u32)__shfl_up((int)i2, off, 64); if (lane >= off) i2 += y; }
+        ostart[tid] = i2 - mine;
+        if (lane == 63) red[0][w] = i2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MID_PER_MAX; j++) {
+        if (!(j < PER && tid * PER + j < BPS)) continue;
+        const u64 G = (u64)k * g.half + (u64)s * BPS + tid * PER + j;          // global bucket index
+        u32 ob = 0;
+        const int bw = (int)(bin[j] >> 6);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ob += q < bw ? red[0][q] : 0u;
+        perm[(u64)k * g.half + (u64)s * BPS + ob + ostart[bin[j]] + local[j]] = (u32)G;
+        if (c[j] > g.long_cap) {                                // an over-long list: work items of LONG_SEG entries each (the long role of k_mid_acc)
+            const u32 nseg = (c[j] + LONG_SEG - 1) / LONG_SEG;
+            const u32 first = atomicAdd(&counters[0], nseg);
+            const u32 lb = atomicAdd(&counters[1], 1u);
+            long_gids[lb] = (u32)G;
+            for (u32 sg = 0; sg < nseg && first + sg < max_items; sg++) {
+                mid_item it;
+                it.gid = (u32)G; it.lo = lo[j] + sg * LONG_SEG; it.hi = it.lo + LONG_SEG < lo[j] + c[j] ? it.lo + LONG_SEG : lo[j] + c[j]; it.first = first; it.lb = lb; it.nseg = nseg; it.pad0 = it.pad1 = 0;
+                items[first + sg] = it;
+            }
+        }
+    }
+    // pass 2: place
+    u32 *dst = sorted + (u64)k * n;
+#pragma unroll 1
+    for (u64 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
+        uint4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const u64 i = i0 + (u64)q * MID_SORT_THREADS; v[q] = i < nvec ? row[i] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u64 i = i0 + (u64)q * MID_SORT_THREADS;
+            if (i >= nvec) break;
+            const u32 x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+            for (int h = 0; h < 8; h++) {
+                const u64 t = 8 * i + h;
+                const int d = t < n ? digit_of((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g) : 0;
+                if (d != 0) {
+                    const u32 b = (u32)((d > 0 ? d : -d) - 1);
+                    if ((b >> bps) == (u32)s) dst[atomicAdd(&cur[b & bmask], 1u)] = (u32)t | (d < 0 ? 0x80000000u : 0u);
+                }
+            }
+        }
+    }
+}
+
+// ---- accumulate ----------------------------------------------------------------------------------------------------------------------------------------------------
+// P + (neg ? -Q : Q) for a projective Niels record Q = (Y+X, Y-X, Z, 2dT): curve_models.rs:411-429 + :365-373 (8 M), the sign folded into operand selection exactly
+// as in ge_madd_signed_p3 (ge26.h) -- -Q swaps the first two entries and negates TT, which only decides which of ZZ2 + TT / ZZ2 - TT plays Z and which plays T of the
+// completed point.  The two groups of four independent products are issued in lockstep (fe26x.h).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ ge_p3 ge_add_cached_signed_p3_lockstep(const ge_p3 &p, const feT &qypx, const feT &qymx, const feT &qz, const feT &qt2d, bool neg) {
+    // (the first four products as two lockstep pairs: as one group of four the kernel needs 184 registers -- two waves per SIMD, or 17 spilled words at three)
+    const lanemask nm = lane_mask(neg);
+    feT r4[4];
+    {
+        feW f2[2]; feL g2[2]; feT r2[2];
+        f2[0] = fe_add(p.Y, p.X); f2[1] = fe_sub(p.Y, p.X);
+#pragma unroll
+        for (int i = 0; i < 10; i++) { g2[0].v[i] = sel_u32(qypx.v[i], qymx.v[i], nm); g2[1].v[i] = sel_u32(qymx.v[i], qypx.v[i], nm); }
+        fe_mul_chain_n<2>(r2, f2, g2);
+        r4[0] = r2[0]; r4[1] = r2[1];
+    }
+    {
+        feW f2[2]; feL g2[2]; feT r2[2];
+        f2[0] = p.T; f2[1] = p.Z; g2[0] = qt2d; g2[1] = qz;
+        fe_mul_chain_n<2>(r2, f2, g2);
+        r4[2] = r2[0]; r4[3] = r2[1];
+    }
+    const feT &PP = r4[0], &MM = r4[1], &TT = r4[2], &ZZ = r4[3];
+    const feL ZZ2 = fe_twice(ZZ);
+    const feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
+    const feL zp = fe_add_lt(ZZ2, TT);
+    const feW zm = fe_sub_w(ZZ2, TT);
+    feW h4[4]; feL k4[4]; feT o4[4];
+#pragma unroll
+    for (int i = 0; i < 10; i++) { h4[0].v[i] = sel_u32(zm.v[i], zp.v[i], nm); h4[1].v[i] = sel_u32(zp.v[i], zm.v[i], nm); }
+    h4[2] = zm; h4[3] = X;
+    k4[0] = X; k4[1] = Y; k4[2] = zp; k4[3] = Y;
+    fe_mul_chain_n<4>(o4, h4, k4);
+    ge_p3 r;
+    r.X = o4[0]; r.Y = o4[1]; r.Z = o4[2]; r.T = o4[3];
+    return r;
+}
+#define mid_madd ge_madd_signed_p3_lockstep
+#else           // (the host pass of hipcc only parses the kernels: fe26x.h is device code)
+C25519_HD ge_p3 ge_add_cached_signed_p3_lockstep(const ge_p3 &p, const feT &qypx, const feT &qymx, const feT &qz, const feT &qt2d, bool neg) {
+    ge_cached q; q.YpX = qypx; q.YmX = qymx; q.Z = qz; q.T2d = qt2d;
+    return ge_p1p1_to_p3(ge_add_cached(p, ge_cached_cneg(q, neg)));
+}
+#define mid_madd ge_madd_signed_p3
+#endif
+// FMT 0: projective Niels records of 160 bytes (k_mid_front); FMT 1: affine Niels records of 128 bytes (devio.h pts_*: decompressed inputs)
+template <int FMT> struct mid_rec;
+template <> struct mid_rec<0> {
+    uint4 q[MID_REC_Q];
+    __device__ __forceinline__ void load(const u32 *recs, u32 idx) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(recs) + (u64)MID_REC_Q * idx;
+#pragma unroll
+        for (int i = 0; i < MID_REC_Q; i++) q[i] = src[i];
+    }
+    __device__ __forceinline__ ge_p3 add_to(const ge_p3 &acc, bool neg) const {
+        const u32 w[40] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w,
+                           q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w, q[8].x, q[8].y, q[8].z, q[8].w, q[9].x, q[9].y, q[9].z, q[9].w};
+        feT a, b, z, t;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { a.v[i] = w[i]; b.v[i] = w[10 + i]; z.v[i] = w[20 + i]; t.v[i] = w[30 + i]; }
+        return ge_add_cached_signed_p3_lockstep(acc, a, b, z, t, neg);
+    }
+};
+template <> struct mid_rec<1> {
+    uint4 q[PTS_Q];
+    __device__ __forceinline__ void load(const u32 *recs, u32 idx) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(recs) + (u64)PTS_Q * idx;
+#pragma unroll
+        for (int i = 0; i < PTS_Q; i++) q[i] = src[i];
+    }
+    __device__ __forceinline__ ge_p3 add_to(const ge_p3 &acc, bool neg) const { return mid_madd(acc, pts_from_q(q), neg); }
+};
+__device__ __forceinline__ ge_p3 mid_wave_sum(ge_p3 acc) {      // complete additions across the 64 lanes; lane 0 ends with the total
+#pragma unroll 1
+    for (int off = 32; off > 0; off >>= 1) {
+        ge_p3 o;
+        for (int i = 0; i < 10; i++) {
+            o.X.v[i] = __shfl_down(acc.X.v[i], off, 64); o.Y.v[i] = __shfl_down(acc.Y.v[i], off, 64);
+            o.Z.v[i] = __shfl_down(acc.Z.v[i], off, 64); o.T.v[i] = __shfl_down(acc.T.v[i], off, 64);
+        }
+        acc = ge_add(acc, o);
+    }
+    return acc;
+}
+// over-long lists (more than long_cap entries: skewed digits -- verify_batch's carry digit puts ~n/2 terms into ONE bucket, equal scalars do it in every window): one wave
+// per segment of LONG_SEG entries; the wave that completes a bucket's last segment adds the segment sums and writes the bucket (the bucket lanes skip those buckets).
+template <int FMT>
+__global__ void __launch_bounds__(256) k_mid_long(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, u64 n, msm_geom g, u32 *__restrict__ buckets, u32 max_items,
+                                                  const mid_item *__restrict__ items, const u32 *__restrict__ counters, u32 *__restrict__ seg_sums, u32 *__restrict__ long_done) {
+    C25519_PRIO_LONG();
+    const u32 nitems = counters[0] < max_items ? counters[0] : max_items;
+    const u32 lane = threadIdx.x & 63u, wv = blockIdx.x * 4u + (threadIdx.x >> 6), nwv = gridDim.x * 4u;
+#pragma unroll 1
+    for (u32 item = wv; item < nitems; item += nwv) {
+        const mid_item it = items[item];
+        const u32 *list = sorted + (u64)(it.gid / (u32)g.half) * n;
+        ge_p3 acc = ge_identity();
+#pragma unroll 1
+        for (u32 i = it.lo + lane; i < it.hi; i += 64) {
+            const u32 e = list[i];
+            mid_rec<FMT> r;
+            r.load(recs, e & 0x7fffffffu);
+            acc = r.add_to(acc, (e >> 31) != 0);
+        }
+        acc = mid_wave_sum(acc);
+        u32 last = 0;
+        if (lane == 0) {
+            p40_store(seg_sums, item, acc);
+            __threadfence();
+            last = atomicAdd(&long_done[it.lb], 1u) == it.nseg - 1u ? 1u : 0u;
+        }
+        last = (u32)__shfl((int)last, 0, 64);
+        if (last) {
+            __threadfence();                                // the other segments' sums, written by other waves (other compute units)
+            ge_p3 tot = ge_identity();
+            bool any = false;
+#pragma unroll 1
+            for (u32 sg = lane; sg < it.nseg && it.first + sg < max_items; sg += 64) {
+                const ge_p3 v = p40_load(seg_sums, it.first + sg);
+                tot = any ? ge_add(tot, v) : v;
+                any = true;
+            }
+            if (it.nseg > 1) tot = mid_wave_sum(tot);
+            if (lane == 0) p40_store(buckets, it.gid, tot);
+        }
+    }
+}
+// one lane per bucket (in the order of perm)
+template <int FMT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
+                                                 msm_geom g, u32 *__restrict__ buckets) {
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = tid < count;
+    const u64 gid = in_range ? perm[tid] : 0;
+    const int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    const u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
+    const bool mine = in_range && hi - lo <= g.long_cap;
+    const u32 *list = sorted + (u64)k * n;
+    const u32 len = mine ? hi - lo : 0u;
+    ge_p3 acc = ge_identity();
+    u32 e = len > 0 ? list[lo] : 0u;
+    // (no record prefetched across the addition: 40 registers more put the kernel at two waves per SIMD (210 VGPRs), and three waves hide the load better than
+    //  a prefetch does -- first version: 131 us at 2^16 terms against the bucket pipeline's 79, profiles/r06_timeline_mid_first.txt)
+#pragma unroll 1
+    for (u32 it = 0; it < len; it++) {
+        mid_rec<FMT> cur;
+        cur.load(recs, e & 0x7fffffffu);
+        const bool neg = (e >> 31) != 0;
+        if (it + 1 < len) e = list[lo + it + 1];
+        acc = cur.add_to(acc, neg);
+        ge_pin(acc);
+    }
+    if (mine) p40_store(buckets, gid, acc);
+}
+
+}  // namespace c25519
+
+// ---- host ----------------------------------------------------------------------------------------------------------------------------------------------------------------
+// upper end of the path (A/B knob MSM_MID_MAX of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5)
+uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 18); return v; }
+bool msm_mid_serves(uint64_t n, const msm_geom &g) { return n > msm_small_max() && n <= msm_mid_max() && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1; }
+
+// The whole pass: digits (+ records), sort, accumulation, reduction; column sums (and, hdr != 0, the record header) to d_slot -- or, ctx->direct_seq != 0, the
+// record published into the context's page-locked host slot.  src_fmt 0: raw 160-byte points at `points`; 1: affine Niels records at `points` (a decompression made them).
+// hdr 0: the slot was initialised by k_slot_init and carries counters of its own (verify_batch); 1: this pass writes the header (MSM).
+// ring (may be null): [0] / [1] bracket k_mid_acc, [2] end of the pass.
+int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring) {
+    if (!msm_mid_serves(n, g) || n >= (1ull << 31)) { ctx->err = "msm: internal error (mid path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
+    hipStream_t st = ctx->stream;
+    const uint64_t dstride = (n + 7) & ~(uint64_t)7;
+    const uint64_t nb = (uint64_t)g.nwin * g.half;
+    const int nseg = red_nseg(g.half);
+    int bps = 0; while ((1 << bps) < g.half && (1 << bps) < MID_BPS_MAX) bps++;          // up to 4096 buckets per slice: k_mid_sort has the reasoning
+    const int SL = g.half >> bps;
+    const unsigned nfront = div_up64(n, 256);
+    const uint64_t entries = (uint64_t)g.nwin * n;
+    const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
+    const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    const size_t oD = carve((size_t)g.nwin * dstride * 2), oB = carve((size_t)g.nwin * (g.half + 1) * 4), oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oPerm = carve(nb * 4);
+    const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oLI = carve((size_t)max_items * sizeof(mid_item)), oLG = carve((size_t)max_long * 4), oLS = carve((size_t)max_items * 160);
+    const size_t oBF = carve((size_t)nfront * 4);
+    // small words zeroed by k_mid_front: [0] long items, [1] long buckets, [2] finished windows (k_reduce_fused4), [8 .. 8 + nwin) finished segments per window,
+    // [64 .. 64 + max_long) finished segments per long bucket
+    const int nzero = 64 + (int)max_long;
+    const size_t oZ = carve((size_t)nzero * 4);
+    int32_t r;
+    if ((r = ctx_reserve(ctx, ctx->tmp_d, off))) return r;
+    uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
+    uint16_t *D = (uint16_t *)(ws + oD);
+    uint32_t *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK), *perm = (uint32_t *)(ws + oPerm), *SW = (uint32_t *)(ws + oSW);
+    mid_item *items = (mid_item *)(ws + oLI);
+    uint32_t *lgids = (uint32_t *)(ws + oLG), *segs = (uint32_t *)(ws + oLS), *blockflags = (uint32_t *)(ws + oBF), *zw = (uint32_t *)(ws + oZ);
+    const uint32_t *recs = (const uint32_t *)points;
+    // raw points: up to MID_PROJ_MAX terms the records are PROJECTIVE (no inversion; 8 M additions in k_mid_acc<0>); above, the batched normaliser (msm.hip
+    // k_prep_raw2) makes affine records on this stream WHILE the digits and the sort run on the second one, and the accumulation is the bucket pipeline's
+    // k_accumulate (7 M mixed additions, wave-cooperative gathers): its 130 us at 2^18 terms hide behind the sort, and the accumulation of 2^18 terms is
+    // throughput, not latency
+    static const uint64_t proj_max = (uint64_t)C25519_KNOB_LL("MID_PROJ_MAX", 1 << 15);
+    const bool proj = src_fmt == 0 && n <= proj_max, norm = src_fmt == 0 && !proj;
+    hipStream_t ss = st;                                            // the stream of the digits and the sort
+    if (src_fmt == 0 && (r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256))) return r;
+    if (norm) {
+        ss = ctx->aux;
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(ss, ctx->ev_fork, 0));
+        if ((r = prep_points(ctx, (const uint8_t *)points, n, C25519_FMT_RAW160, (uint32_t *)ctx->tmp_e.p, 0, nullptr))) return r;
+        recs = (const uint32_t *)ctx->tmp_e.p;
+    }
+    if (proj) {
+        recs = (const uint32_t *)ctx->tmp_e.p;
+        hipLaunchKernelGGL(k_mid_front<0>, dim3(nfront), dim3(256), 0, ss, d_scalars, (const uint8_t *)points, n, g, D, dstride, (uint32_t *)ctx->tmp_e.p, zw, nzero, blockflags);
+    } else hipLaunchKernelGGL(k_mid_front<1>, dim3(nfront), dim3(256), 0, ss, d_scalars, (const uint8_t *)nullptr, n, g, D, dstride, (uint32_t *)nullptr, zw, nzero, blockflags);
+    hipLaunchKernelGGL(k_mid_sort, dim3(g.nwin, SL), dim3(MID_SORT_THREADS), 0, ss, D, n, dstride, g, bps, sorted, base, perm, max_items, items, zw, lgids);
+    if (norm) {
+        HIPCHK(hipEventRecord(ctx->ev_sort, ss));
+        HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
+    }
+    if (ring) HIPCHK(hipEventRecord(ring[0], st));
+    const unsigned nacc = div_up64(nb, 256), nlong = 64;
+    if (proj) {
+        ctx->kname[0] = "c25519::k_mid_acc<0> (mid path: one lane per bucket, 8 M additions on projective Niels records)";
+        hipLaunchKernelGGL(k_mid_acc<0>, dim3(nacc), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets);
+        hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 64);
+    } else {
+        // affine records: the bucket pipeline's accumulation (accum.hip; it skips the over-long lists), then the long role of k_mid_acc alone
+        ctx->kname[0] = launch_accumulate(recs, sorted, base, perm, nb, n, g, buckets, 0, st);
+        hipLaunchKernelGGL(k_mid_long<1>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 64);
+    }
+    HIPCHK(hipEventRecord(ctx->ev_acc, st));
+    if (ring) HIPCHK(hipEventRecord(ring[1], st));
+    reduce_publish pub = {0, nullptr, 0, (uint32_t)terms, (uint32_t)(terms >> 32), (uint32_t)g.c, hdr};
+    uint32_t *out = d_slot;
+    if (ctx->direct_seq) {
+        out = ctx->hd_msm + (size_t)C25519_MAX_SLOTS * C25519_SLOT_U32;
+        pub.on = 1; pub.host_flag = ctx->hd_msm + (size_t)(C25519_MAX_SLOTS + 1) * C25519_SLOT_U32; pub.seq = ctx->direct_seq;
+        static const int lose_every = C25519_KNOB("FAULT_LOSE_PUBLICATION", 0);      // (tuning build only: small.hip has the note)
+        const uint64_t nth = ++ctx->counters[C25519_CTR_PUBLISH_DIRECT];
+        if (lose_every > 0 && nth % (uint64_t)(lose_every > 0 ? lose_every : 1) == 0) pub.seq ^= 0x40000000u;
+    }
+    launch_bucket_reduce_fused4(buckets, g, nseg, SW, out, blockflags, (int)nfront, zw + 8, zw + 2, pub, st);
+    HIPCHK(hipGetLastError());
+    if (ring) HIPCHK(hipEventRecord(ring[2], st));
+    return C25519_OK;
+}

@@ -631,6 +631,14 @@ static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const v
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                     hipStream_t sort_stream, hipEvent_t wait_acc) {
     if (n <= msm_small_max() && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
+    if (ctx->solo && !wait_acc && msm_mid_serves(n, g)) {          // (r6) a single pass of 12 288 .. 2^18 terms over prepared records: the mid path (mid.hip), on the main stream
+        hipStream_t st = ctx->stream;
+        if (sort_stream && sort_stream != st) {                      // (what the caller put on the second stream -- verify_batch: the batch scalars -- comes first)
+            HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
+        }
+        return msm_mid_enqueue(ctx, d_scalars, d_pts, 1, n, g, d_slot, 0, n, ring);
+    }
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
     if (r) return r;
@@ -1096,13 +1104,35 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     static const int small_direct_knob = C25519_KNOB("SMALL_DIRECT", 1);
     ctx->direct_seq = 0;
     ctx->direct_extra = nullptr;
-    if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && n <= msm_small_max() && in_fmt == C25519_FMT_RAW160 && !fetch) {
+    // (r6) the mid path (mid.hip: 12 288 .. 2^18 terms in four launches on this stream) publishes its record the same way
+    bool mid = false;
+    if (passes == 1 && !fetch && n > msm_small_max() && n <= msm_mid_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g); }
+    if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && in_fmt == C25519_FMT_RAW160 && !fetch && (n <= msm_small_max() || mid)) {
         msm_geom gs;
         msm_layout(n, gs);
-        if (gs.half <= 64 && gs.nwin <= 64) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
+        if (mid || (gs.half <= 64 && gs.nwin <= 64)) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
     }
     ctx->want_direct = false;
     ctx->no_direct_once = false;
+    if (mid) {
+        ctx->last_passes.clear();
+        ctx->solo = true;
+        ctx->coarse_wait = nullptr;
+        hipEvent_t *ring = pass_ring(ctx, ctx, 1);
+        HIPCHK(hipEventRecord(ring[3], ctx->stream));
+        if (in_fmt == C25519_FMT_RAW160) r = msm_mid_enqueue(ctx, d_scalars, d_points, 0, n, g, d_record, 1, n, ring);
+        else {
+            // encodings: the slot first (the decompression counts what does not decode into it), then the records, then the pass over them
+            ctx->direct_seq = 0;
+            slot_init(d_record, n, nullptr, ctx->stream, g.c);
+            if ((r = ctx_reserve(ctx, ctx->tmp_e, n * PTS_BYTES + 256))) return r;
+            if ((r = prep_points(ctx, d_points, n, in_fmt, (uint32_t *)ctx->tmp_e.p, 0, slot_flags(d_record) + 1))) return r;
+            r = msm_mid_enqueue(ctx, d_scalars, ctx->tmp_e.p, 1, n, g, d_record, 0, n, ring);
+        }
+        if (r) { ctx->direct_seq = 0; return r; }
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        return C25519_OK;
+    }
     // (r5: letting the sort start on the second stream without the cross-stream wait when the main stream is idle measured level at 2^14 .. 2^20 terms --
     //  the ~20 us before the first kernels is launch latency, not the event: profiles/r05_ab_midrange_streams.txt; not kept)
     if (!ctx->direct_seq) HIPCHK(hipMemsetAsync(sticky, 0, 4, ctx->stream));

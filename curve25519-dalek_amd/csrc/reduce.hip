@@ -205,7 +205,109 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
     if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
 }
 
+// ---- (r6) the two levels in ONE launch, and the record's publication with them (the mid path, mid.hip) ---------------------------------------------------------------
+// Level A as above.  A block that has written its segment pair fences it to the device and counts itself on the window's counter; the block that finishes a window's
+// LAST segment runs level B for that window in place (so level B of one window overlaps level A of the others, and the call has one launch and one 5 - 8 us
+// inter-kernel gap less).  The block that finishes the LAST window writes the record's header (hdr) / ORs the "a scalar has bit 255 set" flag of the front kernel's
+// blocks into the slot, and -- pub.on -- the columns having gone straight into the context's page-locked host slot, releases the sequence word the host polls
+// (msm.hip wait_published; the same mechanism, and the same recovery, as the small path's small_publish).
+// win_done[k], *done_cnt: zeroed by k_mid_front, the kernel that always precedes this one on the stream.
+__global__ void __launch_bounds__(256) k_reduce_fused4(const u32 *__restrict__ buckets, int half, int nwin, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols,
+                                                       const u32 *__restrict__ blockflags, int nflags, u32 *__restrict__ win_done, u32 *__restrict__ done_cnt, reduce_publish pub) {
+    C25519_PRIO_SIDE();
+    __shared__ __attribute__((aligned(16))) u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
+    __shared__ int s_last;
+    const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x) & 3), lane = threadIdx.x & 63;
+    const int bid = (int)blockIdx.x, k = bid / nseg, seg = bid % nseg;
+    const int LB = 1 << lb, b0 = (seg * 64 + lane) * LB;
+    const u32 *B = buckets + (u64)k * half * 40;
+    auto bucket = [&](int b) { return [=](int c) { return b < half ? rc_global(B, (u64)b, c) : rc_ident(c); }; };
+    const int mc = rc_coord(role);
+    {
+        const feT v = bucket(b0 + LB - 1)(mc);
+        rc_put(S, lane, mc, v); rc_put(W, lane, mc, v);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int j = LB - 2; j >= 0; j--) {
+        rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, bucket(b0 + j), scratch, S, lane);
+        if (j > 0) rc_add(role, lane, [&](int c) { return rc_get(W, lane, c); }, [&](int c) { return rc_get(S, lane, c); }, scratch, W, lane);
+    }
+    // (ONE instance of the weighted sum in the code, run once per level)
+#pragma unroll 1
+    for (int level = 0; level < 2; level++) {
+        rc_weighted_sum(role, lane, S, W, tot, scratch, level == 0 ? lb : lb + 6);
+        if (level == 1 || nseg == 1) break;
+        if (lane == 0) {
+            rc_global_put(SW, 2 * (u64)bid, mc, rc_tot(tot, mc));
+            rc_global_put(SW, 2 * (u64)bid + 1, mc, rc_get(S, 0, mc));
+            __threadfence();                                     // (every storing lane fences its own stores, then the block counts itself)
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(&win_done[k], 1u) == (u32)nseg - 1u;
+        __syncthreads();
+        if (!s_last) return;
+        __threadfence();                                         // the other segments' pairs, written by other blocks
+        // level B for window k (k_reduce_b4)
+        rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
+        rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
+        __syncthreads();
+    }
+    rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
+    if (lane == 0) {
+        rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
+        if (pub.on) __threadfence_system(); else __threadfence();
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done_cnt, 1u) == (u32)nwin - 1u;
+    __syncthreads();
+    if (!s_last) return;
+    int bad = 0;
+    for (int i = threadIdx.x; i < nflags; i += 256) bad |= (int)blockflags[i];
+    const int any_bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+        u32 *f = cols + MSM_MAX_WIN * 40;
+        if (pub.hdr) {
+            for (int i = 0; i < 16; i++) f[i] = 0;
+            f[0] = (u32)any_bad; f[REC_TERMS_LO] = pub.terms_lo; f[REC_TERMS_HI] = pub.terms_hi; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = pub.c;
+        } else if (any_bad) atomicOr(f, 1u);
+        if (pub.on) {
+            __threadfence_system();
+            __hip_atomic_store(pub.host_flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+// the flags and the header alone (one block): the mid path with the two-launch reduction (A/B arm MID_REDUCE_FUSED=0)
+__global__ void __launch_bounds__(256) k_mid_finish(u32 *__restrict__ cols, const u32 *__restrict__ blockflags, int nflags, reduce_publish pub) {
+    int bad = 0;
+    for (int i = threadIdx.x; i < nflags; i += 256) bad |= (int)blockflags[i];
+    const int any_bad = __syncthreads_or(bad);
+    if (threadIdx.x == 0) {
+        u32 *f = cols + MSM_MAX_WIN * 40;
+        if (pub.hdr) {
+            for (int i = 0; i < 16; i++) f[i] = 0;
+            f[0] = (u32)any_bad; f[REC_TERMS_LO] = pub.terms_lo; f[REC_TERMS_HI] = pub.terms_hi; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = pub.c;
+        } else if (any_bad) atomicOr(f, 1u);
+        if (pub.on) {
+            __threadfence_system();
+            __hip_atomic_store(pub.host_flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 }  // namespace c25519
+
+void launch_bucket_reduce_fused4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *win_done,
+                                 uint32_t *done_cnt, const c25519::reduce_publish &pub, hipStream_t st) {
+    static const int fused = C25519_KNOB("MID_REDUCE_FUSED", 1);      // A/B knob: 0 = k_reduce_a4 + k_reduce_b4 + k_mid_finish (three launches)
+    if (!fused) {
+        hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, out, nseg == 1 ? 1 : 0, (const u32 *)nullptr, 0);
+        if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, nseg, red_lb_log2(g.half), out, 0);
+        hipLaunchKernelGGL(k_mid_finish, dim3(1), dim3(256), 0, st, out, blockflags, nflags, pub);
+        return;
+    }
+    hipLaunchKernelGGL(k_reduce_fused4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, g.nwin, nseg, red_lb_log2(g.half), SW, out, blockflags, nflags, win_done, done_cnt, pub);
+}
 
 // the bucket reduction of a pass (level A over the segments, level B over the windows) on stream st
 void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st, int k0, int k1) {
