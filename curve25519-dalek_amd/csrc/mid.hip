@@ -1,4 +1,4 @@
-// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in FOUR launches on ONE stream.
+// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^17 terms in SEVEN short launches, all but one on ONE stream.
 //
 // Reference: the same algorithm as msm.hip -- backend/serial/scalar_mul/pippenger.rs:67-160 (signed digits, buckets, running-sum reduction, Horner fold), for the sizes
 // where the reference's heaviest real callers live (edwards.rs:1002-1031 vartime_multiscalar_mul of a Bulletproofs verification; ed25519-dalek/src/batch.rs:225-244
@@ -19,9 +19,9 @@
 //   k_mid_acc     one lane per bucket walking its list (8 M additions on projective Niels records, or 7 M mixed additions on the affine records a decompression
 //                 left: verify_batch / compressed inputs); extra blocks at the END of the grid fold the over-long lists segment by segment, the wave that
 //                 finishes a bucket's last segment sums the segments (no separate combine launch, no second stream).
-//   k_reduce_fused4 (reduce.hip)  level A of the bucket reduction; the block that finishes a window's last segment runs level B for it; the block that finishes the
-//                 last window writes the record's header -- and, for a caller that reads the record on the host right away, publishes it into page-locked host
-//                 memory and releases the sequence word the host polls (the small path's mechanism, msm.hip wait_published, with the same recovery).
+//   k_reduce_a4, k_reduce_b4pub (reduce.hip)  the two levels of the bucket reduction; the level-B block that finishes the last window writes the record's header --
+//                 and, for a caller that reads the record on the host right away, publishes it into page-locked host memory and releases the sequence word the
+//                 host polls (the small path's mechanism, msm.hip wait_published, with the same recovery).
 //
 // Same window layout (msm_layout), same record format, same host fold as the other two paths: a partial-result record of this path folds with any other.
 // Variable time like the paths beside it (digits index gather lists): vartime_multiscalar_mul and verify_batch only.
@@ -48,6 +48,10 @@ namespace c25519 {
 
 constexpr int MID_REC_Q = 10;                 // a projective Niels record: 4 x 10 tight limbs = 160 bytes = ten 16-byte pieces
 struct mid_item { u32 gid, lo, hi, first, lb, nseg, pad0, pad1; };      // one segment of an over-long list: bucket, entries [lo, hi), the bucket's first item, its index, its segments
+// entries per segment of an over-long list: one wave, four additions per lane, then a shuffle tree of six -- the tree and the final sum over the segments are the chain
+// (2 x 6 complete additions, ~45 us); with the bucket pipeline's 1024 entries per segment the sixteen additions per lane in front of them made it 93 us for the ~n / 2
+// entries of verify_batch's carry bucket at 2^14 signatures (profiles/r06_timeline_mid_first.txt)
+constexpr u32 MID_LONG_SEG = 256;
 
 // ---- front: digits + records --------------------------------------------------------------------------------------------------------------------------------
 // SRC 0: raw 160-byte points -> projective Niels records (the same X, Y, Z-only reading as the other two paths: T is whatever the caller stored and is not used);
@@ -58,9 +62,11 @@ __global__ void __launch_bounds__(256) k_mid_front(const uint8_t *__restrict__ s
     if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     int bad = 0;
-    if (t < n) {
-        u32 s[8];
-        load8(scalars, t, s);
+    if (t < dstride) {
+        // (the rows of D are padded to a multiple of eight terms with the scalar 0, whose digits are all zero -- s' = addk puts 2^(wid-1) into every signed window
+        //  and 0 into the unsigned ones: the sort reads whole 16-byte vectors without a bound check)
+        u32 s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < n) load8(scalars, t, s);
         bad = (int)(s[7] >> 31);
         u32 carry = 0;
 #pragma unroll
@@ -74,7 +80,7 @@ __global__ void __launch_bounds__(256) k_mid_front(const uint8_t *__restrict__ s
             for (int i = 0; i < 7; i++) s[i] = __funnelshift_r(s[i], s[i + 1], (u32)wd);
             s[7] >>= wd;
         }
-        if (SRC == 0) {
+        if (SRC == 0 && t < n) {
             const feT X = raw160_fe(points, t, 0), Y = raw160_fe(points, t, 1), Z = raw160_fe(points, t, 2);
             const feT x = fe_mul(X, Z), y = fe_mul(Y, Z), zz = fe_sq(Z), tt = fe_mul(fe_mul(X, Y), fe_d2());
             const feT a = fe_carry(fe_add(y, x)), b = fe_carry(fe_sub(y, x));
@@ -91,47 +97,69 @@ __global__ void __launch_bounds__(256) k_mid_front(const uint8_t *__restrict__ s
 }
 
 // ---- sort: one block per (window, slice) --------------------------------------------------------------------------------------------------------------------------
-// D row of window k (dstride u16, a multiple of 8): read twice as 16-byte vectors.  Pass 1 counts the bucket occupancies of THIS slice, the entries of the slices before
-// it (= where this slice's lists start in the window's sorted array) and of the whole window; then scan, bases, bucket order, long-list items; pass 2 places
-// term | sign << 31 at its final position (LDS cursors).  Any digit distribution is correct (all terms in one bucket: one long list, LDS atomics on one counter).
-// Slices are LARGE (up to 4096 buckets: 32 KB of LDS counters), i.e. few blocks -- 22 at 2^14 terms, 76 at 2^18: every block of a window reads the window's whole row,
-// so the work is (slices per window) x n x windows, and the first version (512 buckets per slice: 32 slices per window at 2^16 terms) spent 96 us at 2^16 and 407 us at
-// 2^18 terms re-deriving the same digits 32 times (profiles/r06_timeline_mid_first.txt).  A block's time is n / 1024 digits per thread and pass whatever the slicing.
+// D row of window k (dstride u16, a multiple of 8, padded with zero digits): read twice as 16-byte vectors.  Pass 1 counts the bucket occupancies of THIS slice, the
+// entries of the slices before it (= where this slice's lists start in the window's sorted array) and of the whole window; then scan, bases, bucket order, long-list
+// items; pass 2 places term | sign << 31 at its final position (LDS cursors).  Any digit distribution is correct (all terms in one bucket: one long list, LDS atomics
+// on one counter).
+// Every block of a window reads the window's whole row, so a block's time is n / 1024 digits per thread and pass whatever the slicing, and the digit loop is what it
+// costs: ~13 instructions per digit, and an LDS atomic only for the digits of THIS slice -- an LDS atomic costs by its active lanes (~1 lane per cycle), so "one atomic
+// per digit, into a spare counter when the digit is outside the slice" (the branch-free form) was 64 us at 2^16 terms; a branch per condition with ~50 instructions
+// per digit and every cursor atomic of pass 2 behind its own wait: 74 us at 2^16, 235 us at 2^18 terms (profiles/r06_timeline_mid_first.txt).
+// Bucket order: the kernel leaves every list's length (totals) and the call's 256-bin length histogram; k_order_place (msm_sort.hip) then orders ALL buckets of the
+// call by length, longest first.  The accumulation's makespan is its longest lists and they must start first: a slice-by-slice order (long lists also in the last
+// blocks to be dispatched) cost the same k_accumulate 132 against 79 us at 2^16 terms; interleaving the slices' ranks repaired that but mixes the narrow windows'
+// lists -- twice as long in half the buckets -- into every wave: 323 against 200 us at 2^18 (profiles/r06_timeline_mid_first.txt).
 constexpr int MID_BPS_MAX = 4096, MID_SORT_THREADS = 1024, MID_PER_MAX = MID_BPS_MAX / MID_SORT_THREADS;
+// The digit tests on the STORED value v (d = v - hw; bucket = |d| - 1; hw = 2^(wid-1) for a signed window, 0 for an unsigned one, whose values above `half` -- only a
+// scalar with bit 255 set has one, and the front kernel has flagged it -- are dropped like digit_of drops them): with r = s * BPS the slice's first bucket,
+//   in this slice      <=>  |d| in [r + 1, r + BPS]   <=>  (v - (hw + r + 1)) <u BPS  or  ((hw - r - 1) - v) <u BPS
+//   in a slice before  <=>  0 < |d| <= r              <=>  v != hw  and  (v - (hw - r)) <=u 2 r
+// -- compares on block-uniform constants instead of a decode per digit (first versions: ~40 instructions per digit, 60 us at 2^16 terms).
+struct mid_slice_consts { u32 hw, lo_pos, lo_neg, lo_before, span_before, vmax, bps_count; };
 __global__ void __launch_bounds__(MID_SORT_THREADS) k_mid_sort(const uint16_t *__restrict__ D, u64 n, u64 dstride, msm_geom g, int bps, u32 *__restrict__ sorted, u32 *__restrict__ base,
-                                                               u32 *__restrict__ perm, u32 max_items, mid_item *__restrict__ items, u32 *__restrict__ counters,
+                                                               u32 *__restrict__ totals, u32 *__restrict__ ord_hist, u32 max_items, mid_item *__restrict__ items, u32 *__restrict__ counters,
                                                                u32 *__restrict__ long_gids) {
-    __shared__ u32 cnt[MID_BPS_MAX], cur[MID_BPS_MAX], oh[256], ostart[256], red[3][16];
+    __shared__ u32 cnt[MID_BPS_MAX], cur[MID_BPS_MAX], oh[256], red[3][16];
     const int k = blockIdx.x, s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int BPS = 1 << bps, PER = BPS > MID_SORT_THREADS ? BPS / MID_SORT_THREADS : 1;      // consecutive buckets per thread (1, 2 or 4)
-    const u32 bmask = (u32)BPS - 1u;
+    const bool uns = k >= g.first_unsigned;
+    mid_slice_consts K;
+    {
+        const u32 r = (u32)s * (u32)BPS;
+        K.hw = uns ? 0u : 1u << (g.wid[k] - 1);
+        K.vmax = uns ? (u32)g.half : 0xffffu;
+        K.bps_count = (u32)BPS;
+        K.lo_pos = K.hw + r + 1u;                 // v - lo_pos = bucket - r for a positive digit
+        K.lo_neg = K.hw - r - 1u;                 // lo_neg - v = bucket - r for a negative digit (wraps far above BPS for an unsigned window or a positive digit)
+        K.lo_before = K.hw - r;                   // |d| <= r  <=>  v - (hw - r) <= 2 r   (r = 0: only v = hw, excluded by the non-zero test)
+        K.span_before = 2u * r;
+        if (uns) { K.lo_neg = 0x80000000u; K.lo_before = 0u; K.span_before = r; }      // unsigned window: no negative digits; |d| <= r <=> v <= r
+    }
     for (int i = tid; i < BPS; i += MID_SORT_THREADS) cnt[i] = 0;
     if (tid < 256) oh[tid] = 0;
     __syncthreads();
     const uint4 *row = reinterpret_cast<const uint4 *>(D + (u64)k * dstride);
-    const u64 nvec = dstride / 8;
+    const u32 nvec = (u32)(dstride / 8);
     u32 before = 0, nz = 0;
     // four 16-byte loads in flight per thread
 #pragma unroll 1
-    for (u64 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
+    for (u32 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
         uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const u64 i = i0 + (u64)q * MID_SORT_THREADS; v[q] = i < nvec ? row[i] : make_uint4(0, 0, 0, 0); }
+        for (int q = 0; q < 4; q++) { const u32 i = i0 + (u32)q * MID_SORT_THREADS; v[q] = row[i < nvec ? i : nvec - 1]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u64 i = i0 + (u64)q * MID_SORT_THREADS;
-            if (i >= nvec) break;
+            const bool live = i0 + (u32)q * MID_SORT_THREADS < nvec;
             const u32 x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
             for (int h = 0; h < 8; h++) {
-                const u64 t = 8 * i + h;
-                const int d = t < n ? digit_of((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g) : 0;
-                if (d != 0) {
-                    const u32 b = (u32)((d > 0 ? d : -d) - 1), sl = b >> bps;
-                    nz++;
-                    before += sl < (u32)s ? 1u : 0u;
-                    if (sl == (u32)s) atomicAdd(&cnt[b & bmask], 1u);
-                }
+                const u32 vv = (h & 1) ? x[h >> 1] >> 16 : x[h >> 1] & 0xffffu;
+                const bool ok = live && vv <= K.vmax;
+                const u32 dp = vv - K.lo_pos, dn = K.lo_neg - vv;
+                const bool on = ok && vv != K.hw;
+                nz += on ? 1u : 0u;
+                before += (on && (vv - K.lo_before) <= K.span_before) ? 1u : 0u;
+                if (ok && (dp < K.bps_count || dn < K.bps_count)) atomicAdd(&cnt[dp < K.bps_count ? dp : dn], 1u);      // (an LDS atomic costs by its ACTIVE lanes)
             }
         }
     }
@@ -150,11 +178,10 @@ __global__ void __launch_bounds__(MID_SORT_THREADS) k_mid_sort(const uint16_t *_
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { const u32 y = (u32)__shfl_up((int)inc, off, 64); if (lane >= off) inc += y; }
     if (lane == 63) red[2][w] = inc;
-    // bucket order of the slice by list length (255 - min(c, 255): longest first), block-local
-    u32 bin[MID_PER_MAX], local[MID_PER_MAX];
+    // the slice's share of the call's length histogram (255 - min(c, 255): longest first)
 #pragma unroll
     for (int j = 0; j < MID_PER_MAX; j++)
-        if (j < PER && tid * PER + j < BPS) { bin[j] = 255u - (c[j] > 255u ? 255u : c[j]); local[j] = atomicAdd(&oh[bin[j]], 1u); }
+        if (j < PER && tid * PER + j < BPS) atomicAdd(&oh[255u - (c[j] > 255u ? 255u : c[j])], 1u);
     __syncthreads();
     u32 wb = 0;
 #pragma unroll
@@ -172,57 +199,51 @@ __global__ void __launch_bounds__(MID_SORT_THREADS) k_mid_sort(const uint16_t *_
         }
     }
     if (s == (int)gridDim.y - 1 && tid == 0) base[(u64)k * (g.half + 1) + g.half] = nz;
-    if (tid < 256) {                                            // exclusive scan of the 256 length classes (four waves)
-        const u32 mine = oh[tid];
-        u32 i2 = mine;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) { const u32 y = (u32)__shfl_up((int)i2, off, 64); if (lane >= off) i2 += y; }
-        ostart[tid] = i2 - mine;
-        if (lane == 63) red[0][w] = i2;
-    }
     __syncthreads();
+    if (tid < 256 && oh[tid]) atomicAdd(&ord_hist[tid], oh[tid]);
 #pragma unroll
     for (int j = 0; j < MID_PER_MAX; j++) {
         if (!(j < PER && tid * PER + j < BPS)) continue;
         const u64 G = (u64)k * g.half + (u64)s * BPS + tid * PER + j;          // global bucket index
-        u32 ob = 0;
-        const int bw = (int)(bin[j] >> 6);
-#pragma unroll
-        for (int q = 0; q < 4; q++) ob += q < bw ? red[0][q] : 0u;
-        perm[(u64)k * g.half + (u64)s * BPS + ob + ostart[bin[j]] + local[j]] = (u32)G;
-        if (c[j] > g.long_cap) {                                // an over-long list: work items of LONG_SEG entries each (the long role of k_mid_acc)
-            const u32 nseg = (c[j] + LONG_SEG - 1) / LONG_SEG;
+        totals[G] = c[j];
+        if (c[j] > g.long_cap) {                                // an over-long list: work items of MID_LONG_SEG entries each (k_mid_long)
+            const u32 nseg = (c[j] + MID_LONG_SEG - 1) / MID_LONG_SEG;
             const u32 first = atomicAdd(&counters[0], nseg);
             const u32 lb = atomicAdd(&counters[1], 1u);
             long_gids[lb] = (u32)G;
             for (u32 sg = 0; sg < nseg && first + sg < max_items; sg++) {
                 mid_item it;
-                it.gid = (u32)G; it.lo = lo[j] + sg * LONG_SEG; it.hi = it.lo + LONG_SEG < lo[j] + c[j] ? it.lo + LONG_SEG : lo[j] + c[j]; it.first = first; it.lb = lb; it.nseg = nseg; it.pad0 = it.pad1 = 0;
+                it.gid = (u32)G; it.lo = lo[j] + sg * MID_LONG_SEG; it.hi = it.lo + MID_LONG_SEG < lo[j] + c[j] ? it.lo + MID_LONG_SEG : lo[j] + c[j]; it.first = first; it.lb = lb; it.nseg = nseg; it.pad0 = it.pad1 = 0;
                 items[first + sg] = it;
             }
         }
     }
-    // pass 2: place
+    // pass 2: place.  The cursor atomics of a vector's digits first, then the stores (the waits for the returned positions then overlap).
     u32 *dst = sorted + (u64)k * n;
 #pragma unroll 1
-    for (u64 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
+    for (u32 i0 = tid; i0 < nvec; i0 += 4 * MID_SORT_THREADS) {
         uint4 v[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const u64 i = i0 + (u64)q * MID_SORT_THREADS; v[q] = i < nvec ? row[i] : make_uint4(0, 0, 0, 0); }
+        for (int q = 0; q < 4; q++) { const u32 i = i0 + (u32)q * MID_SORT_THREADS; v[q] = row[i < nvec ? i : nvec - 1]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const u64 i = i0 + (u64)q * MID_SORT_THREADS;
-            if (i >= nvec) break;
+            const u32 i = i0 + (u32)q * MID_SORT_THREADS;
+            const bool live = i < nvec;
             const u32 x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+            u32 pos[8], ent[8];
+            bool put[8];
 #pragma unroll
             for (int h = 0; h < 8; h++) {
-                const u64 t = 8 * i + h;
-                const int d = t < n ? digit_of((x[h >> 1] >> (16 * (h & 1))) & 0xffffu, k, g) : 0;
-                if (d != 0) {
-                    const u32 b = (u32)((d > 0 ? d : -d) - 1);
-                    if ((b >> bps) == (u32)s) dst[atomicAdd(&cur[b & bmask], 1u)] = (u32)t | (d < 0 ? 0x80000000u : 0u);
-                }
+                const u32 vv = (h & 1) ? x[h >> 1] >> 16 : x[h >> 1] & 0xffffu;
+                const u32 dp = vv - K.lo_pos, dn = K.lo_neg - vv;
+                const bool isp = dp < K.bps_count, isn = dn < K.bps_count;
+                put[h] = live && vv <= K.vmax && (isp || isn);
+                ent[h] = (8u * i + (u32)h) | (isp ? 0u : 0x80000000u);
+                pos[h] = 0;
+                if (put[h]) pos[h] = atomicAdd(&cur[isp ? dp : dn], 1u);
             }
+#pragma unroll
+            for (int h = 0; h < 8; h++) if (put[h]) dst[pos[h]] = ent[h];
         }
     }
 }
@@ -313,7 +334,7 @@ __device__ __forceinline__ ge_p3 mid_wave_sum(ge_p3 acc) {      // complete addi
     return acc;
 }
 // over-long lists (more than long_cap entries: skewed digits -- verify_batch's carry digit puts ~n/2 terms into ONE bucket, equal scalars do it in every window): one wave
-// per segment of LONG_SEG entries; the wave that completes a bucket's last segment adds the segment sums and writes the bucket (the bucket lanes skip those buckets).
+// per segment of MID_LONG_SEG entries; the wave that completes a bucket's last segment adds the segment sums and writes the bucket (the bucket lanes skip those buckets).
 template <int FMT>
 __global__ void __launch_bounds__(256) k_mid_long(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, u64 n, msm_geom g, u32 *__restrict__ buckets, u32 max_items,
                                                   const mid_item *__restrict__ items, const u32 *__restrict__ counters, u32 *__restrict__ seg_sums, u32 *__restrict__ long_done) {
@@ -387,39 +408,47 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------------------------------------------------
 // upper end of the path (A/B knob MSM_MID_MAX of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5)
-uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 18); return v; }
-bool msm_mid_serves(uint64_t n, const msm_geom &g) { return n > msm_small_max() && n <= msm_mid_max() && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1; }
+// upper ends of the path (A/B knobs of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5): raw points up to 2^17 terms (at 2^18 the two
+// paths are level: profiles/r06_ab_mid_knobs.txt); prepared records -- verify_batch's 2n + 1 terms, whose sort is a third of the bucket pipeline's call -- up to 2^18 + 1
+uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 17); return v; }
+static uint64_t msm_mid_max_records() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX_RECORDS", (1 << 18) + 1); return v; }
+bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
+    return n > msm_small_max() && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1;
+}
 
 // The whole pass: digits (+ records), sort, accumulation, reduction; column sums (and, hdr != 0, the record header) to d_slot -- or, ctx->direct_seq != 0, the
 // record published into the context's page-locked host slot.  src_fmt 0: raw 160-byte points at `points`; 1: affine Niels records at `points` (a decompression made them).
 // hdr 0: the slot was initialised by k_slot_init and carries counters of its own (verify_batch); 1: this pass writes the header (MSM).
 // ring (may be null): [0] / [1] bracket k_mid_acc, [2] end of the pass.
 int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring) {
-    if (!msm_mid_serves(n, g) || n >= (1ull << 31)) { ctx->err = "msm: internal error (mid path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
+    if (!msm_mid_serves(n, g, src_fmt != 0) || n >= (1ull << 31)) { ctx->err = "msm: internal error (mid path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
     hipStream_t st = ctx->stream;
     const uint64_t dstride = (n + 7) & ~(uint64_t)7;
     const uint64_t nb = (uint64_t)g.nwin * g.half;
     const int nseg = red_nseg(g.half);
-    int bps = 0; while ((1 << bps) < g.half && (1 << bps) < MID_BPS_MAX) bps++;          // up to 4096 buckets per slice: k_mid_sort has the reasoning
+    // slices per window: enough blocks for the machine (A/B knob MID_SORT_BLOCKS, 128) with 256 .. 4096 buckets each -- k_mid_sort has the reasoning
+    static const int want_blocks = C25519_KNOB("MID_SORT_BLOCKS", 128);
+    int bps = 0; while ((1 << bps) < g.half && (1 << bps) < MID_BPS_MAX) bps++;
+    while (bps > 8 && g.nwin * (g.half >> bps) < want_blocks) bps--;
     const int SL = g.half >> bps;
-    const unsigned nfront = div_up64(n, 256);
+    const unsigned nfront = div_up64(dstride, 256);
     const uint64_t entries = (uint64_t)g.nwin * n;
     const uint32_t max_long = (uint32_t)std::min<uint64_t>(nb, entries / g.long_cap + 1);
-    const uint32_t max_items = (uint32_t)(entries / LONG_SEG + max_long + 1);
+    const uint32_t max_items = (uint32_t)(entries / MID_LONG_SEG + max_long + 1);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    const size_t oD = carve((size_t)g.nwin * dstride * 2), oB = carve((size_t)g.nwin * (g.half + 1) * 4), oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oPerm = carve(nb * 4);
+    const size_t oD = carve((size_t)g.nwin * dstride * 2), oB = carve((size_t)g.nwin * (g.half + 1) * 4), oS = carve((size_t)g.nwin * n * 4), oK = carve(nb * 160), oPerm = carve(nb * 4), oT = carve(nb * 4);
     const size_t oSW = carve((size_t)g.nwin * nseg * 2 * 160), oLI = carve((size_t)max_items * sizeof(mid_item)), oLG = carve((size_t)max_long * 4), oLS = carve((size_t)max_items * 160);
     const size_t oBF = carve((size_t)nfront * 4);
-    // small words zeroed by k_mid_front: [0] long items, [1] long buckets, [2] finished windows (k_reduce_fused4), [8 .. 8 + nwin) finished segments per window,
-    // [64 .. 64 + max_long) finished segments per long bucket
-    const int nzero = 64 + (int)max_long;
+    // small words zeroed by k_mid_front: [0] long items, [1] long buckets, [2] finished windows (k_reduce_b4pub), [64 .. 320) the bucket-order histogram, [320 .. 576) its
+    // cursors, [576 .. 576 + max_long) finished segments per long bucket
+    const int nzero = 576 + (int)max_long;
     const size_t oZ = carve((size_t)nzero * 4);
     int32_t r;
     if ((r = ctx_reserve(ctx, ctx->tmp_d, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_d.p;
     uint16_t *D = (uint16_t *)(ws + oD);
-    uint32_t *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK), *perm = (uint32_t *)(ws + oPerm), *SW = (uint32_t *)(ws + oSW);
+    uint32_t *base = (uint32_t *)(ws + oB), *sorted = (uint32_t *)(ws + oS), *buckets = (uint32_t *)(ws + oK), *perm = (uint32_t *)(ws + oPerm), *SW = (uint32_t *)(ws + oSW), *totals = (uint32_t *)(ws + oT);
     mid_item *items = (mid_item *)(ws + oLI);
     uint32_t *lgids = (uint32_t *)(ws + oLG), *segs = (uint32_t *)(ws + oLS), *blockflags = (uint32_t *)(ws + oBF), *zw = (uint32_t *)(ws + oZ);
     const uint32_t *recs = (const uint32_t *)points;
@@ -427,7 +456,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
     // k_prep_raw2) makes affine records on this stream WHILE the digits and the sort run on the second one, and the accumulation is the bucket pipeline's
     // k_accumulate (7 M mixed additions, wave-cooperative gathers): its 130 us at 2^18 terms hide behind the sort, and the accumulation of 2^18 terms is
     // throughput, not latency
-    static const uint64_t proj_max = (uint64_t)C25519_KNOB_LL("MID_PROJ_MAX", 1 << 15);
+    static const uint64_t proj_max = (uint64_t)C25519_KNOB_LL("MID_PROJ_MAX", 1 << 17);      // (profiles/r06_ab_mid_knobs.txt: 2^16 terms 0.318 against 0.371 ms, 2^17 0.388 against 0.440)
     const bool proj = src_fmt == 0 && n <= proj_max, norm = src_fmt == 0 && !proj;
     hipStream_t ss = st;                                            // the stream of the digits and the sort
     if (src_fmt == 0 && (r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256))) return r;
@@ -442,22 +471,34 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
         recs = (const uint32_t *)ctx->tmp_e.p;
         hipLaunchKernelGGL(k_mid_front<0>, dim3(nfront), dim3(256), 0, ss, d_scalars, (const uint8_t *)points, n, g, D, dstride, (uint32_t *)ctx->tmp_e.p, zw, nzero, blockflags);
     } else hipLaunchKernelGGL(k_mid_front<1>, dim3(nfront), dim3(256), 0, ss, d_scalars, (const uint8_t *)nullptr, n, g, D, dstride, (uint32_t *)nullptr, zw, nzero, blockflags);
-    hipLaunchKernelGGL(k_mid_sort, dim3(g.nwin, SL), dim3(MID_SORT_THREADS), 0, ss, D, n, dstride, g, bps, sorted, base, perm, max_items, items, zw, lgids);
+    hipLaunchKernelGGL(k_mid_sort, dim3(g.nwin, SL), dim3(MID_SORT_THREADS), 0, ss, D, n, dstride, g, bps, sorted, base, totals, zw + 64, max_items, items, zw, lgids);
+    launch_order_place(totals, nb, zw + 64, zw + 320, perm, g, ss);
     if (norm) {
         HIPCHK(hipEventRecord(ctx->ev_sort, ss));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
     }
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
     const unsigned nacc = div_up64(nb, 256), nlong = 64;
+    // Over-long lists.  Prepared records (verify_batch: the carry digit of the 128-bit z_i puts ~n / 2 terms into ONE bucket -- a ~50 us chain of a few dozen waves): on
+    // the second stream, BESIDE the accumulation, which skips those buckets.  Raw points (random scalars have none: the kernel finds an empty work list): behind the
+    // accumulation on this stream -- a 4 us launch, where the two cross-stream hand-overs cost ~10 us each (2^14 terms: 212 against 223 us of GPU span).
+    const bool beside = src_fmt != 0;
+    hipStream_t sl = beside ? ctx->aux : st;
+    if (beside) {
+        HIPCHK(hipEventRecord(ctx->ev_fork, st));
+        HIPCHK(hipStreamWaitEvent(sl, ctx->ev_fork, 0));
+        hipLaunchKernelGGL(k_mid_long<1>, dim3(nlong), dim3(256), 0, sl, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
+        HIPCHK(hipEventRecord(ctx->ev_join, sl));
+    }
     if (proj) {
         ctx->kname[0] = "c25519::k_mid_acc<0> (mid path: one lane per bucket, 8 M additions on projective Niels records)";
         hipLaunchKernelGGL(k_mid_acc<0>, dim3(nacc), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets);
-        hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 64);
+        hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
     } else {
-        // affine records: the bucket pipeline's accumulation (accum.hip; it skips the over-long lists), then the long role of k_mid_acc alone
-        ctx->kname[0] = launch_accumulate(recs, sorted, base, perm, nb, n, g, buckets, 0, st);
-        hipLaunchKernelGGL(k_mid_long<1>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 64);
+        ctx->kname[0] = launch_accumulate(recs, sorted, base, perm, nb, n, g, buckets, 0, st);      // affine records: the bucket pipeline's accumulation (accum.hip)
+        if (!beside) hipLaunchKernelGGL(k_mid_long<1>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
     }
+    if (beside) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     HIPCHK(hipEventRecord(ctx->ev_acc, st));
     if (ring) HIPCHK(hipEventRecord(ring[1], st));
     reduce_publish pub = {0, nullptr, 0, (uint32_t)terms, (uint32_t)(terms >> 32), (uint32_t)g.c, hdr};
@@ -469,7 +510,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
         const uint64_t nth = ++ctx->counters[C25519_CTR_PUBLISH_DIRECT];
         if (lose_every > 0 && nth % (uint64_t)(lose_every > 0 ? lose_every : 1) == 0) pub.seq ^= 0x40000000u;
     }
-    launch_bucket_reduce_fused4(buckets, g, nseg, SW, out, blockflags, (int)nfront, zw + 8, zw + 2, pub, st);
+    launch_bucket_reduce_pub(buckets, g, nseg, SW, out, blockflags, (int)nfront, zw + 2, pub, st);
     HIPCHK(hipGetLastError());
     if (ring) HIPCHK(hipEventRecord(ring[2], st));
     return C25519_OK;

@@ -631,7 +631,7 @@ static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const v
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
                     hipStream_t sort_stream, hipEvent_t wait_acc) {
     if (n <= msm_small_max() && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
-    if (ctx->solo && !wait_acc && msm_mid_serves(n, g)) {          // (r6) a single pass of 12 288 .. 2^18 terms over prepared records: the mid path (mid.hip), on the main stream
+    if (ctx->solo && !wait_acc && msm_mid_serves(n, g, true)) {          // (r6) a single pass of 12 288 .. 2^18 terms over prepared records: the mid path (mid.hip), on the main stream
         hipStream_t st = ctx->stream;
         if (sort_stream && sort_stream != st) {                      // (what the caller put on the second stream -- verify_batch: the batch scalars -- comes first)
             HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
@@ -1106,7 +1106,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     ctx->direct_extra = nullptr;
     // (r6) the mid path (mid.hip: 12 288 .. 2^18 terms in four launches on this stream) publishes its record the same way
     bool mid = false;
-    if (passes == 1 && !fetch && n > msm_small_max() && n <= msm_mid_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g); }
+    if (passes == 1 && !fetch && n > msm_small_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g, in_fmt != C25519_FMT_RAW160); }
     if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && in_fmt == C25519_FMT_RAW160 && !fetch && (n <= msm_small_max() || mid)) {
         msm_geom gs;
         msm_layout(n, gs);

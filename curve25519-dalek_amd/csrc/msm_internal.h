@@ -107,13 +107,14 @@ void launch_merged_table(const uint8_t *in_raw, uint64_t ns, int c, int K, uint8
 void launch_bucket_reduce4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *d_slot, const uint32_t *bad_ws, hipStream_t st, int k0 = 0, int k1 = -1);
 void msm_set_groups(c25519::msm_geom &g, int groups, int last);
 // (r6) the mid path (mid.hip): 12 288 .. msm_mid_max() terms in four launches on one stream.  reduce_publish: what the fused bucket reduction (reduce.hip
-// k_reduce_fused4) does once its last window is through -- hdr: write the record header (terms, width; the MSM) or leave the slot's own (verify_batch: k_slot_init made it);
+// k_reduce_b4pub) does once its last window is through -- hdr: write the record header (terms, width; the MSM) or leave the slot's own (verify_batch: k_slot_init made it);
 // on: the columns went to the context's page-locked host slot, release `seq` into the host's sequence word
 namespace c25519 { struct reduce_publish { int on; uint32_t *host_flag; uint32_t seq, terms_lo, terms_hi, c; int hdr; }; }
-void launch_bucket_reduce_fused4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *win_done,
-                                 uint32_t *done_cnt, const c25519::reduce_publish &pub, hipStream_t st);
+void launch_bucket_reduce_pub(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *done_cnt,
+                              const c25519::reduce_publish &pub, hipStream_t st);
+void launch_order_place(const uint32_t *totals, uint64_t nb, const uint32_t *ord_hist, uint32_t *ord_cursor, uint32_t *perm, const c25519::msm_geom &g, hipStream_t st);
 uint64_t msm_mid_max();
-bool msm_mid_serves(uint64_t n, const c25519::msm_geom &g);
+bool msm_mid_serves(uint64_t n, const c25519::msm_geom &g, bool prepared);      // prepared: the records exist (a decompression made them)
 int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring);
 void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
 void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);

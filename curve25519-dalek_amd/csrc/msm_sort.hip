@@ -370,6 +370,11 @@ __global__ void __launch_bounds__(BS) k_order_place(const u32 *__restrict__ tota
 
 using namespace c25519;
 
+// the bucket order alone (mid.hip): totals[gid] = list length, ord_hist = the call's 256-bin histogram of min(length, 255) (index 255 - length), ord_cursor = 256 zero words
+void launch_order_place(const uint32_t *totals, uint64_t nb, const uint32_t *ord_hist, uint32_t *ord_cursor, uint32_t *perm, const c25519::msm_geom &g, hipStream_t st) {
+    hipLaunchKernelGGL(k_order_place<1024>, dim3(div_up64(nb, 1024)), dim3(1024), 0, st, totals, nb, ord_hist, ord_cursor, perm, g);
+}
+
 // ================================================================================================
 // host side: workspace carve-up and the launches of the sort
 // ================================================================================================

@@ -205,58 +205,30 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
     if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
 }
 
-// ---- (r6) the two levels in ONE launch, and the record's publication with them (the mid path, mid.hip) ---------------------------------------------------------------
-// Level A as above.  A block that has written its segment pair fences it to the device and counts itself on the window's counter; the block that finishes a window's
-// LAST segment runs level B for that window in place (so level B of one window overlaps level A of the others, and the call has one launch and one 5 - 8 us
-// inter-kernel gap less).  The block that finishes the LAST window writes the record's header (hdr) / ORs the "a scalar has bit 255 set" flag of the front kernel's
-// blocks into the slot, and -- pub.on -- the columns having gone straight into the context's page-locked host slot, releases the sequence word the host polls
-// (msm.hip wait_published; the same mechanism, and the same recovery, as the small path's small_publish).
-// win_done[k], *done_cnt: zeroed by k_mid_front, the kernel that always precedes this one on the stream.
-__global__ void __launch_bounds__(256) k_reduce_fused4(const u32 *__restrict__ buckets, int half, int nwin, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols,
-                                                       const u32 *__restrict__ blockflags, int nflags, u32 *__restrict__ win_done, u32 *__restrict__ done_cnt, reduce_publish pub) {
+// ---- (r6) level B with the record's publication (the mid path, mid.hip) -------------------------------------------------------------------------------------------
+// k_reduce_b4, and then: the block that finishes the LAST window writes the record's header (hdr) / ORs the "a scalar has bit 255 set" flag of the front kernel's blocks
+// into the slot, and -- pub.on -- the columns having gone straight into the context's page-locked host slot, releases the sequence word the host polls (msm.hip
+// wait_published; the same mechanism, and the same recovery, as the small path's small_publish).  *done_cnt: zeroed by k_mid_front, the kernel that always precedes
+// this one on the stream.
+// Measured and NOT adopted: both levels in ONE launch (a level-A block fences its segment pair to the device and counts itself on the window's counter; the block that
+// finishes a window's last segment runs level B in place).  One launch and one inter-kernel gap less -- and 137 against 47 + 42 us at 2^14 terms, 220 against 89 + 44 at
+// 2^16: an agent-scope release on this GPU writes the L2 back, and 2800 - 4900 of them (four storing lanes in each of 700 - 1200 blocks) queue up on the eight L2s at
+// ~0.15 us each (profiles/r06_timeline_mid_first.txt).  Here only the 18 - 24 level-B blocks fence.
+__global__ void __launch_bounds__(256) k_reduce_b4pub(const u32 *__restrict__ SW, int nwin, int nseg, int lb, u32 *__restrict__ cols, const u32 *__restrict__ blockflags, int nflags,
+                                                      u32 *__restrict__ done_cnt, reduce_publish pub) {
     C25519_PRIO_SIDE();
     __shared__ __attribute__((aligned(16))) u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
     __shared__ int s_last;
-    const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) + blockIdx.x) & 3), lane = threadIdx.x & 63;
-    const int bid = (int)blockIdx.x, k = bid / nseg, seg = bid % nseg;
-    const int LB = 1 << lb, b0 = (seg * 64 + lane) * LB;
-    const u32 *B = buckets + (u64)k * half * 40;
-    auto bucket = [&](int b) { return [=](int c) { return b < half ? rc_global(B, (u64)b, c) : rc_ident(c); }; };
-    const int mc = rc_coord(role);
-    {
-        const feT v = bucket(b0 + LB - 1)(mc);
-        rc_put(S, lane, mc, v); rc_put(W, lane, mc, v);
-    }
+    const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int k = (int)blockIdx.x, mc = rc_coord(role);
+    rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
+    rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-#pragma unroll 1
-    for (int j = LB - 2; j >= 0; j--) {
-        rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, bucket(b0 + j), scratch, S, lane);
-        if (j > 0) rc_add(role, lane, [&](int c) { return rc_get(W, lane, c); }, [&](int c) { return rc_get(S, lane, c); }, scratch, W, lane);
-    }
-    // (ONE instance of the weighted sum in the code, run once per level)
-#pragma unroll 1
-    for (int level = 0; level < 2; level++) {
-        rc_weighted_sum(role, lane, S, W, tot, scratch, level == 0 ? lb : lb + 6);
-        if (level == 1 || nseg == 1) break;
-        if (lane == 0) {
-            rc_global_put(SW, 2 * (u64)bid, mc, rc_tot(tot, mc));
-            rc_global_put(SW, 2 * (u64)bid + 1, mc, rc_get(S, 0, mc));
-            __threadfence();                                     // (every storing lane fences its own stores, then the block counts itself)
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = atomicAdd(&win_done[k], 1u) == (u32)nseg - 1u;
-        __syncthreads();
-        if (!s_last) return;
-        __threadfence();                                         // the other segments' pairs, written by other blocks
-        // level B for window k (k_reduce_b4)
-        rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
-        rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
-        __syncthreads();
-    }
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb + 6);
     rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
     if (lane == 0) {
         rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
-        if (pub.on) __threadfence_system(); else __threadfence();
+        if (pub.on) __threadfence_system(); else __threadfence();      // (every storing lane fences its own stores, then the block counts itself)
     }
     __syncthreads();
     if (threadIdx.x == 0) s_last = atomicAdd(done_cnt, 1u) == (u32)nwin - 1u;
@@ -277,7 +249,7 @@ __global__ void __launch_bounds__(256) k_reduce_fused4(const u32 *__restrict__ b
         }
     }
 }
-// the flags and the header alone (one block): the mid path with the two-launch reduction (A/B arm MID_REDUCE_FUSED=0)
+// the flags and the header alone (one block): layouts whose windows have a single segment (level A writes the column sums itself)
 __global__ void __launch_bounds__(256) k_mid_finish(u32 *__restrict__ cols, const u32 *__restrict__ blockflags, int nflags, reduce_publish pub) {
     int bad = 0;
     for (int i = threadIdx.x; i < nflags; i += 256) bad |= (int)blockflags[i];
@@ -297,16 +269,12 @@ __global__ void __launch_bounds__(256) k_mid_finish(u32 *__restrict__ cols, cons
 
 }  // namespace c25519
 
-void launch_bucket_reduce_fused4(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *win_done,
-                                 uint32_t *done_cnt, const c25519::reduce_publish &pub, hipStream_t st) {
-    static const int fused = C25519_KNOB("MID_REDUCE_FUSED", 1);      // A/B knob: 0 = k_reduce_a4 + k_reduce_b4 + k_mid_finish (three launches)
-    if (!fused) {
-        hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, out, nseg == 1 ? 1 : 0, (const u32 *)nullptr, 0);
-        if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, nseg, red_lb_log2(g.half), out, 0);
-        hipLaunchKernelGGL(k_mid_finish, dim3(1), dim3(256), 0, st, out, blockflags, nflags, pub);
-        return;
-    }
-    hipLaunchKernelGGL(k_reduce_fused4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, g.nwin, nseg, red_lb_log2(g.half), SW, out, blockflags, nflags, win_done, done_cnt, pub);
+// the bucket reduction of the mid path: level A, then level B with the record's header / publication (a single-segment layout: level A writes the columns, then the flags alone)
+void launch_bucket_reduce_pub(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *done_cnt,
+                              const c25519::reduce_publish &pub, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_a4, dim3((unsigned)(g.nwin * nseg)), dim3(256), 0, st, buckets, g.half, nseg, red_lb_log2(g.half), SW, out, nseg == 1 ? 1 : 0, (const u32 *)nullptr, 0);
+    if (nseg > 1) hipLaunchKernelGGL(k_reduce_b4pub, dim3((unsigned)g.nwin), dim3(256), 0, st, SW, g.nwin, nseg, red_lb_log2(g.half), out, blockflags, nflags, done_cnt, pub);
+    else hipLaunchKernelGGL(k_mid_finish, dim3(1), dim3(256), 0, st, out, blockflags, nflags, pub);
 }
 
 // the bucket reduction of a pass (level A over the segments, level B over the windows) on stream st

@@ -12,6 +12,7 @@ import util
 
 pytestmark = pytest.mark.gpu
 L = util.L
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -498,3 +499,136 @@ def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
         assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx)))), n
         st, got = eng.msm_vartime_t(dx, eng.compress_batch_t(draw), in_fmt=0, out_fmt=0)
         assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sumsq_device(dx)))), n
+
+
+# ---- (r6) the mid path (mid.hip): 12 288 .. 2^17 terms of raw points, up to 2^18 + 1 terms over prepared records -------------------------------------------------
+def _sum_xy(x, y):
+    return sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(x, y)) % L
+
+
+@pytest.mark.parametrize("n", [12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072])
+def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
+    """pippenger.rs:67-160 through the mid path at every kind of size it serves (rows of the digit matrix padded / not padded to eight terms, every window width 12 .. 15,
+    both ends of the range): P_i = y_i B with independent x_i, so the expected point is (sum x_i y_i) B from the ORACLE's fixed-base multiplication; raw points with
+    their projective Z (the fixed-base kernel leaves Z != 1), device and host pointers, then the same points as CompressedEdwardsY and as CompressedRistretto (the
+    decompression's affine records: the other accumulation kernel)."""
+    import torch
+    x = util.rand_scalars(9000 + n, n); y = util.rand_scalars(9500 + n, n)
+    e = util.edge_scalars(); e = e[[int.from_bytes(v.tobytes(), "little") < 2**255 for v in e]]
+    x[:e.shape[0]] = e                                                   # unreduced scalars up to 2^255 - 1 among them: every digit pattern incl. the top window's carry
+    raw = eng.mul_base_batch(y, out_fmt=2)
+    want_pt = orc.ed_mul_base(i2b(_sum_xy(x, y)))
+    want = orc.ed_compress(want_pt)
+    dx, dr = torch.from_numpy(x).cuda(), torch.from_numpy(raw).cuda()
+    st, got = eng.msm_vartime_t(dx, dr, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    st, got = eng.msm_vartime(x, raw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    if n in (12288, 16391, 65536, 131072):
+        enc = eng.compress_batch(raw)
+        st, got = eng.msm_vartime_t(dx, torch.from_numpy(enc).cuda(), in_fmt=0, out_fmt=0)
+        assert st == 0 and got == want
+        ris = eng.compress_batch(raw, out_fmt=1)
+        st, got = eng.msm_vartime_t(dx, torch.from_numpy(ris).cuda(), in_fmt=1, out_fmt=1)
+        assert st == 0 and got == orc.ris_compress(want_pt)
+        bad = enc.copy(); bad[n // 3] = np.frombuffer(i2b(2), np.uint8)      # an encoding that does not decode: Option::None of the reference
+        st, _ = eng.msm_vartime_t(dx, torch.from_numpy(bad).cuda(), in_fmt=0, out_fmt=0)
+        assert st == 1
+
+
+def test_mid_path_against_the_oracles_pippenger_on_arbitrary_points(eng, orc):
+    """13 000 points that are NOT in the prime-order subgroup (decompressed random encodings, Z = 1: the other class of raw input) with edge scalars, judged by the
+    oracle's own Pippenger (pippenger.rs:67-160 restated) -- not by the sum-of-products identity."""
+    enc = util.rand_bytes(4242, 30000)
+    ok = orc.ed_decompress_ok_batch(enc)
+    enc = enc[ok == 1][:13000]
+    n = enc.shape[0]
+    assert n == 13000
+    s = util.rand_scalars(4243, n)
+    e = util.edge_scalars(); e = e[[int.from_bytes(v.tobytes(), "little") < 2**255 for v in e]]
+    s[:e.shape[0]] = e
+    _, raw, okd = eng.decompress_batch(enc)
+    assert okd.all()
+    want = orc.ed_compress(orc.ed_msm(rows(s), [orc.ed_decompress(b) for b in rows(enc)]))
+    st, got = eng.msm_vartime(s, raw, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    st, got = eng.msm_vartime(s, enc, in_fmt=0, out_fmt=0)
+    assert st == 0 and got == want
+
+
+@pytest.mark.parametrize("n", [12288, 40000])
+def test_mid_path_skewed_digits_long_lists(eng, orc, n):
+    """Digit distributions that put thousands of terms into ONE bucket of every window (equal scalars), into two buckets (s and l - s: the same buckets with opposite
+    signs), or leave whole windows empty (small scalars) -- the over-long lists go through k_mid_long's segments and the last-finisher sum; a third of the terms random."""
+    import torch
+    y = util.rand_scalars(777 + n, n)
+    raw = eng.mul_base_batch(y, out_fmt=2)
+    x = util.rand_scalars(778 + n, n)
+    s0 = int.from_bytes(x[0].tobytes(), "little") % L
+    third = n // 3
+    x[:third] = np.frombuffer(i2b(s0), np.uint8)
+    x[third:third + third // 2] = np.frombuffer(i2b(L - s0), np.uint8)
+    x[third + third // 2:2 * third] = np.frombuffer(i2b(5), np.uint8)
+    want = orc.ed_compress(orc.ed_mul_base(i2b(_sum_xy(x, y))))
+    st, got = eng.msm_vartime_t(torch.from_numpy(x).cuda(), torch.from_numpy(raw).cuda(), in_fmt=2, out_fmt=0)
+    assert st == 0 and got == want
+    enc = eng.compress_batch(raw)
+    st, got = eng.msm_vartime(x, enc, in_fmt=0, out_fmt=0)
+    assert st == 0 and got == want
+
+
+def test_mid_path_flags_records_and_fold(eng, orc):
+    """A scalar with bit 255 set fails the call (Scalar invariant #1) wherever it sits; the partial-result RECORD of the mid path (device-resident, header written by the
+    reduction's last block) folds with records of the small path and of the bucket pipeline into the oracle's point; all-zero scalars give the identity."""
+    import torch
+    import curve25519_dalek_amd as pkg
+    n = 20011
+    x = util.rand_scalars(31, n); y = util.rand_scalars(32, n)
+    raw = eng.mul_base_batch(y, out_fmt=2)
+    dx, dr = torch.from_numpy(x).cuda(), torch.from_numpy(raw).cuda()
+    for pos in (0, 255, 256, n - 1):
+        bad = x.copy(); bad[pos, 31] |= 0x80
+        with pytest.raises(pkg.EngineError, match="bit 255"):
+            eng.msm_vartime_t(torch.from_numpy(bad).cuda(), dr, in_fmt=2, out_fmt=0)
+    st, got = eng.msm_vartime_t(dx, dr, in_fmt=2, out_fmt=0)                   # the context is still good
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(_sum_xy(x, y))))
+    z = torch.zeros_like(dx)
+    st, got = eng.msm_vartime_t(z, dr, in_fmt=2, out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(0)))
+    # records: shards of 300 (small path), 20 011 - 300 - 250 000 ... the mid path, and 250 000 terms (bucket pipeline), folded once
+    m = 250000
+    x2 = util.rand_scalars(33, m); y2 = util.rand_scalars(34, m)
+    raw2 = eng.mul_base_batch(y2, out_fmt=2)
+    recs = [eng.msm_partial_record_t(dx[:300], dr[:300]), eng.msm_partial_record_t(dx[300:], dr[300:]),
+            eng.msm_partial_record_t(torch.from_numpy(x2).cuda(), torch.from_numpy(raw2).cuda())]
+    st, got = pkg.engine.fold_partial_records(torch.stack(recs).cpu().numpy(), out_fmt=0)
+    assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b((_sum_xy(x, y) + _sum_xy(x2, y2)) % L)))
+
+
+def test_mid_path_lost_publication_is_recovered(orc):
+    """The mid path publishes its record like the small path does (k_reduce_b4pub -> page-locked host memory -> the sequence word the host polls): the forced loss of
+    every third publication (tuning build) must be recovered through the copy path with the normal result."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, faulthandler
+        faulthandler.dump_traceback_later(300, exit=True)
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        import numpy as np, torch
+        import curve25519_dalek_amd as pkg, util
+        from oracle import orc
+        L = util.L
+        eng = pkg.Engine(0)
+        for n in (12288, 30000, 131072):
+            x = util.rand_scalars(5 + n, n); y = util.rand_scalars(6 + n, n)
+            raw = eng.mul_base_batch(y, out_fmt=2)
+            tot = sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(x, y)) %% L
+            want = orc.ed_compress(orc.ed_mul_base(tot.to_bytes(32, "little")))
+            dx, dr = torch.from_numpy(x).cuda(), torch.from_numpy(raw).cuda()
+            for rep in range(4):
+                st, got = eng.msm_vartime_t(dx, dr, in_fmt=2, out_fmt=0)
+                assert st == 0 and got == want, (n, rep)
+        assert eng.counter(2) == 12 and eng.counter(1) == 4, (eng.counter(2), eng.counter(1))
+        print("ok")
+    """) % (ROOT, ROOT)
+    r = subprocess.run(util.child_argv(code), env=util.tune_env(C25519_FAULT_LOSE_PUBLICATION="3", C25519_PUBLISH_SPIN_US="1000"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
