@@ -81,7 +81,18 @@ namespace c25519 {
 // the prefix products live in a [step][piece][lane] layout (8 lines per instruction), and the records go out through an
 // LDS transpose (piece c of record r at position (c + r) mod 8: conflict-free both ways) as eight fully coalesced
 // stores: 272 look-ups per point and wave.  The block of step j+1 (j-1 on the way back) is in flight during step j.
-template <int CH, int WPB>                                  // points per lane, waves per block
+// NT (round 6, A/B knob PREP_NT): the normaliser's STREAMING traffic -- the raw points it reads (twice) and the prefix products it writes and reads back, 2.7 GB per
+// 2^24-term call -- with the non-temporal cache policy, so that it stops competing for the MALL with the 215 MB of gather records a pass's accumulation lives on (the
+// records it WRITES keep the default policy: they are what the accumulation wants resident).  profiles/r06_ab_mall.txt has the measurement.
+typedef unsigned int nt_u32x4 __attribute__((ext_vector_type(4)));
+template <int NT> __device__ __forceinline__ void prep_store16(uint4 *p, const uint4 &v) {
+    if (NT) __builtin_nontemporal_store((nt_u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<nt_u32x4 *>(p)); else *p = v;
+}
+template <int NT> __device__ __forceinline__ uint4 prep_load16(const uint4 *p) {
+    if (NT) { const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
+    return *p;
+}
+template <int CH, int WPB, int NT = 0>                      // points per lane, waves per block, streaming accesses
 __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     C25519_PRIO_SIDE();
     __shared__ uint4 stage_in[WPB * 640];                    // per wave: 64 points x 160 bytes
@@ -102,12 +113,12 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
         const u64 b4 = (w0 + (u64)(j) * T) * 10;                                                                               \
         if (b4 + 639 <= last4) {                                                                                               \
             _Pragma("unroll") for (int i = 0; i < 10; i++)                                                                    \
-                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + b4 + (u64)(i * 64) + lane), (lds_void *)(sin + i * 64), 16, 0, 0); \
+                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + b4 + (u64)(i * 64) + lane), (lds_void *)(sin + i * 64), 16, 0, NT ? 2 : 0); \
         } else {                                                                                                               \
             _Pragma("unroll") for (int i = 0; i < 10; i++) {                                                                  \
                 u64 a = b4 + (u64)(i * 64) + lane;                                                                             \
                 a = a > last4 ? last4 : a;                                                                                     \
-                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + a), (lds_void *)(sin + i * 64), 16, 0, 0);                 \
+                __builtin_amdgcn_global_load_lds((gbl_void *)(in4 + a), (lds_void *)(sin + i * 64), 16, 0, NT ? 2 : 0);        \
             }                                                                                                                  \
         }                                                                                                                      \
     }
@@ -130,9 +141,9 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
             const bool in = t + (u64)j * T < n;
             const u64 l[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
             affine = affine && (!in || ((l[0] == 1) && ((l[1] | l[2] | l[3] | l[4]) == 0)));
-            pre4[(j * 3 + 0) * 64] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
-            pre4[(j * 3 + 1) * 64] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
-            pre4[(j * 3 + 2) * 64] = make_uint4(acc.v[8], acc.v[9], 0u, 0u);
+            prep_store16<NT>(&pre4[(j * 3 + 0) * 64], make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]));
+            prep_store16<NT>(&pre4[(j * 3 + 1) * 64], make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]));
+            prep_store16<NT>(&pre4[(j * 3 + 2) * 64], make_uint4(acc.v[8], acc.v[9], 0u, 0u));
             acc = fe_select_m(acc, fe_mul(acc, fe_from_limbs51(l)), lane_mask(in));
         }
     }
@@ -140,7 +151,7 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
     if (__ballot(!affine) != 0ull) inv = fe_select_m(inv, fe_invert(acc), lane_mask(!affine));      // (wave-uniform branch, explicit select)
     const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
     uint4 pa = make_uint4(0, 0, 0, 0), pb = pa, pc = pa;     // prefix product of the step about to be unwound
-    if (nj > 0) { pa = pre4[((nj - 1) * 3 + 0) * 64]; pb = pre4[((nj - 1) * 3 + 1) * 64]; pc = pre4[((nj - 1) * 3 + 2) * 64]; }
+    if (nj > 0) { pa = prep_load16<NT>(&pre4[((nj - 1) * 3 + 0) * 64]); pb = prep_load16<NT>(&pre4[((nj - 1) * 3 + 1) * 64]); pc = prep_load16<NT>(&pre4[((nj - 1) * 3 + 2) * 64]); }
     if (nj > 0) C25519_PREP_ISSUE(nj - 1)
 #pragma unroll 1
     for (int j = nj - 1; j >= 0; j--) {
@@ -150,7 +161,7 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
         const uint4 a = pa, b = pb, c = pc;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (j > 0) {
-            pa = pre4[((j - 1) * 3 + 0) * 64]; pb = pre4[((j - 1) * 3 + 1) * 64]; pc = pre4[((j - 1) * 3 + 2) * 64];
+            pa = prep_load16<NT>(&pre4[((j - 1) * 3 + 0) * 64]); pb = prep_load16<NT>(&pre4[((j - 1) * 3 + 1) * 64]); pc = prep_load16<NT>(&pre4[((j - 1) * 3 + 2) * 64]);
             C25519_PREP_ISSUE(j - 1)
         }
         const u64 lx[5] = {x0.x | (u64)x0.y << 32, x0.z | (u64)x0.w << 32, x1.x | (u64)x1.y << 32, x1.z | (u64)x1.w << 32, x2.x | (u64)x2.y << 32};
@@ -913,13 +924,16 @@ int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int
         // A/B proxy (profiles/r04_ab_prep_two_waves.txt): what the normaliser's memory system does with TWO waves per compute unit -- the occupancy
         // an LDS-resident inversion tree (prefix products of 16 points per lane kept in LDS: 40 KB per wave) would leave it
         static const int two_waves = C25519_KNOB("PREP_TWO_WAVES", 0);
+        static const int prep_nt = C25519_KNOB("PREP_NT", 0);             // A/B knob: 1 = streaming accesses for the normaliser's inputs and prefix scratch (large launches)
         if (two_waves && CH == 16) {
             const unsigned b2 = (unsigned)div_up64((n + CH - 1) / CH, 64 * 2);
             if ((r = ctx_reserve(ctx, pre, (size_t)b2 * 2 * CH * 3 * 64 * 16))) return r;
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_prep_raw2<16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 120 * 1024));
             hipLaunchKernelGGL((k_prep_raw2<16, 2>), dim3(b2), dim3(128), 100 * 1024, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
         } else
-        if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        if (CH == 64 && prep_nt) hipLaunchKernelGGL((k_prep_raw2<64, wpb, 1>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else if (CH == 32 && prep_nt) hipLaunchKernelGGL((k_prep_raw2<32, wpb, 1>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+        else if (CH == 64) hipLaunchKernelGGL((k_prep_raw2<64, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
         else if (CH == 32) hipLaunchKernelGGL((k_prep_raw2<32, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
         else if (CH == 8) hipLaunchKernelGGL((k_prep_raw2<8, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
         else if (CH == 4) hipLaunchKernelGGL((k_prep_raw2<4, wpb>), dim3(blocks), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);

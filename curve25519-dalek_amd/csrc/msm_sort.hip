@@ -56,13 +56,18 @@ namespace c25519 {
 //  anyway (bad_scalar); a term beyond n is loaded as s = 0, whose digits are all zero: s' = addk puts 2^(wid-1) into every signed
 //  window and 0 into the unsigned ones -- it is skipped like any zero digit)
 struct sweep_regs { u32 s[SWEEP_TPT][8]; };
+typedef unsigned int sweep_u32x4 __attribute__((ext_vector_type(4)));
 template <int THREADS>
-__device__ __forceinline__ void sweep_load(const uint8_t *__restrict__ scalars, u64 n, u64 lo, const msm_geom &g, sweep_regs &R, u32 *__restrict__ bad_scalar) {
+__device__ __forceinline__ void sweep_load(const uint8_t *__restrict__ scalars, u64 n, u64 lo, const msm_geom &g, sweep_regs &R, u32 *__restrict__ bad_scalar, int nt) {
 #pragma unroll
     for (int r = 0; r < SWEEP_TPT; r++) {
         const u64 t = lo + (u64)r * THREADS + threadIdx.x;
         u32 w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (t < n) load8(scalars, t, w);
+        if (t < n && nt) {                                     // (r6, A/B knob SWEEP_NT: the scalars are read once per pass -- streaming policy, see msm.hip k_prep_raw2)
+            const sweep_u32x4 *q = reinterpret_cast<const sweep_u32x4 *>(scalars) + 2 * t;
+            const sweep_u32x4 a = __builtin_nontemporal_load(q), b = __builtin_nontemporal_load(q + 1);
+            w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+        } else if (t < n) load8(scalars, t, w);
         if (bad_scalar && (w[7] >> 31)) atomicOr(bad_scalar, 1u);
         u32 carry = 0;
 #pragma unroll
@@ -95,7 +100,7 @@ __device__ __forceinline__ u32 sweep_take(sweep_regs &R, int r, int wd) {
 // the shape that FITS beside a k_accumulate held at two waves per SIMD -- profiles/r04_ab_sort_beside_accumulate.txt)
 template <int THREADS>
 __global__ void __launch_bounds__(THREADS) k_sweep_local(const uint8_t *__restrict__ scalars, u64 n, msm_geom g, int SL, u32 *__restrict__ lsg, u32 *__restrict__ bad_blk,
-                                                               u32 *__restrict__ P1, u64 wstride, u32 *__restrict__ zero_words, int nzero) {
+                                                               u32 *__restrict__ P1, u64 wstride, u32 *__restrict__ zero_words, int nzero, int nt) {
     C25519_PRIO_CHAIN();
     extern __shared__ u32 sm[];
     constexpr int NW = THREADS / 64, CHUNK = THREADS * SWEEP_TPT;
@@ -114,7 +119,7 @@ __global__ void __launch_bounds__(THREADS) k_sweep_local(const uint8_t *__restri
     __syncthreads();
     const u64 lo = (u64)j * CHUNK;
     sweep_regs R;
-    sweep_load<THREADS>(scalars, n, lo, g, R, &sbad);
+    sweep_load<THREADS>(scalars, n, lo, g, R, &sbad, nt);
 #pragma unroll 1
     for (int k = 0; k < g.nwin; k++) {
         const int wd = g.wid[k], bps = g.bps[k];
@@ -489,17 +494,18 @@ int32_t msm_enqueue_sort(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n_s
     const int nw1 = sweep_chunk / SWEEP_TPT / 64;
     const size_t lds1 = ((size_t)2 * nw1 * SL + SL + 1 + sweep_chunk) * 4;
     const size_t lds2 = ((size_t)3 * PART_BPS_MAX + PART_CAP + (small_blocks ? 8 * ITER_SMALL : 16 * P2G_ITER)) * 4;
+    static const int sweep_nt = C25519_KNOB("SWEEP_NT", 0);
     if (small_blocks) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<8, ITER_SMALL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_sweep_local<256>, dim3(pchunks), dim3(256), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+        hipLaunchKernelGGL(k_sweep_local<256>, dim3(pchunks), dim3(256), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS, sweep_nt);
     } else if (sweep_threads == 512) {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<16, P2G_ITER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_sweep_local<512>, dim3(pchunks), dim3(512), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+        hipLaunchKernelGGL(k_sweep_local<512>, dim3(pchunks), dim3(512), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS, sweep_nt);
     } else {
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_local<SWEEP_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_part2g<16, P2G_ITER>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-        hipLaunchKernelGGL(k_sweep_local<SWEEP_THREADS>, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS);
+        hipLaunchKernelGGL(k_sweep_local<SWEEP_THREADS>, dim3(pchunks), dim3(SWEEP_THREADS), lds1, st, d_scalars, n, g, SL, lsg, bad_blk, P1, wstride, flags, ZERO_WORDS, sweep_nt);
     }
     hipLaunchKernelGGL(k_bin_totals, dim3((g.nwin * SL + 3) / 4), dim3(256), 0, st, lsg, pchunks, SL, g.nwin * SL, binm, bad_blk, bad_ws, pl.bad_sticky);
     if (pl.ev_partition) HIPCHK(hipEventRecord(pl.ev_partition, st));
