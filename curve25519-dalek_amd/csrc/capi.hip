@@ -254,7 +254,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
-    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all, &ctx->dom, &ctx->prefix2};
+    devbuf *bufs[] = {&ctx->scratch, &ctx->prefix, &ctx->tmp_a, &ctx->tmp_b, &ctx->tmp_c, &ctx->tmp_c2, &ctx->tmp_d, &ctx->tmp_e, &ctx->tmp_f, &ctx->pts_all, &ctx->dom};
     for (devbuf *b : bufs) if (b->p) hipFree(b->p);
     if (ctx->peer) { c25519_ctx_destroy(ctx->peer); ctx->peer = nullptr; }
     if (ctx->d_table && ctx->owns_table) hipFree(ctx->d_table);
@@ -263,7 +263,6 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->aux) { hipStreamSynchronize(ctx->aux); hipStreamDestroy(ctx->aux); }
-    if (ctx->s_prep) { hipStreamSynchronize(ctx->s_prep); hipStreamDestroy(ctx->s_prep); }
     if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
     if (ctx->ev_sort) hipEventDestroy(ctx->ev_sort);
@@ -433,8 +432,7 @@ EXPORT int32_t c25519_ctx_trim(c25519_ctx *ctx) {
     for (c25519_ctx *c = ctx; c; c = c->peer) {
         if (c != ctx && c->stream) HIPCHK(hipStreamSynchronize(c->stream));
         if (c->aux) HIPCHK(hipStreamSynchronize(c->aux));
-        if (c->s_prep) HIPCHK(hipStreamSynchronize(c->s_prep));
-        devbuf *bufs[] = {&c->scratch, &c->prefix, &c->prefix2, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_c2, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->pts_all, &c->dom};
+        devbuf *bufs[] = {&c->scratch, &c->prefix, &c->tmp_a, &c->tmp_b, &c->tmp_c, &c->tmp_c2, &c->tmp_d, &c->tmp_e, &c->tmp_f, &c->pts_all, &c->dom};
         for (devbuf *b : bufs) if (b->p) { HIPCHK(hipFree(b->p)); b->p = nullptr; b->cap = 0; }
     }
     return C25519_OK;

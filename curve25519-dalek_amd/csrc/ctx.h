@@ -61,8 +61,6 @@ struct c25519_ctx {
     c25519_ctx *peer = nullptr;
     bool owns_table = true;
     devbuf scratch, prefix;        // P32 points and 48-byte prefix products
-    devbuf prefix2;                // prefix products of a second normaliser running beside the first (multi-pass MSM: records of the later passes)
-    hipStream_t s_prep = nullptr;  // third stream: that second normaliser (created on first use)
     devbuf tmp_a, tmp_b, tmp_c, tmp_c2, tmp_d, tmp_e, tmp_f;  // staging for the host-pointer entry points / msm
     const uint32_t *cont_buckets = nullptr;                    // where the latest MSM pass on this context keeps its bucket sums (checked by a continuing pass)
     devbuf dom; std::vector<uint8_t> h_dom;                      // Ed25519ph: dom2 of the latest prehashed call (device copy / host source of its upload)

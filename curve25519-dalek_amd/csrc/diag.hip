@@ -326,6 +326,8 @@ __global__ void __launch_bounds__(256) k_probe_femul51(u32 *out, int iters, u32 
 //        0 identity   1 all lanes pull lane 5   2 pseudo-random inside the own 32-lane half (what k_mul_base_ctp<5> issues)
 //        3 pairs 32 lanes apart inside a half: lanes alternate between s and s + 32 (same bank, different lane, if the crossbar had 32 banks)
 //        4 pseudo-random over the whole wave   5 two sources only (lane 0 / lane 32)   6 rotate by one   7 pseudo-random, new selectors every trip
+//        8 .. 12 (r6, ADVICE r5: which = 80 .. 84 / 85 .. 89) MANY-TO-ONE inside a half: groups of k = 2, 4, 8, 16, 32 lanes pull the same (scattered) source lane --
+//        what equal digits in neighbouring lanes make of the selector
 template <int PAT, bool DEP>
 __global__ void __launch_bounds__(256) k_probe_bpermute(u32 *out, int iters, u32 seed) {
     const u32 lane = threadIdx.x & 63u;
@@ -337,6 +339,7 @@ __global__ void __launch_bounds__(256) k_probe_bpermute(u32 *out, int iters, u32
     else if (PAT == 4) src = h & 63u;
     else if (PAT == 5) src = (lane & 1u) << 5;
     else if (PAT == 6) src = (lane + 1u) & 63u;
+    else if (PAT >= 8) { const u32 k = 2u << (PAT - 8); src = (lane & 32u) | ((((lane & 31u) / k) * 7u + 3u) & 31u); }
     int sel = (int)(src << 2);
     int a0 = (int)(threadIdx.x + seed), a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
     for (int i = 0; i < iters; i++) {
@@ -428,6 +431,11 @@ hipError_t launch_probe(int which, uint32_t *out, int iters, unsigned grid, hipS
     case 60 + PAT: hipLaunchKernelGGL((k_probe_bpermute<PAT, true>), dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     C25519_BP(0) C25519_BP(1) C25519_BP(2) C25519_BP(3) C25519_BP(4) C25519_BP(5) C25519_BP(6) C25519_BP(7)
 #undef C25519_BP
+#define C25519_BQ(I) \
+    case 80 + I: hipLaunchKernelGGL((k_probe_bpermute<8 + I, false>), dim3(grid), dim3(256), 0, st, out, iters, 12345u); break; \
+    case 85 + I: hipLaunchKernelGGL((k_probe_bpermute<8 + I, true>), dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
+    C25519_BQ(0) C25519_BQ(1) C25519_BQ(2) C25519_BQ(3) C25519_BQ(4)
+#undef C25519_BQ
     case 70: hipLaunchKernelGGL(k_probe_fe9<false>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     case 71: hipLaunchKernelGGL(k_probe_fe9<true>, dim3(grid), dim3(256), 0, st, out, iters, 12345u); break;
     default: return hipErrorInvalidValue;

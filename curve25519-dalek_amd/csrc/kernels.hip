@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(BS) k_mul_base_ct_split(const uint8_t *__restr
 //     crossbar transfer through the LDS unit that reads no memory.  The digit is the permute's lane selector, nothing else.
 // No select on the digit, no conditional negation (the sign is part of the selector), 24 permutes + 6 reads instead of 96 reads + 434 selects.
 // Whether the permute's duration depends on the selector pattern was measured before adopting it (c25519_microbench 50 .. 67, tools/probes.py,
-// profiles/r05_bpermute_probe.txt: all-equal, identity, random within the group, pairs 32 lanes apart, random over the wave -- see the
+// profiles/r05_instruction_rates.txt and, with the many-to-one patterns, profiles/r06_instruction_rates.txt: all-equal, identity, random within the group,
+// pairs 32 lanes apart, k lanes on one source for k = 2 .. 32, random over the wave -- a MEASURED property of gfx950, not an architectural guarantee: see the
 // constant-time paragraph of include/c25519_hip.h); with W = 5 a lane's sources stay inside its own 32-lane half by construction.
 // EXEC must be all ones at the permutes (an inactive source lane would return zeros): the scalar loop is block-uniform, lanes past the end
 // of the batch run on a zero scalar and are masked at the store.

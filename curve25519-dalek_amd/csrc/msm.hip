@@ -997,18 +997,15 @@ hipEvent_t *pass_ring(c25519_ctx *owner, c25519_ctx *c, uint8_t kind) {
 //                                   of 512 hide the latency of the normaliser's 64-step chains, and no later pass has
 //                                   a normalisation between the reduction before it and its accumulation
 //   otherwise                       the records are at ahead->pts + ahead->offset once ahead->done has fired
-// (r5) split: the launching pass normalises only ITS OWN points on its main stream and the points of all later passes on a third stream, behind the sorts
-//   of the first two passes (first_sorted: pass 0's) -- the accumulations of passes 0 and 1 no longer wait for a 1.8 ms normaliser
-struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; bool split; hipEvent_t first_sorted; };
+// (A third arm -- the launching pass normalising only its own points, the rest on a third stream behind the first two sorts -- was measured in rounds 5 and 6 and
+//  removed: 13.68 against 13.35 - 13.53 ms, with and without streaming accesses; profiles/r05_ab_prep_split.txt, r06_ab_mall.txt.)
+struct pts_ahead { uint32_t *pts; uint64_t n, offset; hipEvent_t done; bool launch; };
 static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_scalars, const uint8_t *d_points, uint64_t n, int in_fmt, const msm_geom &g, uint64_t terms, uint32_t *d_slot,
                                 hipEvent_t wait_acc, const pts_ahead *ahead = nullptr, hipEvent_t wait_in = nullptr,
                                 bool cont = false, bool reduce = true, uint64_t n_carve = 0, uint32_t *d_bad_sticky = nullptr, int parity = -1) {
     int32_t r;
     uint32_t *d_pts;
     if (wait_in) HIPCHK(hipStreamWaitEvent(ctx->stream, wait_in, 0));      // host-pointer calls: this pass's inputs are still on their way up
-    // (r5, pts_ahead split) the second pass leaves the machine to the first one until ITS sort is through: its own accumulation cannot start before
-    // the first one's has finished anyway, and two normalisers + two sorts at once kept the first accumulation waiting for 1.9 ms
-    if (ahead && ahead->launch && ahead->split && ahead->n > n && ahead->first_sorted) HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->first_sorted, 0));
     if (!ahead) {
         if ((r = ctx_reserve(ctx, ctx->tmp_e, std::max(n, n_carve) * PTS_BYTES + 256))) return r;
         d_pts = (uint32_t *)ctx->tmp_e.p;
@@ -1054,16 +1051,12 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     static const int sort_first = C25519_KNOB("SORT_FIRST", 0);
     const bool sorted_first = sort_first && !ahead && !serial_sort && !cont && !wait_in;      // (measured on device-resident single / first passes only)
     if (sorted_first) {
-        pl.ev_partition = sort_first >= 2 ? ctx->ev_z : nullptr;
+        pl.ev_partition = nullptr;
         if ((r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, ctx->aux, pl, nullptr, n_carve, lists_free, sweep_early >= 2 ? parity : -1))) return r;
         if (pl.ev_partition) HIPCHK(hipStreamWaitEvent(ctx->stream, pl.ev_partition, 0));
     }
     if (!ahead) { if ((r = prep_points(ctx, d_points, n, in_fmt, d_pts, 0, slot_flags(d_slot) + 1))) return r; }
-    else if (ahead->launch && ahead->split && ahead->n > n) {
-        // (r5) the records of THIS pass now, on this stream; those of the passes after it on the context's third stream, enqueued below once the sort
-        // of this pass is on its way -- see pts_ahead
-        if ((r = prep_points(ctx, d_points, n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
-    } else if (ahead->launch) {
+    else if (ahead->launch) {
         if ((r = prep_points(ctx, d_points, ahead->n, in_fmt, ahead->pts, 0, slot_flags(d_slot) + 1))) return r;
         HIPCHK(hipEventRecord(ahead->done, ctx->stream));
     } else HIPCHK(hipStreamWaitEvent(ctx->stream, ahead->done, 0));
@@ -1073,16 +1066,6 @@ static int32_t msm_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_
     if (cont && pl.buckets != ctx->cont_buckets) { ctx->err = "msm: internal error (the workspace of a continuing pass moved its buckets)"; return -(int32_t)hipErrorInvalidValue; }
     ctx->cont_buckets = pl.buckets;
     if ((r = msm_enqueue_acc(ctx, pl, d_pts, d_slot, ring, wait_acc, cont, reduce, d_bad_sticky))) return r;
-    if (ahead && ahead->launch && ahead->split && ahead->n > n) {
-        // the records of the passes AFTER this one: third stream of this context, own prefix scratch, behind the sorts of the first two passes (whose
-        // 1024-thread partition blocks need empty compute units and starved beside a normaliser that was launched first: profiles/r05_ab_prep_split.txt)
-        if (!ctx->s_prep) HIPCHK(hipStreamCreateWithFlags(&ctx->s_prep, hipStreamNonBlocking));
-        HIPCHK(hipStreamWaitEvent(ctx->s_prep, owner->ev_in, 0));              // the inputs are complete (recorded by passes_begin on the caller's stream)
-        HIPCHK(hipStreamWaitEvent(ctx->s_prep, ctx->ev_sort, 0));              // this pass's sort (recorded by msm_enqueue_acc above)
-        if (ahead->first_sorted) HIPCHK(hipStreamWaitEvent(ctx->s_prep, ahead->first_sorted, 0));      // pass 0's sort
-        if ((r = prep_points_on(ctx, d_points + n * 160, ahead->n - n, in_fmt, ahead->pts, n, slot_flags(d_slot) + 1, ctx->s_prep, ctx->prefix2))) return r;
-        HIPCHK(hipEventRecord(ahead->done, ctx->s_prep));
-    }
     return C25519_OK;
 }
 // The whole MSM, enqueued: every pass on its stream set, the passes' column sums added on the device, the RECORD (column
@@ -1120,8 +1103,9 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     ctx->direct_extra = nullptr;
     // (r6) the mid path (mid.hip: 12 288 .. 2^18 terms in four launches on this stream) publishes its record the same way
     bool mid = false;
-    if (passes == 1 && !fetch && n > msm_small_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g, in_fmt != C25519_FMT_RAW160); }
-    if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && in_fmt == C25519_FMT_RAW160 && !fetch && (n <= msm_small_max() || mid)) {
+    // (a host-pointer call of ONE pass has nothing to overlap its upload with: the inputs go up in one piece and the pass waits for them)
+    if (passes == 1 && n > msm_small_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g, in_fmt != C25519_FMT_RAW160); }
+    if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && in_fmt == C25519_FMT_RAW160 && ((!fetch && n <= msm_small_max()) || mid)) {
         msm_geom gs;
         msm_layout(n, gs);
         if (mid || (gs.half <= 64 && gs.nwin <= 64)) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
@@ -1133,6 +1117,11 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         ctx->solo = true;
         ctx->coarse_wait = nullptr;
         hipEvent_t *ring = pass_ring(ctx, ctx, 1);
+        if (fetch) {
+            hipEvent_t in_ev = nullptr;
+            if ((r = (*fetch)(0, n, &in_ev))) { ctx->direct_seq = 0; return r; }
+            HIPCHK(hipStreamWaitEvent(ctx->stream, in_ev, 0));
+        }
         HIPCHK(hipEventRecord(ring[3], ctx->stream));
         if (in_fmt == C25519_FMT_RAW160) r = msm_mid_enqueue(ctx, d_scalars, d_points, 0, n, g, d_record, 1, n, ring);
         else {
@@ -1162,7 +1151,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // the reduction of group 0 takes its issue slots and registers from the second group's accumulation (k_accumulate 1.16 -> 1.17 - 1.26 ms over the two
     // launches, each with its own ramp-down): four interleaved repetitions on one box give 1.959 ms (one group) against 1.965 (two); three and four
     // groups 2.06 / 2.18; at 2^20 and 2^18 terms two groups lose 8 % and 17 %.  The default stays ONE group.
-    static const int acc_groups = C25519_KNOB("ACC_GROUPS", 1), acc_last = C25519_KNOB("ACC_LAST", 0);
+    static const int acc_groups = std::min(2, C25519_KNOB("ACC_GROUPS", 1)), acc_last = 0;      // (three / four groups and an uneven last group lost twice and left the build: profiles/r05_ab_window_groups.txt)
     // (groups exist in the chunk-local sort only: single passes below its lower boundary -- the digit-matrix sort's range -- keep one group)
     static const uint64_t chunk_local_min = (uint64_t)C25519_KNOB("SORT_CHUNK_LOCAL_MIN", 1 << 16);
     if (passes == 1 && n > msm_small_max() && n >= chunk_local_min) msm_set_groups(g, acc_groups, acc_last);
@@ -1185,11 +1174,7 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         const int l = (int)(p % L);
         c25519_ctx *c = ps.c[l];
         const bool first = p < (uint64_t)L, last = p + L >= passes;
-        // A/B knob, measured and NOT adopted (profiles/r05_ab_prep_split.txt): 1 = the launching pass normalises only its own points and the rest goes to a
-        // third stream behind the first two sorts, so that the first accumulations start 1.4 ms earlier -- 13.68 against 13.35 - 13.53 ms per 2^24 terms, 7.26
-        // against 7.10 per 2^23: the normaliser is HBM-bound work that is conserved; beside it every accumulation runs 5 - 7 % longer
-        static const int prep_split = C25519_KNOB("PREP_SPLIT", 0);
-        pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p == 1, prep_split != 0 && passes > 2, ctx->ev_sort};
+        pts_ahead ah = {(uint32_t *)ctx->pts_all.p, n - per, lo - per, ctx->ev_pts, p == 1};
         uint32_t *slot = passes == 1 ? d_record : dslot(ctx, l);         // a single pass writes the record itself
         hipEvent_t in_ev = nullptr;
         if (fetch && (r = (*fetch)(lo, m, &in_ev))) return r;
@@ -1343,8 +1328,15 @@ EXPORT int32_t c25519_msm_vartime(c25519_ctx *ctx, const uint8_t *scalars, const
     ge_p3 R;
     uint32_t flags[8];
     const uint64_t pass_terms = n >= (1ull << 20) ? (in_fmt == C25519_FMT_RAW160 ? (1ull << 19) : (1ull << 20)) : 0;
+    ctx->want_direct = true;                               // (the mid path publishes its record itself; the bucket pipeline ignores the wish)
     r = msm_record_enqueue(ctx, d_s, d_p, n, in_fmt, drec(ctx), &fetch, pass_terms);
     if (!r) r = rec_collect(ctx);
+    if (r == C25519_LOST_PUBLICATION) {                     // (never observed; see wait_published: once more through the slot + copy path -- the inputs are on the device)
+        ctx->no_direct_once = true;
+        r = msm_record_enqueue(ctx, d_s, d_p, n, in_fmt, drec(ctx), nullptr, 0);
+        if (!r) r = rec_collect(ctx);
+        if (!r) ctx->err.clear();
+    }
     guard.dismiss();
     const int32_t r2 = ffi_end(ctx, up, 0);
     if (r || (r = r2)) return r;

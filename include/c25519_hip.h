@@ -94,7 +94,10 @@ extern "C" {
  *   identity, all-equal, random-within-the-half, pairs 32 lanes apart and two-source selector patterns (24.2 - 24.4 cycles per
  *   wave-instruction, 71 - 73 cycles of latency); a selector pattern that crosses the two halves at random is 16 % slower --
  *   which is why a lane's sources stay inside its own 32-lane half BY CONSTRUCTION (radix 2^6 over the whole wave was not
- *   built).  Asserted on the compiled code: tests/test_ct_isa.py (exactly 6 + 3 LDS reads and 30 permutes per window, no other
+ *   built).  Round 6 added the many-to-one patterns -- groups of 2, 4, 8, 16, 32 lanes of a half pulling ONE source lane, what equal
+ *   digits in neighbouring lanes make of the selector (c25519_microbench 80-89, profiles/r06_instruction_rates.txt).  This timing
+ *   independence is a MEASURED property of gfx950 (the kernels are built for nothing else), not an architectural guarantee: a port to
+ *   another GPU must repeat the probe, or use the full-window scan.  Asserted on the compiled code: tests/test_ct_isa.py (exactly 6 + 3 LDS reads and 30 permutes per window, no other
  *   memory access, no exec / vcc branch in the window loop).  The full-window scan of rounds 2-4 remains as k_mul_base<5, CT>
  *   behind the CT_FETCH knob of the tuning build (2.77 against 1.84 ms per 2^20 scalars).
  * With this flag those entry points use the fast tables instead -- fixed base: the radix-2^16 tables in HBM, 16

@@ -257,15 +257,17 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  {"C25519_MSM_MIDRANGE_WINDOWS": "0", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
                                  # every pass normalises its own points; the 512-thread partition
                                  {"C25519_PREP_AHEAD": "0", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_SWEEP_THREADS": "512", "C25519_SORT_CHUNK_LOCAL_MIN": "2048"},
-                                 # round 5: single-pass calls in window groups (bucket order, accumulation and reduction group by group), the sort enqueued
-                                 # ahead of the normaliser
-                                 {"C25519_ACC_GROUPS": "2"}, {"C25519_ACC_GROUPS": "4", "C25519_ACC_LAST": "2"}, {"C25519_ACC_GROUPS": "3", "C25519_SORT_FIRST": "1"},
-                                 {"C25519_SORT_FIRST": "2"},
-                                 # the records of the later passes normalised on a third stream (three and more passes of 2^16 terms)
+                                 # round 5: single-pass calls in two window groups (bucket order, accumulation and reduction group by group), the sort enqueued
+                                 # ahead of the normaliser.  (Three / four groups, SORT_FIRST=2, PREP_SPLIT, 7-bit small tables lost on two boxes each and left the
+                                 # tuning build in round 6: profiles/r05_ab_window_groups.txt, r05_ab_prep_split.txt, r05_ab_small_path_range.txt are the record.)
+                                 {"C25519_ACC_GROUPS": "2"}, {"C25519_SORT_FIRST": "1"},
                                  {"C25519_REDUCE_MAIN": "0"}, {"C25519_SMALL_DIRECT": "0"},      # the reduction of a single-pass call on the second stream (rounds 3-4); small calls through their slot
-                                 # the small path's range and window widths: round 4's (4095 terms, 7-bit windows), and 5-bit windows far beyond the default boundary
-                                 {"C25519_MSM_SMALL_MAX": "4095"}, {"C25519_MSM_SMALL_C": "7"}, {"C25519_MSM_SMALL_MAX": "40000", "C25519_MSM_SMALL_C": "5"},
-                                 {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16"}, {"C25519_PREP_SPLIT": "1", "C25519_MSM_PASS_LOG2": "16", "C25519_PASS_LANES": "3"}])
+                                 # the small path's range: round 4's (4095 terms), and 5-bit windows far beyond the default boundary
+                                 {"C25519_MSM_SMALL_MAX": "4095"}, {"C25519_MSM_SMALL_MAX": "40000", "C25519_MSM_SMALL_C": "5"},
+                                 # round 6, the mid path: off (the bucket pipeline from 12 288 terms, as it still serves everything beyond 2^17), the normaliser +
+                                 # k_accumulate arm from 12 288 terms, many small sort slices, up to 2^18 terms; streaming normaliser / sort reads
+                                 {"C25519_MSM_MID_MAX": "0"}, {"C25519_MID_PROJ_MAX": "0"}, {"C25519_MID_SORT_BLOCKS": "1024", "C25519_MSM_MID_MAX": "262144"},
+                                 {"C25519_PREP_NT": "1", "C25519_SWEEP_NT": "1", "C25519_MSM_PASS_LOG2": "20"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in
@@ -279,7 +281,7 @@ def test_msm_kernel_variants_in_a_fresh_process(orc, env):
         from oracle import orc
         eng = pkg.Engine(0)
         L = util.L
-        for n in (1, 63, 65, 1500, 4097, 12000, 20001, 3 * 65536 + 5, 262144 + 64 * 37 + 1, 18 * 65536 + 77):
+        for n in (1, 63, 65, 1500, 4097, 12000, 20001, 70001, 3 * 65536 + 5, 262144 + 64 * 37 + 1, 18 * 65536 + 77):
             x = util.rand_scalars(500 + n, n)
             pts = eng.mul_base_batch(x, out_fmt=2)
             pts[::3] = eng.decompress_batch(eng.compress_batch(pts[::3]))[1]          # a third of the points affine (Z = 1)

@@ -43,10 +43,12 @@ print()
 print("%-72s %14s %14s %16s" % ("ds_bpermute_b32, source lane of lane l", "Gop/s chip", "cycles/wave*", "latency cycles*"))
 pats = {0: "identity (l)", 1: "all lanes pull lane 5", 2: "pseudo-random inside the own 32-lane half (k_mul_base_ctp<5>)", 3: "pairs 32 lanes apart inside a half (s, s + 32 alternating)",
         4: "pseudo-random over the whole wave", 5: "two sources only (lane 0 / lane 32)", 6: "rotate by one", 7: "pseudo-random inside the half, new selectors every trip"}
+for i, k in enumerate((2, 4, 8, 16, 32)):
+    pats[8 + i] = "many-to-one inside the half: groups of %d lanes pull one (scattered) source lane" % k
 rows = []
 for ppat, nm in pats.items():
-    thr = max(e.microbench(50 + ppat, 4000) for _ in range(5))
-    lat = max(e.microbench(160 + ppat, 2000) for _ in range(5))      # + 100: one wave per SIMD; the chain is dependent: rate = 1 / latency
+    thr = max(e.microbench((50 + ppat) if ppat < 8 else (80 + ppat - 8), 4000) for _ in range(5))
+    lat = max(e.microbench((160 + ppat) if ppat < 8 else (185 + ppat - 8), 2000) for _ in range(5))      # + 100: one wave per SIMD; the chain is dependent: rate = 1 / latency
     rows.append((thr, lat))
     print("%-72s %14.1f %14.2f %16.1f" % (nm, thr, 1024 * 64 * 2.4 / thr, 1024 * 64 * 2.4 / lat))
 spread_t = max(r[0] for r in rows) / min(r[0] for r in rows)

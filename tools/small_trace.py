@@ -1,4 +1,4 @@
-"""Traced under rocprofv3 --kernel-trace (tools/r05_call18.sh): six calls each of the small host-pointer entry points, so that the kernel
+"""Traced under rocprofv3 --kernel-trace (docs/lab/r05_call18.sh): six calls each of the small host-pointer entry points, so that the kernel
 timeline of the LAST call of every group can be read off (tools/timeline_tail.py)."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
