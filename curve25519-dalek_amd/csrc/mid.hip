@@ -420,7 +420,13 @@ bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
 // record published into the context's page-locked host slot.  src_fmt 0: raw 160-byte points at `points`; 1: affine Niels records at `points` (a decompression made them).
 // hdr 0: the slot was initialised by k_slot_init and carries counters of its own (verify_batch); 1: this pass writes the header (MSM).
 // ring (may be null): [0] / [1] bracket k_mid_acc, [2] end of the pass.
-int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring) {
+int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const msm_geom &g_in, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring) {
+    // The cap beyond which a list leaves the bucket lanes for k_mid_long: max(48, 3 x mean) here (the bucket pipeline: max(192, 2.5 x mean), set for passes of millions of
+    // terms).  A mid-size call is as long as its longest list: verify_batch of 2^15 signatures with 15-bit windows puts the top 8 bits of the 128-bit z_i into 256 buckets
+    // of ~128 entries each -- just under 192 -- and k_accumulate walked them for 368 us where the call of 2^16 signatures (256 entries each: over the cap) took 85
+    // (profiles/r06_timeline_mid_verify_2p15_long_cap.txt).  One wave per 256 entries handles such a list in ~30 us.
+    msm_geom g = g_in;
+    g.long_cap = (u32)std::max<uint64_t>(48, 3 * (n / (uint64_t)g.half + 1));
     if (!msm_mid_serves(n, g, src_fmt != 0) || n >= (1ull << 31)) { ctx->err = "msm: internal error (mid path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
     hipStream_t st = ctx->stream;
     const uint64_t dstride = (n + 7) & ~(uint64_t)7;
@@ -478,7 +484,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
     }
     if (ring) HIPCHK(hipEventRecord(ring[0], st));
-    const unsigned nacc = div_up64(nb, 256), nlong = 64;
+    const unsigned nacc = div_up64(nb, 256), nlong = 256;      // (one wave per item, four per block: 1024 items in flight)
     // Over-long lists.  Prepared records (verify_batch: the carry digit of the 128-bit z_i puts ~n / 2 terms into ONE bucket -- a ~50 us chain of a few dozen waves): on
     // the second stream, BESIDE the accumulation, which skips those buckets.  Raw points (random scalars have none: the kernel finds an empty work list): behind the
     // accumulation on this stream -- a 4 us launch, where the two cross-stream hand-overs cost ~10 us each (2^14 terms: 212 against 223 us of GPU span).
