@@ -111,4 +111,147 @@ static inline hp3 hp3_mul_by_pow_2(const hp3 &p, int k) {
     return r;
 }
 
+
+// ---- (r6) the doubling chain of the fold on AVX-512 IFMA: four field operations per vector instruction --------------------------------------------------------
+// The Horner fold is ~253 doublings whatever the window width -- 21 of the 28 us a small or mid-size call spends on the host after the GPU is through (DESIGN.md
+// section 4), at ~85 ns per doubling with the 64 x 64 -> 128 multiplier.  A doubling is four independent squarings followed by four independent products
+// (curve_models.rs:381-397 + :365-373) -- exactly the shape the reference's own vector backends exploit (docs/parallel-formulas.md; backend/vector/ifma: four field
+// elements in the lanes of a vector, 52-bit multiply-adds).  Here: lane j of five 256-bit vectors holds field element j in radix 2^51; vpmadd52luq / vpmadd52huq
+// give the low / high 52 bits of a 52 x 52 product, so a limb product a_i b_j contributes lo to position i + j and 2 hi to position i + j + 1 (2^52 = 2 * 2^51).
+// Operands of a multiplication must be below 2^52 (the instruction truncates): every sum / difference is followed by a carry pass, which leaves limbs below
+// 2^51 + 2^17.  Used when the CPU has avx512ifma + avx512vl (checked once); the scalar path above remains for every other host and is the reference in
+// tests/test_fe26_host.py::test_ifma_doubling_chain.
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(C25519_NO_IFMA)
+}  // namespace c25519
+#include <immintrin.h>
+namespace c25519 {
+#define C25519_IFMA_FN __attribute__((target("avx512ifma,avx512vl,avx2"))) static inline
+struct f51x4 { __m256i v[5]; };
+C25519_IFMA_FN __m256i ifma_mask51() { return _mm256_set1_epi64x((long long)H51_MASK); }
+// limbs below 2^63 -> limbs below 2^51 + 2^17 (one pass; the wrap-around of the top carry times 19 goes to limb 0 and is not propagated further)
+C25519_IFMA_FN f51x4 f51x4_carry(f51x4 a) {
+    const __m256i m = ifma_mask51();
+    __m256i c = _mm256_srli_epi64(a.v[0], 51); a.v[0] = _mm256_and_si256(a.v[0], m);
+    a.v[1] = _mm256_add_epi64(a.v[1], c); c = _mm256_srli_epi64(a.v[1], 51); a.v[1] = _mm256_and_si256(a.v[1], m);
+    a.v[2] = _mm256_add_epi64(a.v[2], c); c = _mm256_srli_epi64(a.v[2], 51); a.v[2] = _mm256_and_si256(a.v[2], m);
+    a.v[3] = _mm256_add_epi64(a.v[3], c); c = _mm256_srli_epi64(a.v[3], 51); a.v[3] = _mm256_and_si256(a.v[3], m);
+    a.v[4] = _mm256_add_epi64(a.v[4], c); c = _mm256_srli_epi64(a.v[4], 51); a.v[4] = _mm256_and_si256(a.v[4], m);
+    const __m256i c19 = _mm256_add_epi64(_mm256_add_epi64(_mm256_slli_epi64(c, 4), _mm256_slli_epi64(c, 1)), c);      // 19 c, c < 2^12
+    a.v[0] = _mm256_add_epi64(a.v[0], c19);
+    return a;
+}
+// column sums t[0..9] (t[k] = sum of lo at k + 2 x sum of hi at k - 1) -> reduced limbs
+C25519_IFMA_FN f51x4 f51x4_reduce(const __m256i zl[9], const __m256i zh[9]) {
+    __m256i t[10];
+    t[0] = zl[0];
+    _Pragma("GCC unroll 16") for (int k = 1; k < 9; k++) t[k] = _mm256_add_epi64(zl[k], _mm256_slli_epi64(zh[k - 1], 1));
+    t[9] = _mm256_slli_epi64(zh[8], 1);
+    f51x4 r;
+    _Pragma("GCC unroll 16") for (int k = 0; k < 5; k++) {
+        const __m256i h = t[k + 5];                                       // < 2^57: 19 h < 2^62
+        r.v[k] = _mm256_add_epi64(t[k], _mm256_add_epi64(_mm256_add_epi64(_mm256_slli_epi64(h, 4), _mm256_slli_epi64(h, 1)), h));
+    }
+    return f51x4_carry(r);
+}
+// lane-wise product; limbs of a, b below 2^52
+C25519_IFMA_FN f51x4 f51x4_mul(const f51x4 &a, const f51x4 &b) {
+    __m256i zl[9], zh[9];
+    const __m256i z = _mm256_setzero_si256();
+    _Pragma("GCC unroll 16") for (int k = 0; k < 9; k++) { zl[k] = z; zh[k] = z; }
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++)
+        _Pragma("GCC unroll 16") for (int j = 0; j < 5; j++) {
+            zl[i + j] = _mm256_madd52lo_epu64(zl[i + j], a.v[i], b.v[j]);
+            zh[i + j] = _mm256_madd52hi_epu64(zh[i + j], a.v[i], b.v[j]);
+        }
+    return f51x4_reduce(zl, zh);
+}
+// lane-wise square: the cross products once, doubled in the accumulator (2 a_j would not fit the 52-bit operand)
+C25519_IFMA_FN f51x4 f51x4_sq(const f51x4 &a) {
+    __m256i dl[9], dh[9], xl[9], xh[9];
+    const __m256i z = _mm256_setzero_si256();
+    _Pragma("GCC unroll 16") for (int k = 0; k < 9; k++) { dl[k] = z; dh[k] = z; xl[k] = z; xh[k] = z; }
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+        dl[2 * i] = _mm256_madd52lo_epu64(dl[2 * i], a.v[i], a.v[i]);
+        dh[2 * i] = _mm256_madd52hi_epu64(dh[2 * i], a.v[i], a.v[i]);
+        _Pragma("GCC unroll 16") for (int j = i + 1; j < 5; j++) {
+            xl[i + j] = _mm256_madd52lo_epu64(xl[i + j], a.v[i], a.v[j]);
+            xh[i + j] = _mm256_madd52hi_epu64(xh[i + j], a.v[i], a.v[j]);
+        }
+    }
+    _Pragma("GCC unroll 16") for (int k = 0; k < 9; k++) { dl[k] = _mm256_add_epi64(dl[k], _mm256_slli_epi64(xl[k], 1)); dh[k] = _mm256_add_epi64(dh[k], _mm256_slli_epi64(xh[k], 1)); }
+    return f51x4_reduce(dl, dh);
+}
+C25519_IFMA_FN f51x4 f51x4_load(const h51 &a, const h51 &b, const h51 &c, const h51 &d) {
+    f51x4 r;
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) r.v[i] = _mm256_set_epi64x((long long)d.v[i], (long long)c.v[i], (long long)b.v[i], (long long)a.v[i]);
+    return r;
+}
+C25519_IFMA_FN void f51x4_store(const f51x4 &a, h51 out[4]) {
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+        alignas(32) uint64_t t[4];
+        _mm256_store_si256((__m256i *)t, a.v[i]);
+        _Pragma("GCC unroll 16") for (int j = 0; j < 4; j++) out[j].v[i] = t[j];
+    }
+}
+// 2 p in radix 2^51 (limbs 2^52 - 38, 2^52 - 2, ...): a + 2p - b for limbs of b below 2^52
+C25519_IFMA_FN __m256i ifma_2p(int limb) { return _mm256_set1_epi64x(limb == 0 ? (long long)((1ull << 52) - 38) : (long long)((1ull << 52) - 2)); }
+// k doublings of (X : Y : Z), T of the last one: hp3_mul_by_pow_2 with the four squarings and the four products of every doubling in the lanes of one vector
+C25519_IFMA_FN hp3 hp3_mul_by_pow_2_ifma(const hp3 &p, int k) {
+    if (k <= 0) return p;
+    const h51 xy = h51_add(p.X, p.Y);
+    f51x4 A = f51x4_carry(f51x4_load(p.X, p.Y, p.Z, xy));                 // (X, Y, Z, X + Y), limbs below 2^52
+    f51x4 P = A;
+    _Pragma("GCC unroll 16") for (int it = 0; it < k; it++) {
+        const f51x4 Q = f51x4_sq(A);                                      // (XX, YY, ZZ, S)
+        f51x4 W, U, M1, M2;
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            // W = (YY + XX, YY + 2p - XX, 2 ZZ, S)
+            const __m256i a0 = _mm256_permute4x64_epi64(Q.v[i], 0xE5);   // lanes (1, 1, 2, 3) = (YY, YY, ZZ, S)
+            const __m256i b0 = _mm256_permute4x64_epi64(Q.v[i], 0xA0);   // lanes (0, 0, 2, 2) = (XX, XX, ZZ, ZZ)
+            const __m256i neg = _mm256_sub_epi64(ifma_2p(i), b0);          // 2p - XX in lane 1
+            __m256i add = _mm256_blend_epi32(b0, neg, 0x0C);             // lane 1 <- 2p - XX
+            add = _mm256_blend_epi32(add, _mm256_setzero_si256(), 0xC0); // lane 3 <- 0
+            W.v[i] = _mm256_add_epi64(a0, add);
+        }
+        W = f51x4_carry(W);                                               // (YpX, YmX, ZZ2, S)
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            // U = (S + 2p - YpX, ZZ2 + 2p - YmX, ., .) = (cX, cT, ., .)
+            const __m256i a1 = _mm256_permute4x64_epi64(W.v[i], 0x0B);   // lanes (3, 2, 0, 0) = (S, ZZ2, ., .)
+            const __m256i b1 = _mm256_permute4x64_epi64(W.v[i], 0x04);   // lanes (0, 1, 0, 0) = (YpX, YmX, ., .)
+            U.v[i] = _mm256_add_epi64(a1, _mm256_sub_epi64(ifma_2p(i), b1));
+        }
+        U = f51x4_carry(U);                                               // (cX, cT, ., .)
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            const __m256i cx = _mm256_permute4x64_epi64(U.v[i], 0x00), ct = _mm256_permute4x64_epi64(U.v[i], 0x55);
+            const __m256i w0110 = _mm256_permute4x64_epi64(W.v[i], 0x10);      // lanes (0, 0, 1, 0) = (., YpX, YmX, .)  [lane 1 = W0, lane 2 = W1]
+            const __m256i w1x0 = _mm256_permute4x64_epi64(W.v[i], 0x04);       // lanes (0, 1, 0, 0) = (., YmX, ., YpX)  [lane 1 = W1, lane 3 = W0]
+            M1.v[i] = _mm256_blend_epi32(cx, w0110, 0x3C);                // (cX, YpX, YmX, cX)
+            M2.v[i] = _mm256_blend_epi32(ct, w1x0, 0xCC);                 // (cT, YmX, cT, YpX)
+        }
+        P = f51x4_mul(M1, M2);                                            // (X', Y', Z', T') = (cX cT, YpX YmX, YmX cT, cX YpX)
+        if (it + 1 < k) {
+            _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+                const __m256i yx = _mm256_permute4x64_epi64(P.v[i], 0x55);     // Y' everywhere
+                const __m256i sum = _mm256_add_epi64(_mm256_permute4x64_epi64(P.v[i], 0x00), yx);      // X' + Y'
+                A.v[i] = _mm256_blend_epi32(P.v[i], sum, 0xC0);           // (X', Y', Z', X' + Y')
+            }
+            A = f51x4_carry(A);
+        }
+    }
+    h51 o[4];
+    f51x4_store(P, o);
+    hp3 r; r.X = o[0]; r.Y = o[1]; r.Z = o[2]; r.T = o[3];
+    return r;
+}
+static inline bool host_has_ifma() {
+    static const bool v = __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl");
+    return v;
+}
+// the doubling chain of the fold: IFMA where the host has it
+static inline hp3 hp3_pow2_fast(const hp3 &p, int k) { return host_has_ifma() ? hp3_mul_by_pow_2_ifma(p, k) : hp3_mul_by_pow_2(p, k); }
+#else
+static inline bool host_has_ifma() { return false; }
+static inline hp3 hp3_pow2_fast(const hp3 &p, int k) { return hp3_mul_by_pow_2(p, k); }
+#endif
+
 }  // namespace c25519

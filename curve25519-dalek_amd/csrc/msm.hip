@@ -661,7 +661,7 @@ ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
     // (host51.h: the 5 x 51-bit layout a 64-bit core multiplies natively -- 25 us per fold instead of 74 through the device layout)
     hp3 total = hp3_identity();
     for (int k = g.nwin - 1; k >= 0; k--) {
-        if (k != g.nwin - 1) total = hp3_mul_by_pow_2(total, g.pos[k + 1] - g.pos[k]);
+        if (k != g.nwin - 1) total = hp3_pow2_fast(total, g.pos[k + 1] - g.pos[k]);      // (AVX-512 IFMA where the host has it: host51.h)
         total = hp3_add(total, hp3_from(host_p40(&cols[(size_t)k * 40])));
     }
     return hp3_to(total);
@@ -809,7 +809,7 @@ int32_t records_fold(const uint8_t *records, uint64_t count, ge_p3 &R, uint32_t 
         }
         hp3 total = hp3_identity();
         for (int k = g.nwin - 1; k >= 0; k--) {
-            if (k != g.nwin - 1) total = hp3_mul_by_pow_2(total, g.pos[k + 1] - g.pos[k]);
+            if (k != g.nwin - 1) total = hp3_pow2_fast(total, g.pos[k + 1] - g.pos[k]);      // (AVX-512 IFMA where the host has it: host51.h)
             total = hp3_add(total, hc[(size_t)k]);
         }
         R = hp3_to(total);

@@ -139,3 +139,28 @@ void h_sc28_neg(const uint8_t *a, uint8_t *o) { u32 aw[8], r[8]; memcpy(aw, a, 3
 int h_sc28_canonical(const uint8_t *a) { u32 x[8]; memcpy(x, a, 32); return sc28_words_canonical(x); }
 void h_sc28_roundtrip(const uint8_t *a, uint8_t *o) { u32 x[8], r[8]; memcpy(x, a, 32); sc28_to_words(sc28_from_words(x), r); memcpy(o, r, 32); }
 }
+
+// ---- the host fold's doubling chain: scalar (64 x 64 -> 128) against the AVX-512 IFMA form (csrc/host51.h) -----------------------------------------------------
+#include "../../curve25519-dalek_amd/csrc/host51.h"
+extern "C" {
+int h_has_ifma() { return host_has_ifma() ? 1 : 0; }
+// in: X, Y, Z as 3 x 5 u64 limbs (any values below 2^52); k doublings; out: affine x, y (canonical 32-byte encodings) and x * y against T / Z from each path
+static void h_affine(const hp3 &r, uint8_t *o) {
+    const h51 zi = h51_invert(r.Z);
+    u32 w[8];
+    fe_to_words(h51_to_fe(h51_mul(r.X, zi)), w); memcpy(o, w, 32);
+    fe_to_words(h51_to_fe(h51_mul(r.Y, zi)), w); memcpy(o + 32, w, 32);
+    fe_to_words(h51_to_fe(h51_mul(r.T, zi)), w); memcpy(o + 64, w, 32);
+}
+void h_pow2_scalar(const uint64_t *xyz, int k, uint8_t *o) {
+    hp3 p; for (int i = 0; i < 5; i++) { p.X.v[i] = xyz[i]; p.Y.v[i] = xyz[5 + i]; p.Z.v[i] = xyz[10 + i]; p.T.v[i] = 0; }
+    h_affine(hp3_mul_by_pow_2(p, k), o);
+}
+void h_pow2_ifma(const uint64_t *xyz, int k, uint8_t *o) {
+    hp3 p; for (int i = 0; i < 5; i++) { p.X.v[i] = xyz[i]; p.Y.v[i] = xyz[5 + i]; p.Z.v[i] = xyz[10 + i]; p.T.v[i] = 0; }
+#if defined(__x86_64__) && !defined(C25519_NO_IFMA)
+    if (host_has_ifma()) { h_affine(hp3_mul_by_pow_2_ifma(p, k), o); return; }
+#endif
+    h_affine(hp3_mul_by_pow_2(p, k), o);
+}
+}

@@ -36,7 +36,7 @@ def host(request):
     """Both forms of fe_mul / fe_sq (fe26.h C25519_CHAIN: independent column sums, chained carries)."""
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libfe26host%d.so" % request.param)
-    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "fe9_probe.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h")]
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "fe9_probe.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h", "host51.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DC25519_CHAIN=%d" % request.param, "-o", so, src])
     return C.CDLL(so)
@@ -294,3 +294,54 @@ def test_nine_limb_probe_products_vs_bigint(host):
         assert val(q) % P == val(a) ** 2 % P
         r2 = run(0, r, q)                                    # outputs are valid inputs
         assert val(r2) % P == val(r) * val(q) % P
+
+
+def test_ifma_doubling_chain(host):
+    """(r6) The Horner fold's doubling chain on AVX-512 IFMA (csrc/host51.h hp3_mul_by_pow_2_ifma: four field operations per vector instruction, radix 2^51 in the
+    lanes of 256-bit vectors) against the scalar 64 x 64 -> 128 form and against Python big integers (2^k P on the curve by the affine doubling law): random projective
+    points, limbs at the extremes the inputs may have (2^51 + 2^19 after a carry pass, all-ones 51-bit limbs), the identity, points of small order, 1 .. 40 and 253
+    doublings.  Skipped where the CPU has no avx512ifma (the library then runs the scalar form, which every other test exercises)."""
+    if not host.h_has_ifma():
+        pytest.skip("no avx512ifma on this CPU")
+    rng = random.Random(99)
+    d = (-121665 * pow(121666, P - 2, P)) % P
+
+    def dbl(x, y):                                   # affine doubling on -x^2 + y^2 = 1 + d x^2 y^2
+        x3 = (2 * x * y) * pow((1 + d * x * x * y * y) % P, P - 2, P) % P
+        y3 = (y * y + x * x) * pow((1 - d * x * x * y * y) % P, P - 2, P) % P
+        return x3, y3
+
+    def point():
+        while True:
+            y = rng.randrange(P)
+            u, v = (y * y - 1) % P, (d * y * y + 1) % P
+            x2 = u * pow(v, P - 2, P) % P
+            x = pow(x2, (P + 3) // 8, P)
+            if (x * x - x2) % P:
+                x = x * pow(2, (P - 1) // 4, P) % P
+            if (x * x - x2) % P == 0:
+                return x, y
+
+    def limbs(v, style):
+        v %= P
+        l = [(v >> (51 * i)) & ((1 << 51) - 1) for i in range(5)]
+        if style == 1:                                # the same element plus p, limb by limb: limbs up to 2^52 - 20 (an un-carried sum of two reduced elements)
+            pl = [(1 << 51) - 19] + [(1 << 51) - 1] * 4
+            l = [a + b for a, b in zip(l, pl)]
+        return l
+
+    cases = [(0, 1)] + [point() for _ in range(40)]
+    cases.append((0, P - 1))                          # order 2
+    cases.append((pow(2, (P - 1) // 4, P), 0))        # order 4
+    for idx, (x, y) in enumerate(cases):
+        for k in ([1, 2, 3, 5, 13, 16, 40, 253] if idx < 6 else [rng.randrange(1, 20)]):
+            z = rng.randrange(1, P) if idx else 1
+            xyz = limbs(x * z, idx & 1) + limbs(y * z, 0) + limbs(z, idx & 1)
+            arr = (C.c_uint64 * 15)(*xyz)
+            a, b = C.create_string_buffer(96), C.create_string_buffer(96)
+            host.h_pow2_scalar(arr, k, a); host.h_pow2_ifma(arr, k, b)
+            assert a.raw == b.raw, (idx, k)
+            ex, ey = x, y
+            for _ in range(k):
+                ex, ey = dbl(ex, ey)
+            assert b.raw[:32] == i2b(ex) and b.raw[32:64] == i2b(ey) and b.raw[64:] == i2b(ex * ey % P), (idx, k)
