@@ -448,11 +448,12 @@ def scale_model(w, eng, pkg, torch, dev, head_ms):
                 run()
             torch.cuda.synchronize(dev)
             shard_ms = (time.perf_counter() - t0) / k * 1e3
-        gpu_span = eng.last_kernel_ms()                 # HIP events on the launch stream around the latest call's kernels (first launch .. record written)
+        gpu_span = eng.last_kernel_ms()                 # HIP events on the launch stream around the latest call's kernels (first launch .. record written); a multi-pass
+        #                                                 call spans several stream sets: the main stream's bracket is not its span (reported as null)
         step = shard_ms - fold_ms[1] + fold_ms[N] + (out["exchange_ms_assumed"] if N > 1 else 0.0)
         if N == 1:
             step1 = step
-        out["per_rank"]["N=%d" % N] = {"terms_per_rank": per, "shard_ms_measured": shard_ms, "gpu_span_ms": gpu_span if gpu_span > 0.5 * shard_ms else None,      # (a multi-pass call spans several stream sets: the main stream's bracket is not its span) "fold_ms_measured": fold_ms[N], "predicted_step_ms": step,
+        out["per_rank"]["N=%d" % N] = {"terms_per_rank": per, "shard_ms_measured": shard_ms, "gpu_span_ms": gpu_span if gpu_span > 0.5 * shard_ms else None, "fold_ms_measured": fold_ms[N], "predicted_step_ms": step,
                                        "predicted_speedup": step1 / step, "predicted_efficiency": step1 / step / N}
     out["how"] = ("predicted_step = shard (this GPU, record + read-back + fold of one record) - fold(1) + fold(N) + exchange; strong scaling of the same 2^24 terms.  gpu_span_ms = the latest "
                   "call's kernels on the launch stream (HIP events); shard_ms_measured - gpu_span_ms = launch latency + read-back + host fold.  The wake-up from the final synchronisation "
