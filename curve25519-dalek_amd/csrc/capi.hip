@@ -182,6 +182,7 @@ static bool ctx_make_streams(c25519_ctx *ctx) {
     hipEventCreateWithFlags(&ctx->ev_rebind, hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_acc, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_pts, hipEventDisableTiming);
     for (int q = 0; q < 4; q++) hipEventCreateWithFlags(&ctx->ev_grp[q], hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->ev_split, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->ev_lists[0], hipEventDisableTiming); hipEventCreateWithFlags(&ctx->ev_lists[1], hipEventDisableTiming);
     for (int i = 0; i < c25519_ctx::RING; i++) for (int j = 0; j < c25519_ctx::RING_EV; j++) hipEventCreate(&ctx->ring[i][j]);
     // C25519_MAX_SLOTS pass slots + the context's own record (msm.hip drec)
@@ -271,6 +272,7 @@ EXPORT void c25519_ctx_destroy(c25519_ctx *ctx) {
     if (ctx->ev_rebind) hipEventDestroy(ctx->ev_rebind);
     if (ctx->ev_acc) hipEventDestroy(ctx->ev_acc);
     if (ctx->ev_pts) hipEventDestroy(ctx->ev_pts);
+    if (ctx->ev_split) hipEventDestroy(ctx->ev_split);
     for (int q = 0; q < 2; q++) if (ctx->ev_lists[q]) hipEventDestroy(ctx->ev_lists[q]);
     for (int q = 0; q < 4; q++) if (ctx->ev_grp[q]) hipEventDestroy(ctx->ev_grp[q]);
     if (ctx->s_h2d) { hipStreamSynchronize(ctx->s_h2d); hipStreamDestroy(ctx->s_h2d); }

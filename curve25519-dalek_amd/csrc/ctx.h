@@ -37,6 +37,7 @@ struct c25519_ctx {
     hipStream_t aux = nullptr;     // second stream: latency-bound side chains run beside VALU-bound kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_sort = nullptr, ev_in = nullptr, ev_z = nullptr, ev_rebind = nullptr, ev_acc = nullptr, ev_pts = nullptr;
     hipEvent_t ev_grp[4] = {nullptr, nullptr, nullptr, nullptr};   // single-pass MSM in window groups: [q] = the accumulation of group q has finished (msm.hip msm_enqueue_acc)
+    hipEvent_t ev_split = nullptr;                      // verify_batch in two halves (verify.hip): the keys' records and the basepoint's are complete on the main stream
     hipEvent_t ev_lists[2] = {nullptr, nullptr};        // multi-pass MSM: [q] = recorded when the pass with list parity q was enqueued (the accumulation before it has finished)
     void *h_msm = nullptr;                               // pinned, coherent, device-mapped: C25519_MAX_SLOTS + 1 result slots and the "published" word behind them (msm.hip publish_and_wait)
     // (r5) small calls that answer on the host: the last kernel of the small path writes the record straight into the page-locked host slot (h_msm is coherent and

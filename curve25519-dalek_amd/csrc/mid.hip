@@ -376,7 +376,10 @@ __global__ void __launch_bounds__(256) k_mid_long(const u32 *__restrict__ recs, 
         }
     }
 }
-// one lane per bucket (in the order of perm)
+// one lane per bucket (in the order of perm).  No record is prefetched across the addition: 136 VGPRs, three waves per SIMD, which is what counts once the buckets
+// outnumber the machine's lanes (from ~2^15 terms: the first version kept the next record in registers, 210 VGPRs, and took 131 us at 2^16 terms against 73 now);
+// and below, where every bucket has its lane at once, a prefetching variant (176 VGPRs, two waves) measured level at every size -- a lane's list is a chain of 8 M
+// additions at ~4 us each for a nearly lone wave, not of loads (profiles/r06_ab_mid_prefetch.txt; removed).
 template <int FMT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
                                                  msm_geom g, u32 *__restrict__ buckets) {
@@ -390,8 +393,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     const u32 len = mine ? hi - lo : 0u;
     ge_p3 acc = ge_identity();
     u32 e = len > 0 ? list[lo] : 0u;
-    // (no record prefetched across the addition: 40 registers more put the kernel at two waves per SIMD (210 VGPRs), and three waves hide the load better than
-    //  a prefetch does -- first version: 131 us at 2^16 terms against the bucket pipeline's 79, profiles/r06_timeline_mid_first.txt)
 #pragma unroll 1
     for (u32 it = 0; it < len; it++) {
         mid_rec<FMT> cur;

@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 d
 // Arithmetic: sc28.h -- radix 2^28, folding with l = 2^252 + c; per signature one 512-bit reduction (95 multiplier instructions)
 // and two 5 x 10 limb products with their reductions (95 each), against ~1200 in the 5 x 52 Montgomery form of rounds 1-2.
 __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict__ hram, const uint8_t *__restrict__ sigs, const uint8_t *__restrict__ z16,
-                                                       u64 n, int signed_z, uint8_t *__restrict__ msm_scalars, u32 *__restrict__ partial) {
+                                                       u64 n, int signed_z, uint8_t *__restrict__ msm_scalars, u32 *__restrict__ partial, int store_r = 1) {
     C25519_PRIO_CHAIN();
     __shared__ u32 red[256][10];
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,7 +247,7 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
         u32 out[8];
         sc28_to_words(hz, out);
         store8(msm_scalars, 1 + n + i, out);
-        store8(msm_scalars, 1 + i, zwords);
+        if (store_r) store8(msm_scalars, 1 + i, zwords);      // (split batches: k_z_expand has written it, and the R half's sort may be reading it)
     }
     for (int j = 0; j < 10; j++) red[threadIdx.x][j] = zs.v[j];
     __syncthreads();
@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_batch_scalars(const uint8_t *__restrict
 }
 
 // msm_scalars[0] = -(sum of the per-block partial sums) mod l: one block, strided sums then a tree
-__global__ void __launch_bounds__(256) k_bsum_finish(const u32 *__restrict__ partial, u32 nblk, uint8_t *__restrict__ msm_scalars) {
+__global__ void __launch_bounds__(256) k_bsum_finish(const u32 *__restrict__ partial, u32 nblk, uint8_t *__restrict__ msm_scalars, u64 also_at = 0) {
     C25519_PRIO_CHAIN();
     __shared__ u32 red[256][10];
     sc28 acc = sc28_zero();
@@ -290,7 +290,17 @@ __global__ void __launch_bounds__(256) k_bsum_finish(const u32 *__restrict__ par
         u32 w[8];
         sc28_to_words(sc28_neg(t), w);
         store8(msm_scalars, 0, w);
+        if (also_at) store8(msm_scalars, also_at, w);         // (split batches: B rides at the end of the A half)
     }
+}
+// msm_scalars[1 + i] = |z_i| zero-extended to 32 bytes (device z-mode: sign-magnitude z16): the R half's scalars, available as soon as the z_i are
+__global__ void __launch_bounds__(256) k_z_expand(const uint8_t *__restrict__ z16, u64 n, uint8_t *__restrict__ msm_scalars) {
+    C25519_PRIO_CHAIN();
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u32 *zw = reinterpret_cast<const u32 *>(z16) + 4 * i;
+    const u32 w[8] = {zw[0], zw[1], zw[2], zw[3] & 0x7fffffffu, 0, 0, 0, 0};
+    store8(msm_scalars, 1 + i, w);
 }
 
 hipError_t launch_hram(const uint8_t *msgs, const uint64_t *msg_off, uint64_t msgs_len, const uint8_t *sigs, const uint8_t *pks, uint64_t n, uint8_t *hram, uint32_t *flags, hipStream_t st) {
@@ -410,16 +420,17 @@ __global__ void k_add_point_counters(u32 *__restrict__ d_cnt, const u32 *__restr
 static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uint8_t *d_msgs, const uint64_t *d_msg_off, uint64_t msgs_len,
                                    const uint8_t *d_sigs, const uint8_t *d_pks, const uint8_t *d_pk_points, uint64_t n, uint32_t z_mode,
                                    const uint8_t *d_hram_pre, const uint8_t *d_z_pre, const uint32_t *d_pre_flags, const msm_geom &g, uint64_t terms, uint32_t *d_slot, hipEvent_t wait_acc,
-                                   const verify_stage *stage = nullptr, const verify_pre *pre = nullptr) {
+                                   const verify_stage *stage = nullptr, const verify_pre *pre = nullptr, c25519_ctx *split_peer = nullptr, uint32_t *d_slot_b = nullptr) {
     hipStream_t st = ctx->stream;
     const uint64_t m = 2 * n + 1;
     int32_t r;
-    if ((r = ctx_reserve(ctx, ctx->tmp_e, m * PTS_BYTES + 256))) return r;
+    const bool split = split_peer != nullptr && d_slot_b != nullptr && !d_z_pre && !stage && !pre;      // (r6) the batch in two halves: see the end of this function
+    if ((r = ctx_reserve(ctx, ctx->tmp_e, (m + 1) * PTS_BYTES + 256))) return r;      // (+ 1: split batches keep a second copy of B's record behind the keys')
     // tmp_f: hram (64n) | z16 (16n) | msm scalars (32m) | tree scratch | partial sums
     const unsigned nblk = div_up64(n, 256);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve(m * 32), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32), oP = carve((size_t)nblk * 40);
+    size_t oH = carve(n * 64), oZ = carve((n + 4) * 16), oSc = carve((m + 1) * 32), oT0 = carve((n / 4 + 2) * 32), oT1 = carve((n / 4 + 2) * 32), oP = carve((size_t)nblk * 40);
     const size_t oHr = carve(d_z_pre ? 0 : n * 32);       // h_i mod l, for the device z-tree
     if ((r = ctx_reserve(ctx, ctx->tmp_f, off))) return r;
     uint8_t *ws = (uint8_t *)ctx->tmp_f.p;
@@ -481,7 +492,12 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         HIPCHK(launch_prep_compressed_keys_and_r(d_pks, d_sigs, n, d_pts, d_cnt + 2, st));
         HIPCHK(hipEventRecord(ring[5], st));
     } else {
-        if ((r = prep_A()) || (r = prep_R())) return r;
+        if ((r = prep_A())) return r;
+        if (split) {                                       // B once more, behind the keys' records: the A half is terms n + 1 .. 2n + 1
+            launch_prep_basepoint(d_pts, 2 * n + 1, st);
+            HIPCHK(hipEventRecord(ctx->ev_split, st));
+        }
+        if ((r = prep_R())) return r;
     }
     // (A)
     if (hram_first) { }
@@ -496,6 +512,43 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         HIPCHK(hipEventRecord(ctx->ev_z, sa));
         HIPCHK(hipStreamWaitEvent(st, ctx->ev_z, 0));
         hipLaunchKernelGGL(k_apply_sign, dim3(nblk), dim3(256), 0, st, d_pts, (uint64_t)1, zz, n);
+    }
+    // (r6) TWO HALVES (round-5 verdict, item 6).  The 2n + 1 terms are two different halves: the R half's scalars are the |z_i| themselves (128 bits: 8 windows) and exist
+    // when k_zderive ends; the A half's are z_i h_i mod l (253 bits) and exist only after k_batch_scalars / k_bsum_finish.  As ONE pass the sort of everything waits for the
+    // last scalar and the accumulation for the whole sort (k_accumulate started 1.56 ms into a 2.61 ms call at 2^20 signatures: profiles/r05_verify_timeline.txt).  As two
+    // passes on the two stream sets -- the R half here, the A half (with B behind it) on the peer context -- the R half's sort and accumulation run while the A half's
+    // scalars and sort are still being made; the accumulations follow each other, each half reduces its own buckets (same layout), and the two column-sum slots are added
+    // before the one identity check (k_record_sum).  Device z-mode, single-pass batches of the bucket pipeline only.
+    // MEASURED AND NOT ADOPTED (profiles/r06_ab_verify_split.txt, bit-exact in the full verify / multi / ffi modules): 2^20 signatures 2.80 against 2.60 ms, 2^19 1.66
+    // against 1.50.  The premise does not hold: the R half cannot accumulate before R is decompressed (1.37 ms into the call: 0.33 ms of key normalisation, then 0.97 ms
+    // of decompression on the main stream), its sort beside that decompression takes 0.53 instead of 0.25 ms, and two accumulations + two reductions cost two ramp-downs.
+    // The arm stays behind VERIFY_SPLIT_MIN of the tuning build (default 0 = never) for one round.
+    if (split) {
+        c25519_ctx *pc = split_peer;
+        hipStream_t pa = pc->aux, ps = pc->stream;
+        // R half: |z_i| right behind k_zderive on the second stream; the sort follows there, the accumulation on the main stream behind the decompression of R
+        // (ev_z was recorded above, BEFORE the expansion: the sign application needs only z16; record it again behind the expansion for the A chain)
+        hipLaunchKernelGGL(k_z_expand, dim3(nblk), dim3(256), 0, sa, zz, n, msc);
+        HIPCHK(hipEventRecord(ctx->ev_z, sa));
+        // A chain on the PEER's second stream: it must not queue behind the R half's long-bucket kernels, which wait for the main stream
+        HIPCHK(hipStreamWaitEvent(pa, ctx->ev_z, 0));
+        hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, pa, hr, d_sigs, zz, n, 1, msc, partial, 0);
+        hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, pa, partial, nblk, msc, (u64)(2 * n + 1));
+        HIPCHK(hipGetLastError());
+        // the peer's main stream: behind the keys' records and B's second copy (ev_split, recorded by prep below / above) and behind the R half's accumulation (wait_acc)
+        HIPCHK(hipStreamWaitEvent(ps, ctx->ev_split, 0));
+        hipEvent_t *ring_b = pass_ring(owner, pc, 1);
+        HIPCHK(hipEventRecord(ring_b[3], ps));
+        slot_init(d_slot_b, terms, nullptr, ps, g.c);
+        ctx->solo = false; pc->solo = false;
+        if ((r = msm_enqueue(ctx, msc + 32, n, d_pts + (size_t)1 * (PTS_BYTES / 4), g, d_slot, ring, sa, wait_acc))) return r;
+        if ((r = msm_enqueue(pc, msc + 32 * (n + 1), n + 1, d_pts + (size_t)(n + 1) * (PTS_BYTES / 4), g, d_slot_b, ring_b, pa, ctx->ev_acc))) { if (ctx->err.empty()) ctx->err = pc->err; return r; }
+        // join: the caller's stream continues behind the peer's half; the two slots become one
+        HIPCHK(hipEventRecord(pc->ev_in, ps));
+        HIPCHK(hipStreamWaitEvent(st, pc->ev_in, 0));
+        launch_record_sum(d_slot, d_slot, 2, g.nwin, 1, st);
+        HIPCHK(hipGetLastError());
+        return C25519_OK;
     }
     hipLaunchKernelGGL(k_batch_scalars, dim3(nblk), dim3(256), 0, sa, hr, d_sigs, zz, n, z_mode == C25519_Z_DEVICE ? 1 : 0, msc, partial);
     // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block
@@ -658,8 +711,11 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             const uint64_t lo = (p0 + i) * per, m = std::min(per, n - lo);
             c25519_ctx *c = ps.c[(p0 + i) % ps.lanes];
             const verify_stage stage = [&](int what, hipEvent_t *ready) -> int32_t { return (*fetch)(lo, m, what, ready); };
+            // (r6) a single-pass batch of the bucket pipeline in two halves on the two stream sets (verify_pass_enqueue; A/B knob VERIFY_SPLIT_MIN, 0 = never)
+            static const uint64_t split_min = (uint64_t)C25519_KNOB_LL("VERIFY_SPLIT_MIN", 0);      // MEASURED AND NOT ADOPTED (profiles/r06_ab_verify_split.txt): 2.80 against 2.60 ms at 2^20
+            c25519_ctx *split_peer = (passes == 1 && !fetch && split_min && m >= split_min && !msm_mid_serves(2 * m + 1, g, true) && 2 * m + 1 > msm_small_max()) ? ctx_peer(ctx) : nullptr;
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
-                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr);
+                                    nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr, nullptr, split_peer, split_peer ? dslot(ctx, 1) : nullptr);
             if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
             if (n >= (1ull << 16)) ctx->coarse_wait = c->ev_acc;
