@@ -168,4 +168,46 @@ hipError_t launch_raw_to_p32(const uint8_t *in_raw, u64 n, uint32_t *scratch, hi
     return hipGetLastError();
 }
 
+
+// (r5; in this translation unit since r6: a lone wave's chain of 252 dependent squarings wants the ten independent column sums of fe_sq here -- a multiply-add every
+// ~6 cycles -- not the chained carries of kernels.hip, one dependent chain at ~12 cycles per multiply-add: profiles/r06_small_call_phases.txt)
+// verify_batch of at most 128 signatures: the keys A_i and the R_i as ONE block that needs nothing cleared before it and no second launch for B: record 0 = the basepoint, and
+// bad[0] / bad[1] (keys / R_i that do not decode) are WRITTEN, not counted into -- what the directly published small path of verify_batch runs while the host
+// hashes (verify.hip verify_batch_small_host).  pks / sigs may be page-locked host memory read in place (every byte is read once).
+__global__ void __launch_bounds__(256) k_prep_small_verify(const uint8_t *__restrict__ pks, const uint8_t *__restrict__ pk_points, const uint8_t *__restrict__ sigs, u32 n,
+                                                           u32 *__restrict__ pts, u32 *__restrict__ bad) {
+    const u32 i = threadIdx.x;
+    int bad_a = 0, bad_r = 0;
+    if (i < 2 * n) {
+        const bool is_r = i >= n;
+        const u32 j = is_r ? i - n : i;
+        if (!is_r && pk_points) {
+            // the key's cached point (VerifyingKey, verifying.rs:64-71; any Z): to affine -- one inversion, a chain as long as the decompression beside it
+            feT X = raw160_fe(pk_points, j, 0), Y = raw160_fe(pk_points, j, 1);
+            if (!raw160_z_is_one(pk_points, j)) {
+                const feT zi = fe_invert(raw160_fe(pk_points, j, 2));
+                X = fe_mul(X, zi); Y = fe_mul(Y, zi);
+            }
+            pts_store(pts, (u64)n + 1 + j, X, Y);
+        } else {
+            u32 w[8];
+            load8(is_r ? sigs : pks, is_r ? 2 * (u64)j : (u64)j, w);
+            ge_p3 P;
+            const bool ok = ge_decompress(P, w);
+            pts_store(pts, (u64)(is_r ? 1 : n + 1) + j, P.X, P.Y);
+            bad_a = !ok && !is_r; bad_r = !ok && is_r;
+        }
+    }
+    if (i == 255) { const ge_p3 B = ge_basepoint(); pts_store(pts, 0, B.X, B.Y); }       // (the last lane: idle unless n = 128)
+    const int ca = __syncthreads_count(bad_a), cr = __syncthreads_count(bad_r);
+    if (i == 0) { bad[0] = (u32)ca; bad[1] = (u32)cr; }
+}
+
+hipError_t launch_prep_small_verify(const uint8_t *pks, const uint8_t *pk_points, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad, hipStream_t st) {
+    if (n == 0 || n > 128) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_prep_small_verify, dim3(1), dim3(256), 0, st, pks, pk_points, sigs, (u32)n, pts, bad);
+    return hipGetLastError();
+}
+
+
 }  // namespace c25519

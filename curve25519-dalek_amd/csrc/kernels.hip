@@ -706,37 +706,8 @@ __global__ void __launch_bounds__(256) k_prep_compressed_keys_and_r(const uint8_
     if (!ok) atomicAdd(bad_count + (is_r ? 1 : 0), 1u);
 }
 
-// (r5) the same for at most 128 signatures, as ONE block that needs nothing cleared before it and no second launch for B: record 0 = the basepoint, and
-// bad[0] / bad[1] (keys / R_i that do not decode) are WRITTEN, not counted into -- what the directly published small path of verify_batch runs while the host
-// hashes (verify.hip verify_batch_small_host).  pks / sigs may be page-locked host memory read in place (every byte is read once).
-__global__ void __launch_bounds__(256) k_prep_small_verify(const uint8_t *__restrict__ pks, const uint8_t *__restrict__ pk_points, const uint8_t *__restrict__ sigs, u32 n,
-                                                           u32 *__restrict__ pts, u32 *__restrict__ bad) {
-    const u32 i = threadIdx.x;
-    int bad_a = 0, bad_r = 0;
-    if (i < 2 * n) {
-        const bool is_r = i >= n;
-        const u32 j = is_r ? i - n : i;
-        if (!is_r && pk_points) {
-            // the key's cached point (VerifyingKey, verifying.rs:64-71; any Z): to affine -- one inversion, a chain as long as the decompression beside it
-            feT X = raw160_fe(pk_points, j, 0), Y = raw160_fe(pk_points, j, 1);
-            if (!raw160_z_is_one(pk_points, j)) {
-                const feT zi = fe_invert(raw160_fe(pk_points, j, 2));
-                X = fe_mul(X, zi); Y = fe_mul(Y, zi);
-            }
-            pts_store(pts, (u64)n + 1 + j, X, Y);
-        } else {
-            u32 w[8];
-            load8(is_r ? sigs : pks, is_r ? 2 * (u64)j : (u64)j, w);
-            ge_p3 P;
-            const bool ok = ge_decompress(P, w);
-            pts_store(pts, (u64)(is_r ? 1 : n + 1) + j, P.X, P.Y);
-            bad_a = !ok && !is_r; bad_r = !ok && is_r;
-        }
-    }
-    if (i == 255) { const ge_p3 B = ge_basepoint(); pts_store(pts, 0, B.X, B.Y); }       // (the last lane: idle unless n = 128)
-    const int ca = __syncthreads_count(bad_a), cr = __syncthreads_count(bad_r);
-    if (i == 0) { bad[0] = (u32)ca; bad[1] = (u32)cr; }
-}
+// (k_prep_small_verify -- the same for at most 128 signatures in ONE block -- lives in finish.hip since round 6: a lone wave's 252-squaring chain wants the ten-column
+//  products of that translation unit, not the chained ones of this)
 
 // ================================================================================================
 // launchers
@@ -745,12 +716,6 @@ static inline unsigned div_up(u64 a, u64 b) { return (unsigned)((a + b - 1) / b)
 hipError_t launch_prep_compressed_keys_and_r(const uint8_t *pks, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad_count, hipStream_t st) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(k_prep_compressed_keys_and_r, dim3(div_up(2 * n, 256)), dim3(256), 0, st, pks, sigs, n, pts, bad_count);
-    return hipGetLastError();
-}
-
-hipError_t launch_prep_small_verify(const uint8_t *pks, const uint8_t *pk_points, const uint8_t *sigs, uint64_t n, uint32_t *pts, uint32_t *bad, hipStream_t st) {
-    if (n == 0 || n > 128) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_prep_small_verify, dim3(1), dim3(256), 0, st, pks, pk_points, sigs, (u32)n, pts, bad);
     return hipGetLastError();
 }
 

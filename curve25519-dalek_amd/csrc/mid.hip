@@ -321,6 +321,23 @@ template <> struct mid_rec<1> {
     }
     __device__ __forceinline__ ge_p3 add_to(const ge_p3 &acc, bool neg) const { return mid_madd(acc, pts_from_q(q), neg); }
 };
+// a + b (complete addition, edwards.rs:795-800) with the ten-column products (fe26x.h fe_mul_cols_g): the shuffle tree of k_mid_long is a chain of complete additions
+// on a lone wave, where a product with ten independent column sums issues a multiply-add every ~6 cycles and the chained form of this translation unit one every ~12
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ ge_p3 mid_add_cols(const ge_p3 &p, const ge_p3 &q) {
+    const feT T2d = fe_mul_cols_g(q.T, fe_d2());
+    const feT PP = fe_mul_cols_g(fe_add(p.Y, p.X), fe_add(q.Y, q.X)), MM = fe_mul_cols_g(fe_sub(p.Y, p.X), fe_sub(q.Y, q.X));
+    const feT TT = fe_mul_cols_g(p.T, T2d), ZZ = fe_mul_cols_g(p.Z, q.Z);
+    const feL ZZ2 = fe_twice(ZZ);
+    const feL X = fe_sub(PP, MM), Y = fe_add(PP, MM), Z = fe_add_lt(ZZ2, TT);
+    const feW T = fe_sub_w(ZZ2, TT);
+    ge_p3 r;
+    r.X = fe_mul_cols_g(T, X); r.Y = fe_mul_cols_g(feW(Z), Y); r.Z = fe_mul_cols_g(T, Z); r.T = fe_mul_cols_g(feW(X), Y);
+    return r;
+}
+#else
+C25519_HD ge_p3 mid_add_cols(const ge_p3 &p, const ge_p3 &q) { return ge_add(p, q); }
+#endif
 __device__ __forceinline__ ge_p3 mid_wave_sum(ge_p3 acc) {      // complete additions across the 64 lanes; lane 0 ends with the total
 #pragma unroll 1
     for (int off = 32; off > 0; off >>= 1) {
@@ -329,7 +346,7 @@ __device__ __forceinline__ ge_p3 mid_wave_sum(ge_p3 acc) {      // complete addi
             o.X.v[i] = __shfl_down(acc.X.v[i], off, 64); o.Y.v[i] = __shfl_down(acc.Y.v[i], off, 64);
             o.Z.v[i] = __shfl_down(acc.Z.v[i], off, 64); o.T.v[i] = __shfl_down(acc.T.v[i], off, 64);
         }
-        acc = ge_add(acc, o);
+        acc = mid_add_cols(acc, o);
     }
     return acc;
 }
@@ -368,7 +385,7 @@ __global__ void __launch_bounds__(256) k_mid_long(const u32 *__restrict__ recs, 
 #pragma unroll 1
             for (u32 sg = lane; sg < it.nseg && it.first + sg < max_items; sg += 64) {
                 const ge_p3 v = p40_load(seg_sums, it.first + sg);
-                tot = any ? ge_add(tot, v) : v;
+                tot = any ? mid_add_cols(tot, v) : v;
                 any = true;
             }
             if (it.nseg > 1) tot = mid_wave_sum(tot);

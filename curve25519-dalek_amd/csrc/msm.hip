@@ -1112,6 +1112,19 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     }
     ctx->want_direct = false;
     ctx->no_direct_once = false;
+    if (ctx->direct_seq && !mid) {
+        // (r6) the directly published small call, lean: its two kernels and the bracket of the call -- no phase ring, no fork to the second stream, no pass bookkeeping
+        // (eight event records and a cross-stream wait that a 75 us call spent ~8 us of host time on; c25519_last_call_phase_ms answers -1 for such a call)
+        msm_geom gs;
+        msm_layout(n, gs);
+        ctx->last_passes.clear();
+        ctx->solo = true;
+        ctx->coarse_wait = nullptr;
+        ctx->kname[0] = "c25519::k_small_cols (tables of multiples by repeated addition, one lane per (window, term))";
+        if ((r = msm_small_enqueue(ctx, d_scalars, d_points, 0, n, gs, d_record, ctx->stream))) { ctx->direct_seq = 0; return r; }
+        HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+        return C25519_OK;
+    }
     if (mid) {
         ctx->last_passes.clear();
         ctx->solo = true;

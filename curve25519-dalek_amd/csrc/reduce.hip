@@ -20,7 +20,9 @@
 #include <string>
 // chained-carry products (fe26.h): 92 VGPRs instead of 172 with the ten-column form -- five blocks per compute unit, i.e. all 1088 segment
 // blocks of a 2^21-term pass resident at once (with two per CU the chain would run twice)
+#ifndef C25519_CHAIN
 #define C25519_CHAIN 1
+#endif
 #include "../../include/c25519_hip.h"
 #include "devio.h"
 #include "ctx.h"

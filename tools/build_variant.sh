@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -Wall -Wno
 mkdir -p ab
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o ab/${src%.hip}_$name.o
 objs=""
-for o in kernels finish capi msm msm_sort msm_sort_matrix verify small reduce single extra accum diag; do
+for o in kernels finish capi msm msm_sort msm_sort_matrix verify small reduce single extra accum mid diag; do
   if [ "$o" = "${src%.hip}" ]; then objs="$objs ab/${o}_$name.o"; else objs="$objs tune/$o.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/libc25519hip_$name.so $objs
