@@ -69,6 +69,9 @@ __device__ __forceinline__ ge_p3 p3_from_aniels(const ge_aniels &a) {
     return p;
 }
 
+// (Measured and dropped in round 6, profiles/r06_small_call_phases.txt: 5 .. 16 terms as four groups of four in ONE 1024-thread block, the groups' sums added through LDS, so
+//  that such a call has no k_small_reduce launch -- 128 VGPRs + 18 spilled words at sixteen waves per compute unit: a 16-term call 124 against 70 us, verify_batch of 2 .. 7
+//  signatures 192 against 146 - 150 us.  Four blocks on four compute units and a second launch are the faster form.)
 // (r5) DIRECT publication of a small call's record (small_direct.on): the kernels need no cleared slot before them -- the "bit 255" flag travels as one word
 // per block (blockflags) instead of an atomicOr into the slot -- and the LAST block to finish writes the 16 header / counter words and then releases `seq` into the
 // host's sequence word, with the column sums already written to `cols` in page-locked, coherent host memory: the host polls that word instead of launching a
