@@ -206,6 +206,11 @@ class Workload:
         if self.name in ("msm", "verify"):
             # the latest call's passes (the timed steps are identical; the ring keeps per-pass events)
             acc_ms, passes = eng.last_call_phase_ms(0)
+            if passes == 0 or acc_ms < 0:
+                # the small and the mid path record no per-kernel events (an event record between two kernels is a ~5 us gap on the GPU): the whole call's span instead
+                span = eng.last_kernel_ms()
+                return {"passes_per_step": 1, "k_accumulate_ms_per_launch": None, "reduce_tail_ms_per_pass": None, "pass_span_ms": span, "dominant_ms": span,
+                        "dominant_kernel": "(whole call: " + kname(0) + " and the kernels around it)"}
             tail_ms, _ = eng.last_call_phase_ms(1)
             pass_ms, _ = eng.last_call_phase_ms(2)
             out = {"passes_per_step": passes, "k_accumulate_ms_per_launch": acc_ms / passes, "reduce_tail_ms_per_pass": tail_ms / passes,

@@ -318,7 +318,14 @@ static float ring_phase_ms(hipEvent_t *ev, int phase, uint8_t kind) {
     if (phase < 0 || phase > 3) return -1.f;
     // events 3..5 are only recorded by MSM (kind 1: phase 2) and verify_batch (kind 2: phases 2 and 3) passes; a ring entry
     // last written by another kind of call would report the stale events of an older pass
-    if ((phase == 2 && kind == 0) || (phase == 3 && kind != 2)) return -1.f;
+    if ((phase == 2 && kind == 0) || (phase == 3 && kind != 2 && kind != 3)) return -1.f;
+    if (kind >= 3 && phase != 3) return -1.f;                // (r6) a pass whose MSM took the mid path: no per-kernel events were recorded for it (msm.hip msm_enqueue)
+    if (kind == 3) {                                          // ... its decompression bracket (events 4 -> 5) is there; there is no event 2 of this call to wait for
+        float ms3 = -1.f;
+        if (hipEventSynchronize(ev[5]) != hipSuccess) return -1.f;
+        if (hipEventElapsedTime(&ms3, ev[4], ev[5]) != hipSuccess) return -1.f;
+        return ms3;
+    }
     float ms = -1.f;
     if (hipEventSynchronize(ev[2]) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, ev[from[phase]], ev[to[phase]]) != hipSuccess) return -1.f;

@@ -28,7 +28,7 @@ struct c25519_ctx {
     // decompression of R}
     static const int RING = 64, RING_EV = 6;
     hipEvent_t ring[RING][RING_EV] = {};
-    uint8_t ring_kind[RING] = {};      // who recorded the entry: 0 a per-item call (events 0..2), 1 an MSM pass (0..3), 2 a verify_batch pass (0..5)
+    uint8_t ring_kind[RING] = {};      // who recorded the entry: 0 a per-item call (events 0..2), 1 an MSM pass (0..3), 2 a verify_batch pass (0..5), 3 / 4 a verify_batch / MSM pass whose MSM took the mid path (no events 0..2)
     uint64_t ncalls = 0;
     std::vector<std::pair<c25519_ctx *, int>> last_passes;   // (context, ring index) of every pass of the latest MSM / verify_batch call
     uint32_t *d_table = nullptr;   // fixed-base table of algorithm `w` (LDS window / comb tables: canonical words; radix-2^C: limb records)

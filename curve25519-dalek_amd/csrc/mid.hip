@@ -523,8 +523,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
         if (!beside) hipLaunchKernelGGL(k_mid_long<1>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
     }
     if (beside) HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-    HIPCHK(hipEventRecord(ctx->ev_acc, st));
-    if (ring) HIPCHK(hipEventRecord(ring[1], st));
+    if (ring) { HIPCHK(hipEventRecord(ctx->ev_acc, st)); HIPCHK(hipEventRecord(ring[1], st)); }
     reduce_publish pub = {0, nullptr, 0, (uint32_t)terms, (uint32_t)(terms >> 32), (uint32_t)g.c, hdr};
     uint32_t *out = d_slot;
     if (ctx->direct_seq) {

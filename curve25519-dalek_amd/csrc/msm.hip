@@ -648,7 +648,13 @@ int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const
             HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
             HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
         }
-        return msm_mid_enqueue(ctx, d_scalars, d_pts, 1, n, g, d_slot, 0, n, ring);
+        // (no per-kernel events here either -- each is a ~5 us gap between two kernels of a chain that is all critical path: the ring entry of the caller (a verify_batch pass)
+        //  is marked so that the accumulation / reduction phases of this call answer -1 instead of reading events of an older one; its own phases stay)
+        if (ring) {
+            const int idx = (int)((hipEvent_t(*)[c25519_ctx::RING_EV])ring - ctx->ring);
+            if (idx >= 0 && idx < c25519_ctx::RING) ctx->ring_kind[idx] = (uint8_t)(ctx->ring_kind[idx] == 2 ? 3 : 4);      // 3: verify pass without MSM events, 4: MSM pass without them
+        }
+        return msm_mid_enqueue(ctx, d_scalars, d_pts, 1, n, g, d_slot, 0, n, nullptr);
     }
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);
@@ -1129,13 +1135,14 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
         ctx->last_passes.clear();
         ctx->solo = true;
         ctx->coarse_wait = nullptr;
-        hipEvent_t *ring = pass_ring(ctx, ctx, 1);
+        // (no phase ring for the MSM's own mid-size calls: an event record between two kernels is a ~5 us gap on the GPU -- the lean small path got 30 us of GPU span
+        //  back from eight of them; c25519_last_call_phase_ms answers -1, c25519_last_kernel_ms still brackets the call)
+        hipEvent_t *ring = nullptr;
         if (fetch) {
             hipEvent_t in_ev = nullptr;
             if ((r = (*fetch)(0, n, &in_ev))) { ctx->direct_seq = 0; return r; }
             HIPCHK(hipStreamWaitEvent(ctx->stream, in_ev, 0));
         }
-        HIPCHK(hipEventRecord(ring[3], ctx->stream));
         if (in_fmt == C25519_FMT_RAW160) r = msm_mid_enqueue(ctx, d_scalars, d_points, 0, n, g, d_record, 1, n, ring);
         else {
             // encodings: the slot first (the decompression counts what does not decode into it), then the records, then the pass over them
