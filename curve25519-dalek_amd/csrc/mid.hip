@@ -1,4 +1,4 @@
-// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^17 terms in SEVEN short launches, all but one on ONE stream.
+// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in SEVEN short launches, all but one on ONE stream.
 //
 // Reference: the same algorithm as msm.hip -- backend/serial/scalar_mul/pippenger.rs:67-160 (signed digits, buckets, running-sum reduction, Horner fold), for the sizes
 // where the reference's heaviest real callers live (edwards.rs:1002-1031 vartime_multiscalar_mul of a Bulletproofs verification; ed25519-dalek/src/batch.rs:225-244
@@ -426,9 +426,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------------------------------------------------
 // upper end of the path (A/B knob MSM_MID_MAX of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5)
-// upper ends of the path (A/B knobs of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5): raw points up to 2^17 terms (at 2^18 the two
-// paths are level: profiles/r06_ab_mid_knobs.txt); prepared records -- verify_batch's 2n + 1 terms, whose sort is a third of the bucket pipeline's call -- up to 2^18 + 1
-uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 17); return v; }
+// upper ends of the path (A/B knobs of the tuning build; 0 = off: the bucket pipeline from 12 288 terms as in round 5): raw points up to 2^18 terms (200 000 terms 0.47 against 0.54 ms, 2^18 0.57 against 0.58, 400 000
+// 0.78 against 0.71: profiles/r06_ab_mid_upper_end.txt); prepared records -- verify_batch's 2n + 1 terms, whose sort is a third of the bucket pipeline's call -- up to 2^18 + 1
+uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 18); return v; }
 static uint64_t msm_mid_max_records() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX_RECORDS", (1 << 18) + 1); return v; }
 bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
     return n > msm_small_max() && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1;
@@ -480,7 +480,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
     // k_prep_raw2) makes affine records on this stream WHILE the digits and the sort run on the second one, and the accumulation is the bucket pipeline's
     // k_accumulate (7 M mixed additions, wave-cooperative gathers): its 130 us at 2^18 terms hide behind the sort, and the accumulation of 2^18 terms is
     // throughput, not latency
-    static const uint64_t proj_max = (uint64_t)C25519_KNOB_LL("MID_PROJ_MAX", 1 << 17);      // (profiles/r06_ab_mid_knobs.txt: 2^16 terms 0.318 against 0.371 ms, 2^17 0.388 against 0.440)
+    static const uint64_t proj_max = (uint64_t)C25519_KNOB_LL("MID_PROJ_MAX", 1 << 18);      // (profiles/r06_ab_mid_knobs.txt: 2^16 terms 0.318 against 0.371 ms, 2^17 0.388 against 0.440; r06_ab_mid_upper_end.txt: 2^18 0.572 against 0.618)
     const bool proj = src_fmt == 0 && n <= proj_max, norm = src_fmt == 0 && !proj;
     hipStream_t ss = st;                                            // the stream of the digits and the sort
     if (src_fmt == 0 && (r = ctx_reserve(ctx, ctx->tmp_e, n * 160 + 256))) return r;

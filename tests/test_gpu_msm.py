@@ -508,7 +508,7 @@ def _sum_xy(x, y):
     return sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(x, y)) % L
 
 
-@pytest.mark.parametrize("n", [12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072])
+@pytest.mark.parametrize("n", [12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072, 200003, 262144])
 def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     """pippenger.rs:67-160 through the mid path at every kind of size it serves (rows of the digit matrix padded / not padded to eight terms, every window width 12 .. 15,
     both ends of the range): P_i = y_i B with independent x_i, so the expected point is (sum x_i y_i) B from the ORACLE's fixed-base multiplication; raw points with
@@ -526,7 +526,7 @@ def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     assert st == 0 and got == want
     st, got = eng.msm_vartime(x, raw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == want
-    if n in (12288, 16391, 65536, 131072):
+    if n in (12288, 16391, 65536, 131072, 262144):
         enc = eng.compress_batch(raw)
         st, got = eng.msm_vartime_t(dx, torch.from_numpy(enc).cuda(), in_fmt=0, out_fmt=0)
         assert st == 0 and got == want
@@ -597,8 +597,8 @@ def test_mid_path_flags_records_and_fold(eng, orc):
     z = torch.zeros_like(dx)
     st, got = eng.msm_vartime_t(z, dr, in_fmt=2, out_fmt=0)
     assert st == 0 and got == orc.ed_compress(orc.ed_mul_base(i2b(0)))
-    # records: shards of 300 (small path), 20 011 - 300 - 250 000 ... the mid path, and 250 000 terms (bucket pipeline), folded once
-    m = 250000
+    # records: shards of 300 (small path), 20 011 - 300 terms (the mid path) and 300 000 terms (bucket pipeline), folded once
+    m = 300000
     x2 = util.rand_scalars(33, m); y2 = util.rand_scalars(34, m)
     raw2 = eng.mul_base_batch(y2, out_fmt=2)
     recs = [eng.msm_partial_record_t(dx[:300], dr[:300]), eng.msm_partial_record_t(dx[300:], dr[300:]),
