@@ -125,5 +125,6 @@ def test_msm_window_layout_recomposes_every_scalar():
                 total += d << pos[k]
             assert total == s
     # the small path's 5- and 6-bit windows up to 12 287 terms (round 5; rounds 1-4 also used 7 .. 11 bits there), then the bucket pipeline's: wider than
-    # log2 n - 4 in the latency-bound mid range, log2 n - 4 from 2^20 terms (msm.hip pick_window)
-    assert seen_c == {5, 6, 12, 13, 14, 15, 16, 17}
+    # log2 n - 4 in the latency-bound mid range, log2 n - 4 from 2^20 terms (msm.hip pick_window); round 6 moved 12 288 .. 16 383 terms from 12- to
+    # 13-bit windows (profiles/r06_ab_mid_window.txt), so no default layout is 12 bits wide any more
+    assert seen_c == {5, 6, 13, 14, 15, 16, 17}
