@@ -10,6 +10,8 @@
 #include "devio.h"
 #include "msm_internal.h"
 #include "fe26x.h"
+#include "msm_sort.h"
+#include "mid_long.h"
 
 namespace c25519 {
 
@@ -36,10 +38,10 @@ namespace c25519 {
 #ifndef C25519_ACC_WAVES
 #define C25519_ACC_WAVES 3       // A/B arm (profiles/r04_ab_accumulate_occupancy.txt): 2 leaves a third of every SIMD's registers to other kernels
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C25519_ACC_WAVES, C25519_ACC_WAVES)))
-k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
-             const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets, int cont) {
-    const u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+// (the body: `block` is the block's index among the bucket blocks, `stage` the block's 32 KB of LDS)
+__device__ __forceinline__ void accumulate_body(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
+             const u32 *__restrict__ perm, u64 count, u64 n, const msm_geom &g, u32 *__restrict__ buckets, int cont, u32 block, uint4 *stage) {
+    const u64 tid = (u64)block * blockDim.x + threadIdx.x;
     const bool in_range = tid < count;                     // every lane of a wave keeps loading for the others
     const u64 gid = in_range ? perm[tid] : 0;
     const int k = (int)(gid / g.half), b = (int)(gid % g.half);
@@ -48,7 +50,6 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
     const u32 *list = sorted + (u64)k * n;
     // cont: the bucket sums of the previous pass on this stream set are the starting point (one bucket reduction per call
     // instead of one per pass: msm.hip msm_record_enqueue)
-    __shared__ uint4 stage[(256 / 64) * 8 * 64];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     const u32 lane = threadIdx.x & 63u;
@@ -95,6 +96,28 @@ k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const 
     if (!mine) return;
     p40_store(buckets, gid, acc);
 }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C25519_ACC_WAVES, C25519_ACC_WAVES)))
+k_accumulate(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
+             const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets, int cont) {
+    __shared__ uint4 stage[(256 / 64) * 8 * 64];
+    accumulate_body(pts, sorted, base, perm, count, n, g, buckets, cont, blockIdx.x, stage);
+}
+// (r6) The mid path's accumulation of prepared records (mid.hip: verify_batch of 2^13 .. 2^17 signatures): the same bucket lanes, and IN FRONT of them L.blocks blocks
+// whose waves fold the over-long lists (mid_long.h).  One launch instead of k_accumulate on the main stream with k_mid_long beside it on the second: the two
+// cross-stream hand-overs around that pair were 7 + 12 us of a 460 us call (profiles/r06_timeline_mid_verify_2p14.txt), and the long lists -- the call's longest
+// chains -- are dispatched first.
+struct acc_long_args { const mid_item *items; const u32 *counters; u32 *seg_sums; u32 *long_done; u32 max_items, blocks; };
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C25519_ACC_WAVES, C25519_ACC_WAVES)))
+k_accumulate_long(const u32 *__restrict__ pts, const u32 *__restrict__ sorted, const u32 *__restrict__ base,
+                  const u32 *__restrict__ perm, u64 count, u64 n, msm_geom g, u32 *__restrict__ buckets, acc_long_args L) {
+    __shared__ uint4 stage[(256 / 64) * 8 * 64];
+    if (blockIdx.x < L.blocks) {
+        C25519_PRIO_LONG();
+        mid_long_body<1>(pts, sorted, n, g, buckets, L.max_items, L.items, L.counters, L.seg_sums, L.long_done, blockIdx.x * 4u + (threadIdx.x >> 6), L.blocks * 4u);
+        return;
+    }
+    accumulate_body(pts, sorted, base, perm, count, n, g, buckets, 0, blockIdx.x - L.blocks, stage);
+}
 
 }  // namespace c25519
 
@@ -102,4 +125,11 @@ const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const
     using namespace c25519;
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, pts, sorted, base, perm, count, n, g, buckets, cont);
     return "c25519::k_accumulate (lockstep field products, wave-cooperative gather)";
+}
+const char *launch_accumulate_long(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets,
+                                   const void *items, const uint32_t *counters, uint32_t *seg_sums, uint32_t *long_done, uint32_t max_items, uint32_t long_blocks, hipStream_t st) {
+    using namespace c25519;
+    acc_long_args L = {(const mid_item *)items, counters, seg_sums, long_done, max_items, long_blocks};
+    hipLaunchKernelGGL(k_accumulate_long, dim3((unsigned)((count + 255) / 256) + long_blocks), dim3(256), 0, st, pts, sorted, base, perm, count, n, g, buckets, L);
+    return "c25519::k_accumulate_long (mid path: bucket lanes of k_accumulate behind the blocks of the over-long lists)";
 }

@@ -201,7 +201,7 @@ __global__ void k_prep_basepoint(u32 *pts, u64 dst) {
 
 // long list alone (skewed inputs: e.g. the +1 carry digit of every unsigned 128-bit z_i in verify_batch lands
 // ~n/2 terms in ONE bucket; identical scalars do the same in every window).
-// (k_accumulate lives in accum.hip, built once per carry form of fe_mul: launch_accumulate_c0 / _c1)
+// (k_accumulate lives in accum.hip: the chained-carry products in lockstep)
 // ---- long buckets -------------------------------------------------------------------------------------
 // work list (made by k_order_hist): one item per (long bucket, segment of LONG_SEG entries); item = {gid, lo, hi, slot}
 // sum across the 64 lanes of a wave (complete additions; lane 0 ends with the total)
@@ -643,11 +643,11 @@ static int32_t msm_small_pass(c25519_ctx *ctx, const uint8_t *d_scalars, const v
     return C25519_OK;
 }
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream, hipEvent_t wait_acc) {
+                    hipStream_t sort_stream, hipEvent_t wait_acc, const mid_run *run) {
     if (n <= msm_small_max() && g.half <= 64) return msm_small_pass(ctx, d_scalars, d_pts, 1, n, g, d_slot, ring, sort_stream, wait_acc);   // (g.half: the layout may belong to larger sibling passes)
     if (ctx->solo && !wait_acc && msm_mid_serves(n, g, true)) {          // (r6) a single pass of 12 288 .. 2^18 terms over prepared records: the mid path (mid.hip), on the main stream
         hipStream_t st = ctx->stream;
-        if (sort_stream && sort_stream != st) {                      // (what the caller put on the second stream -- verify_batch: the batch scalars -- comes first)
+        if (!run && sort_stream && sort_stream != st) {              // (what the caller put on the second stream -- verify_batch: the batch scalars -- comes first)
             HIPCHK(hipEventRecord(ctx->ev_sort, sort_stream));
             HIPCHK(hipStreamWaitEvent(st, ctx->ev_sort, 0));
         }
@@ -657,7 +657,7 @@ int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const
             const int idx = (int)((hipEvent_t(*)[c25519_ctx::RING_EV])ring - ctx->ring);
             if (idx >= 0 && idx < c25519_ctx::RING) ctx->ring_kind[idx] = (uint8_t)(ctx->ring_kind[idx] == 2 ? 3 : 4);      // 3: verify pass without MSM events, 4: MSM pass without them
         }
-        return msm_mid_enqueue(ctx, d_scalars, d_pts, 1, n, g, d_slot, 0, n, nullptr);
+        return msm_mid_enqueue(ctx, d_scalars, d_pts, 1, n, g, d_slot, 0, n, nullptr, run);
     }
     msm_plan pl;
     int32_t r = msm_enqueue_sort(ctx, d_scalars, n, g, d_slot, sort_stream, pl);

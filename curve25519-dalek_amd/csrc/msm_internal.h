@@ -85,9 +85,10 @@ struct msm_matrix_sort_args {
 int32_t msm_matrix_sort_enqueue(c25519_ctx *ctx, const c25519::msm_geom &g, const c25519::msm_merged *md, msm_plan &pl, const msm_matrix_sort_args &a, hipStream_t st);
 int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont = false, bool reduce = true,
                         const uint32_t *d_bad_sticky = nullptr);
-// sort + accumulate + reduce of one pass over prepared records; inputs of at most msm_small_max() terms take the small path
+struct mid_run;
+// sort + accumulate + reduce of one pass over prepared records; inputs of at most msm_small_max() terms take the small path (run: see msm_mid_enqueue; honoured by the mid path only)
 int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const uint32_t *d_pts, const c25519::msm_geom &g, uint32_t *d_slot, hipEvent_t *ring,
-                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr);
+                    hipStream_t sort_stream, hipEvent_t wait_acc = nullptr, const struct mid_run *run = nullptr);
 // the whole MSM of at most msm_small_max() terms in two launches, column sums of the layout g to d_slot (small.hip).  src_fmt: 0 = raw 160-byte points,
 // 1 = affine Niels records (128 bytes); flags: the slot's counters (bit 255 of a scalar is ORed into flags[0])
 int32_t msm_small_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *d_points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, hipStream_t st);
@@ -109,17 +110,28 @@ void msm_set_groups(c25519::msm_geom &g, int groups, int last);
 // (r6) the mid path (mid.hip): 12 288 .. msm_mid_max() terms in four launches on one stream.  reduce_publish: what the fused bucket reduction (reduce.hip
 // k_reduce_b4pub) does once its last window is through -- hdr: write the record header (terms, width; the MSM) or leave the slot's own (verify_batch: k_slot_init made it);
 // on: the columns went to the context's page-locked host slot, release `seq` into the host's sequence word
-namespace c25519 { struct reduce_publish { int on; uint32_t *host_flag; uint32_t seq, terms_lo, terms_hi, c; int hdr; }; }
+// dev_flags (hdr 0 and on): the counters of the DEVICE slot (k_slot_init's header, what the hash and decompression kernels counted) -- copied into the published record
+namespace c25519 { struct reduce_publish { int on; uint32_t *host_flag; uint32_t seq, terms_lo, terms_hi, c; int hdr; const uint32_t *dev_flags; }; }
 void launch_bucket_reduce_pub(const uint32_t *buckets, const c25519::msm_geom &g, int nseg, uint32_t *SW, uint32_t *out, const uint32_t *blockflags, int nflags, uint32_t *done_cnt,
                               const c25519::reduce_publish &pub, hipStream_t st);
 void launch_order_place(const uint32_t *totals, uint64_t nb, const uint32_t *ord_hist, uint32_t *ord_cursor, uint32_t *perm, const c25519::msm_geom &g, hipStream_t st);
 uint64_t msm_mid_max();
 bool msm_mid_serves(uint64_t n, const c25519::msm_geom &g, bool prepared);      // prepared: the records exist (a decompression made them)
-int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring);
+// run (may be null; prepared records only): the pass runs on run->stream instead of the context's main stream (verify_batch: the stream its scalars were made on -- no
+// hand-over in front of the digits), waits for run->recs_ready (the records, made on the other stream) only in front of the accumulation, and negates there the
+// records sign_first .. sign_first + sign_count - 1 whose sign_z16 entry (16 bytes each, bit 127) is set (verify.hip k_apply_sign: the sign of the device z-mode's z_i);
+// the context's main stream continues behind the pass
+struct mid_run { hipStream_t stream; hipEvent_t recs_ready; const uint8_t *sign_z16; uint64_t sign_first, sign_count; };
+int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *points, int src_fmt, uint64_t n, const c25519::msm_geom &g, uint32_t *d_slot, int hdr, uint64_t terms, hipEvent_t *ring,
+                        const mid_run *run = nullptr);
+void launch_apply_sign(uint32_t *pts, uint64_t dst0, const uint8_t *z16, uint64_t n, hipStream_t st);      // verify.hip
 void launch_prep_basepoint(uint32_t *pts, uint64_t dst, hipStream_t st);
 void launch_record_sum(uint32_t *rec, const uint32_t *slots, int cnt, int nwin, int first, hipStream_t st);
 // bucket accumulation (accum.hip); returns the kernel's name for the timing records
 const char *launch_accumulate(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets, int cont, hipStream_t st);
+// the same with long_blocks blocks in front that fold the over-long lists of the mid path (items: mid_item work list of mid.hip; counters[0] = its length)
+const char *launch_accumulate_long(const uint32_t *pts, const uint32_t *sorted, const uint32_t *base, const uint32_t *perm, uint64_t count, uint64_t n, const c25519::msm_geom &g, uint32_t *buckets,
+                                   const void *items, const uint32_t *counters, uint32_t *seg_sums, uint32_t *long_done, uint32_t max_items, uint32_t long_blocks, hipStream_t st);
 // cmax (0 = the default, 17): upper limit of the window width -- verify_batch asks for 16 (its z_i are 128-bit: eight 16-bit windows exactly);
 // c_exact (0 = choose): the width itself (records_fold re-derives a record's layout from its header)
 void msm_layout(uint64_t n, c25519::msm_geom &g, int cmax = 0, int c_exact = 0);

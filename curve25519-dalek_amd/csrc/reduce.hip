@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(256) k_reduce_b4pub(const u32 *__restrict__ SW
         if (pub.hdr) {
             for (int i = 0; i < 16; i++) f[i] = 0;
             f[0] = (u32)any_bad; f[REC_TERMS_LO] = pub.terms_lo; f[REC_TERMS_HI] = pub.terms_hi; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = pub.c;
+        } else if (pub.on && pub.dev_flags) {
+            for (int i = 0; i < 16; i++) f[i] = pub.dev_flags[i];      // (written by kernels that precede this one on its stream, or that it waited for: the hash chain, the decompressions)
+            f[0] |= (u32)any_bad;
         } else if (any_bad) atomicOr(f, 1u);
         if (pub.on) {
             __threadfence_system();
@@ -261,6 +264,9 @@ __global__ void __launch_bounds__(256) k_mid_finish(u32 *__restrict__ cols, cons
         if (pub.hdr) {
             for (int i = 0; i < 16; i++) f[i] = 0;
             f[0] = (u32)any_bad; f[REC_TERMS_LO] = pub.terms_lo; f[REC_TERMS_HI] = pub.terms_hi; f[REC_PASSES] = 1; f[REC_MAGIC] = REC_MAGIC_VALUE; f[REC_C] = pub.c;
+        } else if (pub.on && pub.dev_flags) {
+            for (int i = 0; i < 16; i++) f[i] = pub.dev_flags[i];      // (written by kernels that precede this one on its stream, or that it waited for: the hash chain, the decompressions)
+            f[0] |= (u32)any_bad;
         } else if (any_bad) atomicOr(f, 1u);
         if (pub.on) {
             __threadfence_system();

@@ -11,6 +11,7 @@
 #include "../../include/c25519_hip.h"
 #include "devio.h"
 #include "sc_sha.h"
+#include "blake2b.h"
 #include "sc28.h"
 #include "kernels.h"
 #include "ctx.h"
@@ -108,20 +109,18 @@ __global__ void __launch_bounds__(256) k_hram_mod_l(const uint8_t *__restrict__ 
 // device z-mode (C25519_Z_DEVICE; NOT the reference's derivation -- see include/c25519_hip.h).  The z_i must depend on
 // every input bit of the batch (a per-signature or per-subtree derivation allows a 2^64 meet-in-the-middle forgery), so
 // they are derived from the root of a hash tree over what the reference's transcript absorbs (batch.rs:191-199) -- hram_i =
-// H(R_i || A_i || M_i) and the 32-byte s_i of every signature -- with hram_i taken mod l (v4; 32 bytes instead of 64: the batch
+// H(R_i || A_i || M_i) and the 32-byte s_i of every signature -- with hram_i taken mod l (32 bytes instead of 64: the batch
 // equation only ever sees h_i mod l, batch.rs:213-217, so that is the value to bind; two blocks per four signatures instead of three).
-//   node = first 32 bytes of the SHA-512 chaining value after absorbing  TAG(level, inputs, n) || data , where TAG is one
-//   128-byte block (domain separation and shape binding: level, number of inputs of the level, batch size) whose
-//   compression is done once on the host (the per-level IVs below), and `data` has a fixed length per level, so no
-//   length padding is needed: a Merkle-Damgard chain over fixed-length inputs is collision resistant if the compression
-//   function is; 32-byte nodes give the 128-bit level of the z_i.
-//   level 0: data = (hram_4j mod l) || s_4j || ... || (hram_4j+3 mod l) || s_4j+3 (absent = zero bytes): 2 blocks per 4 signatures,
-//            one lane each (v2 chained 12 blocks over 16 signatures per lane: 1024 waves for 2^20 signatures, one per SIMD, 226
-//            VGPRs -- a latency-bound kernel that did not fit beside the decompression; v3: 3 blocks with 64-byte hram_i).
-//   level l: data = four children: ONE compression per node (out[j] = F_level(in[4j] || .. || in[4j+3])[0..32]).  These levels are pure latency
-//            (one dependent SHA-512 compression is ~20 us for a single wave): five of them run inside one block (k_ztree_block).
+// v5 (round 6): the tree's hash is BLAKE2b (RFC 7693; blake2b.h has the reasons -- 12 rounds instead of 80 on a chain of dependent compressions
+// that one wave per SIMD executes; rounds 2-5: SHA-512, v1-v4).  Every node is a PLAIN unkeyed BLAKE2b-256 digest:
+//   node = BLAKE2b-256( TAG(level, inputs, n) || data ), where TAG is one 128-byte block (domain separation and shape binding: the tag string, zeros, then
+//   level, number of inputs of the level and batch size as little-endian u64) whose compression is done once on the host (the per-level states below), and
+//   `data` has a fixed length per level.  32-byte nodes give the 128-bit level of the z_i.
+//   level 0: data = (hram_4j mod l) || s_4j || ... || (hram_4j+3 mod l) || s_4j+3 (absent = zero bytes): 2 blocks per 4 signatures, one lane each
+//   level l: data = four children, ONE compression per node (out[j] = node_l(in[4j] || .. || in[4j+3])).  These levels are pure latency
+//            (one dependent compression is ~8 us for a single wave; SHA-512: 16 - 18): five of them run inside one block (k_ztree_block).
 constexpr int ZTREE_MAX_LEVELS = 16;
-struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };
+struct ztree_ivs { u64 iv[ZTREE_MAX_LEVELS][8]; };       // iv[l]: the BLAKE2b state after TAG(l, ..)
 __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__ hred, const uint8_t *__restrict__ sigs, u64 n, ztree_ivs ivs, uint8_t *__restrict__ out) {
     C25519_PRIO_CHAIN();
     u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -129,22 +128,22 @@ __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__
     if (j >= m_out) return;
     u64 hs[8];
     for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
-    u64 rec[32];                                          // 4 records of 64 bytes = 2 blocks
+    u64 rec[32];                                          // 4 records of 64 bytes = 2 blocks (little-endian words: the bytes as they are)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         const u64 c = 4 * j + r;
         const u64 *h = reinterpret_cast<const u64 *>(hred) + 4 * c, *sg = reinterpret_cast<const u64 *>(sigs) + 8 * c + 4;
 #pragma unroll
-        for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? bswap64(h[q]) : 0ull;
+        for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? h[q] : 0ull;
 #pragma unroll
-        for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? bswap64(sg[q]) : 0ull;
+        for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? sg[q] : 0ull;
     }
 #pragma unroll 1
     for (int blk = 0; blk < 2; blk++) {
         u64 w[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) w[q] = blk == 0 ? rec[q] : rec[16 + q];
-        sha512_compress(hs, w);
+        blake2b_compress(hs, w, 256 + 128 * (u64)blk, blk == 1);
     }
     u64 *o = reinterpret_cast<u64 *>(out) + 4 * j;
     for (int q = 0; q < 4; q++) o[q] = hs[q];
@@ -152,8 +151,8 @@ __global__ void __launch_bounds__(256) k_ztree_first(const uint8_t *__restrict__
 // FIVE levels per launch: a block owns 1024 consecutive nodes of level `level` - 1 and reduces them to ONE node of level `level` + 4 through LDS
 // (4^5 = 1024: the partition is aligned, so every node is the same function of the same children, with the same per-level tag, as when each level
 // was a launch of its own -- rounds 2-3: four launches of one level each and a single-block tail, 317 us of launch gaps and single-wave
-// compressions on the critical chain of verify_batch; now one launch of 256 blocks and the tail: ~200).  nlev: levels to do (5), or "until one
-// node is left" for the tail (m_in <= 1024, one block).  The global node counts decide which children exist, exactly as in ztree_node4.
+// compressions on the critical chain of verify_batch; now one launch of 256 blocks and the tail).  nlev: levels to do (5), or "until one
+// node is left" for the tail (m_in <= 1024, one block).  The global node counts decide which children exist.
 __global__ void __launch_bounds__(256) k_ztree_block(const uint8_t *__restrict__ in, u64 m_in, u32 level, ztree_ivs ivs, uint8_t *__restrict__ out, int nlev) {
     C25519_PRIO_CHAIN();
     __shared__ u64 buf0[1024 * 4], buf1[256 * 4];
@@ -175,7 +174,7 @@ __global__ void __launch_bounds__(256) k_ztree_block(const uint8_t *__restrict__
 #pragma unroll
                 for (int q = 0; q < 4; q++) w[4 * ch + q] = gbase + c < m ? cur[4 * c + q] : 0ull;
             }
-            sha512_compress(hs, w);
+            blake2b_compress(hs, w, 256, true);
             for (int q = 0; q < 4; q++) nxt[4 * threadIdx.x + q] = hs[q];
         }
         __syncthreads();
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(256) k_ztree_block(const uint8_t *__restrict__
     }
     if (threadIdx.x < 4) reinterpret_cast<u64 *>(out)[(u64)blockIdx.x * 4 + threadIdx.x] = cur[threadIdx.x];
 }
-// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of SHA-512(root || LE64(j)) (standard, padded); n4 = ceil(n/4)
+// step 3: (z_4j .. z_4j+3) = the four 16-byte quarters of BLAKE2b-512(root || LE64(j)); n4 = ceil(n/4)
 // lanes, z16 has room for 4*n4 entries.  A quarter is read as SIGN-MAGNITUDE: bit 127 = sign, bits 0..126 = |z_i|, i.e.
 // z_i is uniform on {-(2^127-1) .. 2^127-1} (2^128 - 1 values; a forged batch passes with probability <= 2^-127.99
 // against the reference's 2^-128).  Why signed: the MSM recodes scalars into signed windows, and a magnitude below 2^127
@@ -197,14 +196,13 @@ __global__ void __launch_bounds__(256) k_zderive(const uint8_t *__restrict__ roo
     if (i >= n4) return;
     const u64 *h = reinterpret_cast<const u64 *>(root);
     u64 hs[8], w[16];   // 40-byte message: one block
-    sha512_init(hs);
-    for (int q = 0; q < 4; q++) w[q] = h[q];           // the root is kept as big-endian words of the chaining value
-    w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
-    for (int q = 6; q < 15; q++) w[q] = 0;
-    w[15] = 40 * 8;
-    sha512_compress(hs, w);
+    blake2b_init(hs, 64);
+    for (int q = 0; q < 4; q++) w[q] = h[q];
+    w[4] = i;
+    for (int q = 5; q < 16; q++) w[q] = 0;
+    blake2b_compress(hs, w, 40, true);
     u64 *o = reinterpret_cast<u64 *>(z16) + 8 * i;
-    for (int q = 0; q < 8; q++) o[q] = bswap64(hs[q]);
+    for (int q = 0; q < 8; q++) o[q] = hs[q];
 }
 // R_i <- -R_i where z_i is negative (device z-mode): swap y+x / y-x, negate 2dxy of the stored affine Niels record
 __global__ void __launch_bounds__(256) k_apply_sign(u32 *__restrict__ pts, u64 dst0, const uint8_t *__restrict__ z16, u64 n) {
@@ -318,22 +316,27 @@ hipError_t launch_hram_dom(const uint8_t *dom, uint32_t dom_len, const uint8_t *
 }  // namespace c25519
 
 
+void launch_apply_sign(uint32_t *pts, uint64_t dst0, const uint8_t *z16, uint64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_apply_sign, dim3(div_up64(n, 256)), dim3(256), 0, st, pts, dst0, z16, n);
+}
+
 // ---- verify_batch ---------------------------------------------------------------------------------------
 #include "transcript_host.h"
 
-// IVs of the z tree: iv[l] = SHA-512 chaining value after the one-block tag of level l (see k_ztree_first)
+// states of the z tree: iv[l] = the BLAKE2b-256 state after the one-block tag of level l (see k_ztree_first)
 static void ztree_make_ivs(uint64_t n, ztree_ivs &ivs) {
     uint64_t count = n;                                  // inputs of level 0: signatures
     for (int l = 0; l < ZTREE_MAX_LEVELS; l++) {
-        u64 w[16] = {0};
-        const char tag[] = "c25519-hip/verify_batch/z-tree/v4";
+        if (l > 0 && count <= 1) { for (int q = 0; q < 8; q++) ivs.iv[l][q] = 0; continue; }      // (a level the tree does not have: its state is never read)
+        const char tag[] = "c25519-hip/verify_batch/z-tree/v5";
         static_assert(sizeof(tag) - 1 <= 64, "tag fits the first half of the block");
         uint8_t blk[128] = {0};
         memcpy(blk, tag, sizeof(tag) - 1);
-        for (int q = 0; q < 16; q++) { u64 v = 0; for (int b = 0; b < 8; b++) v = (v << 8) | blk[8 * q + b]; w[q] = v; }
+        u64 w[16];
+        memcpy(w, blk, 128);                             // (little-endian host: the block's bytes as sixteen LE words)
         w[13] = (u64)l; w[14] = count; w[15] = n;        // level, number of inputs of this level, batch size
-        sha512_init(ivs.iv[l]);
-        sha512_compress(ivs.iv[l], w);
+        blake2b_init(ivs.iv[l], 32);
+        blake2b_compress(ivs.iv[l], w, 128, false);
         count = (count + 3) / 4;
     }
 }
@@ -370,10 +373,11 @@ static void ztree_host_zs(const uint8_t *hred, const uint8_t *sigs, uint64_t n, 
         for (int q = 0; q < 8; q++) hs[q] = ivs.iv[0][q];
         for (int r = 0; r < 4; r++) {
             const uint64_t c = 4 * j + r;
-            for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? bswap64(host_le64(hred + 32 * c + 8 * q)) : 0ull;
-            for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? bswap64(host_le64(sigs + 64 * c + 32 + 8 * q)) : 0ull;
+            for (int q = 0; q < 4; q++) rec[8 * r + q] = c < n ? host_le64(hred + 32 * c + 8 * q) : 0ull;
+            for (int q = 0; q < 4; q++) rec[8 * r + 4 + q] = c < n ? host_le64(sigs + 64 * c + 32 + 8 * q) : 0ull;
         }
-        for (int blk = 0; blk < 2; blk++) { u64 w[16]; for (int q = 0; q < 16; q++) w[q] = rec[16 * blk + q]; sha512_compress(hs, w); }
+        blake2b_compress(hs, rec, 256, false);
+        blake2b_compress(hs, rec + 16, 384, true);
         for (int q = 0; q < 4; q++) cur[4 * j + q] = hs[q];
     }
     for (uint32_t level = 1; m > 1; level++) {               // upper levels: four children, one block
@@ -383,20 +387,19 @@ static void ztree_host_zs(const uint8_t *hred, const uint8_t *sigs, uint64_t n, 
             u64 hs[8], w[16];
             for (int q = 0; q < 8; q++) hs[q] = ivs.iv[level][q];
             for (int ch = 0; ch < 4; ch++) for (int q = 0; q < 4; q++) w[4 * ch + q] = 4 * j + ch < m ? cur[4 * (4 * j + ch) + q] : 0ull;
-            sha512_compress(hs, w);
+            blake2b_compress(hs, w, 256, true);
             for (int q = 0; q < 4; q++) nxt[4 * j + q] = hs[q];
         }
         cur.swap(nxt); m = mo;
     }
-    for (uint64_t i = 0; i < (n + 3) / 4; i++) {             // k_zderive: the four quarters of SHA-512(root || LE64(i))
+    for (uint64_t i = 0; i < (n + 3) / 4; i++) {             // k_zderive: the four quarters of BLAKE2b-512(root || LE64(i))
         u64 hs[8], w[16];
-        sha512_init(hs);
+        blake2b_init(hs, 64);
         for (int q = 0; q < 4; q++) w[q] = cur[q];
-        w[4] = bswap64(i); w[5] = 0x8000000000000000ull;
-        for (int q = 6; q < 15; q++) w[q] = 0;
-        w[15] = 40 * 8;
-        sha512_compress(hs, w);
-        for (int q = 0; q < 8; q++) { const u64 v = bswap64(hs[q]); memcpy(z16 + 64 * i + 8 * q, &v, 8); }
+        w[4] = i;
+        for (int q = 5; q < 16; q++) w[q] = 0;
+        blake2b_compress(hs, w, 40, true);
+        memcpy(z16 + 64 * i, hs, 64);
     }
 }
 
@@ -410,6 +413,18 @@ static void ztree_host_zs(const uint8_t *hred, const uint8_t *sigs, uint64_t n, 
 // that array's slice for THIS pass on the copy stream and returns the event to wait for.  So R_i is being decompressed
 // while the keys and messages travel, and the hash chain runs while the (five times larger) key points travel.
 typedef std::function<int32_t(int what, hipEvent_t *ready)> verify_stage;
+// (r6) device z-mode, inputs on the device, up to 2^16 signatures.  The ORDER in which the host enqueues the two chains (it needs ~4 us per launch or event, ~80 us
+// for the whole call, and each chain can only run as far as it has been enqueued): 0 = k_hram, the three decompression launches, then tree / z_i / batch scalars;
+// 1 = k_hram and the tree ahead of the decompression; 2 = the decompression ahead of everything.  A/B knob VERIFY_ORDER of the tuning build; verify_pass_enqueue has the numbers.
+static int verify_order(uint64_t n) {
+    static const int k = C25519_KNOB("VERIFY_ORDER", 0);
+    return n <= (1ull << 16) ? k : 0;
+}
+// ... and a single-pass batch whose 2n + 1-term MSM the mid path serves runs it on the hash chain's stream and publishes its record itself
+static bool verify_on_chain(uint64_t n, const msm_geom &g, bool staged) {
+    static const int k = C25519_KNOB("MID_ON_CHAIN", 1);     // A/B knob of the tuning build
+    return k != 0 && !staged && n <= (1ull << 16) && msm_mid_serves(2 * n + 1, g, true);
+}
 // pre (small batches of the transcript z-mode, may be null): the records of A_i and R_i are ALREADY at their place in the context's record buffer
 // (or will be once `ready` has fired) -- decompressed on the second stream while the hashes went to the host and the z_i came back -- with
 // cnt[0] keys and cnt[1] R_i that do not decode
@@ -454,8 +469,21 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     static const int hram_first_knob = C25519_KNOB("HRAM_FIRST", 1);      // A/B knob: 0 = behind the decompression launches (rounds 1-4)
     // (up to 2^18 signatures: 0.594 -> 0.581 ms at 2^14, 1.034 -> 1.018 at 2^18; at 2^20 the hash kernels then take the compute units ahead of the decompression
     //  and the call is 0.6 % slower: profiles/r05_ab_midrange_streams.txt)
-    const bool hram_first = hram_first_knob && !stage && !hr && n <= (1ull << 18);
+    const int order = (!stage && !hr && !split) ? verify_order(n) : 0;
+    const bool hram_first = hram_first_knob && !stage && !hr && n <= (1ull << 18) && order != 2;
     if (hram_first) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
+    // (r6, late) order 1: the tree and the z_i ahead of the decompression launches as well.  With SHA-512 in the tree (until call 30 of round 6) the chain was the longer
+    // one up to 2^16 signatures and k_ztree_first, enqueued behind the three decompression launches, started 20 us after k_hram had ended
+    // (profiles/r06_timeline_mid_verify_2p14.txt); with BLAKE2b it is the shorter one and the decompression must not start 60 us into the call.
+    const bool chain_first = hram_first && order == 1 && !d_z_pre;
+    // A batch whose MSM takes the mid path (mid.hip) runs that MSM on THIS stream, right behind its scalars: the digits and the sort need nothing else; the records
+    // (main stream) are waited for once, in front of the accumulation, and the sign of z_i is applied to R_i there (msm_mid_enqueue, mid_run).  Before: k_bsum_finish ->
+    // 30 us (event, k_apply_sign on the main stream, event) -> k_mid_front at 2^14 signatures, plus an event record between k_zderive and k_batch_scalars.
+    const bool on_chain = !stage && !d_hram_pre && !d_z_pre && !split && ctx->solo && !wait_acc && !pre && verify_on_chain(n, g, false);
+    if (chain_first) {
+        if ((r = zchain_enqueue(ctx, sa, hred, d_sigs, n, t0, t1, z16))) return r;
+        if (!on_chain) HIPCHK(hipEventRecord(ctx->ev_z, sa));
+    }
     // (S) points: [0] = B, [1..n] = R_i, [n+1..2n] = A_i     (batch.rs:235-244)
     launch_prep_basepoint(d_pts, 0, st);
     auto prep_A = [&]() -> int32_t {
@@ -506,12 +534,16 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     HIPCHK(hipGetLastError());
     const uint8_t *zz = d_z_pre;
     if (!zz) {
-        if ((r = zchain_enqueue(ctx, sa, hred, d_sigs, n, t0, t1, z16))) return r;
+        if (!chain_first) {
+            if ((r = zchain_enqueue(ctx, sa, hred, d_sigs, n, t0, t1, z16))) return r;
+            if (!on_chain) HIPCHK(hipEventRecord(ctx->ev_z, sa));
+        }
         zz = z16;
         // the sign of z_i goes onto the stored R_i (main stream, beside the sort on the second one)
-        HIPCHK(hipEventRecord(ctx->ev_z, sa));
-        HIPCHK(hipStreamWaitEvent(st, ctx->ev_z, 0));
-        hipLaunchKernelGGL(k_apply_sign, dim3(nblk), dim3(256), 0, st, d_pts, (uint64_t)1, zz, n);
+        if (!on_chain) {
+            HIPCHK(hipStreamWaitEvent(st, ctx->ev_z, 0));
+            hipLaunchKernelGGL(k_apply_sign, dim3(nblk), dim3(256), 0, st, d_pts, (uint64_t)1, zz, n);
+        }
     }
     // (r6) TWO HALVES (round-5 verdict, item 6).  The 2n + 1 terms are two different halves: the R half's scalars are the |z_i| themselves (128 bits: 8 windows) and exist
     // when k_zderive ends; the A half's are z_i h_i mod l (253 bits) and exist only after k_batch_scalars / k_bsum_finish.  As ONE pass the sort of everything waits for the
@@ -554,6 +586,11 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     // the basepoint coefficient -sum z_i s_i (batch.rs:240): the per-block partial sums are folded by one more block
     hipLaunchKernelGGL(k_bsum_finish, dim3(1), dim3(256), 0, sa, partial, nblk, msc);
     HIPCHK(hipGetLastError());
+    if (on_chain) {
+        HIPCHK(hipEventRecord(ctx->ev_pts, st));                       // the records of B, R_i and A_i
+        const mid_run run = {sa, ctx->ev_pts, z16, 1, n};
+        return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc, &run);
+    }
     if (stage && d_pk_points && (r = prep_A())) return r;   // the keys' points come last: only the accumulation needs them
     // the MSM's digit/sort phase continues on the second stream while (S) is still decompressing
     return msm_enqueue(ctx, msc, m, d_pts, g, d_slot, ring, sa, wait_acc);
@@ -652,6 +689,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     if (n == 0) return C25519_OK;                      // batch.rs: 1-term MSM 0*B = identity
     if (n >= (1ull << 40)) { ctx->err = "verify_batch: n too large"; return -(int32_t)hipErrorInvalidValue; }
     if (z_mode > 1) { ctx->err = "verify_batch: bad z_mode"; return -(int32_t)hipErrorInvalidValue; }
+    if (!fetch) ctx->host_us[0] = ctx->host_us[1] = wall_us();      // (c25519_last_call_host_us: entered; the collect functions stamp "enqueued" and "results on the host")
     HIPCHK(hipEventRecord(ctx->ev0, ctx->stream));
     int32_t r;
     if (z_mode == C25519_Z_TRANSCRIPT) {
@@ -703,6 +741,14 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
     ctx->solo = passes == 1;
+    // (r6) a single pass through the mid path, inputs on the device: the last reduction block publishes the record -- columns and the slot's counters -- into the
+    // context's page-locked host slot and the host polls the sequence word (msm.hip wait_published, with the small path's recovery: a lost publication re-runs the
+    // batch once through the slot + copy path) instead of a copy-engine launch and a blocking synchronisation behind the last kernel
+    static const int verify_direct_knob = C25519_KNOB("VERIFY_DIRECT", 1);
+    const bool direct = passes == 1 && !fetch && verify_direct_knob && !ctx->no_direct_once && ps.c[0] == ctx && verify_on_chain(n, g, false);
+    ctx->no_direct_once = false;
+    ctx->direct_seq = 0;
+    if (direct) { ctx->direct_seq = ++ctx->publish_seq; if (!ctx->direct_seq) ctx->direct_seq = ++ctx->publish_seq; }
     bool seen[5] = {false, false, false, false, false}, bad_off = false, bad_scalar = false;
     hipEvent_t prev_acc = nullptr;
     for (uint64_t p0 = 0; p0 < passes; p0 += C25519_MAX_SLOTS) {
@@ -716,13 +762,21 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             c25519_ctx *split_peer = (passes == 1 && !fetch && split_min && m >= split_min && !msm_mid_serves(2 * m + 1, g, true) && 2 * m + 1 > msm_small_max()) ? ctx_peer(ctx) : nullptr;
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
                                     nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr, nullptr, split_peer, split_peer ? dslot(ctx, 1) : nullptr);
-            if (r) { if (ctx->err.empty()) ctx->err = c->err; return r; }
+            if (r) { ctx->direct_seq = 0; if (ctx->err.empty()) ctx->err = c->err; return r; }
             prev_acc = ps.lanes > 1 ? c->ev_acc : nullptr;
-            if (n >= (1ull << 16)) ctx->coarse_wait = c->ev_acc;
+            if (n >= (1ull << 16) && !direct) ctx->coarse_wait = c->ev_acc;
         }
-        if ((r = passes_join(ctx, ps)) || (r = slots_collect(ctx, cnt))) return r;
+        if ((r = passes_join(ctx, ps))) { ctx->direct_seq = 0; return r; }
+        if (direct) {
+            r = rec_collect(ctx);                           // (polls for ctx->direct_seq and clears it)
+            if (r == C25519_LOST_PUBLICATION) {             // never observed (profiles/r06_soak_small.txt); tests/test_gpu_verify.py injects it
+                ctx->no_direct_once = true;
+                return verify_batch_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, d_pk_points, n, z_mode, fetch);
+            }
+            if (r) return r;
+        } else if ((r = slots_collect(ctx, cnt))) return r;
         for (int i = 0; i < cnt; i++) {
-            const uint32_t *s = hslot(ctx, i), *f = s + MSM_MAX_WIN * 40;
+            const uint32_t *s = hslot(ctx, direct ? C25519_MAX_SLOTS : i), *f = s + MSM_MAX_WIN * 40;
             if (f[0]) bad_scalar = true;
             if (f[5]) bad_off = true;
             uint32_t fl[8] = {0, 0, f[2], f[3], f[4], 0, 0, 0};
@@ -731,6 +785,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
         }
     }
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    if (!fetch) ctx->host_us[4] = wall_us();
     if (bad_off) { ctx->err = "verify_batch: msg_off is not monotone or runs past msgs_len"; return -(int32_t)hipErrorInvalidValue; }
     if (bad_scalar) { ctx->err = "verify_batch: internal error (batch scalar with bit 255 set)"; return -(int32_t)hipErrorInvalidValue; }
     return seen[C25519_NONE] ? C25519_NONE : seen[C25519_SCALAR_FORMAT] ? C25519_SCALAR_FORMAT : seen[C25519_VERIFY] ? C25519_VERIFY : C25519_OK;

@@ -62,15 +62,19 @@ extern "C" {
  *   a sequential sponge (about 1.7 Keccak-f per signature), so it runs on one host core and bounds the call near
  *   2-3 x 10^6 signatures/s; the curve arithmetic still runs on the GPU.
  * C25519_Z_DEVICE (1, explicit opt-in, NOT the reference's derivation and not a reviewed standard construction):
- *   z_i = a 16-byte quarter of SHA-512(root || LE64(i / 4)), read as sign-magnitude (uniform on the 2^128 - 1 integers
+ *   z_i = a 16-byte quarter of BLAKE2b-512(root || LE64(i / 4)), read as sign-magnitude (uniform on the 2^128 - 1 integers
  *   -(2^127 - 1) .. 2^127 - 1), where root is the root of a hash tree over what the reference's transcript
- *   absorbs: H(R_i || A_i || M_i) -- taken mod l, 32 bytes: the batch equation only sees that residue (batch.rs:213-217) --
- *   and the 32-byte s_i of every signature (level 0: 4 signatures per
- *   node; upper levels 4-ary; node = first 32 bytes of the SHA-512 chaining value after a one-block domain tag
- *   (level, inputs of the level, batch size) and the fixed-length data).  Every z_i depends on every bit of the batch;
+ *   absorbs: H(R_i || A_i || M_i) -- SHA-512 as in Ed25519, taken mod l, 32 bytes: the batch equation only sees that residue
+ *   (batch.rs:213-217) -- and the 32-byte s_i of every signature.  Every node is a plain unkeyed BLAKE2b-256 digest (RFC 7693):
+ *   node = BLAKE2b-256(TAG || data), TAG = one 128-byte block: the string "c25519-hip/verify_batch/z-tree/v5", zero bytes, then
+ *   level, number of inputs of the level and batch size as little-endian u64 (bytes 104 .. 127); level 0: data = (h_i mod l) || s_i of
+ *   4 signatures (256 bytes, absent signatures = zero bytes); upper levels: data = 4 child nodes (128 bytes, absent = zero bytes).
+ *   (Rounds 2-5 built the same tree from SHA-512's compression function, tag .../v4; the values differ.  BLAKE2b because the tree's
+ *   levels are a chain of dependent compressions that one wavefront per SIMD executes, and BLAKE2b's is 12 rounds against 80:
+ *   csrc/blake2b.h.)  tests/pyref.py device_zs restates the derivation with hashlib.blake2b.  Every z_i depends on every bit of the batch;
  *   honest batches give the same verdict in both modes; a batch containing an invalid signature passes with
- *   probability <= 2^-127.99 (reference: 2^-128) under the usual assumption that SHA-512's compression function is
- *   collision resistant and its output unpredictable.  BINDING MARGIN of the tree leaves (v4): the z_i bind (R_i, A_i, M_i) only
+ *   probability <= 2^-127.99 (reference: 2^-128) under the usual assumption that BLAKE2b (and SHA-512 in h_i) is
+ *   collision resistant and its output unpredictable.  BINDING MARGIN of the tree leaves (since v4): the z_i bind (R_i, A_i, M_i) only
  *   through h_i mod l, a 252-bit value, where the reference's transcript absorbs the full 64-byte hash (batch.rs:191-199).  Two
  *   different (R, A, M) triples with equal h mod l would produce identical z_i for two different batch equations; finding such a pair
  *   is a birthday search on 252 bits, about 2^126 hash evaluations -- near, not at, the 128-bit level of the rest of the construction

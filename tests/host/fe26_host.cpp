@@ -120,6 +120,21 @@ void h_sha512_put_bytes(const uint8_t *m, size_t n, size_t pre, uint8_t *o) {
 }
 void h_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint64_t n, uint8_t *zs) { c25519_transcript_zs(hrams, sigs, n, zs); }
 }
+// ---- BLAKE2b (csrc/blake2b.h: the compression function of the device z-mode's hash tree) as the plain unkeyed hash of RFC 7693 section 3.3 ----
+#include "../../curve25519-dalek_amd/csrc/blake2b.h"
+extern "C" {
+void h_blake2b(const uint8_t *msg, uint64_t len, uint32_t outlen, uint8_t *o) {
+    u64 h[8], m[16];
+    blake2b_init(h, outlen);
+    uint64_t off = 0;
+    while (len - off > 128) { memcpy(m, msg + off, 128); off += 128; blake2b_compress(h, m, off, false); }      // (the last block is never empty unless the message is)
+    uint8_t blk[128] = {0};
+    memcpy(blk, msg + off, len - off);
+    memcpy(m, blk, 128);
+    blake2b_compress(h, m, len, true);
+    memcpy(o, h, outlen);
+}
+}
 
 // ---- device scalar arithmetic on 28-bit limbs (csrc/sc28.h) --------------------------------------------------------------
 #include "../../curve25519-dalek_amd/csrc/sc28.h"

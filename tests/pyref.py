@@ -361,30 +361,27 @@ def sha512_compress(h, block):
 
 
 def device_zs(hrams, ss):
-    """hrams = [H(R||A||M)] (64 bytes each), ss = [s] (32 bytes each) -> the n sign-magnitude z_i of the device z-mode (16 bytes each: bit 127 = sign)."""
+    """hrams = [H(R||A||M)] (64 bytes each), ss = [s] (32 bytes each) -> the n sign-magnitude z_i of the device z-mode (16 bytes each: bit 127 = sign).
+    v5 (round 6): every node of the tree is a plain unkeyed BLAKE2b-256 digest (RFC 7693; hashlib), the z_i are quarters of BLAKE2b-512(root || LE64(i / 4)) --
+    written from the description in include/c25519_hip.h (C25519_Z_DEVICE), not from the kernels."""
     import hashlib
     n = len(hrams)
     L = 2**252 + 27742317777372353535851937790883648493
 
-    def iv(level, count):
-        tag = b"c25519-hip/verify_batch/z-tree/v4"
-        blk = tag + bytes(104 - len(tag)) + level.to_bytes(8, "big") + count.to_bytes(8, "big") + n.to_bytes(8, "big")
-        return sha512_compress(_SHA512_IV, blk)
+    def node(level, count, data):
+        tag = b"c25519-hip/verify_batch/z-tree/v5"
+        blk = tag + bytes(104 - len(tag)) + level.to_bytes(8, "little") + count.to_bytes(8, "little") + n.to_bytes(8, "little")
+        return hashlib.blake2b(blk + data, digest_size=32).digest()
 
-    node = lambda h: b"".join(x.to_bytes(8, "big") for x in h[:4])
     leaves = [(int.from_bytes(h, "little") % L).to_bytes(32, "little") + s for h, s in zip(hrams, ss)]
-    count, level, nodes = n, 0, []
-    h0 = iv(0, count)
-    for j in range((n + 3) // 4):                            # level 0: four 64-byte records, two blocks
-        data = b"".join(leaves[4 * j:4 * j + 4]).ljust(256, b"\0")
-        nodes.append(node(sha512_compress(sha512_compress(h0, data[:128]), data[128:])))
-    while len(nodes) > 1:                                    # upper levels: four children, one block
+    count, level = n, 0
+    nodes = [node(0, count, b"".join(leaves[4 * j:4 * j + 4]).ljust(256, b"\0")) for j in range((n + 3) // 4)]      # level 0: four 64-byte records
+    while len(nodes) > 1:                                    # upper levels: four children
         count = (count + 3) // 4
         level += 1
-        hl = iv(level, count)
-        nodes = [node(sha512_compress(hl, b"".join(nodes[4 * j:4 * j + 4]).ljust(128, b"\0"))) for j in range((len(nodes) + 3) // 4)]
+        nodes = [node(level, count, b"".join(nodes[4 * j:4 * j + 4]).ljust(128, b"\0")) for j in range((len(nodes) + 3) // 4)]
     out = []
     for i in range((n + 3) // 4):
-        d = hashlib.sha512(nodes[0] + i.to_bytes(8, "little")).digest()
+        d = hashlib.blake2b(nodes[0] + i.to_bytes(8, "little")).digest()
         out += [d[16 * q:16 * q + 16] for q in range(4)]
     return out[:n]

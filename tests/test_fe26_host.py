@@ -36,7 +36,7 @@ def host(request):
     """Both forms of fe_mul / fe_sq (fe26.h C25519_CHAIN: independent column sums, chained carries)."""
     src = os.path.join(ROOT, "tests", "host", "fe26_host.cpp")
     so = os.path.join(ROOT, "tests", "host", "libfe26host%d.so" % request.param)
-    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "fe9_probe.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h", "host51.h")]
+    deps = [src] + [os.path.join(ROOT, "curve25519-dalek_amd", "csrc", f) for f in ("fe26.h", "fe9_probe.h", "ge26.h", "sc_sha.h", "sc28.h", "transcript_host.h", "constants_gen.h", "host51.h", "blake2b.h")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DC25519_CHAIN=%d" % request.param, "-o", so, src])
     return C.CDLL(so)
@@ -345,3 +345,21 @@ def test_ifma_doubling_chain(host):
             for _ in range(k):
                 ex, ey = dbl(ex, ey)
             assert b.raw[:32] == i2b(ex) and b.raw[32:64] == i2b(ey) and b.raw[64:] == i2b(ex * ey % P), (idx, k)
+
+
+def test_blake2b_compression_function_vs_hashlib(host):
+    """csrc/blake2b.h (the hash of the device z-mode's tree, verify.hip) driven as the plain unkeyed BLAKE2b of RFC 7693: the RFC's "abc" vector (appendix A) and
+    hashlib.blake2b on random messages around every block boundary, digest lengths 32 and 64."""
+    import hashlib
+    abc = ("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+           "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")
+    o = C.create_string_buffer(64)
+    host.h_blake2b(b"abc", C.c_uint64(3), C.c_uint32(64), o)
+    assert o.raw.hex() == abc == hashlib.blake2b(b"abc").hexdigest()
+    rng = random.Random(77)
+    for n in [0, 1, 39, 40, 41, 111, 127, 128, 129, 255, 256, 257, 383, 384, 385, 1000]:
+        for outlen in (32, 64):
+            msg = bytes(rng.randrange(256) for _ in range(n))
+            o = C.create_string_buffer(outlen)
+            host.h_blake2b(msg, C.c_uint64(n), C.c_uint32(outlen), o)
+            assert o.raw == hashlib.blake2b(msg, digest_size=outlen).digest(), (n, outlen)

@@ -195,6 +195,69 @@ def test_verify_batch_with_cached_key_points(eng, orc):
     assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts) == VERIFY
 
 
+_MID_CHAIN_BODY = """
+    import os, sys, faulthandler
+    faulthandler.dump_traceback_later(500, exit=True)
+    sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+    import numpy as np, torch
+    import curve25519_dalek_amd as pkg, util
+    from oracle import orc
+    OK, NONE, SCALAR_FORMAT, VERIFY = 0, 1, 2, 3
+    eng = pkg.Engine(0)
+    calls = 0
+    for n in (6144, 7001, 16384, 40000, 65536):
+        print("n", n, flush=True)
+        seeds = util.rand_bytes(2000 + n, n); msgs = util.rand_bytes(2001 + n, n, 41)
+        pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
+        dm = torch.from_numpy(msgs.reshape(-1)).cuda(); doff = torch.arange(0, 41 * (n + 1), 41, dtype=torch.int64).cuda()
+        ds = torch.from_numpy(sigs).cuda(); dp = torch.from_numpy(pks).cuda()
+        _, dpts, ok = eng.decompress_batch_t(dp)
+        assert bool(ok.all())
+        for pts in (None, dpts):
+            c0 = eng.counter(2)
+            for rep in range(3):
+                assert eng.verify_batch_t(dm, doff, ds, dp, 1, pk_points=pts) == OK, (n, rep)
+            bad = ds.clone(); bad[n // 3, 40] ^= 1                     # s of one signature: the equation fails (or s leaves the canonical range)
+            assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) in (VERIFY, SCALAR_FORMAT)
+            bad = ds.clone(); bad[n - 1, 0] ^= 1                       # R of the last signature
+            assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) == VERIFY
+            bad = ds.clone(); bad[5, 63] |= 0x20                       # s >= 2^253: ScalarFormat -- a COUNTER of the device slot, which the published record must carry
+            assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) == SCALAR_FORMAT
+            bad = ds.clone(); bad[7, 0:32] = torch.from_numpy(np.frombuffer((2).to_bytes(32, "little"), dtype=np.uint8).copy()).cuda()   # an R that does not decode: Verify (batch.rs:244)
+            assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) == VERIFY
+            calls += 7
+            assert eng.counter(2) - c0 == 7, (n, eng.counter(2) - c0)    # every one of them published its record itself
+        badk = dp.clone(); badk[9] = torch.from_numpy(np.frombuffer((2).to_bytes(32, "little"), dtype=np.uint8).copy()).cuda()         # a key that does not decode (key bytes only): None
+        assert eng.verify_batch_t(dm, doff, ds, badk, 1) == NONE
+        calls += 1
+        off2 = doff.clone(); off2[3] = off2[5]                          # offsets that are not monotone: an argument error, also a counter of the slot
+        try:
+            eng.verify_batch_t(dm, off2, ds, dp, 1)
+            raise SystemExit("bad offsets accepted")
+        except pkg.EngineError as e:
+            assert "msg_off" in str(e), str(e)
+        calls += 1
+    lost = eng.counter(1)
+    assert (lost > 0) == EXPECT_LOST, lost
+    assert eng.counter(0) <= lost, (eng.counter(0), lost)                # nothing blocked but the injected losses
+    print("lost", lost, "of", calls, flush=True)
+    print("ok")
+"""
+
+
+@pytest.mark.parametrize("lose", [0, 3])
+def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, lose):
+    """(r6) Device z-mode, inputs on the device, 6144 .. 2^16 signatures: the 2n + 1-term MSM takes the mid path ON the hash chain's stream (digits and sort right
+    behind the batch scalars, the records waited for and signed in front of the accumulation, the over-long lists inside the accumulation's launch) and the last
+    reduction block PUBLISHES the record with the device slot's counters.  Verdicts -- including the ones that live in those counters -- with key bytes and with cached
+    key points; lose = 3: every third publication is dropped (tuning build) and must be recovered through the copy path with the same verdicts."""
+    import subprocess, textwrap
+    code = textwrap.dedent(_MID_CHAIN_BODY % (ROOT, ROOT)).replace("EXPECT_LOST", "True" if lose else "False")
+    env = util.tune_env(C25519_FAULT_LOSE_PUBLICATION=str(lose), C25519_PUBLISH_SPIN_US="1000") if lose else dict(os.environ)
+    r = subprocess.run(util.child_argv(code), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
+
+
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4097, 16385, 16400,
                                2047, 2048, 8191, 32769, 65536, 131073, 262144, 524291])      # (r4) either side of the small path and through the mid-range window layouts of its 2 n + 1 terms
 def test_verify_batch_tree_boundaries(eng, orc, n):
