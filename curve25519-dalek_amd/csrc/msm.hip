@@ -92,7 +92,13 @@ template <int NT> __device__ __forceinline__ uint4 prep_load16(const uint4 *p) {
     if (NT) { const nt_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4 *>(p)); return make_uint4(v.x, v.y, v.z, v.w); }
     return *p;
 }
-template <int CH, int WPB, int NT = 0>                      // points per lane, waves per block, streaming accesses
+// SPEC (round 6): points that are EXPECTED to be affine -- the decompressed points VerifyingKeys carry (verifying.rs:64-71; c25519_decompress_batch writes Z = 1).
+// A wave first runs ONE pass over its points: reads X, Y, Z, writes the record of (X, Y), notes whether every Z was 1 -- no prefix products, no second read, no
+// inversion: 288 instead of 544 bytes per point -- and returns if they all were; a wave that met another Z goes through the general algorithm below from the start
+// (its records are rewritten).  verify_batch of 2^20 signatures with cached key points: the normalisation of the keys is the head of the main stream's chain, 0.35 of
+// its 1.32 ms (profiles/r06_timeline_verify_blake2b.txt); 0.11 this way.  (As two launches -- this pass, then the general kernel returning at once on a device flag --
+// the second launch still took 60 - 70 us beside k_hram: its 128 blocks of 72 KB LDS wait for room.  profiles/r06_ab_prep_affine.txt)
+template <int CH, int WPB, int NT = 0, int SPEC = 0>        // points per lane, waves per block, streaming accesses, speculative affine pass
 __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restrict__ in, u64 n, u32 *__restrict__ prefix, u32 *__restrict__ pts, u64 dst0) {
     C25519_PRIO_SIDE();
     __shared__ uint4 stage_in[WPB * 640];                    // per wave: 64 points x 160 bytes
@@ -125,6 +131,36 @@ __global__ void __launch_bounds__(64 * WPB) k_prep_raw2(const uint8_t *__restric
     const uint4 *my4 = sin + lane * 10;
     const uint2 *my2 = reinterpret_cast<const uint2 *>(sin) + lane * 20;
     uint4 *pre4 = reinterpret_cast<uint4 *>(prefix) + (w0 / 64) * (u64)(CH * 3 * 64) + lane;
+    if (SPEC) {
+        const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
+        bool aff = true;
+        C25519_PREP_ISSUE(0)
+#pragma unroll 1
+        for (int j = 0; j < nj; j++) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint4 x0 = my4[0], x1 = my4[1], y1 = my4[3], y2 = my4[4], z0 = my4[5], z1 = my4[6];
+            const uint2 x2 = my2[4], y0 = my2[5], z2 = my2[14];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (j + 1 < nj) C25519_PREP_ISSUE(j + 1)
+            const u64 lx[5] = {x0.x | (u64)x0.y << 32, x0.z | (u64)x0.w << 32, x1.x | (u64)x1.y << 32, x1.z | (u64)x1.w << 32, x2.x | (u64)x2.y << 32};
+            const u64 ly[5] = {y0.x | (u64)y0.y << 32, y1.x | (u64)y1.y << 32, y1.z | (u64)y1.w << 32, y2.x | (u64)y2.y << 32, y2.z | (u64)y2.w << 32};
+            const u64 lz[5] = {z0.x | (u64)z0.y << 32, z0.z | (u64)z0.w << 32, z1.x | (u64)z1.y << 32, z1.z | (u64)z1.w << 32, z2.x | (u64)z2.y << 32};
+            const bool in = t + (u64)j * T < n;
+            aff = aff && (!in || ((lz[0] == 1) && ((lz[1] | lz[2] | lz[3] | lz[4]) == 0)));
+            uint4 q[PTS_Q];
+            pts_pieces(fe_from_limbs51(lx), fe_from_limbs51(ly), q);
+#pragma unroll
+            for (int i = 0; i < PTS_Q; i++) sout[lane * 8 + ((i + lane) & 7u)] = q[i];
+            uint4 *dst = reinterpret_cast<uint4 *>(pts) + PTS_Q * (dst0 + w0 + (u64)j * T);
+#pragma unroll
+            for (int i = 0; i < PTS_Q; i++) {
+                const u32 r = 8u * i + sub;
+                const uint4 v = sout[i * 64 + lane];
+                if (w0 + (u64)j * T + r < n) dst[r * 8 + coff] = v;
+            }
+        }
+        if (__ballot(!aff) == 0ull) return;                  // every Z of this wave's points was 1: the records are written
+    }
     feT acc = fe_one();
     bool affine = true;
     C25519_PREP_ISSUE(0)
@@ -908,11 +944,12 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
 }
 
 // points in any format -> packed affine Niels at d_pts[dst0..]; *d_badcount counts the encodings that do not decode
-int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount) {
-    return prep_points_on(ctx, d_points, n, in_fmt, d_pts, dst0, d_badcount, ctx->stream, ctx->prefix);
+int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, bool expect_affine) {
+    return prep_points_on(ctx, d_points, n, in_fmt, d_pts, dst0, d_badcount, ctx->stream, ctx->prefix, expect_affine);
 }
 // the same on stream st with the prefix-product scratch `pre` (a second normaliser of one context beside the first needs its own: msm_pass_enqueue)
-int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, hipStream_t st, devbuf &pre) {
+// expect_affine (raw points): the caller's points normally have Z = 1 (VerifyingKey points): k_prep_affine first, the general normaliser only if one did not
+int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, hipStream_t st, devbuf &pre, bool expect_affine) {
     if (n == 0) return C25519_OK;
     if (in_fmt == C25519_FMT_EDWARDS_Y) HIPCHK(launch_prep_compressed(0, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
     else if (in_fmt == C25519_FMT_RISTRETTO) HIPCHK(launch_prep_compressed(1, d_points, 1, n, d_pts, dst0, d_badcount, false, st));
@@ -930,6 +967,21 @@ int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int
         // the prefix buffer is addressed per wave (CH x 3 x 64 pieces): blocks x wpb waves of them
         r = ctx_reserve(ctx, pre, (size_t)blocks * wpb * CH * 3 * 64 * 16);
         if (r) return r;
+        static const int affine_knob = C25519_KNOB("PREP_AFFINE_FIRST", 1);      // A/B knob of the tuning build
+        if (expect_affine && affine_knob && n >= 1024) {
+            // VerifyingKey points: the speculative one-pass form (k_prep_raw2 SPEC), 8 points per lane from 2^18 points (2048 waves at 2^20), 4 below
+            if (n >= (1ull << 18)) {
+                const unsigned bl = (unsigned)div_up64((n + 7) / 8, 64 * wpb);
+                if ((r = ctx_reserve(ctx, pre, (size_t)bl * wpb * 8 * 3 * 64 * 16))) return r;
+                hipLaunchKernelGGL((k_prep_raw2<8, wpb, 0, 1>), dim3(bl), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+            } else {
+                const unsigned bl = (unsigned)div_up64((n + 3) / 4, 64 * wpb);
+                if ((r = ctx_reserve(ctx, pre, (size_t)bl * wpb * 4 * 3 * 64 * 16))) return r;
+                hipLaunchKernelGGL((k_prep_raw2<4, wpb, 0, 1>), dim3(bl), dim3(64 * wpb), 0, st, d_points, n, (uint32_t *)pre.p, d_pts, dst0);
+            }
+            HIPCHK(hipGetLastError());
+            return C25519_OK;
+        }
         // A/B proxy (profiles/r04_ab_prep_two_waves.txt): what the normaliser's memory system does with TWO waves per compute unit -- the occupancy
         // an LDS-resident inversion tree (prefix products of 16 points per lane kept in LDS: 40 KB per wave) would leave it
         static const int two_waves = C25519_KNOB("PREP_TWO_WAVES", 0);

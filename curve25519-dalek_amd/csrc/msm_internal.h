@@ -143,8 +143,9 @@ int32_t msm_merged_core(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, c
 // the table itself: d_table[(k * ns + i)] = affine Niels record of 2^(c k) * P_i, from packed affine Niels / raw points
 int32_t msm_merged_build(c25519_ctx *ctx, const uint8_t *d_points, uint64_t ns, int in_fmt, const c25519::msm_merged &m, uint32_t *d_table, uint32_t *d_badcount);
 // any point format -> packed affine Niels at d_pts[dst0 ..]; *d_badcount counts encodings that do not decode
-int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount);
-int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, hipStream_t st, devbuf &pre);
+// expect_affine (raw points): normally Z = 1 (VerifyingKey points): one cheap pass first, the general normaliser behind it only if a point had another Z (msm.hip k_prep_affine)
+int32_t prep_points(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, bool expect_affine = false);
+int32_t prep_points_on(c25519_ctx *ctx, const uint8_t *d_points, uint64_t n, int in_fmt, uint32_t *d_pts, uint64_t dst0, uint32_t *d_badcount, hipStream_t st, devbuf &pre, bool expect_affine = false);
 void host_encode(const c25519::ge_p3 &R, int out_fmt, uint8_t *out);
 void host_raw160(const c25519::ge_p3 &p, uint8_t *out);
 c25519::ge_p3 host_from_raw160(const uint8_t *in);

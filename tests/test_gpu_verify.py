@@ -193,6 +193,17 @@ def test_verify_batch_with_cached_key_points(eng, orc):
     print("verify_batch 2^20 with cached key points: %.3f ms" % eng.last_kernel_ms())
     ds2 = ds.clone(); ds2[99, 7] ^= 1
     assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts) == VERIFY
+    # (r6) one cached point that is not affine (X, Y, Z, T all scaled): the one-pass normaliser of VerifyingKey points hands the array to the general one
+    p25519 = 2**255 - 19
+    raw = dpts[n - 5].cpu().numpy()
+    w = np.frombuffer(bytes(raw), "<u8").reshape(4, 5)
+    out = []
+    for c in range(4):
+        v = sum(int(w[c, i]) << (51 * i) for i in range(5)) * 0x1234567 % p25519
+        out += [(v >> (51 * i)) & (2**51 - 1) for i in range(5)]
+    dpts2 = dpts.clone(); dpts2[n - 5] = torch.from_numpy(np.array(out, "<u8").view(np.uint8).copy()).cuda()
+    assert eng.verify_batch_t(dm, doff, ds, dp, 1, pk_points=dpts2) == OK
+    assert eng.verify_batch_t(dm, doff, ds2, dp, 1, pk_points=dpts2) == VERIFY
 
 
 _MID_CHAIN_BODY = """
@@ -227,6 +238,29 @@ _MID_CHAIN_BODY = """
             assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) == VERIFY
             calls += 7
             assert eng.counter(2) - c0 == 7, (n, eng.counter(2) - c0)    # every one of them published its record itself
+        # cached points that are NOT affine: the one-pass normaliser of VerifyingKey points (msm.hip k_prep_affine) must hand over to the general one --
+        # one projective point among affine ones, and every point projective
+        import random
+        rnd = random.Random(n)
+        p25519 = 2**255 - 19
+        def scale(raw, lam):                                  # (X : Y : Z : T) -> (lam X : lam Y : lam Z : lam T), limbs of 51 bits
+            w = np.frombuffer(bytes(raw), "<u8").reshape(4, 5)
+            out = []
+            for c in range(4):
+                v = sum(int(w[c, i]) << (51 * i) for i in range(5)) * lam %% p25519
+                out += [(v >> (51 * i)) & (2**51 - 1) for i in range(5)]
+            return np.array(out, "<u8").view(np.uint8)
+        hp = dpts.cpu().numpy()
+        one = hp.copy(); one[n - 3] = scale(hp[n - 3], rnd.randrange(2, p25519))
+        assert eng.verify_batch_t(dm, doff, ds, dp, 1, pk_points=torch.from_numpy(one).cuda()) == OK, n
+        if n <= 16384:
+            allp = np.stack([scale(hp[i], rnd.randrange(2, p25519)) for i in range(n)])
+            dall = torch.from_numpy(allp).cuda()
+            assert eng.verify_batch_t(dm, doff, ds, dp, 1, pk_points=dall) == OK, n
+            bad = ds.clone(); bad[n // 2, 3] ^= 8
+            assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=dall) == VERIFY, n
+            calls += 2
+        calls += 1
         badk = dp.clone(); badk[9] = torch.from_numpy(np.frombuffer((2).to_bytes(32, "little"), dtype=np.uint8).copy()).cuda()         # a key that does not decode (key bytes only): None
         assert eng.verify_batch_t(dm, doff, ds, badk, 1) == NONE
         calls += 1
