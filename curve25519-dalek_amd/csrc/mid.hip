@@ -27,6 +27,7 @@
 // Variable time like the paths beside it (digits index gather lists): vartime_multiscalar_mul and verify_batch only.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <cmath>
 #include <stdlib.h>
 #include <string>
 #define C25519_CHAIN 1
@@ -256,9 +257,9 @@ __global__ void __launch_bounds__(256) k_mid_long(const u32 *__restrict__ recs, 
 // and below, where every bucket has its lane at once, a prefetching variant (176 VGPRs, two waves) measured level at every size -- a lane's list is a chain of 8 M
 // additions at ~4 us each for a nearly lone wave, not of loads (profiles/r06_ab_mid_prefetch.txt; removed).
 template <int FMT>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
-                                                 msm_geom g, u32 *__restrict__ buckets) {
-    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void mid_acc_body(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
+                                             const msm_geom &g, u32 *__restrict__ buckets, u32 block) {
+    const u64 tid = (u64)block * 256 + threadIdx.x;
     const bool in_range = tid < count;
     const u64 gid = in_range ? perm[tid] : 0;
     const int k = (int)(gid / g.half), b = (int)(gid % g.half);
@@ -279,6 +280,89 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
     if (mine) p40_store(buckets, gid, acc);
 }
+template <int FMT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
+                                                 msm_geom g, u32 *__restrict__ buckets) {
+    mid_acc_body<FMT>(recs, sorted, base, perm, count, n, g, buckets, blockIdx.x);
+}
+// (r6, late) ... and with the over-long lists IN the launch: L.blocks blocks in front of the bucket lanes fold them (mid_long.h; the form accum.hip k_accumulate_long gave
+// verify_batch).  This is what lets the cap on a lane's list come down to where it belongs: the accumulation of a mid-size call is not throughput, it is its LONGEST
+// list -- a chain of dependent additions at 3 - 5 us each (2^17 terms: lists of up to 34 entries, 140 us, where the machine needs 100 for all 2.4 M additions; 2^18
+// terms: 51 entries, 238 us against 180) -- and a list handed to a wave costs a ~27 us shuffle tree, beside the bucket lanes instead of behind them.
+struct mid_long_args { const mid_item *items; const u32 *counters; u32 *seg_sums; u32 *long_done; u32 max_items, blocks; };
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc_long(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
+                                                 msm_geom g, u32 *__restrict__ buckets, mid_long_args L) {
+    if (blockIdx.x < L.blocks) {
+        C25519_PRIO_LONG();
+        mid_long_body<0>(recs, sorted, n, g, buckets, L.max_items, L.items, L.counters, L.seg_sums, L.long_done, blockIdx.x * 4u + (threadIdx.x >> 6), L.blocks * 4u);
+        return;
+    }
+    mid_acc_body<0>(recs, sorted, base, perm, count, n, g, buckets, blockIdx.x - L.blocks);
+}
+
+// (r6, late) The same with the WAVE-COOPERATIVE GATHER of accum.hip k_accumulate, for the sizes where the buckets outnumber the machine's lanes (2^16 terms and up):
+// k_mid_acc<0> at 2^18 terms is 66 % VALU-busy and its waves wait 1.6x as long as they issue (profiles/r06_mid_acc_pmc.txt) -- every lane fetches its own 160-byte
+// record with ten 16-byte loads, 640 cache-line look-ups per addition and wave, and nothing is in flight during the addition (a register prefetch costs the third wave
+// per SIMD: r06_ab_mid_prefetch.txt).  Here the records of addition i + 1 travel by DMA into LDS during addition i: pieces 0 .. 7 of a record by the eight lanes
+// 8j .. 8j + 7 (eight instructions of eight lines each, the layout of k_accumulate: piece c of record r at position (c + r) mod 8 of the record's eight slots), pieces 8
+// and 9 by lane pairs (two instructions of 32 lines), 128 look-ups per addition; every lane reads its own record back (ten ds_read_b128) before the next DMA is issued.
+// 40 KB of LDS per block, three blocks per compute unit, the register budget of k_mid_acc.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mid_acc_coop(const u32 *__restrict__ recs, const u32 *__restrict__ sorted, const u32 *__restrict__ base, const u32 *__restrict__ perm, u64 count, u64 n,
+                                                 msm_geom g, u32 *__restrict__ buckets) {
+    __shared__ uint4 stage[(256 / 64) * MID_REC_Q * 64];
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void gbl_void;
+    const u64 tid = (u64)blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = tid < count;                     // every lane of a wave keeps loading for the others
+    const u64 gid = in_range ? perm[tid] : 0;
+    const int k = (int)(gid / g.half), b = (int)(gid % g.half);
+    const u32 lo = base[(u64)k * (g.half + 1) + b], hi = base[(u64)k * (g.half + 1) + b + 1];
+    const bool mine = in_range && hi - lo <= g.long_cap;
+    const u32 *list = sorted + (u64)k * n;
+    const u32 lane = threadIdx.x & 63u;
+    uint4 *slot_a = stage + (threadIdx.x >> 6) * (MID_REC_Q * 64), *slot_b = slot_a + 8 * 64;
+    const uint4 *my_a = slot_a + lane * 8, *my_b = slot_b + lane * 2;
+    const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
+    const u32 len = mine ? hi - lo : 0u;
+    u32 wmax = len;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { u32 o = (u32)__shfl_xor((int)wmax, d, 64); wmax = o > wmax ? o : wmax; }
+    ge_p3 acc = ge_identity();
+    u32 e = 0, e1 = 0;                                   // entries of iterations it and it + 1 (a finished lane keeps a valid index)
+    if (len > 0) e = list[lo];
+    if (len > 1) e1 = list[lo + 1];
+#define C25519_MID_COOP_ISSUE(ent)                                                                                              \
+    {                                                                                                                           \
+        _Pragma("unroll") for (int kk = 0; kk < 8; kk++) {                                                                     \
+            const u32 idx = (u32)__shfl((int)(ent), (int)(8 * kk + sub), 64) & 0x7fffffffu;                                     \
+            const uint4 *src = reinterpret_cast<const uint4 *>(recs) + (u64)MID_REC_Q * idx + coff;                             \
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot_a + kk * 64), 16, 0, 0);                        \
+        }                                                                                                                       \
+        _Pragma("unroll") for (int m = 0; m < 2; m++) {                                                                        \
+            const u32 idx = (u32)__shfl((int)(ent), (int)(32 * m + (lane >> 1)), 64) & 0x7fffffffu;                             \
+            const uint4 *src = reinterpret_cast<const uint4 *>(recs) + (u64)MID_REC_Q * idx + 8 + (lane & 1u);                  \
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot_b + m * 64), 16, 0, 0);                         \
+        }                                                                                                                       \
+    }
+    if (wmax > 0) C25519_MID_COOP_ISSUE(e)
+#pragma unroll 1
+    for (u32 it = 0; it < wmax; it++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        mid_rec<0> cur;
+#pragma unroll
+        for (int c = 0; c < 8; c++) cur.q[c] = my_a[(c + lane) & 7u];
+        cur.q[8] = my_b[0]; cur.q[9] = my_b[1];
+        const bool neg = (e >> 31) != 0, active = it < len;
+        const u32 e_next = e1;
+        if (it + 2 < len) e1 = list[lo + it + 2];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (it + 1 < wmax) C25519_MID_COOP_ISSUE(e_next)
+        if (active) acc = cur.add_to(acc, neg);
+        e = e_next;
+    }
+#undef C25519_MID_COOP_ISSUE
+    if (mine) p40_store(buckets, gid, acc);
+}
 
 }  // namespace c25519
 
@@ -292,6 +376,36 @@ bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
     return n > msm_small_max() && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1;
 }
 
+// The cap on a bucket lane's list (longer lists go to the waves of the long path).  A lane walks its list as a chain of dependent additions, so the accumulation lasts as
+// long as the longest list below the cap; every list above it costs a wave a ~27 us shuffle tree, which is free beside the bucket lanes as long as there are a few
+// hundred of them.  For uniform digits the list lengths of window k are Poisson(n / buckets_k) -- the windows of c - 1 and c - 2 bits have lists twice as long as the
+// others -- so: the smallest cap (>= 8) that leaves an EXPECTED `target` lists above it, never above the rule it replaces (`upper`).  Skewed inputs simply have more
+// long lists than expected; the long path takes whatever it is given.
+static double poisson_tail(double lam, int cap) {           // P(X > cap), X ~ Poisson(lam)
+    double term = std::exp(-lam), cdf = term;
+    for (int i = 1; i <= cap; i++) { term *= lam / i; cdf += term; }
+    return cdf >= 1.0 ? 0.0 : 1.0 - cdf;
+}
+// Measured (profiles/r06_ab_mid_cap.txt; device-resident calls, raw points, with the long lists inside the accumulation's launch): target 64 against the rule it replaces
+// 12 288 terms 0.208 -> 0.197 ms, 2^14 0.225 -> 0.207, 2^15 0.250 -> 0.241, 2^16 0.294 -> 0.287, 2^17 0.378 -> 0.374, 2^18 0.541 -> 0.553 (the accumulation there is
+// throughput: the old cap stays); target 256 the same up to 2^14 and level or worse above; 1024 worse everywhere (a long list costs its wave ten times the
+// additions of the list).  verify_batch: 2^13 signatures 0.333 -> 0.312, level within +-5 us above: the old cap from 2^15 terms.
+static uint32_t mid_pick_cap(uint64_t n, const msm_geom &g, uint32_t upper, bool prepared) {
+    static const int target = C25519_KNOB("MID_LONG_TARGET", 64);       // A/B knob of the tuning build: 0 = the rule of the first mid path, max(48, 3 x mean)
+    static const int force = C25519_KNOB("MID_LONG_TARGET_ALWAYS", 0);  // ... at every size
+    if (target <= 0) return upper;
+    if (!force && n >= (prepared ? (1ull << 15) : (1ull << 18))) return upper;
+    for (uint32_t cap = 8; cap < upper; cap++) {
+        double expect = 0;
+        for (int k = 0; k + 1 < g.nwin; k++) {                // (the overflow window holds a handful of entries)
+            const double buckets = (double)(1u << (k + 2 < g.nwin ? g.wid[k] - 1 : g.wid[k]));
+            expect += buckets * poisson_tail((double)n / buckets, (int)cap);
+        }
+        if (expect <= (double)target) return cap;
+    }
+    return upper;
+}
+
 // The whole pass: digits (+ records), sort, accumulation, reduction; column sums (and, hdr != 0, the record header) to d_slot -- or, ctx->direct_seq != 0, the
 // record published into the context's page-locked host slot.  src_fmt 0: raw 160-byte points at `points`; 1: affine Niels records at `points` (a decompression made them).
 // hdr 0: the slot was initialised by k_slot_init and carries counters of its own (verify_batch); 1: this pass writes the header (MSM).
@@ -303,7 +417,7 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
     // of ~128 entries each -- just under 192 -- and k_accumulate walked them for 368 us where the call of 2^16 signatures (256 entries each: over the cap) took 85
     // (profiles/r06_timeline_mid_verify_2p15_long_cap.txt).  One wave per 256 entries handles such a list in ~30 us.
     msm_geom g = g_in;
-    g.long_cap = (u32)std::max<uint64_t>(48, 3 * (n / (uint64_t)g.half + 1));
+    g.long_cap = mid_pick_cap(n, g, (u32)std::max<uint64_t>(48, 3 * (n / (uint64_t)g.half + 1)), src_fmt != 0);
     if (!msm_mid_serves(n, g, src_fmt != 0) || n >= (1ull << 31)) { ctx->err = "msm: internal error (mid path outside its range)"; return -(int32_t)hipErrorInvalidValue; }
     if (run && src_fmt == 0) { ctx->err = "msm: internal error (mid path: a stream override with raw points)"; return -(int32_t)hipErrorInvalidValue; }
     hipStream_t st = run && run->stream ? run->stream : ctx->stream;
@@ -382,8 +496,21 @@ int32_t msm_mid_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, const void *p
     }
     if (proj) {
         ctx->kname[0] = "c25519::k_mid_acc<0> (mid path: one lane per bucket, 8 M additions on projective Niels records)";
-        hipLaunchKernelGGL(k_mid_acc<0>, dim3(nacc), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets);
-        hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
+        // from 2^16 terms (A/B knob MID_COOP_MIN of the tuning build; 0 = never) the cooperative gather
+        // (the cooperative gather: measured level with the separate launch, profiles/r06_ab_mid_coop.txt; A/B knob MID_COOP_MIN of the tuning build, 0 = never)
+        static const uint64_t coop_min = (uint64_t)C25519_KNOB_LL("MID_COOP_MIN", 0);
+        static const int raw_fused = C25519_KNOB("MID_RAW_FUSED", 1);      // A/B knob: 0 = k_mid_long behind the accumulation on the same stream
+        if (coop_min && n >= coop_min) {
+            hipLaunchKernelGGL(k_mid_acc_coop, dim3(nacc), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets);
+            hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
+        } else if (raw_fused) {
+            ctx->kname[0] = "c25519::k_mid_acc_long (mid path: one lane per bucket, 8 M additions on projective Niels records; over-long lists in front)";
+            const mid_long_args L = {items, zw, segs, zw + 576, max_items, 128u};
+            hipLaunchKernelGGL(k_mid_acc_long, dim3(nacc + L.blocks), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets, L);
+        } else {
+            hipLaunchKernelGGL(k_mid_acc<0>, dim3(nacc), dim3(256), 0, st, recs, sorted, base, perm, nb, n, g, buckets);
+            hipLaunchKernelGGL(k_mid_long<0>, dim3(nlong), dim3(256), 0, st, recs, sorted, n, g, buckets, max_items, items, zw, segs, zw + 576);
+        }
     } else if (fused) {
         ctx->kname[0] = launch_accumulate_long(recs, sorted, base, perm, nb, n, g, buckets, items, zw, segs, zw + 576, max_items, 64, st);
     } else {

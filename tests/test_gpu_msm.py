@@ -267,7 +267,11 @@ def test_msm_affine_and_projective_lanes_mixed(eng, orc):
                                  # round 6, the mid path: off (the bucket pipeline from 12 288 terms, as it still serves everything beyond 2^17), the normaliser +
                                  # k_accumulate arm from 12 288 terms, many small sort slices, up to 2^18 terms; streaming normaliser / sort reads
                                  {"C25519_MSM_MID_MAX": "0"}, {"C25519_MID_PROJ_MAX": "0"}, {"C25519_MID_SORT_BLOCKS": "1024", "C25519_MSM_MID_MAX": "262144"},
-                                 {"C25519_PREP_NT": "1", "C25519_SWEEP_NT": "1", "C25519_MSM_PASS_LOG2": "20"}])
+                                 {"C25519_PREP_NT": "1", "C25519_SWEEP_NT": "1", "C25519_MSM_PASS_LOG2": "20"},
+                                 # round 6, late: the cap on a bucket lane's list (the first mid path's rule; many lists above it at every size), the over-long
+                                 # lists as a launch of their own, the cooperative gather from the first size of the path
+                                 {"C25519_MID_LONG_TARGET": "0"}, {"C25519_MID_LONG_TARGET": "2048", "C25519_MID_LONG_TARGET_ALWAYS": "1"},
+                                 {"C25519_MID_RAW_FUSED": "0"}, {"C25519_MID_COOP_MIN": "12288"}])
 def test_msm_kernel_variants_in_a_fresh_process(orc, env):
     """The remaining knobs (pass size, number of stream sets) are read once per process: 2^16-term passes make a small input
     run many passes (more than the 16 result slots at the largest size: the slots are reused and the record is summed in

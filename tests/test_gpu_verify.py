@@ -216,7 +216,7 @@ _MID_CHAIN_BODY = """
     OK, NONE, SCALAR_FORMAT, VERIFY = 0, 1, 2, 3
     eng = pkg.Engine(0)
     calls = 0
-    for n in (6144, 7001, 16384, 40000, 65536):
+    for n in SIZES:
         print("n", n, flush=True)
         seeds = util.rand_bytes(2000 + n, n); msgs = util.rand_bytes(2001 + n, n, 41)
         pks, sigs = orc.ed25519_keygen_sign_batch(seeds, msgs, threads=os.cpu_count() or 1)
@@ -237,7 +237,7 @@ _MID_CHAIN_BODY = """
             bad = ds.clone(); bad[7, 0:32] = torch.from_numpy(np.frombuffer((2).to_bytes(32, "little"), dtype=np.uint8).copy()).cuda()   # an R that does not decode: Verify (batch.rs:244)
             assert eng.verify_batch_t(dm, doff, bad, dp, 1, pk_points=pts) == VERIFY
             calls += 7
-            assert eng.counter(2) - c0 == 7, (n, eng.counter(2) - c0)    # every one of them published its record itself
+            assert eng.counter(2) - c0 == (7 if EXPECT_DIRECT else 0), (n, eng.counter(2) - c0)    # every one of them published its record itself
         # cached points that are NOT affine: the one-pass normaliser of VerifyingKey points (msm.hip k_prep_affine) must hand over to the general one --
         # one projective point among affine ones, and every point projective
         import random
@@ -279,17 +279,24 @@ _MID_CHAIN_BODY = """
 """
 
 
-@pytest.mark.parametrize("lose", [0, 3])
-def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, lose):
+@pytest.mark.parametrize("env", [{}, {"C25519_FAULT_LOSE_PUBLICATION": "3", "C25519_PUBLISH_SPIN_US": "1000"},
+                                 # the arms the defaults were measured against (profiles/r06_ab_verify_*.txt, r06_ab_prep_affine.txt, r06_ab_mid_cap.txt)
+                                 {"C25519_MID_ON_CHAIN": "0"}, {"C25519_VERIFY_DIRECT": "0", "C25519_MID_LONG_BESIDE": "1"}, {"C25519_VERIFY_ORDER": "1"},
+                                 {"C25519_VERIFY_ORDER": "2", "C25519_PREP_AFFINE_FIRST": "0"}, {"C25519_MID_LONG_TARGET": "2048", "C25519_MID_LONG_TARGET_ALWAYS": "1"}],
+                         ids=["release", "lost-publication", "main-stream", "copy-path-long-beside", "order-1", "order-2-general-normaliser", "low-cap"])
+def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, env):
     """(r6) Device z-mode, inputs on the device, 6144 .. 2^16 signatures: the 2n + 1-term MSM takes the mid path ON the hash chain's stream (digits and sort right
     behind the batch scalars, the records waited for and signed in front of the accumulation, the over-long lists inside the accumulation's launch) and the last
-    reduction block PUBLISHES the record with the device slot's counters.  Verdicts -- including the ones that live in those counters -- with key bytes and with cached
-    key points; lose = 3: every third publication is dropped (tuning build) and must be recovered through the copy path with the same verdicts."""
+    reduction block PUBLISHES the record with the device slot's counters.  Verdicts -- including the ones that live in those counters -- with key bytes, with cached
+    key points (affine, one projective, all projective); every third publication dropped (tuning build) must be recovered through the copy path with the same
+    verdicts; and the same batches through the arms the defaults were measured against."""
     import subprocess, textwrap
-    code = textwrap.dedent(_MID_CHAIN_BODY % (ROOT, ROOT)).replace("EXPECT_LOST", "True" if lose else "False")
-    env = util.tune_env(C25519_FAULT_LOSE_PUBLICATION=str(lose), C25519_PUBLISH_SPIN_US="1000") if lose else dict(os.environ)
-    r = subprocess.run(util.child_argv(code), env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-4000:])
+    lose = "C25519_FAULT_LOSE_PUBLICATION" in env
+    direct = env.get("C25519_MID_ON_CHAIN", "1") != "0" and env.get("C25519_VERIFY_DIRECT", "1") != "0"
+    sizes = "(6144, 7001, 16384, 40000, 65536)" if (not env or lose) else "(6144, 16385, 40000)"
+    code = textwrap.dedent(_MID_CHAIN_BODY % (ROOT, ROOT)).replace("EXPECT_LOST", "True" if lose else "False").replace("EXPECT_DIRECT", "True" if direct else "False").replace("SIZES", sizes)
+    r = subprocess.run(util.child_argv(code), env=util.tune_env(env) if env else dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-2000:], r.stderr[-4000:])
 
 
 @pytest.mark.parametrize("n", [1, 2, 15, 16, 17, 255, 4097, 16385, 16400,
