@@ -67,6 +67,29 @@ vseeds = torch.randint(0, 256, (NV, 32), dtype=torch.uint8, device="cuda", gener
 vm = torch.randint(0, 256, (NV * 16,), dtype=torch.uint8, device="cuda", generator=gl); voff = torch.arange(0, NV * 16 + 1, 16, dtype=torch.int64, device="cuda")
 vpk, vsg = e0.sign_batch_t(vseeds, vm, voff)
 
+# (r6, late) the MID path publishes its record the same way (mid.hip / reduce.hip k_reduce_b4pub): MSMs of 12 288 .. 2^17 terms on the device (a prefix of the
+# large call's inputs: sum lx_i^2 B) and device-z-mode verify_batch of 6144 .. 20 000 signatures (key bytes / cached points; a copy with R_0 tampered)
+lxi = [int.from_bytes(b.tobytes(), "little") for b in lx.cpu().numpy()]
+sq = [0]
+for a in lxi:
+    sq.append((sq[-1] + a * a) % L)
+_want_mid = {}
+
+
+def want_mid(n):
+    if n not in _want_mid:
+        _want_mid[n] = orc.ed_compress(orc.ed_mul_base(sq[n].to_bytes(32, "little")))
+    return _want_mid[n]
+
+
+NM = 20000
+mseeds = torch.randint(0, 256, (NM, 32), dtype=torch.uint8, device="cuda", generator=gl)
+mm = torch.randint(0, 256, (NM * 24,), dtype=torch.uint8, device="cuda", generator=gl); moff = torch.arange(0, NM * 24 + 1, 24, dtype=torch.int64, device="cuda")
+mpk, msg_ = e0.sign_batch_t(mseeds, mm, moff)
+_, mpts, mok = e0.decompress_batch_t(mpk); assert bool(mok.all())
+msg_bad = msg_.clone(); msg_bad[0, 3] ^= 1
+assert e0.verify_batch_t(mm[:24 * 7000], moff[:7001], msg_[:7000], mpk[:7000], 1) == 0
+
 ctxs = [e0, pkg.Engine(0), pkg.Engine(0)]
 lat = {}
 slow = []
@@ -100,7 +123,19 @@ while done < calls:
         wrong += (st != 0 or got != large_want)
         t0 = time.perf_counter(); st = eng.verify_batch_t(vm, voff, vsg, vpk, rnd.randrange(2)); note("large verify_batch 2^12 (device)", NV, time.perf_counter() - t0)
         wrong += (st != 0)
-    if r < 0.30:
+    if r < 0.04:
+        n = rnd.randrange(12288, NL + 1)
+        t0 = time.perf_counter(); st, got = eng.msm_vartime_t(lx[:n], lraw[:n], in_fmt=2, out_fmt=0); note("mid msm 12288 .. 2^17 (device)", n, time.perf_counter() - t0)
+        wrong += (st != 0 or got != want_mid(n))
+    elif r < 0.08:
+        n = rnd.randrange(6144, NM + 1)
+        cached = rnd.random() < 0.5
+        tamper = rnd.random() < 0.2
+        t0 = time.perf_counter()
+        st = eng.verify_batch_t(mm[:24 * n], moff[:n + 1], (msg_bad if tamper else msg_)[:n], mpk[:n], 1, pk_points=mpts[:n] if cached else None)
+        note("mid verify_batch 6144 .. 20000, device z%s" % (" cached points" if cached else ""), n, time.perf_counter() - t0)
+        wrong += (st != (3 if tamper else 0))
+    elif r < 0.30:
         n = log_n()
         t0 = time.perf_counter(); st, got = eng.msm_vartime(x[:n], pts[:n], in_fmt=2, out_fmt=0); note("msm host pointers", n, time.perf_counter() - t0)
         wrong += (st != 0 or got != want_msm(n))
