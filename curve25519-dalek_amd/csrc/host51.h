@@ -243,6 +243,90 @@ C25519_IFMA_FN hp3 hp3_mul_by_pow_2_ifma(const hp3 &p, int k) {
     hp3 r; r.X = o[0]; r.Y = o[1]; r.Z = o[2]; r.T = o[3];
     return r;
 }
+// ---- (r6, late) the WHOLE Horner fold in lane form: the running total stays (X, Y, Z, T) in the lanes of five vectors across doublings and additions ----------
+// k doublings of P = (X, Y, Z, T) in lane form (the loop of hp3_mul_by_pow_2_ifma without the conversions around it)
+C25519_IFMA_FN f51x4 p4_pow2(f51x4 P, int k) {
+    _Pragma("GCC unroll 16") for (int it = 0; it < k; it++) {
+        f51x4 A;
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            const __m256i yx = _mm256_permute4x64_epi64(P.v[i], 0x55);
+            const __m256i sum = _mm256_add_epi64(_mm256_permute4x64_epi64(P.v[i], 0x00), yx);
+            A.v[i] = _mm256_blend_epi32(P.v[i], sum, 0xC0);                // (X, Y, Z, X + Y)
+        }
+        A = f51x4_carry(A);
+        const f51x4 Q = f51x4_sq(A);                                      // (XX, YY, ZZ, S)
+        f51x4 W, U, M1, M2;
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            const __m256i a0 = _mm256_permute4x64_epi64(Q.v[i], 0xE5), b0 = _mm256_permute4x64_epi64(Q.v[i], 0xA0);
+            const __m256i neg = _mm256_sub_epi64(ifma_2p(i), b0);
+            __m256i add = _mm256_blend_epi32(b0, neg, 0x0C);
+            add = _mm256_blend_epi32(add, _mm256_setzero_si256(), 0xC0);
+            W.v[i] = _mm256_add_epi64(a0, add);
+        }
+        W = f51x4_carry(W);                                               // (YpX, YmX, ZZ2, S)
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            const __m256i a1 = _mm256_permute4x64_epi64(W.v[i], 0x0B), b1 = _mm256_permute4x64_epi64(W.v[i], 0x04);
+            U.v[i] = _mm256_add_epi64(a1, _mm256_sub_epi64(ifma_2p(i), b1));
+        }
+        U = f51x4_carry(U);                                               // (cX, cT, ., .)
+        _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+            const __m256i cx = _mm256_permute4x64_epi64(U.v[i], 0x00), ct = _mm256_permute4x64_epi64(U.v[i], 0x55);
+            const __m256i w0110 = _mm256_permute4x64_epi64(W.v[i], 0x10), w1x0 = _mm256_permute4x64_epi64(W.v[i], 0x04);
+            M1.v[i] = _mm256_blend_epi32(cx, w0110, 0x3C);                // (cX, YpX, YmX, cX)
+            M2.v[i] = _mm256_blend_epi32(ct, w1x0, 0xCC);                 // (cT, YmX, cT, YpX)
+        }
+        P = f51x4_mul(M1, M2);                                            // (X', Y', Z', T')
+    }
+    return P;
+}
+// the cached form of a point for p4_add: (Y - X, Y + X, 2 Z, 2 d T) in the lanes (curve_models.rs:365-373 / the reference's CachedPoint, backend/vector/ifma)
+C25519_IFMA_FN f51x4 p4_cached(const hp3 &q) {
+    const h51 d2 = h51_d2(), one = {{1, 0, 0, 0, 0}};
+    f51x4 Q = f51x4_load(h51_sub(q.Y, q.X), h51_add(q.Y, q.X), h51_twice(q.Z), q.T);
+    return f51x4_mul(f51x4_carry(Q), f51x4_load(one, one, one, d2));
+}
+// P + Q (complete addition, edwards.rs:795-800 through curve_models.rs:411-429 and :365-373; the same 9 M as hp3_add) with the four products of each of its two stages
+// in the lanes of one vector
+C25519_IFMA_FN f51x4 p4_add(const f51x4 &P, const f51x4 &Qc) {
+    f51x4 D1;
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+        const __m256i a = _mm256_permute4x64_epi64(P.v[i], 0xE5);         // (Y, Y, Z, T)
+        const __m256i b = _mm256_permute4x64_epi64(P.v[i], 0xA0);         // (X, X, Z, Z)
+        const __m256i neg = _mm256_sub_epi64(ifma_2p(i), b);
+        __m256i add = _mm256_blend_epi32(b, neg, 0x03);                   // lane 0 <- 2p - X, lane 1 = X
+        add = _mm256_blend_epi32(add, _mm256_setzero_si256(), 0xF0);      // lanes 2, 3 <- 0
+        D1.v[i] = _mm256_add_epi64(a, add);                               // (Y - X, Y + X, Z, T)
+    }
+    const f51x4 M = f51x4_mul(f51x4_carry(D1), Qc);                       // (A, B, D, C) = ((Y1-X1)(Y2-X2), (Y1+X1)(Y2+X2), 2 Z1 Z2, 2d T1 T2)
+    f51x4 S, F;
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+        const __m256i sw = _mm256_permute4x64_epi64(M.v[i], 0xB1);        // (B, A, C, D)
+        S.v[i] = _mm256_add_epi64(M.v[i], sw);                            // (H, H, G, G): H = B + A, G = D + C
+        F.v[i] = _mm256_add_epi64(sw, _mm256_sub_epi64(ifma_2p(i), M.v[i]));      // (E, -E, -F, F): E = B - A, F = D - C
+    }
+    S = f51x4_carry(S); F = f51x4_carry(F);
+    f51x4 L, R;
+    _Pragma("GCC unroll 16") for (int i = 0; i < 5; i++) {
+        const __m256i dl = _mm256_permute4x64_epi64(F.v[i], 0x30), sl = _mm256_permute4x64_epi64(S.v[i], 0xAA);
+        L.v[i] = _mm256_blend_epi32(dl, sl, 0x0C);                        // (E, G, F, E)
+        const __m256i dr = _mm256_permute4x64_epi64(F.v[i], 0xFF), sr = _mm256_permute4x64_epi64(S.v[i], 0x20);
+        R.v[i] = _mm256_blend_epi32(sr, dr, 0x03);                        // (F, H, G, H)
+    }
+    return f51x4_mul(L, R);                                               // (E F, G H, F G, E H) = (X3, Y3, Z3, T3)
+}
+// sum_k 2^(pos_k) col_k by Horner, top window first: shift[k] = doublings in front of the addition of column k (shift of the first column handled: ignored)
+C25519_IFMA_FN hp3 hp3_horner_ifma(const hp3 *cols, const int *shift, int n) {
+    const hp3 id = hp3_identity();
+    f51x4 P = f51x4_load(id.X, id.Y, id.Z, id.T);
+    for (int k = 0; k < n; k++) {
+        if (k) P = p4_pow2(P, shift[k]);
+        P = p4_add(P, p4_cached(cols[k]));
+    }
+    h51 o[4];
+    f51x4_store(P, o);
+    hp3 r; r.X = o[0]; r.Y = o[1]; r.Z = o[2]; r.T = o[3];
+    return r;
+}
 static inline bool host_has_ifma() {
     static const bool v = __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl");
     return v;
@@ -253,5 +337,17 @@ static inline hp3 hp3_pow2_fast(const hp3 &p, int k) { return host_has_ifma() ? 
 static inline bool host_has_ifma() { return false; }
 static inline hp3 hp3_pow2_fast(const hp3 &p, int k) { return hp3_mul_by_pow_2(p, k); }
 #endif
+// the fold: columns top window first, shift[k] doublings in front of column k (k >= 1)
+static inline hp3 hp3_horner(const hp3 *cols, const int *shift, int n) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__) && !defined(C25519_NO_IFMA)
+    if (host_has_ifma()) return hp3_horner_ifma(cols, shift, n);
+#endif
+    hp3 total = hp3_identity();
+    for (int k = 0; k < n; k++) {
+        if (k) total = hp3_mul_by_pow_2(total, shift[k]);
+        total = hp3_add(total, cols[k]);
+    }
+    return total;
+}
 
 }  // namespace c25519

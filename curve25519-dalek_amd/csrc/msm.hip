@@ -704,12 +704,15 @@ int32_t msm_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, uint64_t n, const
 // total = sum_k 2^pos_k col_k by Horner (pippenger.rs:159), host arithmetic over <= 56 points
 ge_p3 msm_horner(const uint32_t *cols, const msm_geom &g) {
     // (host51.h: the 5 x 51-bit layout a 64-bit core multiplies natively -- 25 us per fold instead of 74 through the device layout)
-    hp3 total = hp3_identity();
-    for (int k = g.nwin - 1; k >= 0; k--) {
-        if (k != g.nwin - 1) total = hp3_pow2_fast(total, g.pos[k + 1] - g.pos[k]);      // (AVX-512 IFMA where the host has it: host51.h)
-        total = hp3_add(total, hp3_from(host_p40(&cols[(size_t)k * 40])));
+    // (AVX-512 IFMA where the host has it -- doublings and additions with the running total in the lanes of five vectors: host51.h hp3_horner)
+    hp3 c[MSM_MAX_WIN];
+    int shift[MSM_MAX_WIN];
+    for (int j = 0; j < g.nwin; j++) {
+        const int k = g.nwin - 1 - j;
+        c[j] = hp3_from(host_p40(&cols[(size_t)k * 40]));
+        shift[j] = j ? g.pos[k + 1] - g.pos[k] : 0;
     }
-    return hp3_to(total);
+    return hp3_to(hp3_horner(c, shift, g.nwin));
 }
 // ---- how a call's results reach the host ----------------------------------------------------------------------------------------
 // hipMemcpyAsync of the slots into page-locked memory + hipStreamSynchronize (rounds 1-4, the default).  The round-4 verdict suspected 40 - 60 us of

@@ -5,6 +5,7 @@
 #include "../../curve25519-dalek_amd/csrc/ge26.h"
 #include "../../curve25519-dalek_amd/csrc/fe9_probe.h"
 #include <string.h>
+#include <vector>
 using namespace c25519;
 
 static feT load(const uint8_t b[32]) { u32 w[8]; memcpy(w, b, 32); return fe_from_words(w); }
@@ -170,6 +171,15 @@ static void h_affine(const hp3 &r, uint8_t *o) {
 void h_pow2_scalar(const uint64_t *xyz, int k, uint8_t *o) {
     hp3 p; for (int i = 0; i < 5; i++) { p.X.v[i] = xyz[i]; p.Y.v[i] = xyz[5 + i]; p.Z.v[i] = xyz[10 + i]; p.T.v[i] = 0; }
     h_affine(hp3_mul_by_pow_2(p, k), o);
+}
+// the whole fold: n columns (X, Y, Z, T as 4 x 5 u64 limbs each, top window first), shift[k] doublings in front of column k; ifma = 1: the lane form (where the CPU has it)
+void h_horner(const uint64_t *cols, const int *shift, int n, int ifma, uint8_t *o) {
+    std::vector<hp3> c((size_t)n);
+    for (int k = 0; k < n; k++) for (int i = 0; i < 5; i++) { c[k].X.v[i] = cols[20 * k + i]; c[k].Y.v[i] = cols[20 * k + 5 + i]; c[k].Z.v[i] = cols[20 * k + 10 + i]; c[k].T.v[i] = cols[20 * k + 15 + i]; }
+    if (ifma) { h_affine(hp3_horner(c.data(), shift, n), o); return; }
+    hp3 total = hp3_identity();
+    for (int k = 0; k < n; k++) { if (k) total = hp3_mul_by_pow_2(total, shift[k]); total = hp3_add(total, c[k]); }
+    h_affine(total, o);
 }
 void h_pow2_ifma(const uint64_t *xyz, int k, uint8_t *o) {
     hp3 p; for (int i = 0; i < 5; i++) { p.X.v[i] = xyz[i]; p.Y.v[i] = xyz[5 + i]; p.Z.v[i] = xyz[10 + i]; p.T.v[i] = 0; }

@@ -347,6 +347,58 @@ def test_ifma_doubling_chain(host):
             assert b.raw[:32] == i2b(ex) and b.raw[32:64] == i2b(ey) and b.raw[64:] == i2b(ex * ey % P), (idx, k)
 
 
+def test_ifma_horner_fold(host):
+    """(r6) The whole Horner fold with the running total in lane form (csrc/host51.h hp3_horner: p4_pow2 / p4_cached / p4_add on AVX-512 IFMA) against the scalar
+    fold and against Python big integers (affine addition law): 1 .. 56 columns -- random projective points, the identity, points of order 2 and 4, equal neighbours
+    (the addition must be complete) -- with the shifts of real window layouts (5 .. 17 bits).  On a CPU without avx512ifma both calls run the scalar code."""
+    rng = random.Random(123)
+    d = (-121665 * pow(121666, P - 2, P)) % P
+
+    def add(p, q):
+        (x1, y1), (x2, y2) = p, q
+        k = d * x1 * x2 * y1 * y2 % P
+        return ((x1 * y2 + y1 * x2) * pow(1 + k, P - 2, P) % P, (y1 * y2 + x1 * x2) * pow(1 - k, P - 2, P) % P)
+
+    def point():
+        while True:
+            y = rng.randrange(P)
+            u, v = (y * y - 1) % P, (d * y * y + 1) % P
+            x2 = u * pow(v, P - 2, P) % P
+            x = pow(x2, (P + 3) // 8, P)
+            if (x * x - x2) % P:
+                x = x * pow(2, (P - 1) // 4, P) % P
+            if (x * x - x2) % P == 0:
+                return x, y
+
+    def limbs(v):
+        v %= P
+        return [(v >> (51 * i)) & ((1 << 51) - 1) for i in range(5)]
+
+    special = [(0, 1), (0, P - 1), (pow(2, (P - 1) // 4, P), 0)]
+    for trial in range(30):
+        n = rng.choice([1, 2, 3, 16, 22, 43, 51, 56])
+        c = rng.randrange(5, 18)
+        pts = []
+        for k in range(n):
+            r = rng.random()
+            pts.append(rng.choice(special) if r < 0.15 else (pts[-1] if r < 0.25 and pts else point()))
+        shifts = [0] + [rng.choice([c, c - 1, c - 2, 1, 4]) for _ in range(n - 1)]
+        flat = []
+        for (x, y) in pts:
+            z = rng.randrange(1, P)
+            flat += limbs(x * z) + limbs(y * z) + limbs(z) + limbs(x * y * z)
+        arr = (C.c_uint64 * len(flat))(*flat); sh = (C.c_int * n)(*shifts)
+        a, b = C.create_string_buffer(96), C.create_string_buffer(96)
+        host.h_horner(arr, sh, n, 0, a); host.h_horner(arr, sh, n, 1, b)
+        assert a.raw == b.raw, (trial, n)
+        tot = (0, 1)
+        for k in range(n):
+            for _ in range(shifts[k] if k else 0):
+                tot = add(tot, tot)
+            tot = add(tot, pts[k])
+        assert b.raw[:32] == i2b(tot[0]) and b.raw[32:64] == i2b(tot[1]) and b.raw[64:] == i2b(tot[0] * tot[1] % P), (trial, n)
+
+
 def test_blake2b_compression_function_vs_hashlib(host):
     """csrc/blake2b.h (the hash of the device z-mode's tree, verify.hip) driven as the plain unkeyed BLAKE2b of RFC 7693: the RFC's "abc" vector (appendix A) and
     hashlib.blake2b on random messages around every block boundary, digest lengths 32 and 64."""
