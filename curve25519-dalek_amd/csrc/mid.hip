@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // 0.78 against 0.71: profiles/r06_ab_mid_upper_end.txt); prepared records -- verify_batch's 2n + 1 terms, whose sort is a third of the bucket pipeline's call -- up to 2^18 + 1
 uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 18); return v; }
 static uint64_t msm_mid_max_records() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX_RECORDS", (1 << 18) + 1); return v; }
+bool msm_mid_serves_terms(uint64_t n) { return n > msm_small_max() && n <= msm_mid_max_records(); }      // (prepared records; whatever width the caller is about to choose)
 bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
     return n > msm_small_max() && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1;
 }

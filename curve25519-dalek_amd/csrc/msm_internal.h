@@ -116,6 +116,7 @@ void launch_bucket_reduce_pub(const uint32_t *buckets, const c25519::msm_geom &g
                               const c25519::reduce_publish &pub, hipStream_t st);
 void launch_order_place(const uint32_t *totals, uint64_t nb, const uint32_t *ord_hist, uint32_t *ord_cursor, uint32_t *perm, const c25519::msm_geom &g, hipStream_t st);
 uint64_t msm_mid_max();
+bool msm_mid_serves_terms(uint64_t n);      // prepared records: is this term count inside the path's range (before a layout exists)
 bool msm_mid_serves(uint64_t n, const c25519::msm_geom &g, bool prepared);      // prepared: the records exist (a decompression made them)
 // run (may be null; prepared records only): the pass runs on run->stream instead of the context's main stream (verify_batch: the stream its scalars were made on -- no
 // hand-over in front of the digits), waits for run->recs_ready (the records, made on the other stream) only in front of the accumulation, and negates there the

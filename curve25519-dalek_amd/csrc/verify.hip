@@ -737,7 +737,15 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     // that the precedence does not depend on where the batch was cut
     const uint64_t passes = n <= VERIFY_PASS_MAX ? 1 : (n + VERIFY_PASS - 1) / VERIFY_PASS, per = (n + passes - 1) / passes;
     msm_geom g;
-    msm_layout(2 * per + 1, g, 16);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
+    // (r6, late) the window width of a mid-size batch: the MSM's rule (msm.hip pick_window) was tuned on 253-bit scalars; here half of the terms carry 127-bit ones
+    // (nine windows instead of nineteen at 14 bits) and 16-bit windows end exactly on the z_i (no top window of a few bits whose lists are over-long).  Measured
+    // (profiles/r06_ab_verify_window.txt): 2^15 signatures 14 bits 0.411 against the rule's 15 0.417 ms; 2^16: 16 bits 0.476 against 15 bits 0.501; 2^13 / 2^14: the rule (13 / 14).
+    static const int verify_c = C25519_KNOB("VERIFY_C", 0);      // A/B knob of the tuning build: 0 = this rule; 8 .. 16 = that width; -1 = the MSM's rule
+    const uint64_t vterms = 2 * per + 1;
+    int vc = 0;
+    if (verify_c >= 8 && verify_c <= 16 && vterms > msm_small_max()) vc = verify_c;
+    else if (verify_c == 0 && passes == 1 && msm_mid_serves_terms(vterms)) vc = vterms < 24576 ? 13 : vterms < 98304 ? 14 : 16;
+    msm_layout(vterms, g, 16, vc);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
     ctx->solo = passes == 1;
