@@ -425,6 +425,9 @@ static bool verify_on_chain(uint64_t n, const msm_geom &g, bool staged) {
     static const int k = C25519_KNOB("MID_ON_CHAIN", 1);     // A/B knob of the tuning build
     return k != 0 && !staged && n <= (1ull << 16) && msm_mid_serves(2 * n + 1, g, true);
 }
+// keys as BYTES: up to this many signatures A_i and R_i are decompressed by ONE launch of 2n lanes (one latency chain instead of two; rounds 3-5: 4096 -- A/B knob
+// VERIFY_BOTH_MAX of the tuning build; profiles/r06_ab_verify_both.txt)
+static uint64_t verify_both_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("VERIFY_BOTH_MAX", 1 << 16); return v; }
 // pre (small batches of the transcript z-mode, may be null): the records of A_i and R_i are ALREADY at their place in the context's record buffer
 // (or will be once `ready` has fired) -- decompressed on the second stream while the hashes went to the host and the z_i came back -- with
 // cnt[0] keys and cnt[1] R_i that do not decode
@@ -513,7 +516,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
         HIPCHK(hipStreamWaitEvent(st, pre->ready, 0));
         hipLaunchKernelGGL(k_add_point_counters, dim3(1), dim3(64), 0, st, d_cnt, pre->cnt);
         HIPCHK(hipEventRecord(ring[4], st)); HIPCHK(hipEventRecord(ring[5], st));
-    } else if (!d_pk_points && n <= 4096) {
+    } else if (!d_pk_points && n <= verify_both_max()) {
         // small batches of key BYTES: both decompressions in one launch (one latency chain instead of two; d_cnt[2] = bad A, d_cnt[3] = bad R)
         HIPCHK(hipEventRecord(ring[4], st));
         ctx->kname[1] = "c25519::k_prep_compressed_keys_and_r (decompression of A_i and R_i)";
