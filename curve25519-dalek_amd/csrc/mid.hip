@@ -1,4 +1,4 @@
-// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in SEVEN short launches, all but one on ONE stream.
+// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in SIX short launches on ONE stream.
 //
 // Reference: the same algorithm as msm.hip -- backend/serial/scalar_mul/pippenger.rs:67-160 (signed digits, buckets, running-sum reduction, Horner fold), for the sizes
 // where the reference's heaviest real callers live (edwards.rs:1002-1031 vartime_multiscalar_mul of a Bulletproofs verification; ed25519-dalek/src/batch.rs:225-244
@@ -13,12 +13,15 @@
 //                 record (Y+X, Y-X, Z, 2dT) of (XZ : YZ : Z^2 : XY): five field operations, NO inversion.  The accumulation then costs 8 M per addition instead
 //                 of 7 M, which is nothing beside a 265-operation inversion chain while the machine is not full (the small path made the same choice).
 //                 Also zeroes the small counters of the kernels behind it (it always precedes them on the stream: nothing relies on a previous call's clean-up).
-//   k_mid_sort    one block per (window, slice of <= 1024 buckets): count -> scan -> place over the window's row of D, straight into the final gather lists
-//                 (two reads of a row that sits in L2; no partition pass, no digit re-derivation), the bucket bases, a block-local bucket order by list length
-//                 (lanes of a wave walk lists of similar length; a global order is not needed), and the work items of over-long lists.
-//   k_mid_acc     one lane per bucket walking its list (8 M additions on projective Niels records, or 7 M mixed additions on the affine records a decompression
-//                 left: verify_batch / compressed inputs); extra blocks at the END of the grid fold the over-long lists segment by segment, the wave that
-//                 finishes a bucket's last segment sums the segments (no separate combine launch, no second stream).
+//   k_mid_sort    one block per (window, slice of <= 4096 buckets): count -> scan -> place over the window's row of D, straight into the final gather lists
+//                 (two reads of a row that sits in L2; no partition pass, no digit re-derivation), the bucket bases, the list lengths with their histogram, and the
+//                 work items of over-long lists.
+//   k_order_place (msm_sort.hip) all buckets of the call in the order of their list lengths, longest first: the accumulation's makespan is its longest lists, and
+//                 they must start first (a block-local order -- the first version -- cost 132 against 79 us at 2^16 terms).
+//   k_mid_acc_long  one lane per bucket walking its list (8 M additions on projective Niels records; prepared records -- verify_batch / compressed inputs -- take
+//                 accum.hip k_accumulate_long: 7 M mixed additions on the affine records a decompression left); blocks IN FRONT of the bucket lanes fold the
+//                 over-long lists segment by segment (mid_long.h), the wave that finishes a bucket's last segment sums the segments (no separate combine launch, no
+//                 second stream).  Which lists are over-long: mid_pick_cap -- the accumulation lasts as long as the longest list a lane keeps.
 //   k_reduce_a4, k_reduce_b4pub (reduce.hip)  the two levels of the bucket reduction; the level-B block that finishes the last window writes the record's header --
 //                 and, for a caller that reads the record on the host right away, publishes it into page-locked host memory and releases the sequence word the
 //                 host polls (the small path's mechanism, msm.hip wait_published, with the same recovery).
