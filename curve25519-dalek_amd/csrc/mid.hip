@@ -58,7 +58,7 @@ namespace c25519 {
 template <int SRC>
 __global__ void __launch_bounds__(256) k_mid_front(const uint8_t *__restrict__ scalars, const uint8_t *__restrict__ points, u64 n, msm_geom g, uint16_t *__restrict__ D, u64 dstride,
                                                    u32 *__restrict__ recs, u32 *__restrict__ zero_words, int nzero, u32 *__restrict__ blockflags) {
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero_words[i] = 0;
+    for (u32 i = blockIdx.x * 256u + threadIdx.x; i < (u32)nzero; i += gridDim.x * 256u) zero_words[i] = 0;      // (all blocks: with the caps of mid_pick_cap the per-bucket counters of the long path are tens of thousands of words)
     const u64 t = (u64)blockIdx.x * 256 + threadIdx.x;
     int bad = 0;
     if (t < dstride) {
