@@ -782,7 +782,9 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             r = rec_collect(ctx);                           // (polls for ctx->direct_seq and clears it)
             if (r == C25519_LOST_PUBLICATION) {             // never observed (profiles/r06_soak_small.txt); tests/test_gpu_verify.py injects it
                 ctx->no_direct_once = true;
-                return verify_batch_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, d_pk_points, n, z_mode, fetch);
+                const int32_t r2 = verify_batch_impl(ctx, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, d_pk_points, n, z_mode, fetch);
+                if (r2 >= 0) ctx->err.clear();              // (the note of the lost publication: the call has its verdict)
+                return r2;
             }
             if (r) return r;
         } else if ((r = slots_collect(ctx, cnt))) return r;
