@@ -133,9 +133,17 @@ __device__ __forceinline__ void rc_dbl(int role, int lane, u32 *arr, u32 *scratc
     __syncthreads();
 }
 
-// in: S[l], W[l] for the 64 logical lanes.  out: S[l] = sum_l W_l + 2^shift * sum_l l * S_l in EVERY lane; tot = sum_l S_l (one point, 40 words).
+__device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i = 0; i < 10; i++) r.v[i] = tot[c * 10 + i]; return r; }
+// in: S[l], W[l] for the 64 logical lanes.  out: S[0] = sum_l W_l + 2^shift * sum_l l * S_l (in every lane unless scaled_tot); tot = sum_l S_l (one point, 40 words).
 // (wave_weighted_sum of msm.hip: suffix scan, then sum_l l S_l = sum_{l >= 1} T_l, then a butterfly)
-__device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 *W, u32 *tot, u32 *scratch, int shift) {
+// scaled_tot (r6, late; level A of a two-level reduction): lane 63 of W ends with 2^6 * tot.  Level B weights segment j by j * 2^(lb + 6); with the segment totals
+// arriving pre-multiplied by 2^6 it doubles lb times instead of lb + 6 -- six point operations (~13 us) off the tail of EVERY call of 12 288 terms and more -- and the
+// six doublings cost nothing here: in the butterfly only lane 0's result is used, whose cone of operands at the step of distance d is lanes 0 .. d - 1, so lane 63's
+// result is never used, and its threads double the total instead -- in lane 63's slot of W, which is dead by then -- step after step, as a complete addition
+// of a point to itself (edwards.rs:795-800 is complete: P + P is the doubling).
+// plus_tot: the result is sum_l W_l + 2^shift * sum_l l * S_l + tot -- tot rides in lane 0, whose own S (T_0, weight 0) has just been replaced by the identity, from
+// the addition of the W_l on: no step of its own.
+__device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 *W, u32 *tot, u32 *scratch, int shift, bool scaled_tot = false, bool plus_tot = false) {
 #pragma unroll 1
     for (int d = 1; d < 64; d <<= 1) {
         const bool in = lane + d < 64;
@@ -152,13 +160,25 @@ __device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 
     __syncthreads();
 #pragma unroll 1
     for (int i = 0; i < shift; i++) rc_dbl(role, lane, S, scratch);
+    // (the per-lane special cases below are COPIES into the lane's ordinary slot and per-lane array / index selects -- a conditional operand inside rc_add makes every
+    //  wave read both alternatives: level A 47 -> 52 us at 2^14 terms that way)
+    if (plus_tot) {                                          // lane 0's slot holds the identity: the total goes there, with weight 1, in front of the W_l
+        if (lane == 0) rc_put(S, 0, mc, rc_tot(tot, mc));
+        __syncthreads();
+    }
     rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, [&](int c) { return rc_get(W, lane, c); }, scratch, S, lane);
+    if (scaled_tot) {                                        // W is dead from here: lane 63's slot of it carries the doubling chain of the total
+        if (lane == 63) rc_put(W, 63, mc, rc_tot(tot, mc));
+        __syncthreads();
+    }
+    const bool dbl = scaled_tot && lane == 63;
+    u32 *arr = dbl ? W : S;
 #pragma unroll 1
-    for (int d = 32; d > 0; d >>= 1)
-        rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, [&](int c) { return rc_get(S, lane ^ d, c); }, scratch, S, lane);
+    for (int d = 32; d > 0; d >>= 1) {
+        const int o = dbl ? 63 : lane ^ d;
+        rc_add(role, lane, [&](int c) { return rc_get(arr, lane, c); }, [&](int c) { return rc_get(arr, o, c); }, scratch, arr, lane);
+    }
 }
-__device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i = 0; i < 10; i++) r.v[i] = tot[c * 10 + i]; return r; }
-
 // level A: block = segment `seg` (64 x 2^lb buckets, 2^lb per logical lane: 512 / 8, or 1024 / 16 for 17-bit windows) of window k.  direct: the window has a single segment, write col_k itself.
 // k0: first window of the launch (a window group, msm_geom: the blocks of the launch are the segments of windows k0 ..)
 __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ buckets, int half, int nseg, int lb, u32 *__restrict__ SW, u32 *__restrict__ cols, int direct,
@@ -183,17 +203,18 @@ __global__ void __launch_bounds__(256) k_reduce_a4(const u32 *__restrict__ bucke
         rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, bucket(b0 + j), scratch, S, lane);                                          // run += B_j
         if (j > 0) rc_add(role, lane, [&](int c) { return rc_get(W, lane, c); }, [&](int c) { return rc_get(S, lane, c); }, scratch, W, lane);   // acc += run
     }
-    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);       // tot = S_seg, S[0] = W_seg = sum (b - segment base) B_b
+    // S[0] = W_seg = sum (b - segment base + 1) B_b -- the "+ 1" of the weights b + 1 rides along segment by segment (until late in round 6: added once per window, in
+    // level B, as a step of its own) -- and, two levels, W[63] = 2^6 S_seg
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb, !direct, true);
     const int mc = rc_coord(role);
     if (direct) {
-        rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
-        if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
+        if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(S, 0, mc));
     } else if (lane == 0) {
-        rc_global_put(SW, 2 * (u64)bid, mc, rc_tot(tot, mc));
+        rc_global_put(SW, 2 * (u64)bid, mc, rc_get(W, 63, mc));            // 2^6 S_seg
         rc_global_put(SW, 2 * (u64)bid + 1, mc, rc_get(S, 0, mc));
     }
 }
-// level B: one block per window over its nseg <= 64 segment pairs (weight 2^(lb + 6) per segment)
+// level B: one block per window over its nseg <= 64 segment pairs (weight 2^(lb + 6) per segment, of which level A has applied 2^6)
 __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, int nseg, int lb, u32 *__restrict__ cols, int k0) {
     C25519_PRIO_SIDE();
     __shared__ __attribute__((aligned(16))) u32 S[RC_WORDS], W[RC_WORDS], scratch[RC_WORDS], tot[40];
@@ -202,9 +223,8 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-    rc_weighted_sum(role, lane, S, W, tot, scratch, lb + 6);
-    rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
-    if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);        // (S_j arrives as 2^6 S_j, W_j with the weights b + 1: no further doublings, no final addition)
+    if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(S, 0, mc));
 }
 
 // ---- (r6) level B with the record's publication (the mid path, mid.hip) -------------------------------------------------------------------------------------------
@@ -226,10 +246,9 @@ __global__ void __launch_bounds__(256) k_reduce_b4pub(const u32 *__restrict__ SW
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-    rc_weighted_sum(role, lane, S, W, tot, scratch, lb + 6);
-    rc_add(role, lane, [&](int c) { return rc_get(S, 0, c); }, [&](int c) { return rc_tot(tot, c); }, scratch, W, lane);
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);        // (as in k_reduce_b4)
     if (lane == 0) {
-        rc_global_put(cols, (u64)k, mc, rc_get(W, 0, mc));
+        rc_global_put(cols, (u64)k, mc, rc_get(S, 0, mc));
         if (pub.on) __threadfence_system(); else __threadfence();      // (every storing lane fences its own stores, then the block counts itself)
     }
     __syncthreads();
