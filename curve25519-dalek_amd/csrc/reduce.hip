@@ -143,9 +143,10 @@ __device__ __forceinline__ feT rc_tot(const u32 *tot, int c) { feT r; for (int i
 // of a point to itself (edwards.rs:795-800 is complete: P + P is the doubling).
 // plus_tot: the result is sum_l W_l + 2^shift * sum_l l * S_l + tot -- tot rides in lane 0, whose own S (T_0, weight 0) has just been replaced by the identity, from
 // the addition of the W_l on: no step of its own.
-__device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 *W, u32 *tot, u32 *scratch, int shift, bool scaled_tot = false, bool plus_tot = false) {
+// nl (a power of two, <= 64): lanes nl .. 63 hold the identity in S and W (level B of a window with fewer than 64 segments): the scan and the butterfly skip their levels
+__device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 *W, u32 *tot, u32 *scratch, int shift, bool scaled_tot = false, bool plus_tot = false, int nl = 64) {
 #pragma unroll 1
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < nl; d <<= 1) {
         const bool in = lane + d < 64;
         const int o = in ? lane + d : lane;
         rc_add(role, lane, [&](int c) { return rc_get(S, lane, c); }, [&](int c) { return in ? rc_get(S, o, c) : rc_ident(c); }, scratch, S, lane);
@@ -174,7 +175,7 @@ __device__ __forceinline__ void rc_weighted_sum(int role, int lane, u32 *S, u32 
     const bool dbl = scaled_tot && lane == 63;
     u32 *arr = dbl ? W : S;
 #pragma unroll 1
-    for (int d = 32; d > 0; d >>= 1) {
+    for (int d = scaled_tot ? 32 : nl / 2; d > 0; d >>= 1) {
         const int o = dbl ? 63 : lane ^ d;
         rc_add(role, lane, [&](int c) { return rc_get(arr, lane, c); }, [&](int c) { return rc_get(arr, o, c); }, scratch, arr, lane);
     }
@@ -223,7 +224,8 @@ __global__ void __launch_bounds__(256) k_reduce_b4(const u32 *__restrict__ SW, i
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);        // (S_j arrives as 2^6 S_j, W_j with the weights b + 1: no further doublings, no final addition)
+    int nl = 1; while (nl < nseg) nl <<= 1;
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb, false, false, nl);        // (S_j arrives as 2^6 S_j, W_j with the weights b + 1: no further doublings, no final addition)
     if (lane == 0) rc_global_put(cols, (u64)k, mc, rc_get(S, 0, mc));
 }
 
@@ -246,7 +248,8 @@ __global__ void __launch_bounds__(256) k_reduce_b4pub(const u32 *__restrict__ SW
     rc_put(S, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane), mc) : rc_ident(mc));
     rc_put(W, lane, mc, lane < nseg ? rc_global(SW, 2 * ((u64)k * nseg + lane) + 1, mc) : rc_ident(mc));
     __syncthreads();
-    rc_weighted_sum(role, lane, S, W, tot, scratch, lb);        // (as in k_reduce_b4)
+    int nl = 1; while (nl < nseg) nl <<= 1;
+    rc_weighted_sum(role, lane, S, W, tot, scratch, lb, false, false, nl);        // (as in k_reduce_b4)
     if (lane == 0) {
         rc_global_put(cols, (u64)k, mc, rc_get(S, 0, mc));
         if (pub.on) __threadfence_system(); else __threadfence();      // (every storing lane fences its own stores, then the block counts itself)
