@@ -494,7 +494,7 @@ def small_n(pkg, eng, torch, dev, want_cpu):
     orc = None
     if want_cpu:
         from oracle import orc
-    sizes = [1, 2, 4, 8, 16, 32, 64, 128, 256, 384, 512, 768, 1024, 2048, 4096, 8192]      # (the reference's own list ends at 1024; the small path serves up to 12 287 terms)
+    sizes = [1, 2, 4, 8, 16, 32, 64, 128, 256, 384, 512, 768, 1024, 2048, 4096, 8192]      # (the reference's own list ends at 1024; the small path serves up to 6143 terms, the mid path from there)
     nmax = sizes[-1]
     x = rng.integers(0, 256, size=(nmax, 32), dtype=np.uint8); x[:, 31] &= 0x0F
     pts = eng.mul_base_batch(x[::-1].copy(), out_fmt=E.FMT_RAW160)

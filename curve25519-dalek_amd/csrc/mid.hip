@@ -1,10 +1,11 @@
-// The MID-SIZE multiscalar multiplication (round 6): 12 288 .. 2^18 terms in SIX short launches on ONE stream.
+// The MID-SIZE multiscalar multiplication (round 6): 6144 .. 2^18 terms (verify_batch: from 2048 signatures; both from 12 288 terms until late in the round) in SIX short
+// launches on ONE stream.
 //
 // Reference: the same algorithm as msm.hip -- backend/serial/scalar_mul/pippenger.rs:67-160 (signed digits, buckets, running-sum reduction, Horner fold), for the sizes
 // where the reference's heaviest real callers live (edwards.rs:1002-1031 vartime_multiscalar_mul of a Bulletproofs verification; ed25519-dalek/src/batch.rs:225-244
 // verify_batch of 2^13 .. 2^17 signatures).
 //
-// Why a third path.  Between the small path (small.hip, up to 12 287 terms) and the throughput regime (2^20 terms and beyond) the bucket pipeline of msm.hip is a
+// Why a third path.  Between the small path (small.hip, up to 6143 terms) and the throughput regime (2^20 terms and beyond) the bucket pipeline of msm.hip is a
 // chain of 15 - 27 short kernels on two streams: the HOST's launch loop (5 - 8 us per launch, a dozen event operations) put k_accumulate 150 us into a 330 us call
 // at 2^14 terms, the batched inversion of the normaliser is a 78 us latency chain on 64 waves, and the eleven sort kernels of 2 - 9 us each are separated by as much
 // again (profiles/r05_timeline_msm_2p14.txt; whole call 0.03 - 0.17 of the multiplier roof).  Here:
@@ -375,9 +376,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
 // 0.78 against 0.71: profiles/r06_ab_mid_upper_end.txt); prepared records -- verify_batch's 2n + 1 terms, whose sort is a third of the bucket pipeline's call -- up to 2^18 + 1
 uint64_t msm_mid_max() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX", 1 << 18); return v; }
 static uint64_t msm_mid_max_records() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("MSM_MID_MAX_RECORDS", (1 << 18) + 1); return v; }
-bool msm_mid_serves_terms(uint64_t n) { return n > msm_small_max() && n <= msm_mid_max_records(); }      // (prepared records; whatever width the caller is about to choose)
+bool msm_mid_serves_terms(uint64_t n) { return n > verify_small_max() && n <= msm_mid_max_records(); }      // (verify_batch's prepared records; whatever width the caller is about to choose)
+// (prepared records below msm_small_max() terms: only with a layout that is not the small path's -- verify_batch from verify_small_max() + 1 terms chooses one)
 bool msm_mid_serves(uint64_t n, const msm_geom &g, bool prepared) {
-    return n > msm_small_max() && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 && g.ngroups <= 1;
+    return (n > msm_small_max() || (prepared && n > verify_small_max() && g.half > 64)) && n <= (prepared ? msm_mid_max_records() : msm_mid_max()) && g.c >= 8 && g.c <= 16 && g.half >= 64 &&
+           g.ngroups <= 1;
 }
 
 // The cap on a bucket lane's list (longer lists go to the waves of the long path).  A lane walks its list as a chain of dependent additions, so the accumulation lasts as

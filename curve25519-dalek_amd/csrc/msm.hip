@@ -503,9 +503,13 @@ void msm_layout(uint64_t n, msm_geom &g, int cmax_call, int c_exact) {
     // MSM never takes the small path) from 7 .. 12 bits to 6 for 121 .. 722 static points -- twice the digit-terms, all in 32 buckets.
     const bool small_c = n >= 1024 && n <= msm_small_max();
     g.c = c_exact ? c_exact : force_ok ? cforce : small_c ? C25519_KNOB("MSM_SMALL_C", 6) : pick_window(n, cmax_call ? std::min(cmax_call, cmax_env) : cmax_env);
-    // (r6) 12 288 .. 16 383 terms -- the first sizes of the mid path (mid.hip) -- want 13-bit windows, one more than the rule (profiles/r06_ab_mid_window.txt: 12 288 terms
-    //  0.231 -> 0.213 ms; every other size of the path is at its optimum under the rule, which was tuned on the bucket pipeline in round 4)
-    if (!c_exact && !force_ok && !small_c && n > msm_small_max() && n < 16384 && g.c == 12) g.c = 13;
+    // (r6) the first sizes of the mid path (mid.hip) want wider windows than the rule, which was tuned on the bucket pipeline in round 4: 13 bits for 8192 .. 16 383 terms
+    // (profiles/r06_ab_mid_window.txt: 12 288 terms 0.231 -> 0.213 ms) and 12 bits below (the rule: 10; profiles/r06_ab_small_mid_boundary.txt: 6144 terms 0.229 -> 0.165 ms,
+    // 11 bits 0.177, 13 bits 0.175); every other size of the path is at its optimum under the rule
+    if (!c_exact && !force_ok && !small_c && n > msm_small_max() && n < 16384) {
+        if (g.c == 12) g.c = 13;
+        else if (g.c == 10 && n < 8192) g.c = 12;
+    }
     g.half = 1 << (g.c - 1);
     const int low_bits = 253 - (g.c - 1), nsig = (low_bits + g.c - 1) / g.c, wbase = low_bits / nsig, wrem = low_bits % nsig;
     uint32_t a[9] = {0};

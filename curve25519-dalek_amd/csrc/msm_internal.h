@@ -54,10 +54,18 @@ static inline int red_nseg(int half) { const int seg = 64 << red_lb_log2(half); 
 constexpr int REC_TERMS_LO = 8, REC_TERMS_HI = 9, REC_PASSES = 10, REC_MAGIC = 11, REC_C = 12;      // REC_C: the window width of the layout (a record with terms > 0 and no width is rejected by the fold)
 constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
 // inputs up to this many terms take the single-pass small path (small.hip): 5-bit windows below 1024 terms, 6-bit ones from there (A/B knobs of the tuning
-// build: MSM_SMALL_MAX, and MSM_SMALL_C = the width from 1024 terms).  Rounds 4 and early 5: 4095 terms, 7-bit windows from 2048.  Measured
-// (profiles/r05_ab_small_path_range.txt, r05_ab_verify_small_range.txt): with 6-bit windows (20 KB of tables per block instead of 40) the small path beats the
-// bucket pipeline's fifteen launches up to ~14 000 terms -- 4096 terms 0.320 -> 0.158 ms, 8192 0.313 -> 0.227, 12 000 0.331 -> 0.281; 16 384: level.
-inline uint64_t msm_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("MSM_SMALL_MAX", 12287); return v; }
+// build: MSM_SMALL_MAX, and MSM_SMALL_C = the width from 1024 terms).  Rounds 4 and early 5: 4095 terms, 7-bit windows from 2048; round 5 .. late round 6: 12 287
+// terms -- measured against the bucket pipeline's fifteen launches (profiles/r05_ab_small_path_range.txt).  Against the MID path (mid.hip, round 6) the small path
+// holds only up to ~6 000 terms of raw points (profiles/r06_ab_small_mid_boundary.txt, device-resident: 6144 terms 0.164 either way; 8192 0.199 -> 0.177 ms, 10 240
+// 0.237 -> 0.182, 12 287 0.266 -> 0.185 with the 12- / 13-bit windows msm_layout gives those sizes) ...
+inline uint64_t msm_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("MSM_SMALL_MAX", 6143); return v; }
+// ... and verify_batch -- prepared (affine) records, half of the scalars 128 bits long: nine of a mid-path layout's windows instead of all of the small path's -- only
+// up to 2047 signatures (same profile, device z-mode: 2048 signatures 0.296 -> 0.273 ms, 3072 0.327 -> 0.284, 4096 0.358 -> 0.291, 6143 0.417 -> 0.309; 1024: 0.252
+// against 0.257).  The term count up to which a batch's 2n + 1-term MSM stays on the small path (A/B knob VERIFY_SMALL_MAX; never above msm_small_max()):
+inline uint64_t verify_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("VERIFY_SMALL_MAX", 4095); return v < msm_small_max() ? v : msm_small_max(); }
+// what the staged small upload of a host-pointer call (capi.hip ffi_small_upload: every input array in ONE copy on the compute stream) is used for, whichever path the MSM
+// behind it takes: the small path's range of rounds 5 - 6
+inline uint64_t small_upload_max_terms() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("VERIFY_STAGED_MAX", 12287); return v; }      // (A/B knob of the tuning build)
 }
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 static inline uint32_t *slot_flags(uint32_t *slot) { return slot + c25519::MSM_MAX_WIN * 40; }

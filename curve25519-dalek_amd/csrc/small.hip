@@ -1,4 +1,5 @@
-// Small multiscalar multiplications -- up to msm_small_max() = 12 287 terms (round 4: 4095): the reference's own benchmark shapes (benches/dalek_benchmarks.rs:16
+// Small multiscalar multiplications -- up to msm_small_max() = 6143 terms (round 4: 4095; round 5 .. late round 6: 12 287, until the mid path of mid.hip was measured
+// against it: msm_internal.h; verify_batch up to 2047 signatures): the reference's own benchmark shapes (benches/dalek_benchmarks.rs:16
 // MULTISCALAR_SIZES 1 .. 1024; ed25519_benchmarks.rs:53 verify_batch of 4 .. 256 signatures = 9 .. 513 terms) and everything the reference
 // hands to Straus (edwards.rs:1025, below 190 terms).
 //

@@ -746,8 +746,10 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
     static const int verify_c = C25519_KNOB("VERIFY_C", 0);      // A/B knob of the tuning build: 0 = this rule; 8 .. 16 = that width; -1 = the MSM's rule
     const uint64_t vterms = 2 * per + 1;
     int vc = 0;
-    if (verify_c >= 8 && verify_c <= 16 && vterms > msm_small_max()) vc = verify_c;
-    else if (verify_c == 0 && passes == 1 && msm_mid_serves_terms(vterms)) vc = vterms < 24576 ? 13 : vterms < 98304 ? 14 : 16;
+    // (late) ... and 12 bits below 8192 terms, where the mid path takes over from the small one at 2048 signatures (profiles/r06_ab_small_mid_boundary.txt: 3072 signatures 12 bits
+    // 0.284, 13 bits 0.293, 11 bits 0.289 ms)
+    if (verify_c >= 8 && verify_c <= 16 && vterms > verify_small_max()) vc = verify_c;
+    else if (verify_c == 0 && passes == 1 && msm_mid_serves_terms(vterms)) vc = vterms < 8192 ? 12 : vterms < 24576 ? 13 : vterms < 98304 ? 14 : 16;
     msm_layout(vterms, g, 16, vc);        // (the z_i are 128-bit: with 16-bit windows they end on a window boundary; a 17-bit layout leaves a 9-bit stub of 2^20 equal-ish digits)
     pass_set ps;
     if ((r = passes_begin(ctx, passes, ps))) return r;
@@ -770,7 +772,7 @@ static int32_t verify_batch_impl(c25519_ctx *ctx, const uint8_t *d_msgs, const u
             const verify_stage stage = [&](int what, hipEvent_t *ready) -> int32_t { return (*fetch)(lo, m, what, ready); };
             // (r6) a single-pass batch of the bucket pipeline in two halves on the two stream sets (verify_pass_enqueue; A/B knob VERIFY_SPLIT_MIN, 0 = never)
             static const uint64_t split_min = (uint64_t)C25519_KNOB_LL("VERIFY_SPLIT_MIN", 0);      // MEASURED AND NOT ADOPTED (profiles/r06_ab_verify_split.txt): 2.80 against 2.60 ms at 2^20
-            c25519_ctx *split_peer = (passes == 1 && !fetch && split_min && m >= split_min && !msm_mid_serves(2 * m + 1, g, true) && 2 * m + 1 > msm_small_max()) ? ctx_peer(ctx) : nullptr;
+            c25519_ctx *split_peer = (passes == 1 && !fetch && split_min && m >= split_min && !msm_mid_serves(2 * m + 1, g, true) && 2 * m + 1 > verify_small_max()) ? ctx_peer(ctx) : nullptr;
             r = verify_pass_enqueue(ctx, c, d_msgs, d_msg_off + lo, msgs_len, d_sigs + lo * 64, d_pks + lo * 32, d_pk_points ? d_pk_points + lo * 160 : nullptr, m, z_mode,
                                     nullptr, nullptr, nullptr, g, 2 * per + 1, dslot(ctx, i), prev_acc, fetch ? &stage : nullptr, nullptr, split_peer, split_peer ? dslot(ctx, 1) : nullptr);
             if (r) { ctx->direct_seq = 0; if (ctx->err.empty()) ctx->err = c->err; return r; }
@@ -960,7 +962,7 @@ EXPORT int32_t ed25519_verify_batch_keys(c25519_ctx *ctx, const uint8_t *msgs, c
     if (!offsets_ok(msg_off, n)) { ctx->err = "verify_batch: msg_off is not monotone"; return -(int32_t)hipErrorInvalidValue; }
     const uint64_t mlen = msg_off[n];
     int32_t r;
-    if (2 * n + 1 <= msm_small_max() && mlen <= (1u << 20)) {
+    if (2 * n + 1 <= small_upload_max_terms() && mlen <= (1u << 20)) {
         { msm_geom gh; if (verify_small_host_ok(n, z_mode, gh)) return verify_batch_small_host(ctx, msgs, msg_off, sigs, pks, pk_points, n, z_mode, gh); }
         // the reference's own benchmark sizes (ed25519_benchmarks.rs:53: 4 .. 256 signatures) and everything else whose MSM takes the small path:
         // all five arrays through one staged copy on the compute stream (capi.hip ffi_small_upload)

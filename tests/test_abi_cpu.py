@@ -95,7 +95,7 @@ def test_msm_window_layout_recomposes_every_scalar():
     L = 2**252 + 27742317777372353535851937790883648493
     rng = random.Random(7)
     seen_c = set()
-    for n in sorted([1 << lg for lg in range(0, 41)] + [12287, 12288]):
+    for n in sorted([1 << lg for lg in range(0, 41)] + [6143, 6144, 8191, 12287, 12288]):
         c = C.c_int32(); nwin = C.c_int32()
         pos = (C.c_uint8 * 56)(); wid = (C.c_uint8 * 56)(); addk = (C.c_uint32 * 8)()
         assert lib.c25519_msm_geometry(n, C.byref(c), C.byref(nwin), pos, wid, addk) == 0
@@ -124,7 +124,10 @@ def test_msm_window_layout_recomposes_every_scalar():
                     assert abs(d) <= 1 << (wid[k] - 1)     # a signed window of w bits uses 2^(w-1) buckets (msm_slice_params relies on it)
                 total += d << pos[k]
             assert total == s
-    # the small path's 5- and 6-bit windows up to 12 287 terms (round 5; rounds 1-4 also used 7 .. 11 bits there), then the bucket pipeline's: wider than
-    # log2 n - 4 in the latency-bound mid range, log2 n - 4 from 2^20 terms (msm.hip pick_window); round 6 moved 12 288 .. 16 383 terms from 12- to
-    # 13-bit windows (profiles/r06_ab_mid_window.txt), so no default layout is 12 bits wide any more
-    assert seen_c == {5, 6, 13, 14, 15, 16, 17}
+    # the small path's 5- and 6-bit windows up to 6143 terms (round 5 .. late round 6: 12 287; rounds 1-4 also used 7 .. 11 bits there), then the mid path's and
+    # the bucket pipeline's: wider than log2 n - 4 in the latency-bound mid range, log2 n - 4 from 2^20 terms (msm.hip pick_window); round 6 gave 8192 .. 16 383
+    # terms 13-bit windows (profiles/r06_ab_mid_window.txt) and 6144 .. 8191 terms 12-bit ones (profiles/r06_ab_small_mid_boundary.txt)
+    assert seen_c == {5, 6, 12, 13, 14, 15, 16, 17}
+    for n, want in ((1023, 5), (1024, 6), (6143, 6), (6144, 12), (8191, 12), (8192, 13), (16383, 13), (16384, 13), (32768, 14)):
+        c = C.c_int32(); nwin = C.c_int32()
+        assert lib.c25519_msm_geometry(n, C.byref(c), C.byref(nwin), pos, wid, addk) == 0 and c.value == want, (n, c.value)

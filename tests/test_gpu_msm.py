@@ -167,7 +167,7 @@ def test_msm_random_sizes_and_formats(eng, orc):
     windows, the mid-range layouts in between) in all three input encodings: sum-of-squares identity against the oracle's fixed-base multiplication."""
     import torch
     rng = np.random.default_rng(20260924)
-    sizes = sorted(set(int(2 ** rng.uniform(0, 21)) for _ in range(48)) | {1023, 1024, 4095, 4096, 8191, 8192, 12287, 12288, 131071, 1 << 19, (1 << 20) + 1})
+    sizes = sorted(set(int(2 ** rng.uniform(0, 21)) for _ in range(48)) | {1023, 1024, 4095, 4096, 6143, 6144, 8191, 8192, 12287, 12288, 131071, 1 << 19, (1 << 20) + 1})
     for i, n in enumerate(sizes):
         g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
         dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
@@ -496,7 +496,7 @@ def test_msm_every_size_1_to_1024_and_the_small_path_boundaries(eng, orc):
         eng.msm_vartime(hi, pts[:100], in_fmt=2, out_fmt=0)
     # the boundary of the small path and the narrow windows of the sort
     import torch
-    for n in (2047, 2048, 2049, 3000, 4095, 4096, 4097, 8191, 8192, 12287, 12288, 12289, 16383, 16384, 32767, 32768, 50001):
+    for n in (2047, 2048, 2049, 3000, 4095, 4096, 4097, 6143, 6144, 6145, 8191, 8192, 12287, 12288, 12289, 16383, 16384, 32767, 32768, 50001):
         g = torch.Generator(device="cuda"); g.manual_seed(9000 + n)
         dx = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device="cuda", generator=g)
         dx[:, 31] &= 0x0F
@@ -512,7 +512,7 @@ def _sum_xy(x, y):
     return sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(x, y)) % L
 
 
-@pytest.mark.parametrize("n", [12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072, 200003, 262144])
+@pytest.mark.parametrize("n", [6144, 6145, 7001, 8191, 8192, 12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072, 200003, 262144])
 def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     """pippenger.rs:67-160 through the mid path at every kind of size it serves (rows of the digit matrix padded / not padded to eight terms, every window width 12 .. 15,
     both ends of the range): P_i = y_i B with independent x_i, so the expected point is (sum x_i y_i) B from the ORACLE's fixed-base multiplication; raw points with
@@ -530,7 +530,7 @@ def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     assert st == 0 and got == want
     st, got = eng.msm_vartime(x, raw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == want
-    if n in (12288, 16391, 65536, 131072, 262144):
+    if n in (6144, 8191, 12288, 16391, 65536, 131072, 262144):
         enc = eng.compress_batch(raw)
         st, got = eng.msm_vartime_t(dx, torch.from_numpy(enc).cuda(), in_fmt=0, out_fmt=0)
         assert st == 0 and got == want
@@ -562,7 +562,7 @@ def test_mid_path_against_the_oracles_pippenger_on_arbitrary_points(eng, orc):
     assert st == 0 and got == want
 
 
-@pytest.mark.parametrize("n", [12288, 40000])
+@pytest.mark.parametrize("n", [6144, 12288, 40000])
 def test_mid_path_skewed_digits_long_lists(eng, orc, n):
     """Digit distributions that put thousands of terms into ONE bucket of every window (equal scalars), into two buckets (s and l - s: the same buckets with opposite
     signs), or leave whole windows empty (small scalars) -- the over-long lists go through k_mid_long's segments and the last-finisher sum; a third of the terms random."""

@@ -285,7 +285,7 @@ _MID_CHAIN_BODY = """
                                  {"C25519_VERIFY_ORDER": "2", "C25519_PREP_AFFINE_FIRST": "0"}, {"C25519_MID_LONG_TARGET": "2048", "C25519_MID_LONG_TARGET_ALWAYS": "1"}],
                          ids=["release", "lost-publication", "main-stream", "copy-path-long-beside", "order-1", "order-2-general-normaliser", "low-cap"])
 def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, env):
-    """(r6) Device z-mode, inputs on the device, 6144 .. 2^16 signatures: the 2n + 1-term MSM takes the mid path ON the hash chain's stream (digits and sort right
+    """(r6) Device z-mode, inputs on the device, 2048 .. 2^16 signatures (until late in round 6 the small path served up to 6143): the 2n + 1-term MSM takes the mid path ON the hash chain's stream (digits and sort right
     behind the batch scalars, the records waited for and signed in front of the accumulation, the over-long lists inside the accumulation's launch) and the last
     reduction block PUBLISHES the record with the device slot's counters.  Verdicts -- including the ones that live in those counters -- with key bytes, with cached
     key points (affine, one projective, all projective); every third publication dropped (tuning build) must be recovered through the copy path with the same
@@ -293,7 +293,7 @@ def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, env):
     import subprocess, textwrap
     lose = "C25519_FAULT_LOSE_PUBLICATION" in env
     direct = env.get("C25519_MID_ON_CHAIN", "1") != "0" and env.get("C25519_VERIFY_DIRECT", "1") != "0"
-    sizes = "(6144, 7001, 16384, 40000, 65536)" if (not env or lose) else "(6144, 16385, 40000)"
+    sizes = "(2048, 3001, 6144, 7001, 16384, 40000, 65536)" if (not env or lose) else "(2048, 6144, 16385, 40000)"
     code = textwrap.dedent(_MID_CHAIN_BODY % (ROOT, ROOT)).replace("EXPECT_LOST", "True" if lose else "False").replace("EXPECT_DIRECT", "True" if direct else "False").replace("SIZES", sizes)
     r = subprocess.run(util.child_argv(code), env=util.tune_env(env) if env else dict(os.environ), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (env, r.stdout[-2000:], r.stderr[-4000:])

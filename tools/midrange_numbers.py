@@ -19,15 +19,20 @@ for n in [int(v) for v in os.environ.get('MIDRANGE_SIZES', '256,1024,2047,2048,4
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8); x[:, 31] &= 0x0F
     dx = torch.from_numpy(x).cuda()
     dp = e.mul_base_batch_vartime_t(dx, E.FMT_RAW160)
+    fmt = int(os.environ.get('MIDRANGE_FMT', E.FMT_RAW160))      # 2 = raw 160-byte points (default), 0 = CompressedEdwardsY (the decompression's affine records: prepared)
+    if fmt != E.FMT_RAW160:
+        dp = torch.from_numpy(e.compress_batch(dp.cpu().numpy(), out_fmt=fmt)).cuda()
     pts = dp.cpu().numpy()
-    e.msm_vartime(x, pts); e.msm_vartime_t(dx, dp, E.FMT_RAW160)
+    st, res = e.msm_vartime(x, pts, in_fmt=fmt); e.msm_vartime_t(dx, dp, fmt)
+    if os.environ.get('MIDRANGE_DUMP'):      # the encoded result of every size, so that two arms of an A/B can be compared byte for byte
+        with open(os.environ['MIDRANGE_DUMP'], 'a') as f: f.write("%d %d %s\n" % (n, st, res.hex()))
     reps = 30 if n <= 1 << 16 else 8
     ts = []
     for _ in range(reps):
-        t0 = time.perf_counter(); e.msm_vartime(x, pts); ts.append(time.perf_counter() - t0)
+        t0 = time.perf_counter(); e.msm_vartime(x, pts, in_fmt=fmt); ts.append(time.perf_counter() - t0)
     td = []
     for _ in range(reps):
-        torch.cuda.synchronize(); t0 = time.perf_counter(); e.msm_vartime_t(dx, dp, E.FMT_RAW160); td.append(time.perf_counter() - t0)
+        torch.cuda.synchronize(); t0 = time.perf_counter(); e.msm_vartime_t(dx, dp, fmt); td.append(time.perf_counter() - t0)
     c = C.c_int32(); nw = C.c_int32(); pos = (C.c_uint8 * 56)(); wid = (C.c_uint8 * 56)(); ak = (C.c_uint32 * 8)()
     lib.c25519_msm_geometry(n, C.byref(c), C.byref(nw), pos, wid, ak)
     print("%10d %16.3f %16.3f %8d" % (n, sorted(ts)[len(ts) // 2] * 1e3, sorted(td)[len(td) // 2] * 1e3, c.value))
