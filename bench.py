@@ -558,7 +558,7 @@ def mid_n(pkg, eng, torch, dev):
 
     g = torch.Generator(device=dev); g.manual_seed(61)
     from curve25519_dalek_amd import costs
-    for lg in (14, 15, 16, 17, 18):
+    for lg in (13, 14, 15, 16, 17, 18):      # (2^13 terms: the mid path since late in round 6 -- it serves from 6144 terms)
         n = 1 << lg
         x = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g); x[:, 31] &= 0x0F
         y = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g); y[:, 31] &= 0x0F
@@ -577,7 +577,7 @@ def mid_n(pkg, eng, torch, dev):
         out["msm_sizes"].append(n); out["msm_ms"].append(ms)
         out["msm_whole_call_frac_of_theoretical"].append(n * costs.mac(c) / (ms * 1e-3) / 39.3216e12)
         del x, y, raw
-    for lg in (13, 14, 15, 16, 17):
+    for lg in (11, 12, 13, 14, 15, 16, 17):      # (2^11 / 2^12 signatures: the mid path since late in round 6)
         n = 1 << lg
         seeds = torch.randint(0, 256, (n, 32), dtype=torch.uint8, device=dev, generator=g)
         dm = torch.randint(0, 256, (32 * n,), dtype=torch.uint8, device=dev, generator=g); doff = torch.arange(0, 32 * (n + 1), 32, dtype=torch.int64, device=dev)

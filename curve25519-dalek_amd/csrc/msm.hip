@@ -1172,7 +1172,11 @@ static int32_t msm_record_enqueue(c25519_ctx *ctx, const uint8_t *d_scalars, con
     // (r6) the mid path (mid.hip: 12 288 .. 2^18 terms in four launches on this stream) publishes its record the same way
     bool mid = false;
     // (a host-pointer call of ONE pass has nothing to overlap its upload with: the inputs go up in one piece and the pass waits for them)
-    if (passes == 1 && n > msm_small_max()) { msm_layout(n, g); mid = msm_mid_serves(n, g, in_fmt != C25519_FMT_RAW160); }
+    // (late) ENCODED points -- the decompression's affine records, the 7 M accumulation -- leave the small path earlier than raw ones, like verify_batch's: from
+    // verify_small_max() + 1 = 4096 terms, with 12-bit windows up to msm_small_max() (profiles/r06_ab_small_mid_boundary.txt, CompressedEdwardsY, device-resident: 4096 terms
+    // 0.269 -> 0.236 ms, 6143 0.287 -> 0.244; 3072: 0.243 against 0.235, left alone)
+    const bool enc_mid = in_fmt != C25519_FMT_RAW160 && n > verify_small_max() && n <= msm_small_max();
+    if (passes == 1 && (n > msm_small_max() || enc_mid)) { msm_layout(n, g, 0, enc_mid ? 12 : 0); mid = msm_mid_serves(n, g, in_fmt != C25519_FMT_RAW160); }
     if (small_direct_knob && ctx->want_direct && !ctx->no_direct_once && d_record == drec(ctx) && in_fmt == C25519_FMT_RAW160 && ((!fetch && n <= msm_small_max()) || mid)) {
         msm_geom gs;
         msm_layout(n, gs);

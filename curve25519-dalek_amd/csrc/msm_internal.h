@@ -61,11 +61,13 @@ constexpr u32 REC_MAGIC_VALUE = 0x52503235u;               // "52PR"
 inline uint64_t msm_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("MSM_SMALL_MAX", 6143); return v; }
 // ... and verify_batch -- prepared (affine) records, half of the scalars 128 bits long: nine of a mid-path layout's windows instead of all of the small path's -- only
 // up to 2047 signatures (same profile, device z-mode: 2048 signatures 0.296 -> 0.273 ms, 3072 0.327 -> 0.284, 4096 0.358 -> 0.291, 6143 0.417 -> 0.309; 1024: 0.252
-// against 0.257).  The term count up to which a batch's 2n + 1-term MSM stays on the small path (A/B knob VERIFY_SMALL_MAX; never above msm_small_max()):
+// against 0.257).  The term count up to which a batch's 2n + 1-term MSM -- and an MSM over ENCODED points (msm.hip msm_record_enqueue) -- stays on the small path
+// (A/B knob VERIFY_SMALL_MAX; never above msm_small_max()):
 inline uint64_t verify_small_max() { static const uint64_t v = (uint64_t)C25519_KNOB("VERIFY_SMALL_MAX", 4095); return v < msm_small_max() ? v : msm_small_max(); }
-// what the staged small upload of a host-pointer call (capi.hip ffi_small_upload: every input array in ONE copy on the compute stream) is used for, whichever path the MSM
-// behind it takes: the small path's range of rounds 5 - 6
-inline uint64_t small_upload_max_terms() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("VERIFY_STAGED_MAX", 12287); return v; }      // (A/B knob of the tuning build)
+// up to how many terms a host-pointer verify_batch sends its five arrays up through the staged ONE-copy upload (capi.hip ffi_small_upload), whichever path its MSM takes.
+// The general route's per-array pageable copies on the copy stream cost ~70 us more up to 8192 signatures, ~40 at 16 384, nothing from 32 768
+// (profiles/r06_ab_verify_staged_upload.txt; rounds 5 - 6: 12 287 terms, the small path's range)
+inline uint64_t small_upload_max_terms() { static const uint64_t v = (uint64_t)C25519_KNOB_LL("VERIFY_STAGED_MAX", 32769); return v; }      // (A/B knob of the tuning build)
 }
 static inline unsigned div_up64(uint64_t a, uint64_t b) { return (unsigned)((a + b - 1) / b); }
 static inline uint32_t *slot_flags(uint32_t *slot) { return slot + c25519::MSM_MAX_WIN * 40; }

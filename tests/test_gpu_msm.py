@@ -512,7 +512,7 @@ def _sum_xy(x, y):
     return sum(int.from_bytes(a.tobytes(), "little") * int.from_bytes(b.tobytes(), "little") for a, b in zip(x, y)) % L
 
 
-@pytest.mark.parametrize("n", [6144, 6145, 7001, 8191, 8192, 12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072, 200003, 262144])
+@pytest.mark.parametrize("n", [4096, 5001, 6143, 6144, 6145, 7001, 8191, 8192, 12288, 12289, 16383, 16384, 16391, 20000, 32768, 65535, 65536, 100003, 131072, 200003, 262144])
 def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     """pippenger.rs:67-160 through the mid path at every kind of size it serves (rows of the digit matrix padded / not padded to eight terms, every window width 12 .. 15,
     both ends of the range): P_i = y_i B with independent x_i, so the expected point is (sum x_i y_i) B from the ORACLE's fixed-base multiplication; raw points with
@@ -530,9 +530,11 @@ def test_mid_path_sizes_raw_points_and_encodings(eng, orc, n):
     assert st == 0 and got == want
     st, got = eng.msm_vartime(x, raw, in_fmt=2, out_fmt=0)
     assert st == 0 and got == want
-    if n in (6144, 8191, 12288, 16391, 65536, 131072, 262144):
+    if n in (4096, 5001, 6143, 6144, 8191, 12288, 16391, 65536, 131072, 262144):      # (encoded points take the mid path from 4096 terms, raw ones from 6144)
         enc = eng.compress_batch(raw)
         st, got = eng.msm_vartime_t(dx, torch.from_numpy(enc).cuda(), in_fmt=0, out_fmt=0)
+        assert st == 0 and got == want
+        st, got = eng.msm_vartime(x, enc, in_fmt=0, out_fmt=0)
         assert st == 0 and got == want
         ris = eng.compress_batch(raw, out_fmt=1)
         st, got = eng.msm_vartime_t(dx, torch.from_numpy(ris).cuda(), in_fmt=1, out_fmt=1)

@@ -37,5 +37,41 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, st); body(); hipEventRecord(e1, st); hipStreamSynchronize(st); float ms; hipEventElapsedTime(&ms, e0, e1); printf("GPU span direct %.1f us\n", ms * 1e3);
     hipEventRecord(e0, st); hipGraphLaunch(ge, st); hipEventRecord(e1, st); hipStreamSynchronize(st); hipEventElapsedTime(&ms, e0, e1); printf("GPU span graph %.1f us\n", ms * 1e3);
+    // (r6) the shape of a MID-SIZE call (mid.hip): seven dependent kernels of 5 .. 60 us with machine-filling grids on one stream, no copies (the record is published by the
+    // last kernel), the kernel arguments of every call different (a replay must patch them: hipGraphExecKernelNodeSetParams per node)
+    struct shape { int blocks, iters; };
+    const shape mid[7] = {{64, 1500}, {400, 3000}, {1, 1500}, {1400, 9000}, {700, 6000}, {24, 5000}, {1, 300}};
+    int iters_v[7];
+    auto body_mid = [&](int salt) {
+        for (int k = 0; k < 7; k++) { iters_v[k] = mid[k].iters + (salt & 1); hipLaunchKernelGGL(k_spin, dim3(mid[k].blocks), dim3(256), 0, st, d, iters_v[k]); }
+    };
+    for (int i = 0; i < 50; i++) { body_mid(i); hipStreamSynchronize(st); }
+    a.clear(); b.clear(); c.clear(); e.clear();
+    for (int i = 0; i < 500; i++) { double t0 = now_us(); body_mid(i); double t1 = now_us(); hipStreamSynchronize(st); a.push_back(now_us() - t0); c.push_back(t1 - t0); }
+    hipGraph_t g2; hipGraphExec_t ge2;
+    hipStreamBeginCapture(st, hipStreamCaptureModeGlobal); body_mid(0); hipStreamEndCapture(st, &g2);
+    hipGraphInstantiate(&ge2, g2, nullptr, nullptr, 0);
+    size_t nn = 0; hipGraphGetNodes(g2, nullptr, &nn);
+    std::vector<hipGraphNode_t> nodes(nn); hipGraphGetNodes(g2, nodes.data(), &nn);
+    for (int i = 0; i < 50; i++) { hipGraphLaunch(ge2, st); hipStreamSynchronize(st); }
+    for (int i = 0; i < 500; i++) { double t0 = now_us(); hipGraphLaunch(ge2, st); double t1 = now_us(); hipStreamSynchronize(st); b.push_back(now_us() - t0); e.push_back(t1 - t0); }
+    printf("mid shape (7 kernels), direct: call %.1f us (enqueue %.1f)   graph replay, same arguments: call %.1f us (launch %.1f)\n", med(a), med(c), med(b), med(e));
+    // ... and with every node's arguments patched before the replay (what a real call needs: other pointers, other n)
+    std::vector<double> f, f2;
+    for (int i = 0; i < 500; i++) {
+        double t0 = now_us();
+        for (size_t k = 0; k < nn && k < 7; k++) {
+            hipKernelNodeParams kp;
+            if (hipGraphKernelNodeGetParams(nodes[k], &kp) != hipSuccess) continue;
+            int it = mid[k].iters + (i & 1);
+            void *args[2] = {(void *)&d, (void *)&it};
+            kp.kernelParams = args;
+            hipGraphExecKernelNodeSetParams(ge2, nodes[k], &kp);
+        }
+        hipGraphLaunch(ge2, st); double t1 = now_us(); hipStreamSynchronize(st); f.push_back(now_us() - t0); f2.push_back(t1 - t0);
+    }
+    printf("mid shape, graph replay with seven patched nodes: call %.1f us (patch + launch %.1f)\n", med(f), med(f2));
+    hipEventRecord(e0, st); body_mid(0); hipEventRecord(e1, st); hipStreamSynchronize(st); hipEventElapsedTime(&ms, e0, e1); printf("mid shape GPU span direct %.1f us\n", ms * 1e3);
+    hipEventRecord(e0, st); hipGraphLaunch(ge2, st); hipEventRecord(e1, st); hipStreamSynchronize(st); hipEventElapsedTime(&ms, e0, e1); printf("mid shape GPU span graph %.1f us\n", ms * 1e3);
     return 0;
 }
