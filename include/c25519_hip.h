@@ -147,7 +147,7 @@ float c25519_last_kernel_ms(c25519_ctx *ctx);
  * out4[0] inputs staged and their upload enqueued (0 for the device-pointer forms), [1] every kernel enqueued, [2] results on the host (the last
  * kernel writes them into page-locked host memory and the host polls a sequence word: no copy engine, no interrupt), [3] folded and encoded. */
 int32_t c25519_last_call_host_us(const c25519_ctx *ctx, double *out4);
-/* Event counters of a context since its creation (diagnostics; tools/soak_small.py logs them).  Small MSM / verify_batch calls (at most 12 287 terms,
+/* Event counters of a context since its creation (diagnostics; tools/soak_small.py logs them).  Small and mid-size MSM / verify_batch calls (single passes up to 2^18 terms:
  * vartime_multiscalar_mul at the sizes of benches/dalek_benchmarks.rs:16, verify_batch of ed25519-dalek/benches/ed25519_benchmarks.rs:53) end with their last
  * kernel writing the record into page-locked host memory and the host polling a sequence word.  which = 0: calls whose record had not arrived after 2 ms of polling --
  * the host then blocked on the stream (a busy stream, a shared GPU); 1: calls whose record never arrived although the stream drained without error -- each was re-run
@@ -462,7 +462,8 @@ int32_t c25519_selftest_field(c25519_ctx *ctx, int op, int chain, const uint32_t
  * 5 out[0] = (a < l), the word-wise test behind from_canonical_bytes (scalar.rs:259-263); 6 words -> limbs -> words of a < 2^256;
  * 7 r + k*a as the signer chains them: k = a mod l (16 words), a = b[0..8] (unreduced, < 2^256), r = b[8..16] (canonical). */
 int32_t c25519_selftest_scalar(c25519_ctx *ctx, int op, const uint32_t *a_words, const uint32_t *b_words, uint64_t n, uint8_t *out);
-/* The window layout the MSM uses for n terms (host arithmetic, no GPU needed): window k covers bits
+/* The window layout the MSM uses for n terms of RAW points (host arithmetic, no GPU needed; encoded inputs of 4096 .. 6143 terms and verify_batch choose widths of
+ * their own -- every record carries the width it was made with): window k covers bits
  * [pos[k], pos[k] + wid[k]) of s' = s + addk (addk as 8 little-endian 32-bit words); all windows but the last two are
  * signed (digit = slice - 2^(wid-1)).  pos / wid need room for 56 entries.  Used by the CPU tests to check that the
  * digits always recompose the scalar. */
