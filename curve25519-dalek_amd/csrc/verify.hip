@@ -415,10 +415,14 @@ static void ztree_host_zs(const uint8_t *hred, const uint8_t *sigs, uint64_t n, 
 typedef std::function<int32_t(int what, hipEvent_t *ready)> verify_stage;
 // (r6) device z-mode, inputs on the device, up to 2^16 signatures.  The ORDER in which the host enqueues the two chains (it needs ~4 us per launch or event, ~80 us
 // for the whole call, and each chain can only run as far as it has been enqueued): 0 = k_hram, the three decompression launches, then tree / z_i / batch scalars;
-// 1 = k_hram and the tree ahead of the decompression; 2 = the decompression ahead of everything.  A/B knob VERIFY_ORDER of the tuning build; verify_pass_enqueue has the numbers.
-static int verify_order(uint64_t n) {
-    static const int k = C25519_KNOB("VERIFY_ORDER", 0);
-    return n <= (1ull << 16) ? k : 0;
+// 1 = k_hram and the tree ahead of the decompression; 2 = the decompression ahead of everything.  A/B knob VERIFY_ORDER of the tuning build (-1 = the rule below); verify_pass_enqueue has the numbers.
+// (last) The rule (knob -1): order 1 for key BYTES up to 2^14 signatures -- their one decompression launch of 2n lanes is enqueued in a moment, and behind the three launches
+// of order 0 k_ztree_first started 20 us after the 18 us k_hram of a 4096-signature batch had ended (profiles/r06_timeline_mid_boundary_sizes.txt): 2048 .. 16 384
+// signatures -3 .. -8 us in every pair of runs (profiles/r06_ab_verify_order_small.txt); order 0 with the keys' cached points (level, 16 384 signatures +8 us with order 1).
+static int verify_order(uint64_t n, bool key_bytes) {
+    static const int k = C25519_KNOB("VERIFY_ORDER", -1);
+    if (n > (1ull << 16)) return 0;
+    return k >= 0 ? k : (key_bytes && n <= (1ull << 14)) ? 1 : 0;
 }
 // ... and a single-pass batch whose 2n + 1-term MSM the mid path serves runs it on the hash chain's stream and publishes its record itself
 static bool verify_on_chain(uint64_t n, const msm_geom &g, bool staged) {
@@ -472,7 +476,7 @@ static int32_t verify_pass_enqueue(c25519_ctx *owner, c25519_ctx *ctx, const uin
     static const int hram_first_knob = C25519_KNOB("HRAM_FIRST", 1);      // A/B knob: 0 = behind the decompression launches (rounds 1-4)
     // (up to 2^18 signatures: 0.594 -> 0.581 ms at 2^14, 1.034 -> 1.018 at 2^18; at 2^20 the hash kernels then take the compute units ahead of the decompression
     //  and the call is 0.6 % slower: profiles/r05_ab_midrange_streams.txt)
-    const int order = (!stage && !hr && !split) ? verify_order(n) : 0;
+    const int order = (!stage && !hr && !split) ? verify_order(n, d_pk_points == nullptr) : 0;
     const bool hram_first = hram_first_knob && !stage && !hr && n <= (1ull << 18) && order != 2;
     if (hram_first) { hipLaunchKernelGGL(k_hram, dim3(nblk), dim3(256), 0, sa, d_msgs, d_msg_off, msgs_len, d_sigs, d_pks, n, hram, d_cnt + 4, hred); hr = hram; }
     // (r6, late) order 1: the tree and the z_i ahead of the decompression launches as well.  With SHA-512 in the tree (until call 30 of round 6) the chain was the longer

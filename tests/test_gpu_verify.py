@@ -282,8 +282,8 @@ _MID_CHAIN_BODY = """
 @pytest.mark.parametrize("env", [{}, {"C25519_FAULT_LOSE_PUBLICATION": "3", "C25519_PUBLISH_SPIN_US": "1000"},
                                  # the arms the defaults were measured against (profiles/r06_ab_verify_*.txt, r06_ab_prep_affine.txt, r06_ab_mid_cap.txt)
                                  {"C25519_MID_ON_CHAIN": "0"}, {"C25519_VERIFY_DIRECT": "0", "C25519_MID_LONG_BESIDE": "1"}, {"C25519_VERIFY_ORDER": "1"},
-                                 {"C25519_VERIFY_ORDER": "2", "C25519_PREP_AFFINE_FIRST": "0"}, {"C25519_MID_LONG_TARGET": "2048", "C25519_MID_LONG_TARGET_ALWAYS": "1"}],
-                         ids=["release", "lost-publication", "main-stream", "copy-path-long-beside", "order-1", "order-2-general-normaliser", "low-cap"])
+                                 {"C25519_VERIFY_ORDER": "2", "C25519_PREP_AFFINE_FIRST": "0"}, {"C25519_MID_LONG_TARGET": "2048", "C25519_MID_LONG_TARGET_ALWAYS": "1", "C25519_VERIFY_ORDER": "0"}],
+                         ids=["release", "lost-publication", "main-stream", "copy-path-long-beside", "order-1", "order-2-general-normaliser", "low-cap-order-0"])
 def test_verify_batch_mid_path_on_the_hash_chains_stream(orc, env):
     """(r6) Device z-mode, inputs on the device, 2048 .. 2^16 signatures (until late in round 6 the small path served up to 6143): the 2n + 1-term MSM takes the mid path ON the hash chain's stream (digits and sort right
     behind the batch scalars, the records waited for and signed in front of the accumulation, the over-long lists inside the accumulation's launch) and the last

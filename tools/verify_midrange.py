@@ -15,11 +15,12 @@ for n in [int(v) for v in os.environ.get("VERIFY_SIZES", "1024,2047,2048,3000,40
     dm = torch.randint(0, 256, (59 * n,), dtype=torch.uint8, device="cuda"); doff = torch.arange(0, 59 * (n + 1), 59, dtype=torch.int64, device="cuda")
     dpk, dsg = e.sign_batch_t(seeds, dm, doff)
     M = dm.cpu().numpy(); P = dpk.cpu().numpy(); S = dsg.cpu().numpy()
+    dpts = e.decompress_batch_t(dpk)[1] if os.environ.get('VERIFY_POINTS') else None      # VERIFY_POINTS=1: the device-resident columns with the keys' cached points (VerifyingKey)
     msgs = [M[59 * i:59 * i + 59].tobytes() for i in range(n)]; sigs = [S[i].tobytes() for i in range(n)]; pks = [P[i].tobytes() for i in range(n)]
     row = []
     for host in (0, 1):
         for zm in (0, 1):
-            fn = (lambda: e.verify_batch(msgs, sigs, pks, zm)) if host else (lambda: e.verify_batch_t(dm, doff, dsg, dpk, zm))
+            fn = (lambda: e.verify_batch(msgs, sigs, pks, zm)) if host else (lambda: e.verify_batch_t(dm, doff, dsg, dpk, zm, pk_points=dpts))
             for _ in range(3): assert fn() == 0
             ts = []
             for _ in range(25):
