@@ -53,7 +53,12 @@ __device__ __forceinline__ void accumulate_body(const u32 *__restrict__ pts, con
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
     const u32 lane = threadIdx.x & 63u;
+    // (r6, last) the wave's slot from a SCALAR wave index: the LDS destination of every gather (M0) is then scalar arithmetic -- it was a v_or + v_readfirstlane per gather
+#ifdef C25519_ACC_GATHER64      // A/B arm (tools/build_variant.sh): the addressing until the end of round 6
     uint4 *wave_slot = stage + (threadIdx.x >> 6) * (8 * 64);
+#else
+    uint4 *wave_slot = stage + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (8 * 64);
+#endif
     const uint4 *my_rec = wave_slot + lane * 8;
     const u32 sub = lane >> 3, coff = ((lane & 7u) - sub) & 7u;
     const u32 len = mine ? hi - lo : 0u;
@@ -67,12 +72,23 @@ __device__ __forceinline__ void accumulate_body(const u32 *__restrict__ pts, con
     u32 e = 0, e1 = 0;                                   // entries of iterations it and it + 1 (a finished lane keeps a valid index)
     if (len > 0) e = list[lo];
     if (len > 1) e1 = list[lo + 1];
+#ifdef C25519_ACC_GATHER64
 #define C25519_COOP_ISSUE(ent)                                                                                                  \
     _Pragma("unroll") for (int kk = 0; kk < 8; kk++) {                                                                         \
         const u32 idx = (u32)__shfl((int)(ent), (int)(8 * kk + sub), 64) & 0x7fffffffu;                                         \
         const uint4 *src = reinterpret_cast<const uint4 *>(pts) + PTS_Q * (u64)idx + coff;                                      \
         __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(wave_slot + kk * 64), 16, 0, 0);                         \
     }
+#else
+#define C25519_COOP_ISSUE(ent)                                                                                                  \
+    _Pragma("unroll") for (int kk = 0; kk < 8; kk++) {                                                                         \
+        /* the piece's BYTE offset in 32 bits (a pass has at most 2^25 records: launch_accumulate checks), added to the scalar base by the load itself:   \
+           one v_lshl_or_b32 per gather where the 64-bit address took a mask, a 64-bit shift and a 64-bit add (the shift drops the sign bit of the entry) */ \
+        const u32 boff = ((u32)__shfl((int)(ent), (int)(8 * kk + sub), 64) << 7) | (coff << 4);                                 \
+        const char *src = reinterpret_cast<const char *>(pts) + boff;                                                            \
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(wave_slot + kk * 64), 16, 0, 0);                         \
+    }
+#endif
     if (wmax > 0) { C25519_COOP_ISSUE(e) }
 #pragma unroll 1
     for (u32 it = 0; it < wmax; it++) {

@@ -181,7 +181,16 @@ C25519_HD feT fe_carry64(u64 h[10]) {
 #define C25519_CHAIN 0
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && C25519_CHAIN
+// (r6, last) The pin is an INPUT of a volatile empty statement.  Until the end of round 6 it was `asm("" : "+v"(x))` -- a statement that DEFINES the register -- and behind
+// every such statement the compiler's hazard recogniser put an s_nop (it must assume the worst of a statement it cannot see into): 0.45 - 0.75 s_nop per v_mad_u64_u32
+// in every chained-form kernel (k_x25519 334 per ladder step, k_prep_compressed 2354, k_mul_base_ctp 1002).  Same vector instructions either way (tools/isa_stats.py);
+// a lone wave's fe_mul 917 -> 677 cycles, fe_sq 572 -> 423, at eight waves per SIMD -2.5 % (profiles/r06_ab_pin_input.txt); k_mul_base_ctp 1.86 -> 1.77 ms per 2^20
+// scalars, k_prep_compressed -3 %, small MSMs over encoded points -7 %.  -DC25519_PIN_DEF: the old form (A/B).
+#ifndef C25519_PIN_DEF
+#define C25519_PIN(x) asm volatile("" :: "v"(x))
+#else
 #define C25519_PIN(x) asm("" : "+v"(x))
+#endif
 #else
 #define C25519_PIN(x)
 #endif

@@ -38,7 +38,7 @@ __device__ __forceinline__ void fe_mul_chain_n(feT (&r)[N], const feW (&f)[N], c
                 const u32 a = twice ? f2[n][i] : f[n].v[i], b = wrapped ? g19[n][j] : g[n].v[j];
                 if (i == 0) h[n] = (k == 0 ? 0ull : carry[n]) + (u64)a * (u64)b;
                 else h[n] += (u64)a * (u64)b;
-                asm volatile("" : "+v"(h[n]));
+                asm volatile("" : "+v"(h[n]));      // (a DEFINITION here: as an input -- fe26.h C25519_PIN -- k_accumulate spills 21 scratch accesses per addition at its 168 registers; in lockstep the other products' instructions cover the hazard distance anyway: 52 s_nop per 708 products)
             }
         }
 #pragma unroll

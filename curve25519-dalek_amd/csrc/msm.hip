@@ -598,6 +598,8 @@ static_assert(C25519_SLOT_U32 == MSM_MAX_WIN * 40 + 16, "slot layout");
 int32_t msm_enqueue_acc(c25519_ctx *ctx, const msm_plan &pl, const uint32_t *d_pts, uint32_t *d_slot, hipEvent_t *ring, hipEvent_t wait_acc, bool cont, bool reduce,
                         const uint32_t *d_bad_sticky) {
     const msm_geom &g = pl.g;
+    // (k_accumulate's gathers address a record by a 32-bit byte offset from the pass's base: 2^25 records of 128 bytes.  The sorts' entries hold 23- / 24-bit ids.)
+    if (pl.n > (1ull << 25)) { ctx->err = "msm: internal error (a pass of more than 2^25 records)"; return -(int32_t)hipErrorInvalidValue; }
     if (pl.sort_stream && pl.sort_stream != ctx->stream) {                // join: the main stream continues once the lists exist
         HIPCHK(hipEventRecord(ctx->ev_sort, pl.sort_stream));
         HIPCHK(hipStreamWaitEvent(ctx->stream, ctx->ev_sort, 0));
