@@ -519,23 +519,22 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
     __shared__ uint4 stage[8 * 256];
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void gbl_void;
-    uint4 *wave_slot = stage + (threadIdx.x & ~63u);
+    // (r6, last) the wave's slot from a SCALAR wave index, the entry by a 32-bit byte offset from the scalar table base, the eight pieces by the instruction's own offset field
+    // (which also moves the LDS destination: the slot base compensates) -- one v_lshl_add_u32 per window where the 64-bit addresses took eleven vector instructions and
+    // eight v_readfirstlane (accum.hip has the same change; the table is at most 17 x 32 769 entries of 128 bytes: 71 MB)
+    uint4 *wave_slot = stage + (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * 64u;
     uint4 *my_slot = stage + threadIdx.x;
     // the scalar is a shift register: the current window is always its low C bits
     u32 d = s[0] & MASK;
     bool neg = d > HALF;
     u32 carry = neg ? 1u : 0u;
     u32 mag = neg ? (MASK + 1u - d) : d;
-    const uint4 *e = reinterpret_cast<const uint4 *>(tab) + (u64)mag * 8;
-#define C25519_STAGE_ENTRY(src)                                                                                          \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 0), (lds_void *)(wave_slot + 0 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 1), (lds_void *)(wave_slot + 1 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 2), (lds_void *)(wave_slot + 2 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 3), (lds_void *)(wave_slot + 3 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 4), (lds_void *)(wave_slot + 4 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 5), (lds_void *)(wave_slot + 5 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 6), (lds_void *)(wave_slot + 6 * 256), 16, 0, 0);              \
-    __builtin_amdgcn_global_load_lds((gbl_void *)((src) + 7), (lds_void *)(wave_slot + 7 * 256), 16, 0, 0)
+    u32 e = mag << 7;
+#define C25519_STAGE_PIECE(boff, i)                                                                                      \
+    __builtin_amdgcn_global_load_lds((gbl_void *)(reinterpret_cast<const char *>(tab) + (boff)), (lds_void *)(reinterpret_cast<char *>(wave_slot + (i) * 256) - 16 * (i)), 16, 16 * (i), 0)
+#define C25519_STAGE_ENTRY(boff)                                                                                         \
+    C25519_STAGE_PIECE(boff, 0); C25519_STAGE_PIECE(boff, 1); C25519_STAGE_PIECE(boff, 2); C25519_STAGE_PIECE(boff, 3);  \
+    C25519_STAGE_PIECE(boff, 4); C25519_STAGE_PIECE(boff, 5); C25519_STAGE_PIECE(boff, 6); C25519_STAGE_PIECE(boff, 7)
     C25519_STAGE_ENTRY(e);
     ge_p3 P = ge_identity();
 #pragma unroll 1
@@ -559,7 +558,7 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
             neg = !top && d > HALF;
             carry = neg ? 1u : 0u;
             mag = neg ? (MASK + 1u - d) : d;
-            e = reinterpret_cast<const uint4 *>(tab) + ((u64)(j + 1) * ENT + mag) * 8;
+            e = ((u32)(j + 1) * ENT + mag) << 7;
             C25519_STAGE_ENTRY(e);
         }
         ge_aniels A;                                                // the table holds limbs: no unpacking
@@ -570,6 +569,7 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
         ge_pin(P);
     }
 #undef C25519_STAGE_ENTRY
+#undef C25519_STAGE_PIECE
     if (OUT == 1) raw160_store(out_raw, idx, P);
     else if (OUT == 2) {
         uint4 *q = reinterpret_cast<uint4 *>(scratch) + 10 * idx;
