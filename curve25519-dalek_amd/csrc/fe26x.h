@@ -38,7 +38,14 @@ __device__ __forceinline__ void fe_mul_chain_n(feT (&r)[N], const feW (&f)[N], c
                 const u32 a = twice ? f2[n][i] : f[n].v[i], b = wrapped ? g19[n][j] : g[n].v[j];
                 if (i == 0) h[n] = (k == 0 ? 0ull : carry[n]) + (u64)a * (u64)b;
                 else h[n] += (u64)a * (u64)b;
-                asm volatile("" : "+v"(h[n]));      // (a DEFINITION here: as an input -- fe26.h C25519_PIN -- k_accumulate spills 21 scratch accesses per addition at its 168 registers; in lockstep the other products' instructions cover the hazard distance anyway: 52 s_nop per 708 products)
+                // (pins: a DEFINITION for three and four products -- as an input (fe26.h C25519_PIN has the reason) k_accumulate spills 21 scratch accesses per addition at its
+                //  168 registers, and in lockstep the other products' instructions cover most of the hazard distance anyway: 52 s_nop per 708 products; an INPUT for the pairs of
+                //  the mid path (mid_long.h): k_mid_acc_long 168 registers + 48 bytes of scratch -> 148 and none, 94 -> ~50 s_nop per addition)
+#ifdef C25519_PAIR_PIN_DEF      // A/B arm (tools/build_variant.sh)
+                asm volatile("" : "+v"(h[n]));
+#else
+                if (N <= 2) asm volatile("" :: "v"(h[n])); else asm volatile("" : "+v"(h[n]));
+#endif
             }
         }
 #pragma unroll
