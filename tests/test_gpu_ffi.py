@@ -139,12 +139,13 @@ def test_msm_host_twin_many_passes(eng, orc):
     assert st == 1
 
 
-def test_verify_batch_host_twin_both_modes(eng, orc):
+@pytest.mark.parametrize("n", [3000, 9001, 16384, 16385])
+def test_verify_batch_host_twin_both_modes(eng, orc, n):
     """ed25519_verify_batch[_keys] on host pointers (staged uploads in the device z-mode; everything up front in the strict
-    mode): honest / forged / non-canonical s, with and without the keys' points, single pass and several passes"""
+    mode): honest / forged / non-canonical s, with and without the keys' points, single pass and several passes.  Sizes: the one-copy staged upload with the
+    small path's MSM range of rounds 5 - 6 (3000), with the mid path behind it (9001, 16 384: staged since late round 6), and the first size of the general route (16 385)"""
     import curve25519_dalek_amd as pkg
     E = pkg.engine
-    n = 3000
     seeds = util.rand_bytes(901, n); msgs = [bytes(util.rand_bytes(902 + i, 1, 1 + (i % 50))[0]) for i in range(n)]
     pks, sigs = eng.sign_batch(rows(seeds), msgs)
     P, S = rows(pks), rows(sigs)
