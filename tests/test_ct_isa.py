@@ -143,3 +143,49 @@ def test_ladder_loop_has_no_data_dependent_branch(kernels_asm):
     ops = ladders[0]
     assert _exec_branches(ops) == 0, dict(ops)
     assert ops.get("v_cndmask_b32_e64", 0) + ops.get("v_cndmask_b32_e32", 0) >= 40, dict(ops)                   # cswap of (U, W) pairs
+
+
+# ---- (r6, last) what DESIGN.md section 3.7 found in the compiled loops must not come back ------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def accum_asm(tmp_path_factory):
+    return _asm(tmp_path_factory, "accum")
+
+
+def test_chained_products_carry_no_s_nop(kernels_asm):
+    """The chained-carry products pin every partial sum with an empty asm statement (fe26.h C25519_PIN).  As a statement that DEFINES the register it made the
+    compiler's hazard recogniser put an s_nop behind 45 - 75 % of the v_mad_u64_u32 of every chained-form kernel (334 per ladder step of k_x25519: a quarter of a lone
+    wave's time, profiles/r06_ab_pin_input.txt); as an INPUT of a volatile statement it does not.  Asserted on the ladder loop and on the window loop of the
+    constant-time fixed base: a few s_nop per several hundred products, and still exactly the products of the arithmetic (739 = 5 M + 4 S + one small product)."""
+    lad = _functions(kernels_asm, r"_ZN6c255198k_x25519E")
+    assert len(lad) == 1
+    loops = [ops for _, ops in _loops(next(iter(lad.values()))) if ops["v_mad_u64_u32"] > 500]
+    assert loops, "ladder loop not found"
+    for ops in loops:
+        assert ops["v_mad_u64_u32"] == 739, ops["v_mad_u64_u32"]
+        assert ops["s_nop"] <= 20, ops["s_nop"]
+    fns = _functions(kernels_asm, r"_ZN6c2551914k_mul_base_ctpILi5ELi1024ELi0ELb1ELb1E")
+    assert fns
+    for body in fns.values():
+        win = [ops for _, ops in _loops(body) if ops["v_mad_u64_u32"] > 500]
+        assert win
+        for ops in win:
+            assert ops["s_nop"] <= 20, ops["s_nop"]
+
+
+def test_accumulate_gathers_use_scalar_bases(accum_asm):
+    """k_accumulate's eight gathers per addition: the record base and the LDS destination are SCALAR (global_load_lds_dwordx4 v, s[..] with M0 from scalar registers), the
+    per-lane part is one 32-bit offset -- no v_readfirstlane and no 64-bit address arithmetic in the loop (they were 65 of 1 253 vector instructions per addition:
+    profiles/r06_ab_accumulate_gather.txt), no scratch, and the seven products of the mixed addition."""
+    fns = _functions(accum_asm, r"_ZN6c2551912k_accumulateE")
+    assert len(fns) == 1
+    body = next(iter(fns.values()))
+    assert not any(re.match(r"^\s+scratch_", l) for l in body)
+    main = [ops for _, ops in _loops(body) if ops["v_mad_u64_u32"] > 500]
+    assert len(main) >= 1
+    for ops in main:
+        assert ops["v_mad_u64_u32"] == 708, ops["v_mad_u64_u32"]
+        assert ops["v_readfirstlane_b32"] == 0 and ops["v_lshlrev_b64"] == 0, (ops["v_readfirstlane_b32"], ops["v_lshlrev_b64"])
+        assert ops["global_load_lds_dwordx4"] in (8, 16)      # (the text between the loop label and the backward branch also holds the issue of the first gather)
+        assert sum(v for k, v in ops.items() if k.startswith("v_")) <= 1200
+    loads = [l for l in body if "global_load_lds_dwordx4" in l]
+    assert loads and all(re.search(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", l) for l in loads), loads[:3]
