@@ -70,6 +70,7 @@ __device__ __forceinline__ void accumulate_body(const u32 *__restrict__ pts, con
     if (cont && wmax == 0) return;
     ge_p3 acc = (cont && mine) ? p40_load(buckets, gid) : ge_identity();
     u32 e = 0, e1 = 0;                                   // entries of iterations it and it + 1 (a finished lane keeps a valid index)
+    u32 sgn = 0;                                         // (lazy sign: see the addition below)
     if (len > 0) e = list[lo];
     if (len > 1) e1 = list[lo + 1];
 #ifdef C25519_ACC_GATHER64
@@ -105,11 +106,23 @@ __device__ __forceinline__ void accumulate_body(const u32 *__restrict__ pts, con
         //  behind a uniform branch: 76 scratch accesses in the addition at the 168-register budget.  Round 4 PEELED it in front of the loop
         //  instead (kernel-uniform on `cont`; 168 VGPRs, no scratch): level from 2^12 to 2^20 terms and at 2^24, 1.978 against 1.907 ms at 2^21
         //  (k_accumulate 1.21 against 1.12 ms), profiles/r04_ab_first_entry.txt -- not adopted)
+#if defined(C25519_ACC_SIGN_SELECT) || !defined(__HIP_DEVICE_COMPILE__)      // A/B arm (tools/build_variant.sh): the sign by operand selection, rounds 2 - 6
         if (active) acc = ge_madd_acc(acc, pts_from_q(q), neg);
+#else
+        // (r6, last) the sign LAZILY on the accumulator (fe26x.h ge_madd_lazy_p3_lockstep): sgn = all ones while the stored point is MINUS the bucket sum
+        if (active) {
+            const u32 me = (u32)((int)e >> 31), flip = me ^ sgn;
+            sgn = me;
+            acc = ge_madd_lazy_p3_lockstep(acc, pts_from_q(q), flip);
+        }
+#endif
         e = e_next;
     }
 #undef C25519_COOP_ISSUE
     if (!mine) return;
+#if !defined(C25519_ACC_SIGN_SELECT) && defined(__HIP_DEVICE_COMPILE__)
+    acc.X = fe_carry(feW(fe_cond_neg(acc.X, sgn))); acc.T = fe_carry(feW(fe_cond_neg(acc.T, sgn)));      // back to the true sum (tight limbs: p40_store's format)
+#endif
     p40_store(buckets, gid, acc);
 }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C25519_ACC_WAVES, C25519_ACC_WAVES)))

@@ -109,5 +109,37 @@ __device__ __forceinline__ ge_p3 ge_madd_signed_p3_lockstep(const ge_p3 &p, cons
     return r;
 }
 
+// (r6, last) The same addition with the sign handled LAZILY on the accumulator: the caller keeps, per lane, whether the stored point is the true bucket sum or its negative
+// (P + sQ = s (sP + Q)), and `flip` (all ones / zero per lane) says that the stored point must change sides before Q -- as it is -- is added.  -P = (-X, Y, Z, -T): two
+// conditional negations as x ^ m + (c & m) (two cheap instructions per limb: ~100 issue cycles) where the selects on the record's coordinates and on the two sums cost 40
+// v_cndmask_b32 (~185).  The negated coordinates are loose, so Y +- X come out wide: the class fe_mul takes as its first operand anyway.
+__device__ __forceinline__ feL fe_cond_neg(const feT &a, u32 m) {       // m == ~0: 2p - a (a + 2p - a limb by limb, as fe_sub: loose); m == 0: a
+    feL r;
+    const u32 c0 = 0x7ffffdbu & m, ce = 0x7ffffffu & m, co = 0x3ffffffu & m;      // (2p limb + 1) under the mask: ~a + 2p + 1 = 2p - a
+    r.v[0] = (a.v[0] ^ m) + c0;
+#pragma unroll
+    for (int i = 1; i < 10; i++) r.v[i] = (a.v[i] ^ m) + ((i & 1) ? co : ce);
+    return r;
+}
+__device__ __forceinline__ ge_p3 ge_madd_lazy_p3_lockstep(const ge_p3 &p, const ge_aniels &q, u32 flip) {
+    const feL Xs = fe_cond_neg(p.X, flip), Ts = fe_cond_neg(p.T, flip);
+    feW f3[3]; feL g3[3]; feT r3[3];
+    f3[0] = fe_add_w(feL(p.Y), Xs); f3[1] = fe_sub_w(feL(p.Y), Xs); f3[2] = feW(Ts);
+    g3[0] = q.ypx; g3[1] = q.ymx; g3[2] = q.xy2d;
+    fe_mul_chain_n<3>(r3, f3, g3);
+    const feT &PP = r3[0], &MM = r3[1], &TT = r3[2];
+    feL Z2 = fe_twice(p.Z);
+    feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
+    feL zp = fe_add_lt(Z2, TT);
+    feW zm = fe_sub_w(Z2, TT);
+    feW f4[4]; feL g4[4]; feT r4[4];
+    f4[0] = zm; f4[1] = feW(zp); f4[2] = zm; f4[3] = feW(X);
+    g4[0] = X; g4[1] = Y; g4[2] = zp; g4[3] = Y;
+    fe_mul_chain_n<4>(r4, f4, g4);
+    ge_p3 r;
+    r.X = r4[0]; r.Y = r4[1]; r.Z = r4[2]; r.T = r4[3];
+    return r;
+}
+
 }  // namespace c25519
 #endif
