@@ -186,6 +186,8 @@ def test_accumulate_gathers_use_scalar_bases(accum_asm):
         assert ops["v_mad_u64_u32"] == 708, ops["v_mad_u64_u32"]
         assert ops["v_readfirstlane_b32"] == 0 and ops["v_lshlrev_b64"] == 0, (ops["v_readfirstlane_b32"], ops["v_lshlrev_b64"])
         assert ops["global_load_lds_dwordx4"] in (8, 16)      # (the text between the loop label and the backward branch also holds the issue of the first gather)
-        assert sum(v for k, v in ops.items() if k.startswith("v_")) <= 1200
+        assert ops["v_cndmask_b32_e64"] + ops["v_cndmask_b32_e32"] == 0      # (the digit's sign is applied lazily to the accumulator: v_xad_u32, no select -- profiles/r06_ab_lazy_sign.txt)
+        assert ops["v_xad_u32"] >= 20
+        assert sum(v for k, v in ops.items() if k.startswith("v_")) <= 1260      # (loop + the issue of the first gather + the sign fix-up behind the loop, which the text range includes)
     loads = [l for l in body if "global_load_lds_dwordx4" in l]
     assert loads and all(re.search(r"global_load_lds_dwordx4 v\d+, s\[\d+:\d+\]", l) for l in loads), loads[:3]
