@@ -273,15 +273,26 @@ __device__ __forceinline__ void mid_acc_body(const u32 *__restrict__ recs, const
     const u32 len = mine ? hi - lo : 0u;
     ge_p3 acc = ge_identity();
     u32 e = len > 0 ? list[lo] : 0u;
+    u32 sgn = 0;      // (r6, last) the digit's sign lazily on the accumulator, as in accum.hip: all ones while the stored point is MINUS the bucket sum
 #pragma unroll 1
     for (u32 it = 0; it < len; it++) {
         mid_rec<FMT> cur;
         cur.load(recs, e & 0x7fffffffu);
+#ifdef C25519_ACC_SIGN_SELECT      // A/B arm
         const bool neg = (e >> 31) != 0;
         if (it + 1 < len) e = list[lo + it + 1];
         acc = cur.add_to(acc, neg);
+#else
+        const u32 me = (u32)((int)e >> 31), flip = me ^ sgn;
+        sgn = me;
+        if (it + 1 < len) e = list[lo + it + 1];
+        acc = cur.add_to_lazy(acc, flip);
+#endif
         ge_pin(acc);
     }
+#ifndef C25519_ACC_SIGN_SELECT
+    acc.X = fe_carry(feW(fe_cond_neg(acc.X, sgn))); acc.T = fe_carry(feW(fe_cond_neg(acc.T, sgn)));
+#endif
     if (mine) p40_store(buckets, gid, acc);
 }
 template <int FMT>

@@ -50,6 +50,36 @@ __device__ __forceinline__ ge_p3 ge_add_cached_signed_p3_lockstep(const ge_p3 &p
     r.X = o4[0]; r.Y = o4[1]; r.Z = o4[2]; r.T = o4[3];
     return r;
 }
+// ... and with the sign LAZILY on the accumulator (fe26x.h ge_madd_lazy_p3_lockstep has the reasoning): `flip` = all ones in the lanes whose stored point changes sides first
+__device__ __forceinline__ ge_p3 ge_add_cached_lazy_p3_lockstep(const ge_p3 &p, const feT &qypx, const feT &qymx, const feT &qz, const feT &qt2d, u32 flip) {
+    const feL Xs = fe_cond_neg(p.X, flip), Ts = fe_cond_neg(p.T, flip);
+    feT r4[4];
+    {
+        feW f2[2]; feL g2[2]; feT r2[2];
+        f2[0] = fe_add_w(feL(p.Y), Xs); f2[1] = fe_sub_w(feL(p.Y), Xs);
+        g2[0] = qypx; g2[1] = qymx;
+        fe_mul_chain_n<2>(r2, f2, g2);
+        r4[0] = r2[0]; r4[1] = r2[1];
+    }
+    {
+        feW f2[2]; feL g2[2]; feT r2[2];
+        f2[0] = feW(Ts); f2[1] = p.Z; g2[0] = qt2d; g2[1] = qz;
+        fe_mul_chain_n<2>(r2, f2, g2);
+        r4[2] = r2[0]; r4[3] = r2[1];
+    }
+    const feT &PP = r4[0], &MM = r4[1], &TT = r4[2], &ZZ = r4[3];
+    const feL ZZ2 = fe_twice(ZZ);
+    const feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
+    const feL zp = fe_add_lt(ZZ2, TT);
+    const feW zm = fe_sub_w(ZZ2, TT);
+    feW h4[4]; feL k4[4]; feT o4[4];
+    h4[0] = zm; h4[1] = feW(zp); h4[2] = zm; h4[3] = feW(X);
+    k4[0] = X; k4[1] = Y; k4[2] = zp; k4[3] = Y;
+    fe_mul_chain_n<4>(o4, h4, k4);
+    ge_p3 r;
+    r.X = o4[0]; r.Y = o4[1]; r.Z = o4[2]; r.T = o4[3];
+    return r;
+}
 #define mid_madd ge_madd_signed_p3_lockstep
 #else           // (the host pass of hipcc only parses the kernels: fe26x.h is device code)
 C25519_HD ge_p3 ge_add_cached_signed_p3_lockstep(const ge_p3 &p, const feT &qypx, const feT &qymx, const feT &qz, const feT &qt2d, bool neg) {
@@ -75,6 +105,16 @@ template <> struct mid_rec<0> {
         for (int i = 0; i < 10; i++) { a.v[i] = w[i]; b.v[i] = w[10 + i]; z.v[i] = w[20 + i]; t.v[i] = w[30 + i]; }
         return ge_add_cached_signed_p3_lockstep(acc, a, b, z, t, neg);
     }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ ge_p3 add_to_lazy(const ge_p3 &acc, u32 flip) const {
+        const u32 w[40] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w,
+                           q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w, q[8].x, q[8].y, q[8].z, q[8].w, q[9].x, q[9].y, q[9].z, q[9].w};
+        feT a, b, z, t;
+#pragma unroll
+        for (int i = 0; i < 10; i++) { a.v[i] = w[i]; b.v[i] = w[10 + i]; z.v[i] = w[20 + i]; t.v[i] = w[30 + i]; }
+        return ge_add_cached_lazy_p3_lockstep(acc, a, b, z, t, flip);
+    }
+#endif
 };
 template <> struct mid_rec<1> {
     uint4 q[PTS_Q];
@@ -84,6 +124,9 @@ template <> struct mid_rec<1> {
         for (int i = 0; i < PTS_Q; i++) q[i] = src[i];
     }
     __device__ __forceinline__ ge_p3 add_to(const ge_p3 &acc, bool neg) const { return mid_madd(acc, pts_from_q(q), neg); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    __device__ __forceinline__ ge_p3 add_to_lazy(const ge_p3 &acc, u32 flip) const { return ge_madd_lazy_p3_lockstep(acc, pts_from_q(q), flip); }
+#endif
 };
 // a + b (complete addition, edwards.rs:795-800) with the ten-column products (fe26x.h fe_mul_cols_g): the shuffle tree of k_mid_long is a chain of complete additions
 // on a lone wave, where a product with ten independent column sums issues a multiply-add every ~6 cycles and the chained form of this translation unit one every ~12
