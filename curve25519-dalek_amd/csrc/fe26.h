@@ -132,6 +132,16 @@ C25519_HD feW fe_sub_w(const feL &a, const feL &b) {
     return r;
 }
 C25519_HD feL fe_neg(const feT &a) { return fe_sub(fe_zero(), a); }
+// m == ~0: 2p - a (a + 2p - a limb by limb, as fe_sub: loose); m == 0: a.  Two's complement: ~a + (2p limb + 1) -- one v_xad_u32 per limb on the device (the lazy sign of
+// the accumulations: fe26x.h ge_madd_lazy_p3_lockstep, ge26.h ge_madd_lazy_p3)
+C25519_HD feL fe_cond_neg(const feT &a, u32 m) {
+    feL r;
+    const u32 c0 = 0x7ffffdbu & m, ce = 0x7ffffffu & m, co = 0x3ffffffu & m;
+    r.v[0] = (a.v[0] ^ m) + c0;
+    for (int i = 1; i < 10; i++) r.v[i] = (a.v[i] ^ m) + ((i & 1) ? co : ce);
+    C25519_BOUND(r.v, L_EVEN, L_ODD, "fe_cond_neg");
+    return r;
+}
 
 // Weak reduction: all carries computed in parallel (like FieldElement51::reduce, field.rs:290-323).
 // Any limbs < 2^32 in, tight out.

@@ -113,14 +113,6 @@ __device__ __forceinline__ ge_p3 ge_madd_signed_p3_lockstep(const ge_p3 &p, cons
 // (P + sQ = s (sP + Q)), and `flip` (all ones / zero per lane) says that the stored point must change sides before Q -- as it is -- is added.  -P = (-X, Y, Z, -T): two
 // conditional negations as x ^ m + (c & m) (two cheap instructions per limb: ~100 issue cycles) where the selects on the record's coordinates and on the two sums cost 40
 // v_cndmask_b32 (~185).  The negated coordinates are loose, so Y +- X come out wide: the class fe_mul takes as its first operand anyway.
-__device__ __forceinline__ feL fe_cond_neg(const feT &a, u32 m) {       // m == ~0: 2p - a (a + 2p - a limb by limb, as fe_sub: loose); m == 0: a
-    feL r;
-    const u32 c0 = 0x7ffffdbu & m, ce = 0x7ffffffu & m, co = 0x3ffffffu & m;      // (2p limb + 1) under the mask: ~a + 2p + 1 = 2p - a
-    r.v[0] = (a.v[0] ^ m) + c0;
-#pragma unroll
-    for (int i = 1; i < 10; i++) r.v[i] = (a.v[i] ^ m) + ((i & 1) ? co : ce);
-    return r;
-}
 __device__ __forceinline__ ge_p3 ge_madd_lazy_p3_lockstep(const ge_p3 &p, const ge_aniels &q, u32 flip) {
     const feL Xs = fe_cond_neg(p.X, flip), Ts = fe_cond_neg(p.T, flip);
     feW f3[3]; feL g3[3]; feT r3[3];

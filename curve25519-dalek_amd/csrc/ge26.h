@@ -125,6 +125,25 @@ C25519_HD ge_p3 ge_madd_signed_p3(const ge_p3 &p, const ge_aniels &q, bool neg) 
     return r;
 }
 
+// The same addition with the sign LAZILY on the accumulator (r6, last; fe26x.h ge_madd_lazy_p3_lockstep has the reasoning): the caller keeps whether the stored point is
+// the true sum or its negative; `flip` (all ones / zero) says that it changes sides -- X and T negated, one v_xad_u32 per limb -- before Q is added as it is.
+C25519_HD ge_p3 ge_madd_lazy_p3(const ge_p3 &p, const ge_aniels &q, u32 flip) {
+    const feL Xs = fe_cond_neg(p.X, flip), Ts = fe_cond_neg(p.T, flip);
+    feW YpX = fe_add_w(feL(p.Y), Xs), YmX = fe_sub_w(feL(p.Y), Xs);
+    feT PP = fe_mul(YpX, q.ypx), MM = fe_mul(YmX, q.ymx);
+    feT TT = fe_mul(feW(Ts), q.xy2d);
+    feL Z2 = fe_twice(p.Z);
+    feL X = fe_sub(PP, MM), Y = fe_add(PP, MM);
+    feL zp = fe_add_lt(Z2, TT);
+    feW zm = fe_sub_w(Z2, TT);
+    ge_p3 r;
+    r.X = fe_mul(zm, X);
+    r.Y = fe_mul(feW(zp), Y);
+    r.Z = fe_mul(zm, zp);
+    r.T = fe_mul(feW(X), Y);
+    return r;
+}
+
 // (neg ? -Q : Q) as an extended point, for the FIRST addition of a chain (identity + Q): with (y+x, y-x, 2dxy) at hand,
 // (X : Y : Z : T) = (2x : 2y : 2 : 2xy) is (y+x) - (y-x), (y+x) + (y-x), 2 and 2dxy / d -- one multiplication by the
 // constant 1/d instead of the 7 M of a mixed addition onto the identity.  -Q swaps the first two entries, which negates X,

@@ -564,6 +564,8 @@ __global__ void __launch_bounds__(256) k_mul_base_wide(const uint8_t *__restrict
         ge_aniels A;                                                // the table holds limbs: no unpacking
 #pragma unroll
         for (int i = 0; i < 10; i++) { A.ypx.v[i] = tw[i]; A.ymx.v[i] = tw[10 + i]; A.xy2d.v[i] = tw[20 + i]; }
+        // (the digit's sign applied lazily to the running point -- ge26.h ge_madd_lazy_p3, as k_accumulate does -- measured level here: 0.578 against 0.580 of the
+        //  multiplier peak, gpurun call 68; every window's addition waits for the previous one, and the negation sits on that chain)
         if (j == 0) P = ge_from_aniels_signed(A, cur_neg);         // identity + Q: 1 M instead of 7 M (ge26.h)
         else P = ge_madd_signed_p3(P, A, cur_neg);
         ge_pin(P);

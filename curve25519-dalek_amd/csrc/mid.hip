@@ -273,12 +273,14 @@ __device__ __forceinline__ void mid_acc_body(const u32 *__restrict__ recs, const
     const u32 len = mine ? hi - lo : 0u;
     ge_p3 acc = ge_identity();
     u32 e = len > 0 ? list[lo] : 0u;
-    u32 sgn = 0;      // (r6, last) the digit's sign lazily on the accumulator, as in accum.hip: all ones while the stored point is MINUS the bucket sum
+    u32 sgn = 0;      // (A/B arm C25519_MID_SIGN_LAZY: the digit's sign lazily on the accumulator, as in accum.hip.  Measured LEVEL here -- 8192 terms 0.166 - 0.173 against
+                      //  0.167 - 0.169 ms, 2^18 0.530 - 0.542 against 0.522 - 0.535, profiles/r06_ab_lazy_sign.txt: a lane's list is a latency chain, and the negation sits ON it
+                      //  where the selects on the record do not -- so the operand selection stays)
 #pragma unroll 1
     for (u32 it = 0; it < len; it++) {
         mid_rec<FMT> cur;
         cur.load(recs, e & 0x7fffffffu);
-#ifdef C25519_ACC_SIGN_SELECT      // A/B arm
+#ifndef C25519_MID_SIGN_LAZY
         const bool neg = (e >> 31) != 0;
         if (it + 1 < len) e = list[lo + it + 1];
         acc = cur.add_to(acc, neg);
@@ -290,9 +292,10 @@ __device__ __forceinline__ void mid_acc_body(const u32 *__restrict__ recs, const
 #endif
         ge_pin(acc);
     }
-#ifndef C25519_ACC_SIGN_SELECT
+#ifdef C25519_MID_SIGN_LAZY
     acc.X = fe_carry(feW(fe_cond_neg(acc.X, sgn))); acc.T = fe_carry(feW(fe_cond_neg(acc.T, sgn)));
 #endif
+    (void)sgn;
     if (mine) p40_store(buckets, gid, acc);
 }
 template <int FMT>

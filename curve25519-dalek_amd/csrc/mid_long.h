@@ -87,6 +87,12 @@ C25519_HD ge_p3 ge_add_cached_signed_p3_lockstep(const ge_p3 &p, const feT &qypx
     return ge_p1p1_to_p3(ge_add_cached(p, ge_cached_cneg(q, neg)));
 }
 #define mid_madd ge_madd_signed_p3
+C25519_HD ge_p3 ge_add_cached_lazy_p3_lockstep(const ge_p3 &p, const feT &qypx, const feT &qymx, const feT &qz, const feT &qt2d, u32 flip) {
+    ge_p3 a = p; a.X = fe_carry(feW(fe_cond_neg(p.X, flip))); a.T = fe_carry(feW(fe_cond_neg(p.T, flip)));
+    ge_cached q; q.YpX = qypx; q.YmX = qymx; q.Z = qz; q.T2d = qt2d;
+    return ge_p1p1_to_p3(ge_add_cached(a, q));
+}
+#define ge_madd_lazy_p3_lockstep ge_madd_lazy_p3
 #endif
 // FMT 0: projective Niels records of 160 bytes (k_mid_front); FMT 1: affine Niels records of 128 bytes (devio.h pts_*: decompressed inputs)
 template <int FMT> struct mid_rec;
@@ -105,7 +111,6 @@ template <> struct mid_rec<0> {
         for (int i = 0; i < 10; i++) { a.v[i] = w[i]; b.v[i] = w[10 + i]; z.v[i] = w[20 + i]; t.v[i] = w[30 + i]; }
         return ge_add_cached_signed_p3_lockstep(acc, a, b, z, t, neg);
     }
-#if defined(__HIP_DEVICE_COMPILE__)
     __device__ __forceinline__ ge_p3 add_to_lazy(const ge_p3 &acc, u32 flip) const {
         const u32 w[40] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w, q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w, q[4].x, q[4].y, q[4].z, q[4].w,
                            q[5].x, q[5].y, q[5].z, q[5].w, q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w, q[8].x, q[8].y, q[8].z, q[8].w, q[9].x, q[9].y, q[9].z, q[9].w};
@@ -114,7 +119,6 @@ template <> struct mid_rec<0> {
         for (int i = 0; i < 10; i++) { a.v[i] = w[i]; b.v[i] = w[10 + i]; z.v[i] = w[20 + i]; t.v[i] = w[30 + i]; }
         return ge_add_cached_lazy_p3_lockstep(acc, a, b, z, t, flip);
     }
-#endif
 };
 template <> struct mid_rec<1> {
     uint4 q[PTS_Q];
@@ -124,9 +128,7 @@ template <> struct mid_rec<1> {
         for (int i = 0; i < PTS_Q; i++) q[i] = src[i];
     }
     __device__ __forceinline__ ge_p3 add_to(const ge_p3 &acc, bool neg) const { return mid_madd(acc, pts_from_q(q), neg); }
-#if defined(__HIP_DEVICE_COMPILE__)
     __device__ __forceinline__ ge_p3 add_to_lazy(const ge_p3 &acc, u32 flip) const { return ge_madd_lazy_p3_lockstep(acc, pts_from_q(q), flip); }
-#endif
 };
 // a + b (complete addition, edwards.rs:795-800) with the ten-column products (fe26x.h fe_mul_cols_g): the shuffle tree of k_mid_long is a chain of complete additions
 // on a lone wave, where a product with ten independent column sums issues a multiply-add every ~6 cycles and the chained form of this translation unit one every ~12
