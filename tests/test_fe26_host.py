@@ -223,7 +223,23 @@ def test_scalar_sha_transcript_host_vs_oracle(host, orc):
                 out = C.create_string_buffer(64)
                 host.h_sha512_put_bytes(C.byref(src, shift), C.c_size_t(n), C.c_size_t(pre), out)
                 assert out.raw == hashlib.sha512(m).digest(), (n, pre, shift)
-    for n in [1, 2, 7, 40]:
+    # Keccak-f[1600] in every form this host can run (csrc/transcript_host.h: generic, BMI2, AVX-512 planes) against the spec-level permutation of tests/pyref.py
+    import pyref
+    ran = set()
+    for it in range(40):
+        st = bytes(200) if it == 0 else bytes([0xFF]) * 200 if it == 1 else bytes(rng.getrandbits(8) for _ in range(200))
+        want = bytearray(st); pyref.keccak_f1600(want)
+        for which in (0, 1, 2):
+            o = C.create_string_buffer(200)
+            if host.h_keccak_form(st, which, o):
+                ran.add(which)
+                assert o.raw == bytes(want), (it, which)
+    assert 0 in ran
+    host.h_keccak_impl.restype = C.c_char_p
+    assert host.h_keccak_impl() in (b"generic", b"bmi2", b"avx512")
+    # n = 333: 76- and 45-byte framed messages start at every (even / any) position of the 166-byte block, so both the in-block fast path of append_message and
+    # the boundary-crossing duplex calls are taken at every offset
+    for n in [1, 2, 7, 40, 333]:
         hr = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
         sg = [bytes(rng.getrandbits(8) for _ in range(64)) for _ in range(n)]
         got = call(host, "h_transcript_zs", b"".join(hr), b"".join(sg), C.c_uint64(n), out=16 * n)
