@@ -33,3 +33,15 @@ def test_oracle_known_answers_under_asan_ubsan():
                        env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
     assert "passed" in r.stdout and "failed" not in r.stdout
+
+
+@pytest.mark.skipif(_libasan() is None or shutil.which("g++") is None, reason="g++ / libasan not available")
+def test_host_transcript_under_asan_ubsan(tmp_path):
+    """csrc/transcript_host.h (product host code: the strict z-mode's sponge) instrumented: every Keccak-f form the host has on an exactly 200-byte heap
+    state, transcripts of 0 ... 1000 signatures on exactly-sized heap buffers (tests/host/transcript_san.cpp)."""
+    exe = str(tmp_path / "transcript_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-std=c++17",
+                           "-I", os.path.join(ROOT, "curve25519-dalek_amd", "csrc"), os.path.join(ROOT, "tests", "host", "transcript_san.cpp"), "-o", exe])
+    env = dict(os.environ); env["ASAN_OPTIONS"] = "detect_leaks=0:abort_on_error=1"; env["UBSAN_OPTIONS"] = "halt_on_error=1"
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "sanitized ok" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
