@@ -389,6 +389,8 @@ def record(w, dt, steps, warmup, world, mac_peak, cpu_baseline, scaling, clock_h
                      "peak": mac_peak / 1e12, "frac": (mac_achieved / mac_peak) if mac_achieved else None,
                      "traffic": traffic, "traffic_source": traffic_src,
                      "peak_theoretical": mac_theory / 1e12,
+                     # the clock the probe's rate implies (one v_mad_u64_u32 per lane every 4 cycles on every SIMD): which box this line is from -- boxes differ by ~9 %
+                     "probe_implied_clock_ghz": mac_peak / (SIMDS * MAC_LANES_PER_CLK_PER_SIMD) / 1e9, "nominal_clock_ghz": clock_hz / 1e9,
                      "frac_of_theoretical": (mac_achieved / mac_theory) if mac_achieved else None,
                      "kernel": kt["dominant_kernel"], "kernel_ms_per_launch": dom_ms, "launches_per_step": kt["passes_per_step"],
                      "units_per_launch": upl, "mac_per_unit_in_kernel": kmac,
