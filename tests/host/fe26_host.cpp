@@ -120,14 +120,14 @@ void h_sha512_put_bytes(const uint8_t *m, size_t n, size_t pre, uint8_t *o) {
     u32 w[16]; sha512_digest_words(st.h, w); memcpy(o, w, 64);
 }
 void h_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint64_t n, uint8_t *zs) { c25519_transcript_zs(hrams, sigs, n, zs); }
-// every form of Keccak-f[1600] this host can run (generic; BMI2; AVX-512 -- whichever keccak_pick() would take among them is one of these): `which` = 0 / 1 / 2,
+// every form of Keccak-f[1600] this host can run (generic; BMI2; AVX-512VL lane pairs -- whichever keccak_pick() would take among them is one of these): `which` = 0 / 1 / 2,
 // returns 0 when the host lacks the instructions (o untouched)
 int h_keccak_form(const uint8_t *st, int which, uint8_t *o) {
     uint64_t a[25]; memcpy(a, st, 200);
     __builtin_cpu_init();
     if (which == 0) c25519_tr::keccak_f_generic(a);
     else if (which == 1) { if (!(__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2"))) return 0; c25519_tr::keccak_f_bmi2(a); }
-    else { if (!__builtin_cpu_supports("avx512f")) return 0; c25519_tr::keccak_f_avx512(a); }
+    else { if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl"))) return 0; c25519_tr::keccak_f_pairs(a); }
     memcpy(o, a, 200); return 1;
 }
 const char *h_keccak_impl() { return c25519_tr::keccak_impl(); }

@@ -1,4 +1,4 @@
-// The host transcript of the strict z-mode (csrc/transcript_host.h) under AddressSanitizer + UBSan: the AVX-512 permutation's masked loads / stores on an exactly
+// The host transcript of the strict z-mode (csrc/transcript_host.h) under AddressSanitizer + UBSan: the lane-pair permutation's loads / stores on an exactly
 // 200-byte heap state, and append_message's in-block path + the written-out z squeeze at every block offset (tests/test_oracle_sanitized.py builds and runs this).
 #include <cstdio>
 #include <cstring>
@@ -10,7 +10,7 @@ int main() {
     for (int it = 0; it < 2000; it++) {
         uint64_t *a = (uint64_t *)malloc(200), *b = (uint64_t *)malloc(200);
         for (int i = 0; i < 25; i++) a[i] = b[i] = ((uint64_t)rand() << 40) ^ rand();
-        c25519_tr::keccak_f_generic(a); if (__builtin_cpu_supports("avx512f")) c25519_tr::keccak_f_avx512(b); else c25519_tr::keccak_f(b);
+        c25519_tr::keccak_f_generic(a); if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl")) c25519_tr::keccak_f_pairs(b); else c25519_tr::keccak_f(b);
         if (memcmp(a, b, 200)) { printf("MISMATCH\n"); return 1; }
         free(a); free(b);
     }

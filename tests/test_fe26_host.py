@@ -223,7 +223,7 @@ def test_scalar_sha_transcript_host_vs_oracle(host, orc):
                 out = C.create_string_buffer(64)
                 host.h_sha512_put_bytes(C.byref(src, shift), C.c_size_t(n), C.c_size_t(pre), out)
                 assert out.raw == hashlib.sha512(m).digest(), (n, pre, shift)
-    # Keccak-f[1600] in every form this host can run (csrc/transcript_host.h: generic, BMI2, AVX-512 planes) against the spec-level permutation of tests/pyref.py
+    # Keccak-f[1600] in every form this host can run (csrc/transcript_host.h: generic, BMI2, AVX-512VL lane pairs) against the spec-level permutation of tests/pyref.py
     import pyref
     ran = set()
     for it in range(40):
@@ -236,7 +236,7 @@ def test_scalar_sha_transcript_host_vs_oracle(host, orc):
                 assert o.raw == bytes(want), (it, which)
     assert 0 in ran
     host.h_keccak_impl.restype = C.c_char_p
-    assert host.h_keccak_impl() in (b"generic", b"bmi2", b"avx512")
+    assert host.h_keccak_impl() in (b"generic", b"bmi2", b"avx512vl-pairs")
     # n = 333: 76- and 45-byte framed messages start at every (even / any) position of the 166-byte block, so both the in-block fast path of append_message and
     # the boundary-crossing duplex calls are taken at every offset
     for n in [1, 2, 7, 40, 333]:
