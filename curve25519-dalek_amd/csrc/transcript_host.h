@@ -58,73 +58,96 @@ __attribute__((target("bmi,bmi2"))) static void keccak_f_bmi2(uint64_t a[25]) { 
 // scalar operations + ~100 moves: 156 against 178 ns on the GPU box's host (EPYC 9575F, Zen 5), 238 against 352 on a Xeon (profiles/r06_keccak_avx512.txt; the
 // plane-per-zmm forms measured beside it lose to the scalar code on Zen 5: docs/lab/).  Same bytes as the scalar forms (tests/test_fe26_host.py compares every form the
 // host can run with the spec-level permutation of tests/pyref.py; the transcript tests run on whichever keccak_pick() takes).
-__attribute__((target("avx512f,avx512vl"))) static void keccak_f_pairs(uint64_t a[25]) {
-    static const uint64_t RC[24] = C25519_KECCAK_RC;
+#define C25519_KP_CONSTANTS \
+    static const uint64_t RC[24] = C25519_KECCAK_RC; \
     alignas(16) static const uint64_t RH[5][3][2] = {{{0, 36}, {3, 41}, {18, 0}}, {{1, 44}, {10, 45}, {2, 0}}, {{62, 6}, {43, 15}, {61, 0}}, {{28, 55}, {25, 21}, {56, 0}}, {{27, 20}, {39, 8}, {14, 0}}};
-    __m128i r00 = _mm_set_epi64x((long long)a[5], (long long)a[0]), r01 = _mm_set_epi64x((long long)a[15], (long long)a[10]), r02 = _mm_loadl_epi64((const __m128i *)(a + 20));
-    __m128i r10 = _mm_set_epi64x((long long)a[6], (long long)a[1]), r11 = _mm_set_epi64x((long long)a[16], (long long)a[11]), r12 = _mm_loadl_epi64((const __m128i *)(a + 21));
-    __m128i r20 = _mm_set_epi64x((long long)a[7], (long long)a[2]), r21 = _mm_set_epi64x((long long)a[17], (long long)a[12]), r22 = _mm_loadl_epi64((const __m128i *)(a + 22));
-    __m128i r30 = _mm_set_epi64x((long long)a[8], (long long)a[3]), r31 = _mm_set_epi64x((long long)a[18], (long long)a[13]), r32 = _mm_loadl_epi64((const __m128i *)(a + 23));
+#define C25519_KP_LOAD(a) \
+    __m128i r00 = _mm_set_epi64x((long long)a[5], (long long)a[0]), r01 = _mm_set_epi64x((long long)a[15], (long long)a[10]), r02 = _mm_loadl_epi64((const __m128i *)(a + 20)); \
+    __m128i r10 = _mm_set_epi64x((long long)a[6], (long long)a[1]), r11 = _mm_set_epi64x((long long)a[16], (long long)a[11]), r12 = _mm_loadl_epi64((const __m128i *)(a + 21)); \
+    __m128i r20 = _mm_set_epi64x((long long)a[7], (long long)a[2]), r21 = _mm_set_epi64x((long long)a[17], (long long)a[12]), r22 = _mm_loadl_epi64((const __m128i *)(a + 22)); \
+    __m128i r30 = _mm_set_epi64x((long long)a[8], (long long)a[3]), r31 = _mm_set_epi64x((long long)a[18], (long long)a[13]), r32 = _mm_loadl_epi64((const __m128i *)(a + 23)); \
     __m128i r40 = _mm_set_epi64x((long long)a[9], (long long)a[4]), r41 = _mm_set_epi64x((long long)a[19], (long long)a[14]), r42 = _mm_loadl_epi64((const __m128i *)(a + 24));
-    for (int rnd = 0; rnd < 24; rnd++) {
-        __m128i c0 = _mm_ternarylogic_epi64(r00, r01, r02, 0x96); c0 = _mm_xor_si128(c0, _mm_shuffle_epi32(c0, 0x4E));
-        __m128i c1 = _mm_ternarylogic_epi64(r10, r11, r12, 0x96); c1 = _mm_xor_si128(c1, _mm_shuffle_epi32(c1, 0x4E));
-        __m128i c2 = _mm_ternarylogic_epi64(r20, r21, r22, 0x96); c2 = _mm_xor_si128(c2, _mm_shuffle_epi32(c2, 0x4E));
-        __m128i c3 = _mm_ternarylogic_epi64(r30, r31, r32, 0x96); c3 = _mm_xor_si128(c3, _mm_shuffle_epi32(c3, 0x4E));
-        __m128i c4 = _mm_ternarylogic_epi64(r40, r41, r42, 0x96); c4 = _mm_xor_si128(c4, _mm_shuffle_epi32(c4, 0x4E));
-        const __m128i d0 = _mm_xor_si128(c4, _mm_rol_epi64(c1, 1));
-        const __m128i d1 = _mm_xor_si128(c0, _mm_rol_epi64(c2, 1));
-        const __m128i d2 = _mm_xor_si128(c1, _mm_rol_epi64(c3, 1));
-        const __m128i d3 = _mm_xor_si128(c2, _mm_rol_epi64(c4, 1));
-        const __m128i d4 = _mm_xor_si128(c3, _mm_rol_epi64(c0, 1));
-        const __m128i t00 = _mm_rolv_epi64(_mm_xor_si128(r00, d0), _mm_load_si128((const __m128i *)RH[0][0]));
-        const __m128i t01 = _mm_rolv_epi64(_mm_xor_si128(r01, d0), _mm_load_si128((const __m128i *)RH[0][1]));
-        const __m128i t02 = _mm_rolv_epi64(_mm_xor_si128(r02, d0), _mm_load_si128((const __m128i *)RH[0][2]));
-        const __m128i t10 = _mm_rolv_epi64(_mm_xor_si128(r10, d1), _mm_load_si128((const __m128i *)RH[1][0]));
-        const __m128i t11 = _mm_rolv_epi64(_mm_xor_si128(r11, d1), _mm_load_si128((const __m128i *)RH[1][1]));
-        const __m128i t12 = _mm_rolv_epi64(_mm_xor_si128(r12, d1), _mm_load_si128((const __m128i *)RH[1][2]));
-        const __m128i t20 = _mm_rolv_epi64(_mm_xor_si128(r20, d2), _mm_load_si128((const __m128i *)RH[2][0]));
-        const __m128i t21 = _mm_rolv_epi64(_mm_xor_si128(r21, d2), _mm_load_si128((const __m128i *)RH[2][1]));
-        const __m128i t22 = _mm_rolv_epi64(_mm_xor_si128(r22, d2), _mm_load_si128((const __m128i *)RH[2][2]));
-        const __m128i t30 = _mm_rolv_epi64(_mm_xor_si128(r30, d3), _mm_load_si128((const __m128i *)RH[3][0]));
-        const __m128i t31 = _mm_rolv_epi64(_mm_xor_si128(r31, d3), _mm_load_si128((const __m128i *)RH[3][1]));
-        const __m128i t32 = _mm_rolv_epi64(_mm_xor_si128(r32, d3), _mm_load_si128((const __m128i *)RH[3][2]));
-        const __m128i t40 = _mm_rolv_epi64(_mm_xor_si128(r40, d4), _mm_load_si128((const __m128i *)RH[4][0]));
-        const __m128i t41 = _mm_rolv_epi64(_mm_xor_si128(r41, d4), _mm_load_si128((const __m128i *)RH[4][1]));
-        const __m128i t42 = _mm_rolv_epi64(_mm_xor_si128(r42, d4), _mm_load_si128((const __m128i *)RH[4][2]));
-        const __m128i n00 = _mm_unpacklo_epi64(t00, t30), n01 = _mm_unpacklo_epi64(t10, t40), n02 = _mm_move_epi64(t20);
-        const __m128i n10 = _mm_unpackhi_epi64(t10, t40), n11 = _mm_unpackhi_epi64(t20, t00), n12 = _mm_srli_si128(t30, 8);
-        const __m128i n20 = _mm_unpacklo_epi64(t21, t01), n21 = _mm_unpacklo_epi64(t31, t11), n22 = _mm_move_epi64(t41);
-        const __m128i n30 = _mm_unpackhi_epi64(t31, t11), n31 = _mm_unpackhi_epi64(t41, t21), n32 = _mm_srli_si128(t01, 8);
-        const __m128i n40 = _mm_unpacklo_epi64(t42, t22), n41 = _mm_unpacklo_epi64(t02, t32), n42 = _mm_move_epi64(t12);
-        r00 = _mm_ternarylogic_epi64(n00, n10, n20, 0xD2);
-        r01 = _mm_ternarylogic_epi64(n01, n11, n21, 0xD2);
-        r02 = _mm_ternarylogic_epi64(n02, n12, n22, 0xD2);
-        r10 = _mm_ternarylogic_epi64(n10, n20, n30, 0xD2);
-        r11 = _mm_ternarylogic_epi64(n11, n21, n31, 0xD2);
-        r12 = _mm_ternarylogic_epi64(n12, n22, n32, 0xD2);
-        r20 = _mm_ternarylogic_epi64(n20, n30, n40, 0xD2);
-        r21 = _mm_ternarylogic_epi64(n21, n31, n41, 0xD2);
-        r22 = _mm_ternarylogic_epi64(n22, n32, n42, 0xD2);
-        r30 = _mm_ternarylogic_epi64(n30, n40, n00, 0xD2);
-        r31 = _mm_ternarylogic_epi64(n31, n41, n01, 0xD2);
-        r32 = _mm_ternarylogic_epi64(n32, n42, n02, 0xD2);
-        r40 = _mm_ternarylogic_epi64(n40, n00, n10, 0xD2);
-        r41 = _mm_ternarylogic_epi64(n41, n01, n11, 0xD2);
-        r42 = _mm_ternarylogic_epi64(n42, n02, n12, 0xD2);
-        r00 = _mm_xor_si128(r00, _mm_loadl_epi64((const __m128i *)(RC + rnd)));
+#define C25519_KP_ROUNDS \
+    for (int rnd = 0; rnd < 24; rnd++) { \
+        __m128i c0 = _mm_ternarylogic_epi64(r00, r01, r02, 0x96); c0 = _mm_xor_si128(c0, _mm_shuffle_epi32(c0, 0x4E)); \
+        __m128i c1 = _mm_ternarylogic_epi64(r10, r11, r12, 0x96); c1 = _mm_xor_si128(c1, _mm_shuffle_epi32(c1, 0x4E)); \
+        __m128i c2 = _mm_ternarylogic_epi64(r20, r21, r22, 0x96); c2 = _mm_xor_si128(c2, _mm_shuffle_epi32(c2, 0x4E)); \
+        __m128i c3 = _mm_ternarylogic_epi64(r30, r31, r32, 0x96); c3 = _mm_xor_si128(c3, _mm_shuffle_epi32(c3, 0x4E)); \
+        __m128i c4 = _mm_ternarylogic_epi64(r40, r41, r42, 0x96); c4 = _mm_xor_si128(c4, _mm_shuffle_epi32(c4, 0x4E)); \
+        const __m128i d0 = _mm_xor_si128(c4, _mm_rol_epi64(c1, 1)); \
+        const __m128i d1 = _mm_xor_si128(c0, _mm_rol_epi64(c2, 1)); \
+        const __m128i d2 = _mm_xor_si128(c1, _mm_rol_epi64(c3, 1)); \
+        const __m128i d3 = _mm_xor_si128(c2, _mm_rol_epi64(c4, 1)); \
+        const __m128i d4 = _mm_xor_si128(c3, _mm_rol_epi64(c0, 1)); \
+        const __m128i t00 = _mm_rolv_epi64(_mm_xor_si128(r00, d0), _mm_load_si128((const __m128i *)RH[0][0])); \
+        const __m128i t01 = _mm_rolv_epi64(_mm_xor_si128(r01, d0), _mm_load_si128((const __m128i *)RH[0][1])); \
+        const __m128i t02 = _mm_rolv_epi64(_mm_xor_si128(r02, d0), _mm_load_si128((const __m128i *)RH[0][2])); \
+        const __m128i t10 = _mm_rolv_epi64(_mm_xor_si128(r10, d1), _mm_load_si128((const __m128i *)RH[1][0])); \
+        const __m128i t11 = _mm_rolv_epi64(_mm_xor_si128(r11, d1), _mm_load_si128((const __m128i *)RH[1][1])); \
+        const __m128i t12 = _mm_rolv_epi64(_mm_xor_si128(r12, d1), _mm_load_si128((const __m128i *)RH[1][2])); \
+        const __m128i t20 = _mm_rolv_epi64(_mm_xor_si128(r20, d2), _mm_load_si128((const __m128i *)RH[2][0])); \
+        const __m128i t21 = _mm_rolv_epi64(_mm_xor_si128(r21, d2), _mm_load_si128((const __m128i *)RH[2][1])); \
+        const __m128i t22 = _mm_rolv_epi64(_mm_xor_si128(r22, d2), _mm_load_si128((const __m128i *)RH[2][2])); \
+        const __m128i t30 = _mm_rolv_epi64(_mm_xor_si128(r30, d3), _mm_load_si128((const __m128i *)RH[3][0])); \
+        const __m128i t31 = _mm_rolv_epi64(_mm_xor_si128(r31, d3), _mm_load_si128((const __m128i *)RH[3][1])); \
+        const __m128i t32 = _mm_rolv_epi64(_mm_xor_si128(r32, d3), _mm_load_si128((const __m128i *)RH[3][2])); \
+        const __m128i t40 = _mm_rolv_epi64(_mm_xor_si128(r40, d4), _mm_load_si128((const __m128i *)RH[4][0])); \
+        const __m128i t41 = _mm_rolv_epi64(_mm_xor_si128(r41, d4), _mm_load_si128((const __m128i *)RH[4][1])); \
+        const __m128i t42 = _mm_rolv_epi64(_mm_xor_si128(r42, d4), _mm_load_si128((const __m128i *)RH[4][2])); \
+        const __m128i n00 = _mm_unpacklo_epi64(t00, t30), n01 = _mm_unpacklo_epi64(t10, t40), n02 = _mm_move_epi64(t20); \
+        const __m128i n10 = _mm_unpackhi_epi64(t10, t40), n11 = _mm_unpackhi_epi64(t20, t00), n12 = _mm_srli_si128(t30, 8); \
+        const __m128i n20 = _mm_unpacklo_epi64(t21, t01), n21 = _mm_unpacklo_epi64(t31, t11), n22 = _mm_move_epi64(t41); \
+        const __m128i n30 = _mm_unpackhi_epi64(t31, t11), n31 = _mm_unpackhi_epi64(t41, t21), n32 = _mm_srli_si128(t01, 8); \
+        const __m128i n40 = _mm_unpacklo_epi64(t42, t22), n41 = _mm_unpacklo_epi64(t02, t32), n42 = _mm_move_epi64(t12); \
+        r00 = _mm_ternarylogic_epi64(n00, n10, n20, 0xD2); \
+        r01 = _mm_ternarylogic_epi64(n01, n11, n21, 0xD2); \
+        r02 = _mm_ternarylogic_epi64(n02, n12, n22, 0xD2); \
+        r10 = _mm_ternarylogic_epi64(n10, n20, n30, 0xD2); \
+        r11 = _mm_ternarylogic_epi64(n11, n21, n31, 0xD2); \
+        r12 = _mm_ternarylogic_epi64(n12, n22, n32, 0xD2); \
+        r20 = _mm_ternarylogic_epi64(n20, n30, n40, 0xD2); \
+        r21 = _mm_ternarylogic_epi64(n21, n31, n41, 0xD2); \
+        r22 = _mm_ternarylogic_epi64(n22, n32, n42, 0xD2); \
+        r30 = _mm_ternarylogic_epi64(n30, n40, n00, 0xD2); \
+        r31 = _mm_ternarylogic_epi64(n31, n41, n01, 0xD2); \
+        r32 = _mm_ternarylogic_epi64(n32, n42, n02, 0xD2); \
+        r40 = _mm_ternarylogic_epi64(n40, n00, n10, 0xD2); \
+        r41 = _mm_ternarylogic_epi64(n41, n01, n11, 0xD2); \
+        r42 = _mm_ternarylogic_epi64(n42, n02, n12, 0xD2); \
+        r00 = _mm_xor_si128(r00, _mm_loadl_epi64((const __m128i *)(RC + rnd))); \
     }
-    a[0] = (uint64_t)_mm_cvtsi128_si64(r00); a[5] = (uint64_t)_mm_extract_epi64(r00, 1); a[10] = (uint64_t)_mm_cvtsi128_si64(r01); a[15] = (uint64_t)_mm_extract_epi64(r01, 1); a[20] = (uint64_t)_mm_cvtsi128_si64(r02);
-    a[1] = (uint64_t)_mm_cvtsi128_si64(r10); a[6] = (uint64_t)_mm_extract_epi64(r10, 1); a[11] = (uint64_t)_mm_cvtsi128_si64(r11); a[16] = (uint64_t)_mm_extract_epi64(r11, 1); a[21] = (uint64_t)_mm_cvtsi128_si64(r12);
-    a[2] = (uint64_t)_mm_cvtsi128_si64(r20); a[7] = (uint64_t)_mm_extract_epi64(r20, 1); a[12] = (uint64_t)_mm_cvtsi128_si64(r21); a[17] = (uint64_t)_mm_extract_epi64(r21, 1); a[22] = (uint64_t)_mm_cvtsi128_si64(r22);
-    a[3] = (uint64_t)_mm_cvtsi128_si64(r30); a[8] = (uint64_t)_mm_extract_epi64(r30, 1); a[13] = (uint64_t)_mm_cvtsi128_si64(r31); a[18] = (uint64_t)_mm_extract_epi64(r31, 1); a[23] = (uint64_t)_mm_cvtsi128_si64(r32);
+#define C25519_KP_STORE(a) \
+    a[0] = (uint64_t)_mm_cvtsi128_si64(r00); a[5] = (uint64_t)_mm_extract_epi64(r00, 1); a[10] = (uint64_t)_mm_cvtsi128_si64(r01); a[15] = (uint64_t)_mm_extract_epi64(r01, 1); a[20] = (uint64_t)_mm_cvtsi128_si64(r02); \
+    a[1] = (uint64_t)_mm_cvtsi128_si64(r10); a[6] = (uint64_t)_mm_extract_epi64(r10, 1); a[11] = (uint64_t)_mm_cvtsi128_si64(r11); a[16] = (uint64_t)_mm_extract_epi64(r11, 1); a[21] = (uint64_t)_mm_cvtsi128_si64(r12); \
+    a[2] = (uint64_t)_mm_cvtsi128_si64(r20); a[7] = (uint64_t)_mm_extract_epi64(r20, 1); a[12] = (uint64_t)_mm_cvtsi128_si64(r21); a[17] = (uint64_t)_mm_extract_epi64(r21, 1); a[22] = (uint64_t)_mm_cvtsi128_si64(r22); \
+    a[3] = (uint64_t)_mm_cvtsi128_si64(r30); a[8] = (uint64_t)_mm_extract_epi64(r30, 1); a[13] = (uint64_t)_mm_cvtsi128_si64(r31); a[18] = (uint64_t)_mm_extract_epi64(r31, 1); a[23] = (uint64_t)_mm_cvtsi128_si64(r32); \
     a[4] = (uint64_t)_mm_cvtsi128_si64(r40); a[9] = (uint64_t)_mm_extract_epi64(r40, 1); a[14] = (uint64_t)_mm_cvtsi128_si64(r41); a[19] = (uint64_t)_mm_extract_epi64(r41, 1); a[24] = (uint64_t)_mm_cvtsi128_si64(r42);
+__attribute__((target("avx512f,avx512vl"))) static void keccak_f_pairs(uint64_t a[25]) { C25519_KP_CONSTANTS C25519_KP_LOAD(a) C25519_KP_ROUNDS C25519_KP_STORE(a) }
+// The z squeeze of the batch transcript with the state staying in the 15 registers from one z to the next (transcript.rs:200-206: meta_ad(len16) + prf(16) per z; every z
+// after the first finds the sponge 16 bytes into a fresh block, so an iteration is: header / length / padding bytes XORed into lanes 2, 3 and 20, the permutation, lanes 0
+// and 1 out and zeroed -- the written-out form in c25519_transcript_zs below, minus 25 loads and 25 stores of the state per z).  Requires pos == 16, pos_begin == 0; leaves them so.
+__attribute__((target("avx512f,avx512vl"))) static void keccak_squeeze_pairs(uint64_t a[25], uint8_t *zs, uint64_t n, uint64_t k2, uint64_t k3, uint64_t k20) {
+    C25519_KP_CONSTANTS C25519_KP_LOAD(a)
+    const __m128i x2 = _mm_set_epi64x(0, (long long)k2), x3 = _mm_set_epi64x(0, (long long)k3), x20 = _mm_set_epi64x(0, (long long)k20), keep_hi = _mm_set_epi64x(-1, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        r20 = _mm_xor_si128(r20, x2); r30 = _mm_xor_si128(r30, x3); r02 = _mm_xor_si128(r02, x20);          // lanes 2, 3, 20 are the low halves of r[2][0], r[3][0], r[0][2]
+        C25519_KP_ROUNDS
+        _mm_storeu_si128((__m128i *)(zs + 16 * i), _mm_unpacklo_epi64(r00, r10));                             // lanes 0 and 1
+        r00 = _mm_and_si128(r00, keep_hi); r10 = _mm_and_si128(r10, keep_hi);
+    }
+    C25519_KP_STORE(a)
 }
+#undef C25519_KP_CONSTANTS
+#undef C25519_KP_LOAD
+#undef C25519_KP_ROUNDS
+#undef C25519_KP_STORE
 
 typedef void (*keccak_fn)(uint64_t *);
 static inline keccak_fn keccak_pick() {
     __builtin_cpu_init();
+#if !defined(C25519_KECCAK_MAX_FORM) || C25519_KECCAK_MAX_FORM >= 2      // (the macro: tests/test_fe26_host.py builds one harness without the vector form, so that the scalar forms' transcript path runs on an AVX-512 host too)
     if (__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512vl")) return keccak_f_pairs;
+#endif
     return (__builtin_cpu_supports("bmi") && __builtin_cpu_supports("bmi2")) ? keccak_f_bmi2 : keccak_f_generic;
 }
 static inline void keccak_f(uint64_t a[25]) { static const keccak_fn f = keccak_pick(); f(a); }
@@ -214,14 +237,18 @@ static void c25519_transcript_zs(const uint8_t *hrams, const uint8_t *sigs, uint
     uint8_t zeros[32] = {0};                                                         // ZeroRng, batch.rs:49-76
     t.meta_ad((const uint8_t *)"rng", 3, false); t.key(zeros, 32);                   // transcript.rs:157-173
     const uint8_t len16[4] = {16, 0, 0, 0};
+    typedef c25519_tr::strobe S;
+    // lanes 2 / 3 / 20 of the block a z after the first starts in (pos = 16, pos_begin = 0): meta_ad(len16) header {0, M|A} at bytes 16, 17 and the length at 18 .. 21; prf header
+    // {17, I|A|C} at 22, 23; run_f at pos 24: pos_begin 23, the 0x04 of STROBE's padding at 25, 0x80 at R + 1 = 167
+    const uint64_t k2 = ((uint64_t)(S::FM | S::FA) << 8) | (16ull << 16) | (17ull << 48) | ((uint64_t)(S::FI | S::FA | S::FC) << 56), k3 = 23ull | (0x04ull << 8), k20 = 0x80ull << 56;
     for (uint64_t i = 0; i < n; i++) {                                               // transcript.rs:200-206
-        if (t.pos == 16 && t.pos_begin == 0) {     // (r6) every z after the first finds the sponge 16 bytes into a fresh block: the two operations below written out (eight header / length bytes, the permutation prf's C flag forces, 16 bytes out and zeroed)
-            uint8_t *b = t.bytes();
-            b[17] ^= c25519_tr::strobe::FM | c25519_tr::strobe::FA; b[18] ^= 16;                                                         // meta_ad(len16): header {0, M|A}, began at 17
-            b[22] ^= 17; b[23] ^= c25519_tr::strobe::FI | c25519_tr::strobe::FA | c25519_tr::strobe::FC;                                  // prf: header {17, I|A|C}, began at 23
-            b[24] ^= 23; b[25] ^= 0x04; b[c25519_tr::strobe::R + 1] ^= 0x80;                                                             // run_f at pos 24
+        if (t.pos == 16 && t.pos_begin == 0) {     // (r6) every z after the first finds the sponge 16 bytes into a fresh block: the two operations written out, on whole lanes
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+            if (c25519_tr::keccak_pick() == c25519_tr::keccak_f_pairs) { c25519_tr::keccak_squeeze_pairs(t.st, zs + 16 * i, n - i, k2, k3, k20); break; }
+#endif
+            t.st[2] ^= k2; t.st[3] ^= k3; t.st[20] ^= k20;
             c25519_tr::keccak_f(t.st);
-            memcpy(zs + 16 * i, b, 16); memset(b, 0, 16);                                                                                // pos = 16, pos_begin = 0 again
+            memcpy(zs + 16 * i, t.st, 16); t.st[0] = 0; t.st[1] = 0;                   // pos = 16, pos_begin = 0 again
             continue;
         }
         t.meta_ad(len16, 4, false); t.prf(zs + 16 * i, 16);
