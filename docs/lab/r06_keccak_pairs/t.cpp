@@ -6,6 +6,8 @@
 #include "pairs.h"
 #include "rc_list.h"
 #include "pairs2.h"
+#include "pairs3.h"
+#include "pairs4.h"
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main() {
     uint64_t a[25], b[25]; srand(3);
@@ -17,8 +19,10 @@ int main() {
         printf("pairs: %.1f ns (%llx)   ", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
         memset(st, 1, sizeof st); t0 = now(); for (int i = 0; i < N; i++) kp::keccak_f_pairs2(st); t1 = now();
         printf("pairs2: %.1f ns (%llx)   ", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
-        memset(st, 1, sizeof st); t0 = now(); for (int i = 0; i < N; i++) c25519_tr::keccak_f_avx512(st); t1 = now();
-        printf("avx512 planes: %.1f ns (%llx)   ", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
+        memset(st, 1, sizeof st); t0 = now(); for (int i = 0; i < N; i++) kp::keccak_f_pairs3(st); t1 = now();
+        printf("pairs3: %.1f ns (%llx)   ", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
+        memset(st, 1, sizeof st); t0 = now(); for (int i = 0; i < N; i++) kp::keccak_f_pairs4(st); t1 = now();
+        printf("pairs4: %.1f ns (%llx)   ", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
         memset(st, 1, sizeof st); t0 = now(); for (int i = 0; i < N; i++) c25519_tr::keccak_f_bmi2(st); t1 = now();
         printf("bmi2: %.1f ns (%llx)\n", (t1 - t0) / N * 1e9, (unsigned long long)st[0]);
     }
